@@ -1,0 +1,103 @@
+"""Deterministic synthetic weights and inputs for the feature2face generator.
+
+No checkpoint of the reference is obtainable offline (README.md:52 points at
+Google Drive), so every parity test, the smoke test and bench.py run on
+synthetic state dicts of the reference's exact architecture.  The generator is
+a counter-based hash (splitmix64 finaliser over the element index), so the same
+(seed, key) always yields the same tensor on any machine and any numpy/torch
+version -- the golden fixtures under tests/golden/ depend on that.
+
+Statistics follow the recipe SURVEY.md 8c validated not to saturate tanh:
+  conv weight   zero mean, std 0.02      (reference init: networks.py:360, N(0, 0.02))
+  BN weight     mean 1,   std 0.02       (networks.py:374)
+  BN bias       std 0.05                 (perturbed: the reference inits it to 0)
+  running_mean  std 0.05
+  running_var   U(0.9, 1.6)
+Uniform distributions of matching variance stand in for the normals; the
+distribution shape is irrelevant for parity.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .topology import Topology, build_topology
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def uniform01(n: int, stream: int) -> np.ndarray:
+    """n float32 values in [0,1), a pure function of (stream, index)."""
+    if n == 0:
+        return np.zeros(0, np.float32)
+    half = (n + 1) // 2
+    with np.errstate(over="ignore"):
+        ctr = np.arange(half, dtype=np.uint64) + (np.uint64(stream & 0xFFFFFFFF) << np.uint64(32))
+        h = _splitmix(ctr)
+    out = np.empty(half * 2, np.float32)
+    out[0::2] = (h >> np.uint64(40)).astype(np.float32)            # top 24 bits
+    out[1::2] = ((h >> np.uint64(16)) & np.uint64(0xFFFFFF)).astype(np.float32)
+    out *= np.float32(1.0 / (1 << 24))
+    return out[:n]
+
+
+def _stream(seed: int, key: str) -> int:
+    return (zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF
+
+
+def symmetric(n: int, std: float, stream: int) -> np.ndarray:
+    """zero-mean uniform with the given standard deviation."""
+    a = np.float32(std * np.sqrt(3.0))
+    return (uniform01(n, stream) * np.float32(2.0) - np.float32(1.0)) * a
+
+
+def make_state_dict(topo: Topology, seed: int = 1234) -> Dict[str, np.ndarray]:
+    """numpy state dict with the reference's key names (no 'module.' prefix)."""
+    sd: Dict[str, np.ndarray] = {}
+    for key, shape in topo.tensors.items():
+        n = int(np.prod(shape)) if shape else 1
+        s = _stream(seed, key)
+        if key.endswith("num_batches_tracked"):
+            sd[key] = np.zeros((), np.int64)
+        elif key.endswith("running_var"):
+            sd[key] = (uniform01(n, s) * np.float32(0.7) + np.float32(0.9)).reshape(shape)
+        elif key.endswith("running_mean") or key.endswith(".bias"):
+            sd[key] = symmetric(n, 0.05, s).reshape(shape)
+        elif len(shape) == 1:  # BN weight
+            sd[key] = (np.float32(1.0) + symmetric(n, 0.02, s)).reshape(shape)
+        else:                  # conv weight, OIHW
+            sd[key] = symmetric(n, 0.02, s).reshape(shape)
+    return sd
+
+
+def make_inputs(batch: int, size: int = 512, seed: int = 99, cand_batch: int = 1,
+                cand_channels: int = 12) -> Tuple[np.ndarray, np.ndarray]:
+    """(feature_map [B,1,S,S] with exact {0,1} values -- face_dataset.py:280 divides a
+    uint8 0/255 raster by 255 --, cand_image [Bc,12,S,S] in [-1,1) -- demo.py:89-95)."""
+    feat = np.empty((batch, 1, size, size), np.float32)
+    for b in range(batch):
+        u = uniform01(size * size, _stream(seed + b, "feature_map"))
+        feat[b, 0] = (u > np.float32(0.97)).astype(np.float32).reshape(size, size)
+    cand = np.empty((cand_batch, cand_channels, size, size), np.float32)
+    for b in range(cand_batch):
+        u = uniform01(cand_channels * size * size, _stream(seed + 1000 + b, "cand_image"))
+        cand[b] = (u * np.float32(2.0) - np.float32(1.0)).reshape(cand_channels, size, size)
+    return feat, cand
+
+
+def synthetic(variant: str = "large", ngf: int = 64, num_downs: int = 8, size: int = 512,
+              seed: int = 1234):
+    topo = build_topology(variant, ngf=ngf, num_downs=num_downs, size=size)
+    return topo, make_state_dict(topo, seed)
