@@ -1,0 +1,177 @@
+/*
+ * lspf2f.h -- C ABI of the MI355X-native feature2face renderer (liblspf2f.so).
+ *
+ * The reference (YuanxunLu/LiveSpeechPortraits) has no FFI: the hot path sits behind plain
+ * Python classes.  Each entry point below names the reference interface it stands in for
+ * (file:line under the reference tree).  INTEGRATION.md shows the ctypes stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every function returns LSPF2F_OK (0) or a negative lspf2f_status; nothing throws across
+ *     the ABI; lspf2f_last_error() returns a thread-local message for the last failure.
+ *   - plain pointers and sizes only.  "dev" pointers are HIP device pointers (e.g.
+ *     torch.Tensor.data_ptr() of a ROCm tensor); "host" pointers are ordinary memory.
+ *   - the library never allocates device memory: the caller provides the packed-weight arena
+ *     and the workspace (sizes are queried), so PyTorch's allocator stays the only owner of HBM.
+ *   - lspf2f_forward() enqueues kernels on the given hipStream_t and returns; it never
+ *     synchronises the device and is graph-capturable.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ *   - there is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef LSPF2F_H
+#define LSPF2F_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSPF2F_ABI_VERSION 1
+
+typedef enum lspf2f_status {
+    LSPF2F_OK = 0,
+    LSPF2F_ERR_INVALID_ARGUMENT = -1,
+    LSPF2F_ERR_UNSUPPORTED = -2,     /* e.g. size == 'small' (networks.py:680-769), ngf % 32 != 0 */
+    LSPF2F_ERR_MISSING_TENSOR = -3,  /* a state-dict key the network needs was never supplied */
+    LSPF2F_ERR_SHAPE = -4,
+    LSPF2F_ERR_STATE = -5,           /* call order violated (e.g. forward before bind) */
+    LSPF2F_ERR_HIP = -6,             /* a HIP runtime call failed */
+    LSPF2F_ERR_NO_DEVICE = -7
+} lspf2f_status;
+
+/* Generator variant = opt.size of the reference (models/feature2face_G.py:16-21,
+ * config/May.yaml:23 'large', config/Obama1.yaml:23 'normal'). */
+typedef enum lspf2f_variant {
+    LSPF2F_VARIANT_NORMAL = 0,  /* Feature2FaceGenerator_normal, networks.py:458-483: 1 ResidualBlock/side */
+    LSPF2F_VARIANT_LARGE = 1    /* Feature2FaceGenerator_large,  networks.py:554-579: 2 ResidualBlocks/side */
+} lspf2f_variant;
+
+typedef enum lspf2f_dtype {
+    LSPF2F_DTYPE_F32 = 0        /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+} lspf2f_dtype;
+
+/* flags for lspf2f_config.flags */
+#define LSPF2F_FLAG_KEEP_INTERMEDIATES 1u  /* give every layer output its own workspace region
+                                              (debug / per-layer parity tests); default is
+                                              liveness-based reuse */
+
+/* Mirrors the option fields the reference reads on this path
+ * (options/base_options_feature2face.py:49-50 ngf / n_downsample_G, :40 loadSize; the
+ * constructor arguments of feature2face_G.py:19-21). */
+typedef struct lspf2f_config {
+    int32_t abi_version;   /* LSPF2F_ABI_VERSION */
+    int32_t variant;       /* lspf2f_variant */
+    int32_t input_nc;      /* 13 = 1 feature-map channel + 12 candidate channels */
+    int32_t feat_nc;       /* channels that come from feature_map (1); the rest from cand_image */
+    int32_t output_nc;     /* 3 */
+    int32_t ngf;           /* 64 */
+    int32_t num_downs;     /* 8 */
+    int32_t height;        /* 512 (square frames: height == width) */
+    int32_t width;
+    int32_t max_batch;     /* largest batch lspf2f_forward() will be given */
+    int32_t dtype;         /* lspf2f_dtype */
+    uint32_t flags;
+} lspf2f_config;
+
+typedef struct lspf2f_handle lspf2f_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+
+/* Replaces: Feature2Face_G.__init__ (models/feature2face_G.py:9-24) + the module construction
+ * of networks.py:554-572 / 458-476.  Builds the static execution plan; touches no device. */
+int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
+int lspf2f_destroy(lspf2f_handle *h);
+const char *lspf2f_last_error(void);
+int lspf2f_abi_version(void);
+
+/* ---- weights: state dict in, packed arena out -------------------------------------------- */
+
+/* Replaces: net.load_state_dict(state_dict, strict=False) (models/base_model.py:219).
+ * The expected tensors are exactly the reference's state-dict entries (minus
+ * num_batches_tracked), keys WITHOUT the DataParallel 'module.' prefix,
+ * e.g. "netG.model.model.0.weight". */
+int lspf2f_num_tensors(const lspf2f_handle *h);
+/* name/shape of expected tensor i; dims[] receives up to 4 extents, *ndim their count */
+int lspf2f_tensor_info(const lspf2f_handle *h, int i, const char **name, int64_t dims[4], int *ndim);
+/* Supply one tensor (host pointer, fp32, contiguous, OIHW for conv weights).  The data is
+ * copied.  Unknown keys are an error (the reference's strict=False would silently ignore). */
+int lspf2f_set_tensor(lspf2f_handle *h, const char *key, const float *host, size_t numel);
+
+/* Size of the packed arena, and the host-side pack: checks every expected tensor was supplied
+ * (LSPF2F_ERR_MISSING_TENSOR otherwise -- the reference is silent here), folds eval-mode
+ * BatchNorm (networks.py:606-607, 664, 667; eps 1e-5) into per-channel scale/shift and
+ * reorders conv weights OIHW -> [Cout][ky][kx][Cin].  Pure CPU; the blob is what rank 0
+ * broadcasts over RCCL to the other GPUs. */
+size_t lspf2f_packed_bytes(const lspf2f_handle *h);
+int lspf2f_pack_weights(lspf2f_handle *h, void *host_blob, size_t bytes);
+/* Attach a device copy of the packed blob (caller-owned, must outlive the handle's use). */
+int lspf2f_bind_weights(lspf2f_handle *h, const void *dev_blob, size_t bytes);
+
+/* ---- workspace --------------------------------------------------------------------------- */
+
+size_t lspf2f_workspace_bytes(const lspf2f_handle *h, int batch);
+int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+
+/* Replaces: Feature2FaceModel.inference(feature_map, cand_image)
+ * (models/feature2face_model.py:225-237) -> Feature2Face_G.forward (feature2face_G.py:27-34)
+ * -> Feature2FaceGenerator_{large,normal}.forward (networks.py:575-579 / 479-483).
+ *   feat_dev  [batch][feat_nc][H][W]            fp32 NCHW
+ *   cand_dev  [cand_batch][input_nc-feat_nc][H][W]  fp32 NCHW; cand_batch is 1 (broadcast to
+ *             every frame, as demo.py:266 passes it) or == batch; NULL iff feat_nc == input_nc
+ *             (the reference's `cand_image == None` branch)
+ *   out_dev   [batch][output_nc][H][W]          fp32 NCHW, values in [-1, 1] (tanh)
+ * The torch.cat of the reference is never materialised. */
+int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch,
+                   float *out_dev, int batch, void *hip_stream);
+
+/* ---- introspection (tests, bench, profiling) ---------------------------------------------- */
+
+typedef struct lspf2f_layer_info {
+    const char *name;        /* "L0.down", "L3.d.res1.b", "L0.up", ... */
+    const char *kernel;      /* which kernel family executes it */
+    int32_t cin, cout, h_in, h_out, stride;
+    int32_t upsample, concat, residual, relu, tanh_out;
+    int32_t tile_m, tile_n, split_k;
+    int64_t flops_per_frame;          /* 2*Cout*Cin*9*Hout*Wout */
+    int64_t act_bytes_per_frame;      /* algorithmic activation bytes */
+    int64_t weight_bytes;
+    int64_t w_offset;                 /* byte offsets into the packed blob (-1: none) */
+    int64_t scale_offset;
+    int64_t shift_offset;
+    int64_t out_offset;               /* byte offset of the output in the workspace for the
+                                         batch last bound via lspf2f_plan_batch(); NHWC */
+} lspf2f_layer_info;
+
+int lspf2f_num_layers(const lspf2f_handle *h);
+/* (re)plans buffers for `batch` frames; forward() does this implicitly */
+int lspf2f_plan_batch(lspf2f_handle *h, int batch);
+int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *out);
+/* forward with a hipEvent pair around every layer; ms_per_layer[num_layers] receives the
+ * durations.  Synchronises the stream (profiling aid, not the hot path). */
+int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *cand_dev,
+                         int cand_batch, float *out_dev, int batch, void *hip_stream,
+                         float *ms_per_layer);
+
+/* Single fused 3x3 convolution, the unit the generator is made of, exposed for per-kernel
+ * parity tests against torch.nn.functional.conv2d (+ batch_norm eval + relu).
+ *   src0/src1 NHWC [batch][hs][ws][c0|c1] (src1 may be NULL, c1 = 0; both are read as
+ *   cat([src0, src1], channel)); w_packed [cout][3][3][c0+c1]; scale/shift [cout] or NULL;
+ *   residual NHWC [batch][ho][wo][cout] or NULL; out NHWC [batch][ho][wo][cout].
+ *   stride in {1,2}; upsample: nearest x2 before the conv (stride must be 1).
+ *   tile_m/tile_n/split_k = 0 selects the planner's choice; scratch is needed when split_k != 1
+ *   (size from lspf2f_conv3x3_scratch_bytes). */
+size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride,
+                                    int upsample, int tile_m, int tile_n, int split_k);
+int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, const float *scale,
+                   const float *shift, const float *residual, float *out, int batch, int hs, int ws,
+                   int c0, int c1, int cout, int stride, int upsample, int relu, int tile_m,
+                   int tile_n, int split_k, void *scratch, size_t scratch_bytes, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSPF2F_H */

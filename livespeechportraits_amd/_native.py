@@ -1,0 +1,113 @@
+"""ctypes binding of liblspf2f.so (include/lspf2f.h).
+
+There is deliberately no fallback: if the shared library is missing or does not
+load, importing the hot path raises -- a GPU box must never silently run
+something else (see DESIGN.md "No CPU path").
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_uint32, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblspf2f.so")
+ABI_VERSION = 1
+
+OK = 0
+ERR_NAMES = {
+    -1: "INVALID_ARGUMENT", -2: "UNSUPPORTED", -3: "MISSING_TENSOR", -4: "SHAPE",
+    -5: "STATE", -6: "HIP", -7: "NO_DEVICE",
+}
+VARIANT_IDS = {"normal": 0, "large": 1}
+FLAG_KEEP_INTERMEDIATES = 1
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class Lspf2fError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lspf2f error %d (%s): %s" % (code, ERR_NAMES.get(code, "?"), msg))
+        self.code = code
+
+
+class Config(Structure):
+    _fields_ = [("abi_version", c_int32), ("variant", c_int32), ("input_nc", c_int32),
+                ("feat_nc", c_int32), ("output_nc", c_int32), ("ngf", c_int32),
+                ("num_downs", c_int32), ("height", c_int32), ("width", c_int32),
+                ("max_batch", c_int32), ("dtype", c_int32), ("flags", c_uint32)]
+
+
+class LayerInfo(Structure):
+    _fields_ = [("name", c_char_p), ("kernel", c_char_p),
+                ("cin", c_int32), ("cout", c_int32), ("h_in", c_int32), ("h_out", c_int32),
+                ("stride", c_int32), ("upsample", c_int32), ("concat", c_int32),
+                ("residual", c_int32), ("relu", c_int32), ("tanh_out", c_int32),
+                ("tile_m", c_int32), ("tile_n", c_int32), ("split_k", c_int32),
+                ("flops_per_frame", c_int64), ("act_bytes_per_frame", c_int64),
+                ("weight_bytes", c_int64), ("w_offset", c_int64), ("scale_offset", c_int64),
+                ("shift_offset", c_int64), ("out_offset", c_int64)]
+
+
+# every symbol include/lspf2f.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "lspf2f_create": (c_int, [POINTER(Config), POINTER(c_void_p)]),
+    "lspf2f_destroy": (c_int, [c_void_p]),
+    "lspf2f_last_error": (c_char_p, []),
+    "lspf2f_abi_version": (c_int, []),
+    "lspf2f_num_tensors": (c_int, [c_void_p]),
+    "lspf2f_tensor_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int64 * 4), POINTER(c_int)]),
+    "lspf2f_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "lspf2f_packed_bytes": (c_size_t, [c_void_p]),
+    "lspf2f_pack_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspf2f_bind_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspf2f_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "lspf2f_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspf2f_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "lspf2f_num_layers": (c_int, [c_void_p]),
+    "lspf2f_plan_batch": (c_int, [c_void_p, c_int]),
+    "lspf2f_layer_info_get": (c_int, [c_void_p, c_int, POINTER(LayerInfo)]),
+    "lspf2f_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                     POINTER(c_float)]),
+    "lspf2f_conv3x3_scratch_bytes": (c_size_t, [c_int] * 11),
+    "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load liblspf2f.so and bind every declared symbol; raises NativeLibraryError loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C livespeechportraits_amd/csrc`). There is no CPU/PyTorch fallback."
+            % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError("%s does not export %s" % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lspf2f_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("ABI version mismatch: library %d, binding %d"
+                                 % (lib.lspf2f_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        msg = load().lspf2f_last_error()
+        raise Lspf2fError(rc, msg.decode() if msg else "")

@@ -1,0 +1,338 @@
+// C ABI of liblspf2f.so (include/lspf2f.h).  Host side: owns the plan, never owns device memory.
+#include "../../include/lspf2f.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+
+using namespace lspf2f;
+
+struct lspf2f_handle {
+    Plan plan;
+    lspf2f_config cfg{};
+    const char *blob = nullptr;   // device, caller-owned
+    size_t blob_size = 0;
+    char *ws = nullptr;           // device, caller-owned
+    size_t ws_size = 0;
+    bool packed = false;
+    std::vector<std::string> kernel_names;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+static int hipfail(hipError_t e, const char *what)
+{
+    return fail(LSPF2F_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+static std::once_flag g_init_once;
+static hipError_t g_init_err = hipSuccess;
+static hipError_t ensure_init()
+{
+    std::call_once(g_init_once, [] { g_init_err = igemm_init(); });
+    return g_init_err;
+}
+
+extern "C" {
+
+const char *lspf2f_last_error(void) { return g_err.c_str(); }
+int lspf2f_abi_version(void) { return LSPF2F_ABI_VERSION; }
+
+int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
+{
+    if (!cfg || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    if (cfg->abi_version != LSPF2F_ABI_VERSION) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "ABI version mismatch");
+    if (cfg->dtype != LSPF2F_DTYPE_F32) return fail(LSPF2F_ERR_UNSUPPORTED, "only LSPF2F_DTYPE_F32 is implemented");
+    if (cfg->height != cfg->width) return fail(LSPF2F_ERR_UNSUPPORTED, "frames must be square (loadSize x loadSize)");
+    if (cfg->max_batch < 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "max_batch must be >= 1");
+    lspf2f_handle *h = new (std::nothrow) lspf2f_handle();
+    if (!h) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "out of host memory");
+    h->cfg = *cfg;
+    const std::string e = h->plan.build(cfg->variant, cfg->input_nc, cfg->feat_nc, cfg->output_nc, cfg->ngf,
+                                        cfg->num_downs, cfg->height,
+                                        (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0);
+    if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
+    h->plan.plan_batch(cfg->max_batch);
+    *out = h;
+    return LSPF2F_OK;
+}
+
+int lspf2f_destroy(lspf2f_handle *h)
+{
+    delete h;
+    return LSPF2F_OK;
+}
+
+int lspf2f_num_tensors(const lspf2f_handle *h) { return h ? (int)h->plan.params.size() : fail(LSPF2F_ERR_INVALID_ARGUMENT, "null handle"); }
+
+int lspf2f_tensor_info(const lspf2f_handle *h, int i, const char **name, int64_t dims[4], int *ndim)
+{
+    if (!h || i < 0 || i >= (int)h->plan.params.size()) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "bad tensor index");
+    const ParamDesc &p = h->plan.params[i];
+    if (name) *name = p.key.c_str();
+    if (ndim) *ndim = (int)p.dims.size();
+    if (dims) for (size_t d = 0; d < p.dims.size() && d < 4; ++d) dims[d] = p.dims[d];
+    return LSPF2F_OK;
+}
+
+int lspf2f_set_tensor(lspf2f_handle *h, const char *key, const float *host, size_t numel)
+{
+    if (!h || !key || !host) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    auto it = h->plan.param_index.find(key);
+    if (it == h->plan.param_index.end())
+        return fail(LSPF2F_ERR_INVALID_ARGUMENT, std::string("unexpected state-dict key: ") + key);
+    ParamDesc &p = h->plan.params[it->second];
+    if (numel != p.numel())
+        return fail(LSPF2F_ERR_SHAPE, std::string("size mismatch for ") + key + ": got " + std::to_string(numel) +
+                                          ", expected " + std::to_string(p.numel()));
+    p.data.assign(host, host + numel);
+    p.set = true;
+    h->packed = false;
+    return LSPF2F_OK;
+}
+
+size_t lspf2f_packed_bytes(const lspf2f_handle *h) { return h ? h->plan.blob_bytes : 0; }
+
+int lspf2f_pack_weights(lspf2f_handle *h, void *host_blob, size_t bytes)
+{
+    if (!h || !host_blob) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    const std::string e = h->plan.pack(host_blob, bytes);
+    if (!e.empty())
+        return fail(e.rfind("missing", 0) == 0 ? LSPF2F_ERR_MISSING_TENSOR : LSPF2F_ERR_INVALID_ARGUMENT, e);
+    // the fp32 copies are no longer needed once packed
+    for (auto &p : h->plan.params) { std::vector<float>().swap(p.data); }
+    h->packed = true;
+    return LSPF2F_OK;
+}
+
+int lspf2f_bind_weights(lspf2f_handle *h, const void *dev_blob, size_t bytes)
+{
+    if (!h || !dev_blob) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes < h->plan.blob_bytes) return fail(LSPF2F_ERR_SHAPE, "packed weight arena too small");
+    if ((uintptr_t)dev_blob % 256) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "weight arena must be 256-byte aligned");
+    h->blob = static_cast<const char *>(dev_blob);
+    h->blob_size = bytes;
+    return LSPF2F_OK;
+}
+
+size_t lspf2f_workspace_bytes(const lspf2f_handle *h, int batch)
+{
+    if (!h || batch < 1) return 0;
+    return h->plan.workspace_bytes(batch);
+}
+
+int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes)
+{
+    if (!h || !dev_workspace) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    if ((uintptr_t)dev_workspace % 256) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    h->ws = static_cast<char *>(dev_workspace);
+    h->ws_size = bytes;
+    return LSPF2F_OK;
+}
+
+int lspf2f_num_layers(const lspf2f_handle *h) { return h ? (int)h->plan.layers.size() : fail(LSPF2F_ERR_INVALID_ARGUMENT, "null handle"); }
+
+int lspf2f_plan_batch(lspf2f_handle *h, int batch)
+{
+    if (!h || batch < 1 || batch > h->cfg.max_batch) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "batch out of range");
+    h->plan.plan_batch(batch);
+    return LSPF2F_OK;
+}
+
+static const char *kernel_name(const LayerDesc &l)
+{
+    switch (l.kind) {
+    case kFirstConv: return "first_conv";
+    case kLastConv: return "last_conv";
+    default: return l.splits > 1 ? "igemm3x3_f32+splitk_reduce" : "igemm3x3_f32";
+    }
+}
+
+int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
+{
+    if (!h || !o || i < 0 || i >= (int)h->plan.layers.size()) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "bad layer index");
+    const LayerDesc &l = h->plan.layers[i];
+    o->name = l.name.c_str();
+    o->kernel = kernel_name(l);
+    o->cin = l.cin; o->cout = l.cout; o->h_in = l.hs; o->h_out = l.ho; o->stride = l.stride;
+    o->upsample = l.up; o->concat = l.concat; o->residual = l.residual; o->relu = l.relu; o->tanh_out = l.tanh_out;
+    o->tile_m = l.bm; o->tile_n = l.bn; o->split_k = l.splits;
+    o->flops_per_frame = h->plan.layer_flops(l);
+    o->act_bytes_per_frame = h->plan.layer_act_bytes(l);
+    o->weight_bytes = (int64_t)l.cout * l.cin * 9 * 4;
+    o->w_offset = l.w_off; o->scale_offset = l.scale_off; o->shift_offset = l.shift_off;
+    o->out_offset = l.out >= 0 ? (int64_t)h->plan.tensors[l.out].offset : -1;
+    return LSPF2F_OK;
+}
+
+}  // extern "C"
+
+static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, const float *cand, int cand_batch,
+                     float *out, int batch, hipStream_t s)
+{
+    const Plan &P = h->plan;
+    auto tptr = [&](int t) -> float * { return t < 0 ? nullptr : reinterpret_cast<float *>(h->ws + P.tensors[t].offset); };
+    auto bptr = [&](int64_t off) -> const float * { return off < 0 ? nullptr : reinterpret_cast<const float *>(h->blob + off); };
+    hipError_t e = hipSuccess;
+    if (l.kind == kFirstConv) {
+        FirstConvParams p{};
+        p.feat = feat; p.cand = cand; p.w = bptr(l.w_off); p.out = tptr(l.out);
+        p.B = batch; p.H = l.hs; p.W = l.hs; p.feat_nc = P.feat_nc; p.cand_nc = P.input_nc - P.feat_nc;
+        p.cand_batch = cand_batch; p.Cout = l.cout;
+        e = launch_first_conv(p, s);
+    } else if (l.kind == kLastConv) {
+        LastConvParams p{};
+        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.out = out;
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out;
+        e = launch_last_conv(p, s);
+    } else {
+        IgemmParams p{};
+        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off);
+        p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = tptr(l.res); p.out = tptr(l.out);
+        p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho;
+        p.C0 = l.c0; p.C1 = l.c1; p.Cin = l.cin; p.Cout = l.cout;
+        p.stride = l.stride; p.up = l.up; p.relu = l.relu;
+        p.M = batch * l.ho * l.ho;
+        p.ktiles_total = 9 * l.cin / 32;
+        p.splits = l.splits;
+        p.ktiles_per_split = (p.ktiles_total + l.splits - 1) / l.splits;
+        e = launch_igemm(p, l.bm, l.bn, s);
+        if (e == hipSuccess && l.splits > 1) e = launch_splitk_reduce(p, s);
+    }
+    if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
+    return LSPF2F_OK;
+}
+
+static int check_forward_args(lspf2f_handle *h, const float *feat, const float *cand, int cand_batch, float *out,
+                              int batch)
+{
+    if (!h || !feat || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    if (batch < 1 || batch > h->cfg.max_batch) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "batch out of range (max_batch)");
+    const int cand_nc = h->plan.input_nc - h->plan.feat_nc;
+    if (cand_nc > 0 && !cand) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "cand_image is required (input_nc > feat_nc)");
+    if (cand_nc > 0 && cand_batch != 1 && cand_batch != batch)
+        return fail(LSPF2F_ERR_SHAPE, "cand_batch must be 1 (broadcast) or equal to batch");
+    if (!h->blob) return fail(LSPF2F_ERR_STATE, "weights not bound (lspf2f_bind_weights)");
+    if (!h->ws) return fail(LSPF2F_ERR_STATE, "workspace not bound (lspf2f_bind_workspace)");
+    h->plan.plan_batch(batch);
+    if (h->ws_size < h->plan.act_bytes + h->plan.partial_bytes)
+        return fail(LSPF2F_ERR_STATE, "workspace too small for this batch (lspf2f_workspace_bytes)");
+    const hipError_t e = ensure_init();
+    if (e != hipSuccess) return hipfail(e, "kernel attribute setup");
+    return LSPF2F_OK;
+}
+
+extern "C" {
+
+int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch, float *out_dev,
+                   int batch, void *hip_stream)
+{
+    int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev, batch);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    for (const auto &l : h->plan.layers) {
+        rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, batch, s);
+        if (rc) return rc;
+    }
+    return LSPF2F_OK;
+}
+
+int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch,
+                         float *out_dev, int batch, void *hip_stream, float *ms_per_layer)
+{
+    if (!ms_per_layer) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null ms_per_layer");
+    int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev, batch);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int n = (int)h->plan.layers.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return fail(LSPF2F_ERR_HIP, "hipEventCreate failed");
+    (void)hipEventRecord(ev[0], s);
+    for (int i = 0; i < n && !rc; ++i) {
+        rc = run_layer(h, h->plan.layers[i], feat_dev, cand_dev, cand_batch, out_dev, batch, s);
+        (void)hipEventRecord(ev[i + 1], s);
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) rc = hipfail(e, "hipStreamSynchronize");
+    if (!rc)
+        for (int i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms_per_layer[i], ev[i], ev[i + 1]);
+    for (auto &x : ev) (void)hipEventDestroy(x);
+    return rc;
+}
+
+size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride, int upsample,
+                                    int tile_m, int tile_n, int split_k)
+{
+    (void)ws;
+    const int ho = upsample ? 2 * hs : (stride == 2 ? hs / 2 : hs);
+    const int M = batch * ho * ho;
+    int bm = tile_m, bn = tile_n, sp = split_k;
+    if (!bm || !bn || !sp) {
+        int a, b, c;
+        choose_tiling(M, cout, 9 * (c0 + c1) / 32, &a, &b, &c);
+        if (!bm || !bn) { bm = a; bn = b; }
+        if (!sp) sp = c;
+    }
+    return sp > 1 ? (size_t)sp * M * cout * sizeof(float) : 0;
+}
+
+int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, const float *scale,
+                   const float *shift, const float *residual, float *out, int batch, int hs, int ws, int c0,
+                   int c1, int cout, int stride, int upsample, int relu, int tile_m, int tile_n, int split_k,
+                   void *scratch, size_t scratch_bytes, void *hip_stream)
+{
+    if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
+    if ((c0 % 32) || (c1 % 32) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1))
+        return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32");
+    if (cout % 4) return fail(LSPF2F_ERR_UNSUPPORTED, "cout must be a multiple of 4");
+    if (stride != 1 && stride != 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "stride must be 1 or 2");
+    if (upsample && stride != 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "upsample requires stride 1");
+    if ((scale == nullptr) != (shift == nullptr)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "scale and shift come together");
+    hipError_t e = ensure_init();
+    if (e != hipSuccess) return hipfail(e, "kernel attribute setup");
+    IgemmParams p{};
+    p.src0 = src0; p.src1 = c1 ? src1 : nullptr; p.w = w_packed; p.scale = scale; p.shift = shift;
+    p.residual = residual; p.out = out;
+    p.B = batch; p.Hs = hs; p.Ws = ws;
+    p.Ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
+    p.Wo = p.Ho;
+    p.C0 = c0; p.C1 = c1; p.Cin = c0 + c1; p.Cout = cout; p.stride = stride; p.up = upsample; p.relu = relu;
+    p.M = batch * p.Ho * p.Wo;
+    p.ktiles_total = 9 * p.Cin / 32;
+    int bm = tile_m, bn = tile_n, sp = split_k;
+    {
+        int a, b, c;
+        choose_tiling(p.M, cout, p.ktiles_total, &a, &b, &c);
+        if (!bm || !bn) { bm = a; bn = b; }
+        if (!sp) sp = c;
+    }
+    if (!igemm_tile_supported(bm, bn)) return fail(LSPF2F_ERR_UNSUPPORTED, "tile shape not instantiated");
+    if (sp < 1 || sp > p.ktiles_total) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "bad split_k");
+    p.ktiles_per_split = (p.ktiles_total + sp - 1) / sp;
+    sp = (p.ktiles_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    p.splits = sp;
+    if (sp > 1) {
+        if (!scratch || scratch_bytes < (size_t)sp * p.M * cout * sizeof(float))
+            return fail(LSPF2F_ERR_STATE, "split-K scratch missing or too small");
+        p.partial = static_cast<float *>(scratch);
+    }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    e = launch_igemm(p, bm, bn, s);
+    if (e == hipSuccess && sp > 1) e = launch_splitk_reduce(p, s);
+    if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 launch");
+    return LSPF2F_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// Host-visible launch interface of the gfx950 kernels (kernels.hip).  Internal to liblspf2f.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace lspf2f {
+
+// One fused 3x3 convolution as an implicit GEMM:  M = B*Ho*Wo output pixels, N = Cout,
+// K = 9*Cin ordered (ky, kx, ci) with ci running over src0's channels then src1's.
+struct IgemmParams {
+    const float *src0, *src1;   // NHWC [B][Hs][Ws][C0|C1]; src1 == nullptr when C1 == 0
+    const float *w;             // [Cout][9*Cin]
+    const float *scale, *shift; // [Cout] folded BatchNorm, or nullptr (identity)
+    const float *residual;      // NHWC [M][Cout] or nullptr
+    float *out;                 // NHWC [M][Cout]
+    float *partial;             // split-K scratch [splits][M][Cout] (splits > 1)
+    int B, Hs, Ws, Ho, Wo;
+    int C0, C1, Cin, Cout;
+    int stride;                 // 1 | 2
+    int up;                     // nearest x2 upsample in front of the conv (Ho = 2*Hs)
+    int relu;
+    int M;
+    int ktiles_total;           // 9*Cin/32
+    int ktiles_per_split;
+    int splits;
+};
+
+struct TileConfig { int bm, bn; };
+// tile shapes the igemm kernel is instantiated for
+static const TileConfig kTileConfigs[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {32, 64}};
+static const int kNumTileConfigs = sizeof(kTileConfigs) / sizeof(kTileConfigs[0]);
+
+bool igemm_tile_supported(int bm, int bn);
+hipError_t igemm_init();  // raises the dynamic-LDS limit of the big-tile instantiations
+hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, hipStream_t s);
+hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s);
+
+// First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
+struct FirstConvParams {
+    const float *feat;   // [B][feat_nc][H][W]
+    const float *cand;   // [cand_batch][cand_nc][H][W] or nullptr
+    const float *w;      // [(ci*9 + ky*3 + kx)][Cout]
+    float *out;          // NHWC [B][H/2][W/2][Cout]
+    int B, H, W, feat_nc, cand_nc, cand_batch, Cout;
+};
+hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
+
+// Last layer: Upsample x2 -> Conv 3x3 s1 p1 over cat([src0, src1]) -> tanh, NHWC in, NCHW out.
+struct LastConvParams {
+    const float *src0, *src1;  // NHWC [B][Hs][Ws][C0|C1]
+    const float *w;            // [(tap*Cout + co)][Cin]
+    float *out;                // NCHW [B][Cout][2Hs][2Ws]
+    int B, Hs, Ws, C0, C1, Cout;
+    int apply_tanh;
+};
+hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);
+
+}  // namespace lspf2f

@@ -1,0 +1,415 @@
+// gfx950 (MI355X / CDNA4) kernels of the feature2face generator.  Written for wave64 + MFMA;
+// no other target is supported.
+//
+//  igemm3x3_f32      fused 3x3 conv as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32):
+//                    im2col gather (stride 1|2, optional nearest-x2 upsample, optional second
+//                    source = the never-materialised torch.cat) -> LDS -> MFMA -> epilogue
+//                    (folded BatchNorm scale/shift, residual add, ReLU) or split-K partials.
+//  splitk_reduce     deterministic z-ordered reduction of split-K partials + the same epilogue.
+//  first_conv        13->ngf stride-2 conv reading the two NCHW API tensors, ReLU, NHWC out.
+//  last_conv         2*ngf->3 conv with fused upsample + tanh, NHWC in, NCHW out.
+//
+// Reference semantics: models/networks.py:592-640 (level layout), :650-675 (ResidualBlock),
+// :575-579 (tanh); BatchNorm eval folding validated in SURVEY.md 8c.
+#include "kernels.h"
+
+namespace lspf2f {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 32;    // K-tile (floats); Cin % 32 == 0 so a K-tile never straddles a tap
+static constexpr int LDK = 36;   // LDS row pitch in floats: 144 B makes the 16 rows of a
+                                 // ds_read_b128 lane group hit 16 distinct 16-B bank slots
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams p)
+{
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int RPP = NT / 8;            // tile rows staged per pass (8 threads x float4 = one 32-float row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                      // [2][BM][LDK]
+    float *Bs = smem + 2 * BM * LDK;       // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.y;
+    const int kt_begin = z * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
+    if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
+
+    const int lrow = tid >> 3;
+    const int lq = (tid & 7) * 4;
+
+    // ---- per-thread im2col row descriptors (fixed for the whole K loop) ----
+    int a_pix[PA];   // b*Hs*Ws, or -1 when the row is past M
+    int a_oy[PA], a_ox[PA];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + i * RPP + lrow;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int r = m - b * HoWo;
+            const int oy = r / p.Wo;
+            a_oy[i] = oy * p.stride - 1;
+            a_ox[i] = (r - oy * p.Wo) * p.stride - 1;
+            a_pix[i] = b * p.Hs * p.Ws;
+        } else {
+            a_pix[i] = -1; a_oy[i] = 0; a_ox[i] = 0;
+        }
+    }
+    const int hlim = p.up ? 2 * p.Hs : p.Hs;
+    const int wlim = p.up ? 2 * p.Ws : p.Ws;
+    const int K = 9 * p.Cin;
+    const float *wrow[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + i * RPP + lrow;
+        wrow[i] = (n < p.Cout) ? p.w + (size_t)n * K + lq : nullptr;
+    }
+
+    // K-tile cursor: tap = ky*3+kx, c = channel offset inside the concatenated input
+    int tap = (kt_begin * BK) / p.Cin;
+    int c = kt_begin * BK - tap * p.Cin;
+
+    float4 ra[PA], rb[PB];
+    auto fetch = [&](int kt) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const float *src; int cs, cc;
+        if (c < p.C0) { src = p.src0; cs = p.C0; cc = c; }
+        else          { src = p.src1; cs = p.C1; cc = c - p.C0; }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int uy = a_oy[i] + ky, ux = a_ox[i] + kx;
+            const bool ok = (a_pix[i] >= 0) & (uy >= 0) & (uy < hlim) & (ux >= 0) & (ux < wlim);
+            const int iy = p.up ? (uy >> 1) : uy, ix = p.up ? (ux >> 1) : ux;
+            ra[i] = ok ? *reinterpret_cast<const float4 *>(
+                             src + (size_t)(a_pix[i] + iy * p.Ws + ix) * cs + cc + lq)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            rb[i] = wrow[i] ? *reinterpret_cast<const float4 *>(wrow[i] + (size_t)kt * BK)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        c += BK;
+        if (c == p.Cin) { c = 0; ++tap; }
+    };
+    auto stage = [&](int buf) {
+        float *A = As + buf * BM * LDK, *Bq = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<float4 *>(A + (i * RPP + lrow) * LDK + lq) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            *reinterpret_cast<float4 *>(Bq + (i * RPP + lrow) * LDK + lq) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: lane l supplies row (l&31), k-quad (l>>5) of each 8-wide k group.
+    // The MFMA's k index (l>>5) then pairs k and k+4 -- any K permutation is fine as long as
+    // A and B use the same one.
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    auto compute = [&](int buf) {
+        const float *A = As + buf * BM * LDK + (wm * TM * 32 + frow) * LDK + fk;
+        const float *Bq = Bs + buf * BN * LDK + (wn * TN * 32 + frow) * LDK + fk;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(A + i * 32 * LDK + kb * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(Bq + j * 32 * LDK + kb * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop: register prefetch of tile kt+1 while tile kt is multiplied out of LDS ----
+    if (kt_begin < kt_end) {
+        fetch(kt_begin);
+        stage(0);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool more = kt + 1 < kt_end;
+            if (more) fetch(kt + 1);
+            compute(cur);
+            if (more) stage(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int ccol = lane & 31, crow = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + ccol;
+        if (n >= p.Cout) continue;
+        float sc = 1.f, sh = 0.f;
+        if (p.splits == 1 && p.scale) { sc = p.scale[n]; sh = p.shift[n]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + crow;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.splits > 1) {
+                    p.partial[((size_t)z * p.M + m) * p.Cout + n] = v;
+                } else {
+                    v = v * sc + sh;
+                    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[(size_t)m * p.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// out[m][n] = epilogue(sum_z partial[z][m][n]), z ascending (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
+{
+    const size_t total4 = (size_t)p.M * p.Cout / 4;
+    const size_t stride4 = total4;   // per split
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float4 *pp = reinterpret_cast<const float4 *>(p.partial) + i;
+        float4 s = pp[0];
+        for (int z = 1; z < p.splits; ++z) {
+            const float4 t = pp[(size_t)z * stride4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const int n = (int)((i * 4) % p.Cout);
+        if (p.scale) {
+            const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
+            const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
+            s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y;
+            s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
+        }
+        if (p.residual) {
+            const float4 r = reinterpret_cast<const float4 *>(p.residual)[i];
+            s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+        }
+        if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+        reinterpret_cast<float4 *>(p.out)[i] = s;
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
+{
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
+    const size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN>), dim3(ntm * ntn, p.splits), dim3(64 * WGM * WGN),
+                       smem, s, p);
+    return hipGetLastError();
+}
+
+bool igemm_tile_supported(int bm, int bn)
+{
+    for (int i = 0; i < kNumTileConfigs; ++i)
+        if (kTileConfigs[i].bm == bm && kTileConfigs[i].bn == bn) return true;
+    return false;
+}
+
+hipError_t igemm_init()
+{
+    // 128x128 needs 73,728 B of dynamic LDS (> the 64 KiB default cap)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<128, 128, 2, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * (128 + 128) * LDK * (int)sizeof(float));
+    return e;
+}
+
+hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, hipStream_t s)
+{
+    if (bm == 128 && bn == 128) return launch_igemm_t<128, 128, 2, 2>(p, s);
+    if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2>(p, s);
+    if (bm == 64 && bn == 128) return launch_igemm_t<64, 128, 2, 2>(p, s);
+    if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2>(p, s);
+    if (bm == 32 && bn == 128) return launch_igemm_t<32, 128, 1, 4>(p, s);
+    if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2>(p, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
+{
+    const size_t total4 = (size_t)p.M * p.Cout / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// First layer.  One thread = one output pixel x 32 output channels (blockIdx.y picks the
+// channel slab).  Lanes run along ox, so the stride-2 NCHW reads of a wave cover one contiguous
+// 512-B span per (ci, ky) that all three kx taps share; weights are broadcast from LDS.
+// Reference: cat (feature2face_model.py:231) + Conv2d(13, ngf, 3, 2, 1, bias=False) + ReLU
+// (networks.py:594, :603, :619 `down = [downconv, downrelu]`).
+__global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [K][32]
+    const int cin = p.feat_nc + p.cand_nc;
+    const int K = cin * 9;
+    const int co0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < K * 32; i += blockDim.x) {
+        const int k = i >> 5, j = i & 31;
+        wsm[i] = p.w[(size_t)k * p.Cout + co0 + j];
+    }
+    __syncthreads();
+
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)p.B * Ho * Wo) return;
+    const int b = (int)(gid / (Ho * Wo));
+    const int r = (int)(gid - (long)b * Ho * Wo);
+    const int oy = r / Wo, ox = r - oy * Wo;
+
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+
+    const size_t plane = (size_t)p.H * p.W;
+#pragma unroll 1
+    for (int ci = 0; ci < cin; ++ci) {
+        const float *src = (ci < p.feat_nc)
+            ? p.feat + ((size_t)b * p.feat_nc + ci) * plane
+            : p.cand + ((size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc + (ci - p.feat_nc)) * plane;
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+#pragma unroll 1
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx - 1;
+                const bool ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+                const float v = ok ? src[(size_t)iy * p.W + ix] : 0.f;
+                const float4 *wr = reinterpret_cast<const float4 *>(wsm + (ci * 9 + ky * 3 + kx) * 32);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 w4 = wr[j];
+                    acc[4 * j + 0] += v * w4.x; acc[4 * j + 1] += v * w4.y;
+                    acc[4 * j + 2] += v * w4.z; acc[4 * j + 3] += v * w4.w;
+                }
+            }
+        }
+    }
+    float4 *o = reinterpret_cast<float4 *>(p.out + (size_t)gid * p.Cout + co0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = make_float4(fmaxf(acc[4 * j], 0.f), fmaxf(acc[4 * j + 1], 0.f),
+                           fmaxf(acc[4 * j + 2], 0.f), fmaxf(acc[4 * j + 3], 0.f));
+}
+
+hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
+{
+    const long total = (long)p.B * (p.H / 2) * (p.W / 2);
+    const int K = (p.feat_nc + p.cand_nc) * 9;
+    hipLaunchKernelGGL(first_conv, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
+                       (size_t)K * 32 * sizeof(float), s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Last layer.  One thread = one output pixel, all CO (<= 4) output channels; reads the
+// half-resolution NHWC sources directly (the x2 nearest upsample is the (y>>1, x>>1) gather,
+// the concat is two base pointers), weights broadcast from LDS, tanh, NCHW store (lanes run
+// along x => coalesced 256-B stores per channel plane).
+// Reference: nn.Upsample(2,'nearest') + Conv2d(2*ngf, 3, 3, 1, 1, bias=False) (networks.py:610-611)
+// + torch.tanh (networks.py:577).
+template <int CO>
+__global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [9][CO][Cin]
+    const int cin = p.C0 + p.C1;
+    for (int i = threadIdx.x; i < 9 * CO * cin; i += blockDim.x) wsm[i] = p.w[i];
+    __syncthreads();
+
+    const int H = 2 * p.Hs, W = 2 * p.Ws;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)p.B * H * W) return;
+    const int b = (int)(gid / ((long)H * W));
+    const int r = (int)(gid - (long)b * H * W);
+    const int y = r / W, x = r - y * W;
+
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+
+    for (int ky = 0; ky < 3; ++ky) {
+        const int uy = y + ky - 1;
+        if (uy < 0 || uy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ux = x + kx - 1;
+            if (ux < 0 || ux >= W) continue;
+            const size_t pix = ((size_t)b * p.Hs + (uy >> 1)) * p.Ws + (ux >> 1);
+            const float *wt = wsm + (ky * 3 + kx) * CO * cin;
+            const float4 *s0 = reinterpret_cast<const float4 *>(p.src0 + pix * p.C0);
+            for (int c4 = 0; c4 < p.C0 / 4; ++c4) {
+                const float4 v = s0[c4];
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * cin + c4 * 4);
+                    acc[co] += v.x * w4.x + v.y * w4.y + v.z * w4.z + v.w * w4.w;
+                }
+            }
+            if (p.C1) {
+                const float4 *s1 = reinterpret_cast<const float4 *>(p.src1 + pix * p.C1);
+                for (int c4 = 0; c4 < p.C1 / 4; ++c4) {
+                    const float4 v = s1[c4];
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * cin + p.C0 + c4 * 4);
+                        acc[co] += v.x * w4.x + v.y * w4.y + v.z * w4.z + v.w * w4.w;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+        p.out[(((size_t)b * CO + co) * H + y) * W + x] = p.apply_tanh ? tanhf(acc[co]) : acc[co];
+}
+
+hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
+{
+    const long total = (long)p.B * 4 * p.Hs * p.Ws;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    const size_t smem = (size_t)9 * p.Cout * (p.C0 + p.C1) * sizeof(float);
+    switch (p.Cout) {
+    case 1: hipLaunchKernelGGL(last_conv<1>, grid, dim3(256), smem, s, p); break;
+    case 2: hipLaunchKernelGGL(last_conv<2>, grid, dim3(256), smem, s, p); break;
+    case 3: hipLaunchKernelGGL(last_conv<3>, grid, dim3(256), smem, s, p); break;
+    case 4: hipLaunchKernelGGL(last_conv<4>, grid, dim3(256), smem, s, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace lspf2f

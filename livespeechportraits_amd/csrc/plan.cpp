@@ -1,0 +1,357 @@
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace lspf2f {
+
+static const double kBnEps = 1e-5;   // nn.BatchNorm2d default (networks.py never overrides it)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void choose_tiling(int M, int N, int ktiles, int *bm_out, int *bn_out, int *splits_out)
+{
+    // Candidates, largest first.  MFMA-bound fp32: big tiles cut L2->LDS traffic, but the chip has
+    // 256 CUs and wants >= ~2 workgroups per CU, so shrink the tile (then split K) until the
+    // launch is wide enough.
+    static const int cand[][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}};
+    const int want = 384;
+    int best = -1;
+    long best_tiles = 0;
+    if (M <= 32) {
+        // <= 4x4 spatial at batch 1: pure weight streaming; the 2-wave 32x64 shape gives the most
+        // workgroups per weight byte
+        best = 4;
+        best_tiles = (long)((N + 63) / 64);
+    } else {
+        for (int i = 0; i < 4; ++i) {
+            const int bm = cand[i][0], bn = cand[i][1];
+            if (bn > 64 && N < 128) continue;      // N <= 64: only the bn = 64 shapes
+            if (bm > 64 && M <= 64) continue;
+            const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+            best = i; best_tiles = tiles;          // ends on 64x64 (+ split-K) if nothing is wide enough
+            if (tiles >= want) break;
+        }
+    }
+    int splits = 1;
+    if (best_tiles < want) {
+        splits = (int)((512 + best_tiles - 1) / best_tiles);
+        const int max_splits = std::max(1, ktiles / 4);   // keep >= 4 K-tiles per split
+        splits = std::min(splits, max_splits);
+        // make every split non-empty
+        const int per = (ktiles + splits - 1) / splits;
+        splits = (ktiles + per - 1) / per;
+    }
+    *bm_out = cand[best][0];
+    *bn_out = cand[best][1];
+    *splits_out = splits;
+}
+
+static void level_channels(int depth, int ngf, int input_nc, int output_nc, int *cin, int *inner, int *cout)
+{
+    // networks.py:557-570: innermost and the num_downs-5 middle blocks are ngf*8 -> ngf*8, then
+    // ngf*4 -> ngf*8, ngf*2 -> ngf*4, ngf -> ngf*2, outermost output_nc/input_nc -> ngf.
+    if (depth == 0) { *cin = input_nc; *inner = ngf; *cout = output_nc; return; }
+    const int mo = std::min(1 << (depth - 1), 8), mi = std::min(1 << depth, 8);
+    *cin = ngf * mo; *inner = ngf * mi; *cout = ngf * mo;
+}
+
+namespace {
+struct Builder {
+    Plan &p;
+    explicit Builder(Plan &plan) : p(plan) {}
+
+    void add_param(const std::string &key, std::vector<int64_t> dims)
+    {
+        ParamDesc d;
+        d.key = key;
+        d.dims = std::move(dims);
+        p.param_index[key] = (int)p.params.size();
+        p.params.push_back(std::move(d));
+    }
+    void add_bn(const std::string &key, int c)
+    {
+        add_param(key + ".weight", {c});
+        add_param(key + ".bias", {c});
+        add_param(key + ".running_mean", {c});
+        add_param(key + ".running_var", {c});
+    }
+    int add_tensor(const std::string &name, int c, int h, int def)
+    {
+        TensorDesc t;
+        t.name = name; t.c = c; t.h = h; t.def = def;
+        p.tensors.push_back(t);
+        return (int)p.tensors.size() - 1;
+    }
+    void use(int t, int layer) { if (t >= 0) p.tensors[t].last_use = std::max(p.tensors[t].last_use, layer); }
+
+    int add_layer(LayerDesc l)
+    {
+        const int idx = (int)p.layers.size();
+        use(l.src0, idx); use(l.src1, idx); use(l.res, idx);
+        p.layers.push_back(std::move(l));
+        return idx;
+    }
+
+    // ResidualBlock (networks.py:650-675): conv-BN-ReLU-conv-BN, += x, ReLU
+    int res_block(const std::string &lname, const std::string &key, int x, int c, int h)
+    {
+        add_param(key + ".block.0.weight", {c, c, 3, 3});
+        add_bn(key + ".block.1", c);
+        add_param(key + ".block.3.weight", {c, c, 3, 3});
+        add_bn(key + ".block.4", c);
+        LayerDesc a;
+        a.name = lname + ".a"; a.kind = kIgemm; a.src0 = x; a.cin = a.c0 = c; a.cout = c;
+        a.hs = a.ho = h; a.stride = 1; a.relu = true;
+        a.wkey = key + ".block.0.weight"; a.bnkey = key + ".block.1";
+        a.out = add_tensor(a.name, c, h, (int)p.layers.size());
+        const int ta = a.out;
+        add_layer(a);
+        LayerDesc b;
+        b.name = lname + ".b"; b.kind = kIgemm; b.src0 = ta; b.res = x; b.cin = b.c0 = c; b.cout = c;
+        b.hs = b.ho = h; b.stride = 1; b.relu = true; b.residual = true;
+        b.wkey = key + ".block.3.weight"; b.bnkey = key + ".block.4";
+        b.out = add_tensor(b.name, c, h, (int)p.layers.size());
+        const int tb = b.out;
+        add_layer(b);
+        return tb;
+    }
+
+    // one skip block; x = tensor id of its input (-1: the API input), returns the tensor id of
+    // model(x)'s up-side output (the second half of cat([x, model(x)])); -1 for the outermost.
+    int level(int depth, const std::string &pfx, int x, int h_in)
+    {
+        const bool outer = depth == 0, innermost = depth == p.num_downs - 1;
+        int cin, inner, cout;
+        level_channels(depth, p.ngf, p.input_nc, p.output_nc, &cin, &inner, &cout);
+        const int hd = h_in / 2;
+        const std::string L = "L" + std::to_string(depth);
+        int i = 0;
+        auto key = [&](int idx) { return pfx + ".model." + std::to_string(idx); };
+
+        LayerDesc d;
+        d.name = L + ".down"; d.kind = outer ? kFirstConv : kIgemm; d.src0 = x;
+        d.cin = d.c0 = cin; d.cout = inner; d.hs = h_in; d.ho = hd; d.stride = 2; d.relu = true;
+        d.wkey = key(i) + ".weight";
+        add_param(d.wkey, {inner, cin, 3, 3});
+        ++i;
+        if (!outer && !innermost) { d.bnkey = key(i); add_bn(d.bnkey, inner); ++i; }
+        ++i;  // ReLU
+        d.out = add_tensor(d.name, inner, hd, (int)p.layers.size());
+        int cur = d.out;
+        add_layer(d);
+        for (int r = 0; r < p.nres; ++r) { cur = res_block(L + ".d.res" + std::to_string(r), key(i), cur, inner, hd); ++i; }
+
+        int below = -1;
+        if (!innermost) { below = level(depth + 1, key(i), cur, hd); ++i; }
+        ++i;  // Upsample
+
+        LayerDesc u;
+        u.name = L + ".up"; u.kind = outer ? kLastConv : kIgemm; u.src0 = cur; u.src1 = below;
+        u.c0 = inner; u.c1 = innermost ? 0 : inner; u.cin = u.c0 + u.c1; u.cout = cout;
+        u.hs = hd; u.ho = h_in; u.stride = 1; u.up = true; u.concat = !innermost;
+        u.relu = !outer; u.tanh_out = outer;
+        u.wkey = key(i) + ".weight";
+        add_param(u.wkey, {cout, u.cin, 3, 3});
+        ++i;
+        if (!outer) { u.bnkey = key(i); add_bn(u.bnkey, cout); i += 2; }
+        if (outer) { u.out = -1; add_layer(u); return -1; }
+        u.out = add_tensor(u.name, cout, h_in, (int)p.layers.size());
+        cur = u.out;
+        add_layer(u);
+        for (int r = 0; r < p.nres; ++r) { cur = res_block(L + ".u.res" + std::to_string(r), key(i), cur, cout, h_in); ++i; }
+        return cur;
+    }
+};
+}  // namespace
+
+std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc_, int ngf_, int num_downs_,
+                        int size_, bool keep)
+{
+    if (variant_ != 0 && variant_ != 1)
+        return "variant must be 0 (normal) or 1 (large); the 'small' U-Net (networks.py:680-769) is not supported";
+    if (ngf_ <= 0 || ngf_ % 32 != 0) return "ngf must be a positive multiple of 32 (MFMA K-tile = 32 channels)";
+    if (num_downs_ < 5 || num_downs_ > 12) return "num_downs must be in [5, 12] (networks.py:563)";
+    if (size_ <= 0 || size_ % (1 << num_downs_) != 0) return "frame size must be a multiple of 2**num_downs";
+    if (output_nc_ < 1 || output_nc_ > 4) return "output_nc must be in [1, 4]";
+    if (input_nc_ < 1 || feat_nc_ < 0 || feat_nc_ > input_nc_) return "bad input_nc / feat_nc";
+    variant = variant_; nres = variant_ == 1 ? 2 : 1;
+    input_nc = input_nc_; feat_nc = feat_nc_; output_nc = output_nc_; ngf = ngf_; num_downs = num_downs_;
+    size = size_; keep_intermediates = keep;
+    layers.clear(); tensors.clear(); params.clear(); param_index.clear();
+    Builder b(*this);
+    b.level(0, "netG.model", -1, size);
+
+    // blob layout
+    size_t off = 0;
+    for (auto &l : layers) {
+        off = align_up(off, 256);
+        l.w_off = (int64_t)off;
+        off += (size_t)l.cout * l.cin * 9 * sizeof(float);
+        if (!l.bnkey.empty()) {
+            off = align_up(off, 256);
+            l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
+            off = align_up(off, 256);
+            l.shift_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
+        }
+    }
+    blob_bytes = align_up(off, 256);
+    planned_batch = 0;
+    return "";
+}
+
+int64_t Plan::layer_flops(const LayerDesc &l) const { return 2ll * l.cout * l.cin * 9 * l.ho * l.ho; }
+
+int64_t Plan::layer_act_bytes(const LayerDesc &l) const
+{
+    int64_t e = (int64_t)l.cin * l.hs * l.hs + (int64_t)l.cout * l.ho * l.ho;
+    if (l.residual) e += (int64_t)l.cout * l.ho * l.ho;
+    return e * 4;
+}
+
+namespace {
+struct Arena {
+    std::vector<std::pair<size_t, size_t>> free_;   // (offset, size), sorted by offset, coalesced
+    size_t end = 0;
+    size_t alloc(size_t n)
+    {
+        // best fit among free blocks
+        int best = -1;
+        for (int i = 0; i < (int)free_.size(); ++i)
+            if (free_[i].second >= n && (best < 0 || free_[i].second < free_[best].second)) best = i;
+        if (best >= 0) {
+            const size_t off = free_[best].first;
+            if (free_[best].second == n) free_.erase(free_.begin() + best);
+            else { free_[best].first += n; free_[best].second -= n; }
+            return off;
+        }
+        // grow; reuse a trailing free block if it touches the end
+        if (!free_.empty() && free_.back().first + free_.back().second == end) {
+            const size_t off = free_.back().first;
+            free_.pop_back();
+            end = off + n;
+            return off;
+        }
+        const size_t off = end;
+        end += n;
+        return off;
+    }
+    void release(size_t off, size_t n)
+    {
+        auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (size_t)0));
+        it = free_.insert(it, {off, n});
+        // coalesce with next / previous
+        if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) {
+            it->second += (it + 1)->second;
+            free_.erase(it + 1);
+        }
+        if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+            (it - 1)->second += it->second;
+            free_.erase(it);
+        }
+    }
+};
+
+struct BatchLayout { size_t act_bytes, partial_bytes; };
+
+BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, std::vector<LayerDesc> *tiled)
+{
+    Arena a;
+    std::vector<size_t> off(p.tensors.size(), 0);
+    auto bytes_of = [&](const TensorDesc &t) {
+        return align_up((size_t)t.c * t.h * t.h * (size_t)batch * sizeof(float), 256);
+    };
+    size_t partial = 0;
+    for (int li = 0; li < (int)p.layers.size(); ++li) {
+        const LayerDesc &l = p.layers[li];
+        if (l.out >= 0) off[l.out] = a.alloc(bytes_of(p.tensors[l.out]));
+        if (!p.keep_intermediates)
+            for (int t : {l.src0, l.src1, l.res})
+                if (t >= 0 && p.tensors[t].last_use == li) {
+                    // a tensor may appear twice among (src0, src1, res) only if the graph is
+                    // malformed; the U-Net never does that
+                    a.release(off[t], bytes_of(p.tensors[t]));
+                }
+        if (l.kind == kIgemm) {
+            int bm, bn, splits;
+            const int M = batch * l.ho * l.ho;
+            choose_tiling(M, l.cout, 9 * l.cin / 32, &bm, &bn, &splits);
+            if (tiled) { (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; }
+            if (splits > 1) partial = std::max(partial, (size_t)splits * M * l.cout * sizeof(float));
+        }
+    }
+    if (offsets) *offsets = off;
+    return {align_up(a.end, 256), align_up(partial, 256)};
+}
+}  // namespace
+
+void Plan::plan_batch(int batch)
+{
+    if (batch == planned_batch) return;
+    std::vector<size_t> off;
+    const BatchLayout bl = layout_for(*this, batch, &off, &layers);
+    for (size_t i = 0; i < tensors.size(); ++i) tensors[i].offset = off[i];
+    act_bytes = bl.act_bytes;
+    partial_bytes = bl.partial_bytes;
+    partial_offset = act_bytes;
+    planned_batch = batch;
+}
+
+size_t Plan::workspace_bytes(int batch) const
+{
+    const BatchLayout bl = layout_for(*this, batch, nullptr, nullptr);
+    return bl.act_bytes + bl.partial_bytes;
+}
+
+std::string Plan::pack(void *blob, size_t bytes) const
+{
+    if (bytes < blob_bytes) return "packed blob buffer too small";
+    for (const auto &pd : params)
+        if (!pd.set) return "missing state-dict tensor: " + pd.key;
+    std::memset(blob, 0, blob_bytes);
+    char *base = static_cast<char *>(blob);
+    auto get = [&](const std::string &k) -> const ParamDesc & { return params[param_index.at(k)]; };
+    for (const auto &l : layers) {
+        const float *W = get(l.wkey).data.data();           // OIHW
+        float *dst = reinterpret_cast<float *>(base + l.w_off);
+        const int cin = l.cin, cout = l.cout;
+        if (l.kind == kIgemm) {
+            // [co][tap][ci]  -- the implicit-GEMM B operand, K contiguous per output channel
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        dst[((size_t)co * 9 + t) * cin + ci] = W[((size_t)co * cin + ci) * 9 + t];
+        } else if (l.kind == kFirstConv) {
+            // [ci][tap][co]  -- broadcast rows for the direct first-layer kernel
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        dst[((size_t)ci * 9 + t) * cout + co] = W[((size_t)co * cin + ci) * 9 + t];
+        } else {
+            // [tap][co][ci]
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        dst[((size_t)t * cout + co) * cin + ci] = W[((size_t)co * cin + ci) * 9 + t];
+        }
+        if (!l.bnkey.empty()) {
+            // eval-mode BatchNorm2d folded to y = x*scale + shift, applied AFTER accumulation
+            // (same order as conv -> BN in the reference)
+            const float *g = get(l.bnkey + ".weight").data.data();
+            const float *b = get(l.bnkey + ".bias").data.data();
+            const float *m = get(l.bnkey + ".running_mean").data.data();
+            const float *v = get(l.bnkey + ".running_var").data.data();
+            float *sc = reinterpret_cast<float *>(base + l.scale_off);
+            float *sh = reinterpret_cast<float *>(base + l.shift_off);
+            for (int c = 0; c < cout; ++c) {
+                const double s = (double)g[c] / std::sqrt((double)v[c] + kBnEps);
+                sc[c] = (float)s;
+                sh[c] = (float)((double)b[c] - (double)m[c] * s);
+            }
+        }
+    }
+    return "";
+}
+
+}  // namespace lspf2f

@@ -1,0 +1,77 @@
+// Static execution plan of the feature2face generator: the residual U-Net unrolled into a flat
+// list of fused conv launches, the expected state-dict tensors, the packed-weight blob layout
+// and the liveness-based workspace layout.  Host-only C++ (no HIP types).
+//
+// Reference structure restated: models/networks.py:554-572 (large) / 458-476 (normal) build the
+// nest; :592-640 (and :496-544) order each level's nn.Sequential; :650-675 ResidualBlock.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace lspf2f {
+
+enum LayerKind { kFirstConv = 0, kIgemm = 1, kLastConv = 2 };
+
+struct TensorDesc {        // an activation tensor in the workspace (NHWC)
+    std::string name;
+    int c = 0, h = 0;      // channels, spatial extent (square)
+    int def = -1;          // index of the producing layer
+    int last_use = -1;     // index of the last consuming layer
+    size_t offset = 0;     // byte offset in the workspace for the planned batch
+};
+
+struct LayerDesc {
+    std::string name;
+    LayerKind kind = kIgemm;
+    int src0 = -1, src1 = -1, res = -1, out = -1;   // TensorDesc ids (-1: none / API tensor)
+    int cin = 0, c0 = 0, c1 = 0, cout = 0;
+    int hs = 0;            // spatial extent of the tensor(s) read
+    int ho = 0;            // spatial extent written
+    int stride = 1;
+    bool up = false, relu = false, tanh_out = false, concat = false, residual = false;
+    std::string wkey;      // state-dict key of the OIHW weight
+    std::string bnkey;     // state-dict prefix of the following BatchNorm2d ("" = none)
+    int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
+    // per-batch tiling decision
+    int bm = 0, bn = 0, splits = 1;
+};
+
+struct ParamDesc {         // an expected state-dict entry
+    std::string key;
+    std::vector<int64_t> dims;
+    std::vector<float> data;
+    bool set = false;
+    size_t numel() const { size_t n = 1; for (auto d : dims) n *= (size_t)d; return n; }
+};
+
+struct Plan {
+    int variant = 1, nres = 2, input_nc = 13, feat_nc = 1, output_nc = 3, ngf = 64, num_downs = 8, size = 512;
+    bool keep_intermediates = false;
+    std::vector<LayerDesc> layers;
+    std::vector<TensorDesc> tensors;
+    std::vector<ParamDesc> params;
+    std::map<std::string, int> param_index;
+    size_t blob_bytes = 0;
+
+    // per-batch state
+    int planned_batch = 0;
+    size_t act_bytes = 0;       // activation arena
+    size_t partial_bytes = 0;   // split-K scratch
+    size_t partial_offset = 0;
+
+    std::string build(int variant, int input_nc, int feat_nc, int output_nc, int ngf, int num_downs,
+                      int size, bool keep);   // returns "" or an error message
+    void plan_batch(int batch);
+    size_t workspace_bytes(int batch) const;   // without mutating the current plan
+    std::string pack(void *blob, size_t bytes) const;   // "" or error
+    int64_t layer_flops(const LayerDesc &l) const;
+    int64_t layer_act_bytes(const LayerDesc &l) const;
+};
+
+// tile / split-K heuristic shared by the planner and lspf2f_conv3x3
+void choose_tiling(int M, int N, int ktiles, int *bm, int *bn, int *splits);
+
+}  // namespace lspf2f

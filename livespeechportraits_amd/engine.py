@@ -1,0 +1,194 @@
+"""Host-side owner of one liblspf2f handle: state dict in, frames out.
+
+PyTorch is plumbing here: it owns the device allocations (packed-weight arena,
+workspace, inputs/outputs) and the stream; every FLOP of the generator runs in
+the hand-written gfx950 kernels behind the C ABI (include/lspf2f.h).
+
+Replaces, behind ``Feature2FaceModel.inference`` (models/feature2face_model.py:225-237):
+``Feature2Face_G.forward`` (models/feature2face_G.py:27-34) and
+``Feature2FaceGenerator_{large,normal}.forward`` (models/networks.py:575-579, 479-483).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+class Engine:
+    def __init__(self, variant: str = "large", input_nc: int = 13, feat_nc: int = 1,
+                 output_nc: int = 3, ngf: int = 64, num_downs: int = 8, size: int = 512,
+                 max_batch: int = 1, keep_intermediates: bool = False):
+        if variant not in N.VARIANT_IDS:
+            raise ValueError("opt.size must be 'normal' or 'large' for the HIP renderer "
+                             "(got %r; the 'small' U-Net is not on the shipped path)" % (variant,))
+        self.lib = N.load()
+        self.variant, self.input_nc, self.feat_nc, self.output_nc = variant, input_nc, feat_nc, output_nc
+        self.ngf, self.num_downs, self.size, self.max_batch = ngf, num_downs, size, max_batch
+        cfg = N.Config(N.ABI_VERSION, N.VARIANT_IDS[variant], input_nc, feat_nc, output_nc, ngf,
+                       num_downs, size, size, max_batch, 0,
+                       N.FLAG_KEEP_INTERMEDIATES if keep_intermediates else 0)
+        h = ctypes.c_void_p()
+        N.check(self.lib.lspf2f_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self._blob_dev: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+        self.device: Optional[torch.device] = None
+
+    # ---- lifecycle -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.lspf2f_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ----------------------------------------------------------------------
+    def expected_tensors(self) -> Dict[str, tuple]:
+        out = {}
+        name = ctypes.c_char_p()
+        dims = (ctypes.c_int64 * 4)()
+        nd = ctypes.c_int()
+        for i in range(self.lib.lspf2f_num_tensors(self._h)):
+            N.check(self.lib.lspf2f_tensor_info(self._h, i, ctypes.byref(name), ctypes.byref(dims),
+                                                ctypes.byref(nd)))
+            out[name.value.decode()] = tuple(int(dims[d]) for d in range(nd.value))
+        return out
+
+    def load_state_dict(self, sd: Mapping[str, object], strict: bool = True) -> List[str]:
+        """Feed every expected tensor to the library.  Keys may carry the DataParallel
+        'module.' prefix (models/base_model.py:213-215).  Unlike the reference's
+        strict=False, a missing key is an error; extra keys (num_batches_tracked, or a
+        discriminator's) are returned."""
+        norm = {}
+        for k, v in sd.items():
+            norm[k[7:] if k.startswith("module.") else k] = v
+        expected = self.expected_tensors()
+        missing = [k for k in expected if k not in norm]
+        if missing and strict:
+            raise KeyError("checkpoint is missing %d generator tensors, e.g. %s" % (len(missing), missing[:3]))
+        for k, shape in expected.items():
+            if k not in norm:
+                continue
+            v = norm[k]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if tuple(v.shape) != shape:
+                raise ValueError("shape mismatch for %s: checkpoint %s, network %s" % (k, v.shape, shape))
+            N.check(self.lib.lspf2f_set_tensor(self._h, k.encode(), v.ctypes.data, v.size))
+        return [k for k in norm if k not in expected]
+
+    def packed_bytes(self) -> int:
+        return int(self.lib.lspf2f_packed_bytes(self._h))
+
+    def pack(self) -> torch.Tensor:
+        """BN fold + layout reorder on the host (C++); returns the blob as a CPU uint8 tensor."""
+        blob = torch.empty(self.packed_bytes(), dtype=torch.uint8)
+        N.check(self.lib.lspf2f_pack_weights(self._h, blob.data_ptr(), blob.numel()))
+        return blob
+
+    def bind(self, blob: torch.Tensor, device: Optional[torch.device] = None) -> None:
+        """Attach a packed blob.  A CPU blob is uploaded to ``device``; a device blob (e.g.
+        the receive buffer of the RCCL broadcast) is used in place."""
+        if blob.device.type != "cuda":
+            if device is None:
+                raise ValueError("device required to upload a host blob")
+            if not torch.cuda.is_available():
+                raise N.NativeLibraryError("no ROCm device visible: the feature2face HIP renderer has no CPU path")
+            blob = blob.to(device)
+        if blob.dtype != torch.uint8 or blob.numel() < self.packed_bytes():
+            raise ValueError("bad packed blob")
+        self.device = blob.device
+        self._blob_dev = blob
+        N.check(self.lib.lspf2f_bind_weights(self._h, blob.data_ptr(), blob.numel()))
+        self._ensure_workspace(self.max_batch)
+
+    def _ensure_workspace(self, batch: int) -> None:
+        need = int(self.lib.lspf2f_workspace_bytes(self._h, batch))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            N.check(self.lib.lspf2f_bind_workspace(self._h, self._ws.data_ptr(), self._ws.numel()))
+
+    # ---- hot path -----------------------------------------------------------------------
+    def _check_inputs(self, feat: torch.Tensor, cand: Optional[torch.Tensor]):
+        if self._blob_dev is None:
+            raise RuntimeError("weights not bound: call load_state_dict() / pack() / bind() first")
+        s, cand_nc = self.size, self.input_nc - self.feat_nc
+        if feat.dim() != 4 or tuple(feat.shape[1:]) != (self.feat_nc, s, s):
+            raise ValueError("feature_map must be [B,%d,%d,%d], got %s" % (self.feat_nc, s, s, tuple(feat.shape)))
+        b = feat.shape[0]
+        if b < 1 or b > self.max_batch:
+            raise ValueError("batch %d outside [1, max_batch=%d]" % (b, self.max_batch))
+        for t in (feat, cand):
+            if t is None:
+                continue
+            if t.device != self.device:
+                raise ValueError("input on %s, engine on %s" % (t.device, self.device))
+            if t.dtype != torch.float32:
+                raise TypeError("inputs must be float32")
+        if cand_nc:
+            if cand is None:
+                raise ValueError("cand_image is required for input_nc=%d" % self.input_nc)
+            if cand.dim() != 4 or tuple(cand.shape[1:]) != (cand_nc, s, s) or cand.shape[0] not in (1, b):
+                raise ValueError("cand_image must be [1 or B,%d,%d,%d], got %s" % (cand_nc, s, s, tuple(cand.shape)))
+        return b
+
+    def forward(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        b = self._check_inputs(feat, cand)
+        feat = feat.contiguous()
+        cand = cand.contiguous() if cand is not None else None
+        if out is None:
+            out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self.lib.lspf2f_forward(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
+                                        cand.shape[0] if cand is not None else 0, out.data_ptr(), b,
+                                        ctypes.c_void_p(stream)))
+        return out
+
+    def forward_timed(self, feat, cand, out=None):
+        b = self._check_inputs(feat, cand)
+        if out is None:
+            out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device)
+        n = self.lib.lspf2f_num_layers(self._h)
+        ms = (ctypes.c_float * n)()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self.lib.lspf2f_forward_timed(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
+                                              cand.shape[0] if cand is not None else 0, out.data_ptr(), b,
+                                              ctypes.c_void_p(stream), ms))
+        return out, [float(x) for x in ms]
+
+    # ---- introspection -------------------------------------------------------------------
+    def layers(self, batch: Optional[int] = None) -> List[dict]:
+        if batch is not None:
+            N.check(self.lib.lspf2f_plan_batch(self._h, batch))
+        info = N.LayerInfo()
+        out = []
+        for i in range(self.lib.lspf2f_num_layers(self._h)):
+            N.check(self.lib.lspf2f_layer_info_get(self._h, i, ctypes.byref(info)))
+            d = {f: getattr(info, f) for f, _ in N.LayerInfo._fields_}
+            d["name"] = d["name"].decode()
+            d["kernel"] = d["kernel"].decode()
+            out.append(d)
+        return out
+
+    def workspace_bytes(self, batch: int) -> int:
+        return int(self.lib.lspf2f_workspace_bytes(self._h, batch))
+
+    def intermediate(self, name: str, batch: int) -> torch.Tensor:
+        """NHWC view [B,H,W,C] of a layer output inside the workspace (meaningful after a
+        forward of that batch on an engine built with keep_intermediates=True)."""
+        for l in self.layers(batch):
+            if l["name"] == name and l["out_offset"] >= 0:
+                n = batch * l["h_out"] * l["h_out"] * l["cout"]
+                raw = self._ws[l["out_offset"]: l["out_offset"] + 4 * n]
+                return raw.view(torch.float32).view(batch, l["h_out"], l["h_out"], l["cout"])
+        raise KeyError(name)

@@ -1,0 +1,49 @@
+"""Drop-in for the reference's ``models/feature2face_model.py`` -- inference side.
+
+Same class name (so ``create_model`` finds it by the lowercase-name rule,
+models/__init__.py:29-49), same constructor ``(opt)``, ``model_names``, ``setup``,
+``eval`` and the hot entry point
+
+    inference(feature_map [B,1,H,W], cand_image [B|1,12,H,W] | None) -> [B,3,H,W] in [-1,1]
+
+(models/feature2face_model.py:225-237), executed by liblspf2f on an MI355X.  ``cand_image``
+may have batch 1 while ``feature_map`` has batch B: the candidate stack is constant per
+person (demo.py:89-95), so it is broadcast inside the first kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import networks
+from .base_model import BaseModel
+from .feature2face_G import Feature2Face_G
+
+
+class Feature2FaceModel(BaseModel):
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        if self.isTrain:
+            raise NotImplementedError("Feature2FaceModel training (optimize_parameters, discriminator, "
+                                      "VGG/GAN losses) is out of scope of the HIP renderer")
+        self.model_names = ["Feature2Face_G"]
+        self.Feature2Face_G = networks.init_net(Feature2Face_G(opt), init_type="normal", init_gain=0.02,
+                                                gpu_ids=self.gpu_ids)
+
+    def _g(self) -> Feature2Face_G:
+        net = self.Feature2Face_G
+        return net.module if isinstance(net, networks.SingleDeviceParallel) else net
+
+    def inference(self, feature_map, cand_image):
+        with torch.no_grad():
+            return self._g().render(feature_map, cand_image)
+
+    # the reference's abstract training hooks (base_model.py:70-86); kept so callers that probe
+    # for them get a clear message instead of an AttributeError
+    def set_input(self, data=None, data_info=None):
+        raise NotImplementedError("training path is out of scope")
+
+    def forward(self):
+        raise NotImplementedError("training path is out of scope")
+
+    def optimize_parameters(self):
+        raise NotImplementedError("training path is out of scope")

@@ -1,0 +1,25 @@
+"""``from livespeechportraits_amd.models import create_model`` -- the reference's factory
+(models/__init__.py:29-71) for the one model this package replaces."""
+from __future__ import annotations
+
+import importlib
+
+from ..base_model import BaseModel
+
+
+def find_model_using_name(model_name: str):
+    if model_name != "feature2face":
+        raise NotImplementedError("livespeechportraits_amd replaces only --model feature2face; "
+                                  "%r stays with the reference implementation" % (model_name,))
+    lib = importlib.import_module("livespeechportraits_amd.feature2face_model")
+    target = model_name.replace("_", "") + "model"
+    for name, cls in vars(lib).items():
+        if name.lower() == target and isinstance(cls, type) and issubclass(cls, BaseModel):
+            return cls
+    raise ImportError("no BaseModel subclass named like %s" % target)
+
+
+def create_model(opt):
+    instance = find_model_using_name(opt.model)(opt)
+    print("model [%s] was created" % type(instance).__name__)
+    return instance

@@ -1,0 +1,169 @@
+"""Parameter containers of the feature2face generator + the bridge to the HIP engine.
+
+These nn.Modules exist for ONE reason: to own parameters/buffers under exactly the
+names the reference's checkpoints use (``netG.model.model.<idx>...``), so that
+``load_state_dict`` / ``state_dict`` / ``torch.save`` round-trip unmodified
+``Feature2Face.pkl`` files.  Their ``forward`` never touches torch.nn compute: it
+hands the tensors to liblspf2f (hand-written gfx950 kernels).  There is no CPU path.
+
+Key layout restated from (not copied from) the reference:
+  models/networks.py:592-640 / 496-544   per-level Sequential order
+  models/networks.py:650-675             ResidualBlock.block indices 0,1,3,4
+  models/networks.py:347-402             init_weights: conv N(0, 0.02), BN weight N(1, 0.02), bias 0
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+from .topology import VARIANTS, level_channels
+
+
+class _Slot(nn.Identity):
+    """Parameter-free placeholder that keeps nn.Sequential indices aligned with the
+    reference (stands where it has nn.ReLU / nn.Upsample)."""
+
+
+def _conv(cin: int, cout: int, stride: int) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class ResidualBlock(nn.Module):
+    """Container for conv-BN-ReLU-conv-BN (+x, ReLU) -- keys block.{0,1,3,4}."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.block = nn.Sequential(_conv(channels, channels, 1), nn.BatchNorm2d(channels), _Slot(),
+                                   _conv(channels, channels, 1), nn.BatchNorm2d(channels))
+
+
+class ResUnetSkipConnectionBlock(nn.Module):
+    """One nesting level; ``model`` mirrors the reference's Sequential index by index."""
+
+    def __init__(self, depth: int, num_downs: int, nres: int, ngf: int, input_nc: int, output_nc: int):
+        super().__init__()
+        outer, innermost = depth == 0, depth == num_downs - 1
+        cin, inner, cout = level_channels(depth, ngf, input_nc, output_nc)
+        seq = [_conv(cin, inner, 2)]
+        if not (outer or innermost):
+            seq.append(nn.BatchNorm2d(inner))
+        seq.append(_Slot())                                   # ReLU
+        seq += [ResidualBlock(inner) for _ in range(nres)]
+        if not innermost:
+            seq.append(ResUnetSkipConnectionBlock(depth + 1, num_downs, nres, ngf, input_nc, output_nc))
+        seq.append(_Slot())                                   # Upsample
+        seq.append(_conv(inner if innermost else 2 * inner, cout, 1))
+        if not outer:
+            seq += [nn.BatchNorm2d(cout), _Slot()]
+            seq += [ResidualBlock(cout) for _ in range(nres)]
+        self.model = nn.Sequential(*seq)
+
+
+class Feature2FaceGenerator(nn.Module):
+    """Feature2FaceGenerator_{normal,large}: parameters here, arithmetic in liblspf2f."""
+
+    def __init__(self, variant: str, input_nc: int = 13, output_nc: int = 3, num_downs: int = 8,
+                 ngf: int = 64, feat_nc: int = 1):
+        super().__init__()
+        self.variant, self.input_nc, self.output_nc = variant, input_nc, output_nc
+        self.num_downs, self.ngf, self.feat_nc = num_downs, ngf, feat_nc
+        self.model = ResUnetSkipConnectionBlock(0, num_downs, VARIANTS[variant], ngf, input_nc, output_nc)
+        self._engine: Optional[Engine] = None
+        self._blob: Optional[torch.Tensor] = None      # packed weights on the device
+        self._dirty = True
+        self.register_load_state_dict_post_hook(lambda *_: self.mark_dirty())
+
+    # -- weight ingress ------------------------------------------------------------
+    def mark_dirty(self):
+        self._dirty = True
+
+    def _key_prefix(self) -> str:
+        return "netG.model"
+
+    def _engine_for(self, size: int, batch: int, device: torch.device) -> Engine:
+        e = self._engine
+        if e is None or e.size != size or e.max_batch < batch:
+            mb = batch if e is None else max(batch, e.max_batch)
+            e = Engine(self.variant, self.input_nc, self.feat_nc, self.output_nc, self.ngf,
+                       self.num_downs, size, mb)
+            if self._engine is not None and not self._dirty and self._blob is not None \
+                    and self._blob.device == device:
+                e.bind(self._blob)        # blob layout does not depend on size / batch
+            else:
+                self._dirty = True
+            self._engine = e
+        if self._dirty or e.device != device:
+            sd = {"netG." + k: v for k, v in self.state_dict().items()}
+            e.load_state_dict(sd)
+            e.bind(e.pack(), device)
+            self._blob = e._blob_dev
+            self._dirty = False
+        return e
+
+    def adopt_packed(self, engine: Engine) -> None:
+        """Use an engine whose weights were bound elsewhere (multi-GPU: the blob arrived by
+        RCCL broadcast, this rank never saw a state dict)."""
+        self._engine, self._blob, self._dirty = engine, engine._blob_dev, False
+
+    # -- forward ---------------------------------------------------------------------
+    def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor]) -> torch.Tensor:
+        if feat.device.type != "cuda":
+            raise RuntimeError(
+                "the feature2face HIP renderer needs ROCm tensors (got %s); there is no CPU fallback -- "
+                "the reference's own CPU path is models/networks.py run under PyTorch" % feat.device)
+        e = self._engine_for(feat.shape[-1], feat.shape[0], feat.device)
+        return e.forward(feat.float(), cand.float() if cand is not None else None)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x = cat([feature_map, cand_image], 1) as the reference's G receives it."""
+        feat = x[:, :self.feat_nc].contiguous()
+        cand = x[:, self.feat_nc:].contiguous() if self.input_nc > self.feat_nc else None
+        return self.render(feat, cand)
+
+
+def Feature2FaceGenerator_normal(input_nc=13, output_nc=3, num_downs=8, ngf=64):
+    return Feature2FaceGenerator("normal", input_nc, output_nc, num_downs, ngf)
+
+
+def Feature2FaceGenerator_large(input_nc=13, output_nc=3, num_downs=8, ngf=64):
+    return Feature2FaceGenerator("large", input_nc, output_nc, num_downs, ngf)
+
+
+def init_weights(net: nn.Module, init_type: str = "normal", init_gain: float = 0.02) -> None:
+    """Same distributions as the reference's default ('normal') initialisation."""
+    if init_type != "normal":
+        raise NotImplementedError("only init_type='normal' (the one feature2face_model.py:27 uses)")
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.normal_(0.0, init_gain)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.normal_(1.0, init_gain)
+                m.bias.zero_()
+            if isinstance(m, Feature2FaceGenerator):
+                m.mark_dirty()
+
+
+class SingleDeviceParallel(nn.Module):
+    """Stands where the reference wraps G in nn.DataParallel (networks.py:400): same
+    ``.module`` attribute, same 'module.' key prefix in state dicts, no replicate/scatter --
+    multi-GPU here is one process per GPU (livespeechportraits_amd/distributed.py)."""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+
+def init_net(net: nn.Module, init_type="normal", init_gain=0.02, gpu_ids=()):
+    init_weights(net, init_type, init_gain)
+    if len(gpu_ids) > 0:
+        if not torch.cuda.is_available():
+            raise RuntimeError("gpu_ids=%r but no ROCm device is visible" % (list(gpu_ids),))
+        net = SingleDeviceParallel(net.to("cuda:%d" % gpu_ids[0]))
+    return net

@@ -1,0 +1,121 @@
+"""Per-kernel parity: the fused implicit-GEMM 3x3 conv (lspf2f_conv3x3, the unit the generator
+is made of) against torch.nn.functional on the host CPU, in every mode the network uses it:
+stride 1/2, nearest-x2 upsample prologue, two-source (concat) K loop, folded-BN epilogue,
+residual add, ReLU, split-K, every instantiated tile shape, ragged M / N edges.
+A/B are random and asymmetric, so a transposed C/D mapping cannot pass.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), split_k=0):
+    """x0/x1: NCHW cpu tensors; w OIHW. Returns NCHW cpu tensor computed by the HIP kernel."""
+    from livespeechportraits_amd import _native as N
+    lib = N.load()
+    b, c0, hs, ws = x0.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout = w.shape[0]
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    d0 = nhwc(x0)
+    d1 = nhwc(x1) if x1 is not None else None
+    wp = w.permute(0, 2, 3, 1).contiguous().to(dev)          # [co][ky][kx][ci]
+    dsc = scale.to(dev) if scale is not None else None
+    dsh = shift.to(dev) if shift is not None else None
+    ho = 2 * hs if up else (hs + stride - 1) // stride
+    dres = nhwc(res) if res is not None else None
+    out = torch.full((b, ho, ho, cout), float("nan"), device=dev)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, int(up), tile[0], tile[1], split_k)
+    scratch = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    rc = lib.lspf2f_conv3x3(p(d0), p(d1), p(wp), p(dsc), p(dsh), p(dres), p(out), b, hs, ws, c0, c1, cout,
+                            stride, int(up), int(relu), tile[0], tile[1], split_k, p(scratch), scratch.numel(),
+                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    N.check(rc)
+    torch.cuda.synchronize()
+    return out.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def ref_conv(x0, x1, w, scale, shift, res, stride, up, relu):
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    x = x.double()
+    if up:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    y = F.conv2d(x, w.double(), None, stride, 1)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res.double()
+    if relu:
+        y = F.relu(y)
+    return y.float()
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * 2 - 1
+
+
+CASES = [
+    # b, c0, c1, cout, hs, stride, up, bn, res, relu, tile, split
+    (1, 64, 0, 64, 32, 1, False, True, False, True, (0, 0), 0),        # res-block conv a
+    (1, 64, 0, 64, 32, 1, False, True, True, True, (0, 0), 0),         # res-block conv b (+x)
+    (2, 64, 0, 128, 32, 2, False, True, False, True, (0, 0), 0),       # down conv
+    (1, 128, 0, 128, 16, 2, False, False, False, True, (0, 0), 0),     # innermost down conv (no BN)
+    (1, 64, 64, 32, 16, 1, True, True, False, True, (0, 0), 0),        # up conv: upsample + concat
+    (1, 128, 0, 128, 2, 1, True, True, False, True, (0, 0), 0),        # innermost up conv, tiny spatial
+    (1, 512, 0, 512, 2, 1, False, True, True, True, (0, 0), 0),        # 2x2 spatial weight-streaming
+    (1, 512, 0, 512, 4, 2, False, True, False, True, (0, 0), 0),       # 4 -> 2
+    (3, 32, 0, 32, 8, 1, False, True, False, False, (0, 0), 0),        # ngf=32-style, Cout < tile
+    (1, 64, 0, 96, 24, 1, False, True, False, True, (0, 0), 0),        # ragged N (96) and M (576)
+]
+for tm, tn in [(128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64)]:
+    CASES.append((1, 64, 32, 160, 20, 1, False, True, True, True, (tm, tn), 1))   # ragged everything
+    CASES.append((1, 96, 0, 128, 12, 1, True, True, False, True, (tm, tn), 3))    # forced split-K
+    CASES.append((2, 64, 0, 64, 18, 2, False, False, False, False, (tm, tn), 2))
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_s%d_up%d_bn%d_res%d_relu%d_t%dx%d_k%d" % (
+    c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10][0], c[10][1], c[11]))
+def test_conv3x3_modes(cfg, gpu_device):
+    b, c0, c1, cout, hs, stride, up, bn, res, relu, tile, split = cfg
+    x0 = rnd(b, c0, hs, hs, seed=1)
+    x1 = rnd(b, c1, hs, hs, seed=2) if c1 else None
+    w = rnd(cout, c0 + c1, 3, 3, seed=3) * 0.05
+    scale = rnd(cout, seed=4) * 0.5 + 1.0 if bn else None
+    shift = rnd(cout, seed=5) * 0.1 if bn else None
+    ho = 2 * hs if up else (hs + stride - 1) // stride
+    r = rnd(b, cout, ho, ho, seed=6) if res else None
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, up, relu, tile, split)
+    ref = ref_conv(x0, x1, w, scale, shift, r, stride, up, relu)
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all(), "kernel left unwritten (NaN) outputs"
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5, err
+
+
+def test_conv3x3_impulse_layout(gpu_device):
+    """Known-answer test: a one-hot input and a one-hot weight tap must land on exactly one
+    output pixel/channel -- catches any transposed fragment or K-permutation mismatch."""
+    c, h = 64, 8
+    x = torch.zeros(1, c, h, h)
+    x[0, 37, 5, 2] = 2.0
+    w = torch.zeros(64, c, 3, 3)
+    w[11, 37, 0, 2] = 3.0          # out[11][oy][ox] += 3 * in[37][oy-1][ox+1]
+    got = run_conv(gpu_device, x, None, w, None, None, None, 1, False, False)
+    exp = torch.zeros(1, 64, h, h)
+    exp[0, 11, 6, 1] = 6.0
+    assert torch.equal(got, exp)
+
+
+def test_conv3x3_rejects_bad_arguments(gpu_device):
+    from livespeechportraits_amd import _native as N
+    x = rnd(1, 48, 8, 8)          # 48 % 32 != 0
+    w = rnd(64, 48, 3, 3)
+    with pytest.raises(N.Lspf2fError):
+        run_conv(gpu_device, x, None, w, None, None, None, 1, False, False)
