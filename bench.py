@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- 512x512 frames/sec of the Feature2FaceGenerator forward on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path (lspf2f_forward) over one batch of synthetic frames per GPU,
+inputs already resident in HBM.  Default workload = BASELINE.json configs[1]: May ('large'),
+batch 1, fp32.  Weak scaling: per-GPU work is fixed, value = frames all ranks rendered / time.
+Rank 0 prints ONE JSON line (+ roofline and cpu_baseline objects).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--variant", default="large", choices=["large", "normal"])
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--layers", default=None, help="write the per-layer timing table to this file")
+    a = ap.parse_args()
+
+    from livespeechportraits_amd import distributed as D
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.topology import build_topology
+
+    rank, world, local = D.init_process_group()
+    if world != a.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    dev = torch.device("cuda:%d" % local)
+    torch.cuda.set_device(dev)
+
+    topo = build_topology(a.variant, size=a.size)
+    B = a.batch
+    eng = Engine(a.variant, size=a.size, max_batch=max(B, 8 if not a.no_extra and world == 1 else B))
+    sd = synth.make_state_dict(topo, 1234) if rank == 0 else None
+    D.setup_engine(eng, sd, dev)          # pack on rank 0, ONE RCCL broadcast, bind everywhere
+
+    feat_np, cand_np = synth.make_inputs(B, a.size, seed=99 + 1000 * rank, cand_batch=1)
+    feat = torch.from_numpy(feat_np).to(dev)
+    cand = torch.from_numpy(cand_np).to(dev)
+    out = torch.empty((B, 3, a.size, a.size), device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        eng.forward(feat, cand, out)
+    torch.cuda.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        eng.forward(feat, cand, out)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ev_ms = ev0.elapsed_time(ev1) / a.steps     # device-side, this rank's stream
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / a.steps
+    fps = world * B * a.steps / elapsed
+    flops_step = topo.flops_per_frame() * B
+
+    # per-layer timing (hipEvent pair around every launch, on the launch stream)
+    layers = eng.layers(B)
+    reps = 5
+    acc = np.zeros(len(layers))
+    for _ in range(reps):
+        _, ms = eng.forward_timed(feat, cand, out)
+        acc += np.array(ms)
+    acc /= reps
+    ig = [i for i, l in enumerate(layers) if l["kernel"].startswith("igemm")]
+    ig_ms = float(acc[ig].sum())
+    ig_flops = sum(layers[i]["flops_per_frame"] for i in ig) * B
+    achieved = ig_flops / (ig_ms * 1e-3) / 1e12
+    if a.layers:
+        with open(a.layers, "w") as f:
+            f.write("# per-layer hipEvent timing, %s batch %d, mean of %d passes\n" % (a.variant, B, reps))
+            f.write("%-16s %-28s %5s %5s %4s %4s %9s %3s %9s %8s %8s\n" % (
+                "layer", "kernel", "cin", "cout", "hin", "hout", "tile", "spl", "GFLOP", "us", "TFLOP/s"))
+            for l, m in zip(layers, acc):
+                gf = l["flops_per_frame"] * B / 1e9
+                f.write("%-16s %-28s %5d %5d %4d %4d %4dx%-4d %3d %9.3f %8.1f %8.2f\n" % (
+                    l["name"], l["kernel"], l["cin"], l["cout"], l["h_in"], l["h_out"], l["tile_m"], l["tile_n"],
+                    l["split_k"], gf, m * 1e3, gf / m if m > 0 else 0))
+            f.write("# sum %.3f ms; igemm family %.3f ms = %.2f TFLOP/s\n" % (acc.sum(), ig_ms, achieved))
+
+    roofline = {
+        "bound": "mfma", "kernel": "igemm3x3_f32 (all %d launches of one frame batch)" % len(ig),
+        "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "flops_per_launch_set": ig_flops, "ms_per_launch_set": round(ig_ms, 4),
+        "whole_forward": {"achieved": round(flops_step / (ev_ms * 1e-3) / 1e12, 2),
+                          "frac": round(flops_step / (ev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                          "ms_device": round(ev_ms, 4)},
+    }
+
+    cpu_baseline = None
+    if not a.no_cpu_baseline:
+        from oracle import torch_oracle
+        sd_t = torch_oracle.to_torch(sd)
+        x = torch.cat([torch.from_numpy(feat_np[:1]), torch.from_numpy(cand_np)], 1)
+        n_timed = 4
+        tmin, tmed, threads = torch_oracle.time_cpu(sd_t, x, topo.nres, topo.num_downs, repeats=n_timed)
+        cpu_baseline = {"value": round(1.0 / tmin, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+                        "median_value": round(1.0 / tmed, 3),
+                        "sample": "%s generator, batch 1, %dx%d fp32, 1 warm-up + %d timed frames of "
+                                  "oracle/torch_oracle.py (torch %s CPU/oneDNN, %d threads)"
+                                  % (a.variant, a.size, a.size, n_timed, torch.__version__, threads)}
+
+    extra = None
+    if not a.no_extra and world == 1 and B == 1:
+        # throughput configuration (BASELINE.json configs[3] shape: 8 frames per GPU, shared candidates)
+        f8 = torch.from_numpy(synth.make_inputs(8, a.size, seed=99, cand_batch=1)[0]).to(dev)
+        o8 = torch.empty((8, 3, a.size, a.size), device=dev)
+        for _ in range(3):
+            eng.forward(f8, cand, o8)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n8 = max(5, a.steps // 5)
+        for _ in range(n8):
+            eng.forward(f8, cand, o8)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        extra = {"batch8_frames_per_s": round(8 * n8 / dt, 2),
+                 "batch8_tflops": round(topo.flops_per_frame() * 8 * n8 / dt / 1e12, 2)}
+
+    line = {
+        "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s generator (%s), batch %d per GPU, %dx%d, fp32, synthetic weights+inputs"
+                               % (a.variant, "May" if a.variant == "large" else "Obama1", B, a.size, a.size),
+                   "global_batch": world * B, "parallelism": "dp%d (frames sharded, one RCCL weight broadcast)" % world,
+                   "gflop_per_frame": round(topo.flops_per_frame() / 1e9, 2)},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+    if extra:
+        line["extra"] = extra
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

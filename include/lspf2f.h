@@ -56,6 +56,8 @@ typedef enum lspf2f_dtype {
 #define LSPF2F_FLAG_KEEP_INTERMEDIATES 1u  /* give every layer output its own workspace region
                                               (debug / per-layer parity tests); default is
                                               liveness-based reuse */
+#define LSPF2F_FLAG_NO_GRAPH 2u            /* launch every kernel eagerly instead of replaying a
+                                              cached hipGraph (also: env LSP_HIP_GRAPH=0) */
 
 /* Mirrors the option fields the reference reads on this path
  * (options/base_options_feature2face.py:49-50 ngf / n_downsample_G, :40 loadSize; the

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -15,6 +16,29 @@
 
 using namespace lspf2f;
 
+struct GraphKey {
+    const void *feat, *cand, *out, *ws, *blob;
+    int cand_batch, batch;
+    bool operator==(const GraphKey &o) const
+    {
+        return feat == o.feat && cand == o.cand && out == o.out && ws == o.ws && blob == o.blob &&
+               cand_batch == o.cand_batch && batch == o.batch;
+    }
+};
+
+struct CachedGraph {
+    GraphKey key{};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void reset()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr;
+    }
+};
+static const size_t kMaxCachedGraphs = 8;   // demo.py-style callers cycle through a few buffers
+
 struct lspf2f_handle {
     Plan plan;
     lspf2f_config cfg{};
@@ -23,7 +47,20 @@ struct lspf2f_handle {
     char *ws = nullptr;           // device, caller-owned
     size_t ws_size = 0;
     bool packed = false;
-    std::vector<std::string> kernel_names;
+    bool use_graph = true;
+    hipStream_t cap_stream = nullptr;
+    std::vector<CachedGraph> graphs;
+    size_t next_victim = 0;
+    void drop_graphs()
+    {
+        for (auto &g : graphs) g.reset();
+        graphs.clear();
+    }
+    ~lspf2f_handle()
+    {
+        drop_graphs();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    }
 };
 
 static thread_local std::string g_err;
@@ -61,6 +98,8 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
                                         (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0);
     if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
     h->plan.plan_batch(cfg->max_batch);
+    h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
+    if (const char *env = std::getenv("LSP_HIP_GRAPH")) h->use_graph = h->use_graph && std::strcmp(env, "0") != 0;
     *out = h;
     return LSPF2F_OK;
 }
@@ -118,6 +157,7 @@ int lspf2f_bind_weights(lspf2f_handle *h, const void *dev_blob, size_t bytes)
     if (!h || !dev_blob) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (bytes < h->plan.blob_bytes) return fail(LSPF2F_ERR_SHAPE, "packed weight arena too small");
     if ((uintptr_t)dev_blob % 256) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "weight arena must be 256-byte aligned");
+    h->drop_graphs();
     h->blob = static_cast<const char *>(dev_blob);
     h->blob_size = bytes;
     return LSPF2F_OK;
@@ -133,6 +173,7 @@ int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes)
 {
     if (!h || !dev_workspace) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if ((uintptr_t)dev_workspace % 256) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    h->drop_graphs();
     h->ws = static_cast<char *>(dev_workspace);
     h->ws_size = bytes;
     return LSPF2F_OK;
@@ -240,10 +281,51 @@ int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_de
     int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev, batch);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    for (const auto &l : h->plan.layers) {
-        rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, batch, s);
-        if (rc) return rc;
+
+    // The ~80-150 launches of one forward are replayed from a hipGraph (captured once per
+    // distinct set of pointers on a private stream), which removes the per-launch host cost that
+    // dominates the <= 16x16 levels at batch 1.  If the caller is itself capturing `s`, or graphs
+    // are disabled, launch eagerly into `s` instead.
+    bool eager = !h->use_graph;
+    if (!eager) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s != nullptr && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) eager = true;
     }
+    if (eager) {
+        for (const auto &l : h->plan.layers) {
+            rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, batch, s);
+            if (rc) return rc;
+        }
+        return LSPF2F_OK;
+    }
+
+    GraphKey key{feat_dev, cand_dev, out_dev, h->ws, h->blob, cand_batch, batch};
+    CachedGraph *g = nullptr;
+    for (auto &c : h->graphs)
+        if (c.exec && c.key == key) { g = &c; break; }
+    if (!g) {
+        if (!h->cap_stream) {
+            const hipError_t e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithFlags");
+        }
+        if (h->graphs.size() < kMaxCachedGraphs) h->graphs.emplace_back();
+        g = &h->graphs[h->next_victim++ % h->graphs.size()];
+        g->reset();
+        hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return hipfail(e, "hipStreamBeginCapture");
+        for (const auto &l : h->plan.layers) {
+            rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, batch, h->cap_stream);
+            if (rc) break;
+        }
+        e = hipStreamEndCapture(h->cap_stream, &g->graph);
+        if (rc) { g->reset(); return rc; }
+        if (e != hipSuccess) { g->reset(); return hipfail(e, "hipStreamEndCapture"); }
+        e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { g->reset(); return hipfail(e, "hipGraphInstantiate"); }
+        g->key = key;
+    }
+    const hipError_t e = hipGraphLaunch(g->exec, s);
+    if (e != hipSuccess) return hipfail(e, "hipGraphLaunch");
     return LSPF2F_OK;
 }
 

@@ -113,18 +113,47 @@ def to_torch(sd_np) -> Dict[str, torch.Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
 
 
-def time_cpu(sd, x, nres, num_downs=8, repeats: int = 5, threads: Optional[int] = None):
-    """cpu_baseline helper: seconds per frame (min, median) of this restatement on the
-    host cores, 1 warm-up call first."""
+def time_cpu(sd, x, nres, num_downs=8, repeats: int = 4, threads: Optional[int] = None,
+             budget_s: float = 25.0):
+    """cpu_baseline helper: (min s/frame, median s/frame, threads used) of this restatement on
+    the host cores.  The GPU box advertises more logical CPUs than the
+    pod may use (256 threads ran 20x slower than 32), so unless ``threads`` is given the thread
+    count is calibrated: 1 warm-up + 1 timed frame at 8, 16, 32, 64 ... threads (bounded by the
+    affinity mask), keeping the fastest, then ``repeats`` timed frames within ``budget_s``."""
     import os
     import time
     import statistics
-    threads = threads or os.cpu_count() or 1
-    torch.set_num_threads(threads)
-    generator_forward(sd, x, nres, num_downs)
-    ts: List[float] = []
-    for _ in range(repeats):
+
+    def one():
         t0 = time.perf_counter()
         generator_forward(sd, x, nres, num_downs)
-        ts.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = os.cpu_count() or 1
+    t_start = time.perf_counter()
+    if threads is None:
+        best_t, best_n = None, None
+        n = min(8, avail)
+        while True:
+            torch.set_num_threads(n)
+            one()
+            t = one()
+            if best_t is None or t < best_t:
+                best_t, best_n = t, n
+            elif t > 1.3 * best_t:
+                break
+            if n >= min(avail, 128) or time.perf_counter() - t_start > budget_s / 2:
+                break
+            n = min(2 * n, avail)
+        threads = best_n
+    torch.set_num_threads(threads)
+    one()
+    ts: List[float] = []
+    for _ in range(repeats):
+        ts.append(one())
+        if time.perf_counter() - t_start > budget_s and len(ts) >= 2:
+            break
     return min(ts), statistics.median(ts), threads
