@@ -137,7 +137,7 @@ typedef struct lspf2f_layer_info {
     const char *kernel;      /* which kernel family executes it */
     int32_t cin, cout, h_in, h_out, stride;
     int32_t upsample, concat, residual, relu, tanh_out;
-    int32_t tile_m, tile_n, split_k;
+    int32_t tile_m, tile_n, split_k, k_group;
     int64_t flops_per_frame;          /* 2*Cout*Cin*9*Hout*Wout */
     int64_t act_bytes_per_frame;      /* algorithmic activation bytes */
     int64_t weight_bytes;
@@ -164,14 +164,16 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
  *   cat([src0, src1], channel)); w_packed [cout][3][3][c0+c1]; scale/shift [cout] or NULL;
  *   residual NHWC [batch][ho][wo][cout] or NULL; out NHWC [batch][ho][wo][cout].
  *   stride in {1,2}; upsample: nearest x2 before the conv (stride must be 1).
- *   tile_m/tile_n/split_k = 0 selects the planner's choice; scratch is needed when split_k != 1
+ *   tile_m/tile_n/split_k/k_group = 0 selects the planner's choice (k_group = K-tiles fetched
+ *   per pipeline step: 1, 2 or 4); scratch is needed when split_k != 1
  *   (size from lspf2f_conv3x3_scratch_bytes). */
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride,
-                                    int upsample, int tile_m, int tile_n, int split_k);
+                                    int upsample, int tile_m, int tile_n, int split_k, int k_group);
 int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, const float *scale,
                    const float *shift, const float *residual, float *out, int batch, int hs, int ws,
                    int c0, int c1, int cout, int stride, int upsample, int relu, int tile_m,
-                   int tile_n, int split_k, void *scratch, size_t scratch_bytes, void *hip_stream);
+                   int tile_n, int split_k, int k_group, void *scratch, size_t scratch_bytes,
+                   void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ class LayerInfo(Structure):
                 ("cin", c_int32), ("cout", c_int32), ("h_in", c_int32), ("h_out", c_int32),
                 ("stride", c_int32), ("upsample", c_int32), ("concat", c_int32),
                 ("residual", c_int32), ("relu", c_int32), ("tanh_out", c_int32),
-                ("tile_m", c_int32), ("tile_n", c_int32), ("split_k", c_int32),
+                ("tile_m", c_int32), ("tile_n", c_int32), ("split_k", c_int32), ("k_group", c_int32),
                 ("flops_per_frame", c_int64), ("act_bytes_per_frame", c_int64),
                 ("weight_bytes", c_int64), ("w_offset", c_int64), ("scale_offset", c_int64),
                 ("shift_offset", c_int64), ("out_offset", c_int64)]
@@ -72,8 +72,8 @@ SIGNATURES = {
     "lspf2f_layer_info_get": (c_int, [c_void_p, c_int, POINTER(LayerInfo)]),
     "lspf2f_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                      POINTER(c_float)]),
-    "lspf2f_conv3x3_scratch_bytes": (c_size_t, [c_int] * 11),
-    "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
+    "lspf2f_conv3x3_scratch_bytes": (c_size_t, [c_int] * 12),
+    "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 13 + [c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

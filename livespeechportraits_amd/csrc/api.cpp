@@ -205,7 +205,7 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     o->kernel = kernel_name(l);
     o->cin = l.cin; o->cout = l.cout; o->h_in = l.hs; o->h_out = l.ho; o->stride = l.stride;
     o->upsample = l.up; o->concat = l.concat; o->residual = l.residual; o->relu = l.relu; o->tanh_out = l.tanh_out;
-    o->tile_m = l.bm; o->tile_n = l.bn; o->split_k = l.splits;
+    o->tile_m = l.bm; o->tile_n = l.bn; o->split_k = l.splits; o->k_group = l.group;
     o->flops_per_frame = h->plan.layer_flops(l);
     o->act_bytes_per_frame = h->plan.layer_act_bytes(l);
     o->weight_bytes = (int64_t)l.cout * l.cin * 9 * 4;
@@ -247,7 +247,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.ktiles_total = 9 * l.cin / 32;
         p.splits = l.splits;
         p.ktiles_per_split = (p.ktiles_total + l.splits - 1) / l.splits;
-        e = launch_igemm(p, l.bm, l.bn, s);
+        e = launch_igemm(p, l.bm, l.bn, l.group, s);
         if (e == hipSuccess && l.splits > 1) e = launch_splitk_reduce(p, s);
     }
     if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
@@ -354,25 +354,26 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
 }
 
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride, int upsample,
-                                    int tile_m, int tile_n, int split_k)
+                                    int tile_m, int tile_n, int split_k, int k_group)
 {
     (void)ws;
     const int ho = upsample ? 2 * hs : (stride == 2 ? hs / 2 : hs);
     const int M = batch * ho * ho;
     int bm = tile_m, bn = tile_n, sp = split_k;
     if (!bm || !bn || !sp) {
-        int a, b, c;
-        choose_tiling(M, cout, 9 * (c0 + c1) / 32, &a, &b, &c);
+        int a, b, c, g;
+        choose_tiling(M, cout, 9 * (c0 + c1) / 32, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; }
         if (!sp) sp = c;
     }
+    (void)k_group;
     return sp > 1 ? (size_t)sp * M * cout * sizeof(float) : 0;
 }
 
 int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, const float *scale,
                    const float *shift, const float *residual, float *out, int batch, int hs, int ws, int c0,
                    int c1, int cout, int stride, int upsample, int relu, int tile_m, int tile_n, int split_k,
-                   void *scratch, size_t scratch_bytes, void *hip_stream)
+                   int k_group, void *scratch, size_t scratch_bytes, void *hip_stream)
 {
     if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
@@ -393,14 +394,15 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
     p.C0 = c0; p.C1 = c1; p.Cin = c0 + c1; p.Cout = cout; p.stride = stride; p.up = upsample; p.relu = relu;
     p.M = batch * p.Ho * p.Wo;
     p.ktiles_total = 9 * p.Cin / 32;
-    int bm = tile_m, bn = tile_n, sp = split_k;
+    int bm = tile_m, bn = tile_n, sp = split_k, grp = k_group;
     {
-        int a, b, c;
-        choose_tiling(p.M, cout, p.ktiles_total, &a, &b, &c);
-        if (!bm || !bn) { bm = a; bn = b; }
+        int a, b, c, g;
+        choose_tiling(p.M, cout, p.ktiles_total, &a, &b, &c, &g);
+        if (!bm || !bn) { bm = a; bn = b; if (!grp) grp = g; }
         if (!sp) sp = c;
+        if (!grp) grp = 1;
     }
-    if (!igemm_tile_supported(bm, bn)) return fail(LSPF2F_ERR_UNSUPPORTED, "tile shape not instantiated");
+    if (!igemm_group_supported(bm, bn, grp)) return fail(LSPF2F_ERR_UNSUPPORTED, "tile shape / k_group not instantiated");
     if (sp < 1 || sp > p.ktiles_total) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "bad split_k");
     p.ktiles_per_split = (p.ktiles_total + sp - 1) / sp;
     sp = (p.ktiles_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
@@ -411,7 +413,7 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
         p.partial = static_cast<float *>(scratch);
     }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    e = launch_igemm(p, bm, bn, s);
+    e = launch_igemm(p, bm, bn, grp, s);
     if (e == hipSuccess && sp > 1) e = launch_splitk_reduce(p, s);
     if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 launch");
     return LSPF2F_OK;

@@ -32,7 +32,9 @@ static const int kNumTileConfigs = sizeof(kTileConfigs) / sizeof(kTileConfigs[0]
 
 bool igemm_tile_supported(int bm, int bn);
 hipError_t igemm_init();  // raises the dynamic-LDS limit of the big-tile instantiations
-hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, hipStream_t s);
+// g = K-tiles per pipeline step: 1 (all shapes), 2 (128x64, 64x64), 4 (64x64, 32x64)
+bool igemm_group_supported(int bm, int bn, int g);
+hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t s);
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s);
 
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.

@@ -21,18 +21,24 @@ static constexpr int BK = 32;    // K-tile (floats); Cin % 32 == 0 so a K-tile n
 static constexpr int LDK = 36;   // LDS row pitch in floats: 144 B makes the 16 rows of a
                                  // ds_read_b128 lane group hit 16 distinct 16-B bank slots
 
-template <int BM, int BN, int WGM, int WGN>
+// G = K-tiles staged per pipeline step (one barrier per G tiles, G tiles of global loads in
+// flight per thread).  G = 1 for long K loops; G = 4 turns a short split-K range (<= 4 tiles)
+// into a single load -> LDS -> MFMA pass, which is what the latency-bound <= 8x8 levels need.
+template <int BM, int BN, int WGM, int WGN, int G>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams p)
 {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int RPP = NT / 8;            // tile rows staged per pass (8 threads x float4 = one 32-float row)
     constexpr int PA = BM / RPP, PB = BN / RPP;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    constexpr int TILE_A = BM * LDK, TILE_B = BN * LDK;
     static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "bad tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                      // [2][BM][LDK]
-    float *Bs = smem + 2 * BM * LDK;       // [2][BN][LDK]
+    // double-buffered unless the whole K range fits one step
+    const int nbuf = p.ktiles_per_split > G ? 2 : 1;
+    float *As = smem;                          // [nbuf][G][BM][LDK]
+    float *Bs = smem + nbuf * G * TILE_A;      // [nbuf][G][BN][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,40 +84,55 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
         wrow[i] = (n < p.Cout) ? p.w + (size_t)n * K + lq : nullptr;
     }
 
-    // K-tile cursor: tap = ky*3+kx, c = channel offset inside the concatenated input
+    // K-tile cursor of the NEXT tile to fetch: tap = ky*3+kx, c = channel offset inside the
+    // concatenated input
     int tap = (kt_begin * BK) / p.Cin;
     int c = kt_begin * BK - tap * p.Cin;
 
-    float4 ra[PA], rb[PB];
+    float4 ra[G][PA], rb[G][PB];
+    // fetch K-tiles kt .. kt+G-1 into registers (tiles at or past kt_end are zero)
     auto fetch = [&](int kt) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const float *src; int cs, cc;
-        if (c < p.C0) { src = p.src0; cs = p.C0; cc = c; }
-        else          { src = p.src1; cs = p.C1; cc = c - p.C0; }
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int uy = a_oy[i] + ky, ux = a_ox[i] + kx;
-            const bool ok = (a_pix[i] >= 0) & (uy >= 0) & (uy < hlim) & (ux >= 0) & (ux < wlim);
-            const int iy = p.up ? (uy >> 1) : uy, ix = p.up ? (ux >> 1) : ux;
-            ra[i] = ok ? *reinterpret_cast<const float4 *>(
-                             src + (size_t)(a_pix[i] + iy * p.Ws + ix) * cs + cc + lq)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < G; ++g) {
+            if (kt + g < kt_end) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const float *src; int cs, cc;
+                if (c < p.C0) { src = p.src0; cs = p.C0; cc = c; }
+                else          { src = p.src1; cs = p.C1; cc = c - p.C0; }
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    const int uy = a_oy[i] + ky, ux = a_ox[i] + kx;
+                    const bool ok = (a_pix[i] >= 0) & (uy >= 0) & (uy < hlim) & (ux >= 0) & (ux < wlim);
+                    const int iy = p.up ? (uy >> 1) : uy, ix = p.up ? (ux >> 1) : ux;
+                    ra[g][i] = ok ? *reinterpret_cast<const float4 *>(
+                                        src + (size_t)(a_pix[i] + iy * p.Ws + ix) * cs + cc + lq)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    rb[g][i] = wrow[i] ? *reinterpret_cast<const float4 *>(wrow[i] + (size_t)(kt + g) * BK)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                c += BK;
+                if (c == p.Cin) { c = 0; ++tap; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PA; ++i) ra[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PB; ++i) rb[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < PB; ++i)
-            rb[i] = wrow[i] ? *reinterpret_cast<const float4 *>(wrow[i] + (size_t)kt * BK)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        c += BK;
-        if (c == p.Cin) { c = 0; ++tap; }
     };
     auto stage = [&](int buf) {
-        float *A = As + buf * BM * LDK, *Bq = Bs + buf * BN * LDK;
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<float4 *>(A + (i * RPP + lrow) * LDK + lq) = ra[i];
+        for (int g = 0; g < G; ++g) {
+            float *A = As + (buf * G + g) * TILE_A, *Bq = Bs + (buf * G + g) * TILE_B;
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
-            *reinterpret_cast<float4 *>(Bq + (i * RPP + lrow) * LDK + lq) = rb[i];
+            for (int i = 0; i < PA; ++i)
+                *reinterpret_cast<float4 *>(A + (i * RPP + lrow) * LDK + lq) = ra[g][i];
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                *reinterpret_cast<float4 *>(Bq + (i * RPP + lrow) * LDK + lq) = rb[g][i];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -127,36 +148,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     // A and B use the same one.
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     auto compute = [&](int buf) {
-        const float *A = As + buf * BM * LDK + (wm * TM * 32 + frow) * LDK + fk;
-        const float *Bq = Bs + buf * BN * LDK + (wn * TN * 32 + frow) * LDK + fk;
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
-            float4 a[TM], b[TN];
+        for (int g = 0; g < G; ++g) {
+            const float *A = As + (buf * G + g) * TILE_A + (wm * TM * 32 + frow) * LDK + fk;
+            const float *Bq = Bs + (buf * G + g) * TILE_B + (wn * TN * 32 + frow) * LDK + fk;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(A + i * 32 * LDK + kb * 8);
+            for (int kb = 0; kb < BK / 8; ++kb) {
+                float4 a[TM], b[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(Bq + j * 32 * LDK + kb * 8);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(A + i * 32 * LDK + kb * 8);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(Bq + j * 32 * LDK + kb * 8);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
         }
     };
 
-    // ---- main loop: register prefetch of tile kt+1 while tile kt is multiplied out of LDS ----
+    // ---- main loop: register prefetch of step s+1 while step s is multiplied out of LDS ----
     if (kt_begin < kt_end) {
         fetch(kt_begin);
         stage(0);
         __syncthreads();
         int cur = 0;
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const bool more = kt + 1 < kt_end;
-            if (more) fetch(kt + 1);
+        for (int kt = kt_begin; kt < kt_end; kt += G) {
+            const bool more = kt + G < kt_end;
+            if (more) fetch(kt + G);
             compute(cur);
             if (more) stage(cur ^ 1);
             __syncthreads();
@@ -192,41 +216,69 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     }
 }
 
-// out[m][n] = epilogue(sum_z partial[z][m][n]), z ascending (deterministic)
+// out = epilogue(sum_z partial[z]).  Block = 64 float4 columns x 4 z-lanes: z-lane y adds
+// partials y, y+4, y+8, ... (ascending), then the four lane sums are added in lane order --
+// a fixed summation tree, so results are bit-reproducible run to run.
 __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
 {
-    const size_t total4 = (size_t)p.M * p.Cout / 4;
-    const size_t stride4 = total4;   // per split
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (size_t)gridDim.x * blockDim.x) {
+    __shared__ float4 red[3][64];
+    const unsigned total4 = (unsigned)(((size_t)p.M * p.Cout) >> 2);
+    const unsigned x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const unsigned i = blockIdx.x * 64u + x;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4) {
         const float4 *pp = reinterpret_cast<const float4 *>(p.partial) + i;
-        float4 s = pp[0];
-        for (int z = 1; z < p.splits; ++z) {
-            const float4 t = pp[(size_t)z * stride4];
+        int zz = (int)y;
+        for (; zz + 12 < p.splits; zz += 16) {
+            const float4 t0 = pp[(size_t)zz * total4], t1 = pp[(size_t)(zz + 4) * total4];
+            const float4 t2 = pp[(size_t)(zz + 8) * total4], t3 = pp[(size_t)(zz + 12) * total4];
+            s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+            s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+            s.x += t2.x; s.y += t2.y; s.z += t2.z; s.w += t2.w;
+            s.x += t3.x; s.y += t3.y; s.z += t3.z; s.w += t3.w;
+        }
+        for (; zz < p.splits; zz += 4) {
+            const float4 t = pp[(size_t)zz * total4];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
-        const int n = (int)((i * 4) % p.Cout);
-        if (p.scale) {
-            const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
-            const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
-            s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y;
-            s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
-        }
-        if (p.residual) {
-            const float4 r = reinterpret_cast<const float4 *>(p.residual)[i];
-            s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
-        }
-        if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-        reinterpret_cast<float4 *>(p.out)[i] = s;
     }
+    if (y) red[y - 1][x] = s;
+    __syncthreads();
+    if (y || i >= total4) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 t = red[k][x];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const unsigned n = (i * 4u) % (unsigned)p.Cout;
+    if (p.scale) {
+        const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
+        const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y;
+        s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
+    }
+    if (p.residual) {
+        const float4 r = reinterpret_cast<const float4 *>(p.residual)[i];
+        s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+    }
+    if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    reinterpret_cast<float4 *>(p.out)[i] = s;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int G>
 static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
 {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
-    const size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN>), dim3(ntm * ntn, p.splits), dim3(64 * WGM * WGN),
+    constexpr size_t smem_max = (size_t)2 * G * (BM + BN) * LDK * sizeof(float);
+    const size_t smem = p.ktiles_per_split > G ? smem_max : smem_max / 2;
+    static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
+    if (smem_max > 64 * 1024 && !attr_done) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<BM, BN, WGM, WGN, G>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN, G>), dim3(ntm * ntn, p.splits), dim3(64 * WGM * WGN),
                        smem, s, p);
     return hipGetLastError();
 }
@@ -238,32 +290,41 @@ bool igemm_tile_supported(int bm, int bn)
     return false;
 }
 
-hipError_t igemm_init()
+bool igemm_group_supported(int bm, int bn, int g)
 {
-    // 128x128 needs 73,728 B of dynamic LDS (> the 64 KiB default cap)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<128, 128, 2, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * (128 + 128) * LDK * (int)sizeof(float));
-    return e;
+    if (g == 1) return igemm_tile_supported(bm, bn);
+    if (g == 2) return (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
+    if (g == 4) return (bm == 64 && bn == 64) || (bm == 32 && bn == 64);
+    return false;
 }
 
-hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, hipStream_t s)
+hipError_t igemm_init() { return hipSuccess; }
+
+hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
 {
-    if (bm == 128 && bn == 128) return launch_igemm_t<128, 128, 2, 2>(p, s);
-    if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2>(p, s);
-    if (bm == 64 && bn == 128) return launch_igemm_t<64, 128, 2, 2>(p, s);
-    if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2>(p, s);
-    if (bm == 32 && bn == 128) return launch_igemm_t<32, 128, 1, 4>(p, s);
-    if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2>(p, s);
+    if (g == 4) {
+        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 4>(p, s);
+        if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 4>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (g == 2) {
+        if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 2>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 2>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (bm == 128 && bn == 128) return launch_igemm_t<128, 128, 2, 2, 1>(p, s);
+    if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 1>(p, s);
+    if (bm == 64 && bn == 128) return launch_igemm_t<64, 128, 2, 2, 1>(p, s);
+    if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 1>(p, s);
+    if (bm == 32 && bn == 128) return launch_igemm_t<32, 128, 1, 4, 1>(p, s);
+    if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 1>(p, s);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
 {
     const size_t total4 = (size_t)p.M * p.Cout / 4;
-    int blocks = (int)((total4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

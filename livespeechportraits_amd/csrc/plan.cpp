@@ -10,7 +10,7 @@ static const double kBnEps = 1e-5;   // nn.BatchNorm2d default (networks.py neve
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-void choose_tiling(int M, int N, int ktiles, int *bm_out, int *bn_out, int *splits_out)
+void choose_tiling(int M, int N, int ktiles, int *bm_out, int *bn_out, int *splits_out, int *group_out)
 {
     // Candidates, largest first.  MFMA-bound fp32: big tiles cut L2->LDS traffic, but the chip has
     // 256 CUs and wants >= ~2 workgroups per CU, so shrink the tile (then split K) until the
@@ -43,9 +43,16 @@ void choose_tiling(int M, int N, int ktiles, int *bm_out, int *bn_out, int *spli
         const int per = (ktiles + splits - 1) / splits;
         splits = (ktiles + per - 1) / per;
     }
+    int group = 1;
+    if (M <= 64) {
+        // latency-bound weight streaming: 4 K-tiles per workgroup, fetched in one step
+        splits = std::max(1, (ktiles + 3) / 4);
+        group = 4;
+    }
     *bm_out = cand[best][0];
     *bn_out = cand[best][1];
     *splits_out = splits;
+    *group_out = group;
 }
 
 static void level_channels(int depth, int ngf, int input_nc, int output_nc, int *cin, int *inner, int *cout)
@@ -274,10 +281,10 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                     a.release(off[t], bytes_of(p.tensors[t]));
                 }
         if (l.kind == kIgemm) {
-            int bm, bn, splits;
+            int bm, bn, splits, group;
             const int M = batch * l.ho * l.ho;
-            choose_tiling(M, l.cout, 9 * l.cin / 32, &bm, &bn, &splits);
-            if (tiled) { (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; }
+            choose_tiling(M, l.cout, 9 * l.cin / 32, &bm, &bn, &splits, &group);
+            if (tiled) { (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group; }
             if (splits > 1) partial = std::max(partial, (size_t)splits * M * l.cout * sizeof(float));
         }
     }

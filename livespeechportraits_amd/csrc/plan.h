@@ -36,7 +36,7 @@ struct LayerDesc {
     std::string bnkey;     // state-dict prefix of the following BatchNorm2d ("" = none)
     int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
     // per-batch tiling decision
-    int bm = 0, bn = 0, splits = 1;
+    int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
 };
 
 struct ParamDesc {         // an expected state-dict entry
@@ -72,6 +72,6 @@ struct Plan {
 };
 
 // tile / split-K heuristic shared by the planner and lspf2f_conv3x3
-void choose_tiling(int M, int N, int ktiles, int *bm, int *bn, int *splits);
+void choose_tiling(int M, int N, int ktiles, int *bm, int *bn, int *splits, int *group);
 
 }  // namespace lspf2f

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), split_k=0):
+def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), split_k=0, k_group=0):
     """x0/x1: NCHW cpu tensors; w OIHW. Returns NCHW cpu tensor computed by the HIP kernel."""
     from livespeechportraits_amd import _native as N
     lib = N.load()
@@ -30,11 +30,11 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     ho = 2 * hs if up else (hs + stride - 1) // stride
     dres = nhwc(res) if res is not None else None
     out = torch.full((b, ho, ho, cout), float("nan"), device=dev)
-    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, int(up), tile[0], tile[1], split_k)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, int(up), tile[0], tile[1], split_k, k_group)
     scratch = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     rc = lib.lspf2f_conv3x3(p(d0), p(d1), p(wp), p(dsc), p(dsh), p(dres), p(out), b, hs, ws, c0, c1, cout,
-                            stride, int(up), int(relu), tile[0], tile[1], split_k, p(scratch), scratch.numel(),
+                            stride, int(up), int(relu), tile[0], tile[1], split_k, k_group, p(scratch), scratch.numel(),
                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     N.check(rc)
     torch.cuda.synchronize()
@@ -78,6 +78,32 @@ for tm, tn in [(128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64)]:
     CASES.append((1, 64, 32, 160, 20, 1, False, True, True, True, (tm, tn), 1))   # ragged everything
     CASES.append((1, 96, 0, 128, 12, 1, True, True, False, True, (tm, tn), 3))    # forced split-K
     CASES.append((2, 64, 0, 64, 18, 2, False, False, False, False, (tm, tn), 2))
+
+
+# K-tiles-per-step variants (k_group 2 / 4), including ranges that are not a multiple of the
+# group (tail tiles are zero-filled) and the single-step (one LDS buffer) path
+GROUP_CASES = []
+for (tm, tn), g in [((128, 64), 2), ((64, 64), 2), ((64, 64), 4), ((32, 64), 4)]:
+    GROUP_CASES.append((1, 64, 32, 96, 10, 1, False, True, True, True, (tm, tn), 1, g))   # 27 tiles, 1 split
+    GROUP_CASES.append((1, 64, 0, 64, 6, 1, True, True, False, True, (tm, tn), 5, g))     # 18 tiles / 5 splits = 4,4,4,4,2
+    GROUP_CASES.append((1, 128, 0, 64, 4, 2, False, False, False, False, (tm, tn), 9, g))  # 36 tiles / 9 = 4 each: single step
+
+
+@pytest.mark.parametrize("cfg", GROUP_CASES, ids=lambda c: "c%d+%d_o%d_h%d_t%dx%d_k%d_g%d" % (
+    c[1], c[2], c[3], c[4], c[10][0], c[10][1], c[11], c[12]))
+def test_conv3x3_k_groups(cfg, gpu_device):
+    b, c0, c1, cout, hs, stride, up, bn, res, relu, tile, split, g = cfg
+    x0 = rnd(b, c0, hs, hs, seed=11)
+    x1 = rnd(b, c1, hs, hs, seed=12) if c1 else None
+    w = rnd(cout, c0 + c1, 3, 3, seed=13) * 0.05
+    scale = rnd(cout, seed=14) * 0.5 + 1.0 if bn else None
+    shift = rnd(cout, seed=15) * 0.1 if bn else None
+    ho = 2 * hs if up else (hs + stride - 1) // stride
+    r = rnd(b, cout, ho, ho, seed=16) if res else None
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, up, relu, tile, split, g)
+    ref = ref_conv(x0, x1, w, scale, shift, r, stride, up, relu)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2e-5
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_s%d_up%d_bn%d_res%d_relu%d_t%dx%d_k%d" % (

@@ -64,32 +64,38 @@ def main():
             if tn > max(64, cout) or (tm > 64 and M <= 64):
                 continue
             tiles = -(-M // tm) * -(-cout // tn)
-            for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 36, 48, 72):
-                if sp > kt // 2 or tiles * sp > 8192 or (tiles * sp < 96 and sp < kt // 2):
+            for sp in (1, 2, 3, 4, 6, 8, 12, 16, 18, 24, 36, 48, 72):
+                if sp > kt // 4 or tiles * sp > 8192 or (tiles * sp < 96 and sp < kt // 2):
                     continue
-                sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, stride, up, tm, tn, sp)
+                sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, stride, up, tm, tn, sp, 1)
                 scratch = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
+                for g in (1, 2, 4):
+                    if g == 2 and (tm, tn) not in ((128, 64), (64, 64)):
+                        continue
+                    if g == 4 and (tm, tn) not in ((64, 64), (32, 64)):
+                        continue
 
-                def run():
-                    N.check(lib.lspf2f_conv3x3(P(x0), P(x1), P(w), P(sc), P(sh), None, P(out), b, hs, hs, c0, c1,
-                                               cout, stride, up, 1, tm, tn, sp, P(scratch), scratch.numel(), stream))
-                for _ in range(3):
-                    run()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                reps = 20
-                e0.record()
-                for _ in range(reps):
-                    run()
-                e1.record()
-                torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / reps
-                res.append((us, tm, tn, sp, tiles * sp))
+                    def run():
+                        N.check(lib.lspf2f_conv3x3(P(x0), P(x1), P(w), P(sc), P(sh), None, P(out), b, hs, hs, c0, c1,
+                                                   cout, stride, up, 1, tm, tn, sp, g, P(scratch), scratch.numel(),
+                                                   stream))
+                    for _ in range(3):
+                        run()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    reps = 20
+                    e0.record()
+                    for _ in range(reps):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1e3 / reps
+                    res.append((us, tm, tn, sp, tiles * sp, g))
         res.sort()
         best = res[0]
-        lines.append("%-16s M=%-7d N=%-4d K=%-5d best %7.1f us %6.1f TF  tile %dx%d split %d (%d WGs)" % (
-            name, M, cout, 9 * (c0 + c1), best[0], flops / best[0] / 1e6, best[1], best[2], best[3], best[4]))
-        for us, tm, tn, sp, wgs in res[:8]:
-            lines.append("      %7.1f us %6.1f TF  %3dx%-3d split %-2d WGs %d" % (us, flops / us / 1e6, tm, tn, sp, wgs))
+        lines.append("%-16s M=%-7d N=%-4d K=%-5d best %7.1f us %6.1f TF  tile %dx%d split %d g%d (%d WGs)" % (
+            name, M, cout, 9 * (c0 + c1), best[0], flops / best[0] / 1e6, best[1], best[2], best[3], best[5], best[4]))
+        for us, tm, tn, sp, wgs, g in res[:10]:
+            lines.append("      %7.1f us %6.1f TF  %3dx%-3d split %-2d g%d WGs %d" % (us, flops / us / 1e6, tm, tn, sp, g, wgs))
     txt = "\n".join(lines)
     print(txt)
     if a.out:
