@@ -138,7 +138,8 @@ typedef struct lspf2f_layer_info {
     int32_t cin, cout, h_in, h_out, stride;
     int32_t upsample, concat, residual, relu, tanh_out;
     int32_t tile_m, tile_n, split_k, k_group;
-    int64_t flops_per_frame;          /* 2*Cout*Cin*9*Hout*Wout */
+    int64_t flops_per_frame;          /* algorithmic: 2*Cout*Cin*9*Hout*Wout */
+    int64_t exec_flops_per_frame;     /* what the kernel issues (4/9 of it for sub-pixel up-convs) */
     int64_t act_bytes_per_frame;      /* algorithmic activation bytes */
     int64_t weight_bytes;
     int64_t w_offset;                 /* byte offsets into the packed blob (-1: none) */
@@ -163,7 +164,9 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
  *   src0/src1 NHWC [batch][hs][ws][c0|c1] (src1 may be NULL, c1 = 0; both are read as
  *   cat([src0, src1], channel)); w_packed [cout][3][3][c0+c1]; scale/shift [cout] or NULL;
  *   residual NHWC [batch][ho][wo][cout] or NULL; out NHWC [batch][ho][wo][cout].
- *   stride in {1,2}; upsample: nearest x2 before the conv (stride must be 1).
+ *   stride in {1,2}; upsample: 0 none; 1 nearest x2 before the conv (9-tap gather form, stride 1);
+ *   2 the same op in sub-pixel form: w_packed is [4 parities][cout][2][2][c0+c1] with the
+ *   aliasing 3x3 taps pre-summed (see plan.cpp pack()).
  *   tile_m/tile_n/split_k/k_group = 0 selects the planner's choice (k_group = K-tiles fetched
  *   per pipeline step: 1, 2 or 4); scratch is needed when split_k != 1
  *   (size from lspf2f_conv3x3_scratch_bytes). */

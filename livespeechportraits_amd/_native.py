@@ -47,7 +47,7 @@ class LayerInfo(Structure):
                 ("stride", c_int32), ("upsample", c_int32), ("concat", c_int32),
                 ("residual", c_int32), ("relu", c_int32), ("tanh_out", c_int32),
                 ("tile_m", c_int32), ("tile_n", c_int32), ("split_k", c_int32), ("k_group", c_int32),
-                ("flops_per_frame", c_int64), ("act_bytes_per_frame", c_int64),
+                ("flops_per_frame", c_int64), ("exec_flops_per_frame", c_int64), ("act_bytes_per_frame", c_int64),
                 ("weight_bytes", c_int64), ("w_offset", c_int64), ("scale_offset", c_int64),
                 ("shift_offset", c_int64), ("out_offset", c_int64)]
 

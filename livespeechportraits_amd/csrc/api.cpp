@@ -204,11 +204,12 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     o->name = l.name.c_str();
     o->kernel = kernel_name(l);
     o->cin = l.cin; o->cout = l.cout; o->h_in = l.hs; o->h_out = l.ho; o->stride = l.stride;
-    o->upsample = l.up; o->concat = l.concat; o->residual = l.residual; o->relu = l.relu; o->tanh_out = l.tanh_out;
+    o->upsample = l.up || l.up4; o->concat = l.concat; o->residual = l.residual; o->relu = l.relu; o->tanh_out = l.tanh_out;
     o->tile_m = l.bm; o->tile_n = l.bn; o->split_k = l.splits; o->k_group = l.group;
     o->flops_per_frame = h->plan.layer_flops(l);
     o->act_bytes_per_frame = h->plan.layer_act_bytes(l);
-    o->weight_bytes = (int64_t)l.cout * l.cin * 9 * 4;
+    o->weight_bytes = (int64_t)l.cout * l.cin * (l.up4 ? 16 : 9) * 4;
+    o->exec_flops_per_frame = l.up4 ? o->flops_per_frame * 4 / 9 : o->flops_per_frame;
     o->w_offset = l.w_off; o->scale_offset = l.scale_off; o->shift_offset = l.shift_off;
     o->out_offset = l.out >= 0 ? (int64_t)h->plan.tensors[l.out].offset : -1;
     return LSPF2F_OK;
@@ -243,8 +244,10 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho;
         p.C0 = l.c0; p.C1 = l.c1; p.Cin = l.cin; p.Cout = l.cout;
         p.stride = l.stride; p.up = l.up; p.relu = l.relu;
-        p.M = batch * l.ho * l.ho;
-        p.ktiles_total = 9 * l.cin / 32;
+        p.up4 = l.up4;
+        p.Mout = batch * l.ho * l.ho;
+        p.M = l.up4 ? batch * l.hs * l.hs : p.Mout;
+        p.ktiles_total = (l.up4 ? 4 : 9) * l.cin / 32;
         p.splits = l.splits;
         p.ktiles_per_split = (p.ktiles_total + l.splits - 1) / l.splits;
         e = launch_igemm(p, l.bm, l.bn, l.group, s);
@@ -357,17 +360,19 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
                                     int tile_m, int tile_n, int split_k, int k_group)
 {
     (void)ws;
-    const int ho = upsample ? 2 * hs : (stride == 2 ? hs / 2 : hs);
-    const int M = batch * ho * ho;
+    const int ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
+    const int Mout = batch * ho * ho;
+    const bool up4 = upsample == 2;
+    const int M = up4 ? batch * hs * hs : Mout;
     int bm = tile_m, bn = tile_n, sp = split_k;
     if (!bm || !bn || !sp) {
         int a, b, c, g;
-        choose_tiling(M, cout, 9 * (c0 + c1) / 32, &a, &b, &c, &g);
+        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / 32, up4 ? 4 : 1, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; }
         if (!sp) sp = c;
     }
     (void)k_group;
-    return sp > 1 ? (size_t)sp * M * cout * sizeof(float) : 0;
+    return sp > 1 ? (size_t)sp * Mout * cout * sizeof(float) : 0;
 }
 
 int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, const float *scale,
@@ -391,13 +396,16 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
     p.B = batch; p.Hs = hs; p.Ws = ws;
     p.Ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
     p.Wo = p.Ho;
-    p.C0 = c0; p.C1 = c1; p.Cin = c0 + c1; p.Cout = cout; p.stride = stride; p.up = upsample; p.relu = relu;
-    p.M = batch * p.Ho * p.Wo;
-    p.ktiles_total = 9 * p.Cin / 32;
+    if (upsample < 0 || upsample > 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "upsample must be 0, 1 or 2");
+    p.C0 = c0; p.C1 = c1; p.Cin = c0 + c1; p.Cout = cout; p.stride = stride; p.relu = relu;
+    p.up = upsample == 1; p.up4 = upsample == 2;
+    p.Mout = batch * p.Ho * p.Wo;
+    p.M = p.up4 ? batch * hs * ws : p.Mout;
+    p.ktiles_total = (p.up4 ? 4 : 9) * p.Cin / 32;
     int bm = tile_m, bn = tile_n, sp = split_k, grp = k_group;
     {
         int a, b, c, g;
-        choose_tiling(p.M, cout, p.ktiles_total, &a, &b, &c, &g);
+        choose_tiling(p.M, cout, p.ktiles_total, p.up4 ? 4 : 1, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; if (!grp) grp = g; }
         if (!sp) sp = c;
         if (!grp) grp = 1;
@@ -408,7 +416,7 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
     sp = (p.ktiles_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
     p.splits = sp;
     if (sp > 1) {
-        if (!scratch || scratch_bytes < (size_t)sp * p.M * cout * sizeof(float))
+        if (!scratch || scratch_bytes < (size_t)sp * p.Mout * cout * sizeof(float))
             return fail(LSPF2F_ERR_STATE, "split-K scratch missing or too small");
         p.partial = static_cast<float *>(scratch);
     }

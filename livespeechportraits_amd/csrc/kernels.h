@@ -17,10 +17,12 @@ struct IgemmParams {
     int B, Hs, Ws, Ho, Wo;
     int C0, C1, Cin, Cout;
     int stride;                 // 1 | 2
-    int up;                     // nearest x2 upsample in front of the conv (Ho = 2*Hs)
+    int up;                     // nearest x2 upsample in front of the conv (Ho = 2*Hs), 9-tap gather form
+    int up4;                    // same op in sub-pixel form: 4 parities x 2x2 taps, w = [4][Cout][4*Cin]
     int relu;
-    int M;
-    int ktiles_total;           // 9*Cin/32
+    int M;                      // GEMM rows per launch slice (up4: B*Hs*Ws per parity, else B*Ho*Wo)
+    int Mout;                   // output pixels B*Ho*Wo
+    int ktiles_total;           // taps*Cin/32 (taps = 9, or 4 for up4)
     int ktiles_per_split;
     int splits;
 };

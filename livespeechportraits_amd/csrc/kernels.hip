@@ -45,8 +45,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
+    // up4 (sub-pixel form of Upsample x2 + Conv3x3): blockIdx.x also enumerates the 4 output
+    // parities (py, px); each is a 2x2-tap conv over the LOW-res source with pre-summed weights,
+    // M counts low-res positions, and row m lands on output pixel (2y+py, 2x+px).
     const int ntn = (p.Cout + BN - 1) / BN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    int bx = blockIdx.x, par = 0;
+    if (p.up4) { par = bx & 3; bx >>= 2; }
+    const int py = par >> 1, px = par & 1;
+    const int mt = bx / ntn, nt = bx - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
     const int z = blockIdx.y;
     const int kt_begin = z * p.ktiles_per_split;
@@ -59,16 +65,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     // ---- per-thread im2col row descriptors (fixed for the whole K loop) ----
     int a_pix[PA];   // b*Hs*Ws, or -1 when the row is past M
     int a_oy[PA], a_ox[PA];
-    const int HoWo = p.Ho * p.Wo;
+    const int rw = p.up4 ? p.Ws : p.Wo;                 // extent of the M index space
+    const int rhw = p.up4 ? p.Hs * p.Ws : p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int m = m0 + i * RPP + lrow;
         if (m < p.M) {
-            const int b = m / HoWo;
-            const int r = m - b * HoWo;
-            const int oy = r / p.Wo;
-            a_oy[i] = oy * p.stride - 1;
-            a_ox[i] = (r - oy * p.Wo) * p.stride - 1;
+            const int b = m / rhw;
+            const int r = m - b * rhw;
+            const int oy = r / rw;
+            a_oy[i] = oy * p.stride - 1 + py;
+            a_ox[i] = (r - oy * rw) * p.stride - 1 + px;
             a_pix[i] = b * p.Hs * p.Ws;
         } else {
             a_pix[i] = -1; a_oy[i] = 0; a_ox[i] = 0;
@@ -76,12 +83,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     }
     const int hlim = p.up ? 2 * p.Hs : p.Hs;
     const int wlim = p.up ? 2 * p.Ws : p.Ws;
-    const int K = 9 * p.Cin;
+    const int tw = p.up4 ? 2 : 3;                       // taps per row
+    const int K = tw * tw * p.Cin;
+    const float *wbase = p.w + (size_t)par * p.Cout * K;
     const float *wrow[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int n = n0 + i * RPP + lrow;
-        wrow[i] = (n < p.Cout) ? p.w + (size_t)n * K + lq : nullptr;
+        wrow[i] = (n < p.Cout) ? wbase + (size_t)n * K + lq : nullptr;
     }
 
     // K-tile cursor of the NEXT tile to fetch: tap = ky*3+kx, c = channel offset inside the
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (kt + g < kt_end) {
-                const int ky = tap / 3, kx = tap - ky * 3;
+                const int ky = tap / tw, kx = tap - ky * tw;
                 const float *src; int cs, cc;
                 if (c < p.C0) { src = p.src0; cs = p.C0; cc = c; }
                 else          { src = p.src1; cs = p.C1; cc = c - p.C0; }
@@ -202,14 +211,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + crow;
                 if (m >= p.M) continue;
+                size_t orow = (size_t)m;          // output pixel index (NHWC row)
+                if (p.up4) {
+                    const int b = m / rhw;
+                    const int rr = m - b * rhw;
+                    const int y = rr / rw, x = rr - y * rw;
+                    orow = ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
+                }
                 float v = acc[i][j][r];
                 if (p.splits > 1) {
-                    p.partial[((size_t)z * p.M + m) * p.Cout + n] = v;
+                    p.partial[((size_t)z * p.Mout + orow) * p.Cout + n] = v;
                 } else {
                     v = v * sc + sh;
-                    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+                    if (p.residual) v += p.residual[orow * p.Cout + n];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[(size_t)m * p.Cout + n] = v;
+                    p.out[orow * p.Cout + n] = v;
                 }
             }
         }
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
 __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
 {
     __shared__ float4 red[3][64];
-    const unsigned total4 = (unsigned)(((size_t)p.M * p.Cout) >> 2);
+    const unsigned total4 = (unsigned)(((size_t)p.Mout * p.Cout) >> 2);
     const unsigned x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const unsigned i = blockIdx.x * 64u + x;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -269,6 +285,7 @@ template <int BM, int BN, int WGM, int WGN, int G>
 static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
 {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
+    const int npar = p.up4 ? 4 : 1;
     constexpr size_t smem_max = (size_t)2 * G * (BM + BN) * LDK * sizeof(float);
     const size_t smem = p.ktiles_per_split > G ? smem_max : smem_max / 2;
     static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
@@ -278,7 +295,7 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN, G>), dim3(ntm * ntn, p.splits), dim3(64 * WGM * WGN),
+    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN, G>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
                        smem, s, p);
     return hipGetLastError();
 }
@@ -323,7 +340,7 @@ hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t
 
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
 {
-    const size_t total4 = (size_t)p.M * p.Cout / 4;
+    const size_t total4 = (size_t)p.Mout * p.Cout / 4;
     hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -10,8 +10,9 @@ static const double kBnEps = 1e-5;   // nn.BatchNorm2d default (networks.py neve
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-void choose_tiling(int M, int N, int ktiles, int *bm_out, int *bn_out, int *splits_out, int *group_out)
+void choose_tiling(int M, int N, int ktiles, int par, int *bm_out, int *bn_out, int *splits_out, int *group_out)
 {
+    // par = independent GEMM slices per launch (4 output parities in sub-pixel up-conv form)
     // Candidates, largest first.  MFMA-bound fp32: big tiles cut L2->LDS traffic, but the chip has
     // 256 CUs and wants >= ~2 workgroups per CU, so shrink the tile (then split K) until the
     // launch is wide enough.
@@ -23,13 +24,13 @@ void choose_tiling(int M, int N, int ktiles, int *bm_out, int *bn_out, int *spli
         // <= 4x4 spatial at batch 1: pure weight streaming; the 2-wave 32x64 shape gives the most
         // workgroups per weight byte
         best = 4;
-        best_tiles = (long)((N + 63) / 64);
+        best_tiles = (long)par * ((N + 63) / 64);
     } else {
         for (int i = 0; i < 4; ++i) {
             const int bm = cand[i][0], bn = cand[i][1];
             if (bn > 64 && N < 128) continue;      // N <= 64: only the bn = 64 shapes
             if (bm > 64 && M <= 64) continue;
-            const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+            const long tiles = (long)par * ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
             best = i; best_tiles = tiles;          // ends on 64x64 (+ split-K) if nothing is wide enough
             if (tiles >= want) break;
         }
@@ -195,7 +196,12 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
     for (auto &l : layers) {
         off = align_up(off, 256);
         l.w_off = (int64_t)off;
-        off += (size_t)l.cout * l.cin * 9 * sizeof(float);
+        // up-convs of the compute-bound levels run in sub-pixel form: 4 parities x 2x2 taps
+        // (16/9 of the 9-tap weight bytes, 4/9 of the FLOPs); the weight-streaming-bound
+        // small levels keep the 9-tap gather form.
+        l.up4 = l.kind == kIgemm && l.up && l.ho >= kUp4MinExtent;
+        if (l.up4) l.up = false;
+        off += (size_t)l.cout * l.cin * (l.up4 ? 16 : 9) * sizeof(float);
         if (!l.bnkey.empty()) {
             off = align_up(off, 256);
             l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
@@ -282,10 +288,11 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 }
         if (l.kind == kIgemm) {
             int bm, bn, splits, group;
-            const int M = batch * l.ho * l.ho;
-            choose_tiling(M, l.cout, 9 * l.cin / 32, &bm, &bn, &splits, &group);
+            const int Mout = batch * l.ho * l.ho;
+            const int M = l.up4 ? batch * l.hs * l.hs : Mout;
+            choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / 32, l.up4 ? 4 : 1, &bm, &bn, &splits, &group);
             if (tiled) { (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group; }
-            if (splits > 1) partial = std::max(partial, (size_t)splits * M * l.cout * sizeof(float));
+            if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }
     }
     if (offsets) *offsets = off;
@@ -323,7 +330,27 @@ std::string Plan::pack(void *blob, size_t bytes) const
         const float *W = get(l.wkey).data.data();           // OIHW
         float *dst = reinterpret_cast<float *>(base + l.w_off);
         const int cin = l.cin, cout = l.cout;
-        if (l.kind == kIgemm) {
+        if (l.kind == kIgemm && l.up4) {
+            // sub-pixel form of Upsample(x2, nearest) + Conv3x3: output parity (py, px) only ever
+            // sees 2x2 distinct source pixels, so the 3x3 taps that alias onto the same source
+            // pixel are pre-summed (in double, rounded once):
+            //   py = 0: source rows {y-1: ky 0} {y: ky 1,2}     py = 1: {y: ky 0,1} {y+1: ky 2}
+            // layout [parity][co][a*2+b][ci]
+            static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};   // [parity][a] -> k range
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    for (int co = 0; co < cout; ++co)
+                        for (int ci = 0; ci < cin; ++ci) {
+                            const float *w9 = W + ((size_t)co * cin + ci) * 9;
+                            for (int a = 0; a < 2; ++a)
+                                for (int b = 0; b < 2; ++b) {
+                                    double acc = 0.0;
+                                    for (int ky = lo[py][a]; ky <= hi[py][a]; ++ky)
+                                        for (int kx = lo[px][b]; kx <= hi[px][b]; ++kx) acc += (double)w9[ky * 3 + kx];
+                                    dst[(((size_t)(py * 2 + px) * cout + co) * 4 + a * 2 + b) * cin + ci] = (float)acc;
+                                }
+                        }
+        } else if (l.kind == kIgemm) {
             // [co][tap][ci]  -- the implicit-GEMM B operand, K contiguous per output channel
             for (int co = 0; co < cout; ++co)
                 for (int ci = 0; ci < cin; ++ci)

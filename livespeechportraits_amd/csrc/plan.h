@@ -32,6 +32,7 @@ struct LayerDesc {
     int ho = 0;            // spatial extent written
     int stride = 1;
     bool up = false, relu = false, tanh_out = false, concat = false, residual = false;
+    bool up4 = false;      // upsample conv executed in sub-pixel form (4 parities x 2x2 taps)
     std::string wkey;      // state-dict key of the OIHW weight
     std::string bnkey;     // state-dict prefix of the following BatchNorm2d ("" = none)
     int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
@@ -72,6 +73,7 @@ struct Plan {
 };
 
 // tile / split-K heuristic shared by the planner and lspf2f_conv3x3
-void choose_tiling(int M, int N, int ktiles, int *bm, int *bn, int *splits, int *group);
+void choose_tiling(int M, int N, int ktiles, int par, int *bm, int *bn, int *splits, int *group);
+static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 
 }  // namespace lspf2f

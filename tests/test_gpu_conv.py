@@ -24,7 +24,10 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
     d0 = nhwc(x0)
     d1 = nhwc(x1) if x1 is not None else None
-    wp = w.permute(0, 2, 3, 1).contiguous().to(dev)          # [co][ky][kx][ci]
+    if up == 2:
+        wp = pack_subpixel(w).to(dev)                        # [parity][co][a][b][ci]
+    else:
+        wp = w.permute(0, 2, 3, 1).contiguous().to(dev)      # [co][ky][kx][ci]
     dsc = scale.to(dev) if scale is not None else None
     dsh = shift.to(dev) if shift is not None else None
     ho = 2 * hs if up else (hs + stride - 1) // stride
@@ -39,6 +42,25 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     N.check(rc)
     torch.cuda.synchronize()
     return out.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def pack_subpixel(w):
+    """Independent (numpy-free, torch float64) statement of the sub-pixel weight fold: for output
+    parity (py, px) of Upsample(x2, nearest) + Conv3x3, the 3x3 taps that read the same source pixel
+    are summed.  [co][ci][3][3] -> [4][co][2][2][ci]"""
+    groups = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}   # parity -> tap groups for a = 0, 1
+    wd = w.double()
+    out = torch.zeros(4, w.shape[0], 2, 2, w.shape[1], dtype=torch.float64)
+    for py in (0, 1):
+        for px in (0, 1):
+            for a in (0, 1):
+                for b in (0, 1):
+                    acc = 0
+                    for ky in groups[py][a]:
+                        for kx in groups[px][b]:
+                            acc = acc + wd[:, :, ky, kx]
+                    out[py * 2 + px, :, a, b, :] = acc
+    return out.float().contiguous()
 
 
 def ref_conv(x0, x1, w, scale, shift, res, stride, up, relu):
@@ -104,6 +126,33 @@ def test_conv3x3_k_groups(cfg, gpu_device):
     ref = ref_conv(x0, x1, w, scale, shift, r, stride, up, relu)
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 2e-5
+
+
+SUBPIXEL_CASES = [
+    # b, c0, c1, cout, hs, tile, split, group
+    (1, 64, 64, 64, 16, (0, 0), 0, 0),        # concat up-conv, planner's choice
+    (2, 32, 0, 96, 9, (64, 64), 1, 1),        # odd extent, ragged tiles, batch 2
+    (1, 128, 128, 32, 8, (128, 64), 2, 2),    # split-K + K groups: partials land on scattered output rows
+    (1, 64, 0, 128, 4, (64, 128), 4, 1),
+    (1, 32, 32, 64, 2, (32, 64), 2, 4),
+]
+
+
+@pytest.mark.parametrize("cfg", SUBPIXEL_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_t%dx%d_k%d_g%d" % (
+    c[0], c[1], c[2], c[3], c[4], c[5][0], c[5][1], c[6], c[7]))
+def test_conv3x3_subpixel_upsample(cfg, gpu_device):
+    """upsample=2 (4 parities x 2x2 taps, pre-summed weights) == Upsample(2,'nearest') + Conv3x3."""
+    b, c0, c1, cout, hs, tile, split, g = cfg
+    x0 = rnd(b, c0, hs, hs, seed=21)
+    x1 = rnd(b, c1, hs, hs, seed=22) if c1 else None
+    w = rnd(cout, c0 + c1, 3, 3, seed=23) * 0.05
+    scale, shift = rnd(cout, seed=24) * 0.5 + 1.0, rnd(cout, seed=25) * 0.1
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, True, tile, split, g)
+    ref = ref_conv(x0, x1, w, scale, shift, None, 1, True, True)
+    got9 = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 1, True)
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2e-5
+    assert (got - got9).abs().max().item() <= 2e-5   # both forms of the same op agree
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_s%d_up%d_bn%d_res%d_relu%d_t%dx%d_k%d" % (
