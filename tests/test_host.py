@@ -1,0 +1,226 @@
+"""CPU: host logic -- key map, C++ plan, BN-fold packer, C-ABI surface, model wrapper API,
+error behaviour.  No GPU compute is called here."""
+import argparse
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def opt_ns(**kw):
+    d = dict(model="feature2face", gpu_ids=[], isTrain=False, size="large", ngf=64, n_downsample_G=8, fp16=0,
+             checkpoints_dir="/tmp", name="t", load_epoch="none", verbose=False)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+# ---- C ABI surface -------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    from livespeechportraits_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "lspf2f.h")).read()
+    declared = set(re.findall(r"\b(lspf2f_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "header parse failed"
+    lib = ctypes.CDLL(N.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "liblspf2f.so does not export %s" % name
+    assert declared == set(N.SIGNATURES), "ctypes binding and header disagree: %s" % (declared ^ set(N.SIGNATURES))
+    assert N.load().lspf2f_abi_version() == N.ABI_VERSION
+
+
+def test_create_rejects_unsupported_configs():
+    from livespeechportraits_amd import _native as N
+    from livespeechportraits_amd.engine import Engine
+    with pytest.raises(ValueError):
+        Engine("small")
+    for kw in (dict(ngf=48), dict(num_downs=4), dict(size=500), dict(output_nc=5)):
+        with pytest.raises(N.Lspf2fError) as ei:
+            Engine("large", **kw)
+        assert ei.value.code == -2
+    e = Engine("normal", ngf=32, num_downs=5, size=64)
+    with pytest.raises(N.Lspf2fError):   # forward before weights are bound -> STATE error, not a crash
+        N.check(e.lib.lspf2f_forward(e._h, ctypes.c_void_p(8), ctypes.c_void_p(8), 1, ctypes.c_void_p(8), 1, None))
+
+
+# ---- key map / plan ---------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["large", "normal"])
+def test_key_map_matches_reference_dump(variant):
+    """Python topology == C++ plan == nn.Module skeleton == keys dumped from the reference."""
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.feature2face_G import Feature2Face_G
+    from livespeechportraits_amd.topology import build_topology
+    ref = json.load(open(os.path.join(GOLDEN, "keys_%s.json" % variant)))
+    topo = build_topology(variant)
+    assert {k: list(v) for k, v in topo.tensors.items()} == ref
+    assert list(topo.tensors) == list(ref)                       # same order as the reference state dict
+    eng = Engine(variant)
+    exp = eng.expected_tensors()
+    assert {k: list(v) for k, v in exp.items()} == {k: v for k, v in ref.items() if not k.endswith("num_batches_tracked")}
+    mod = Feature2Face_G(opt_ns(size=variant))
+    sd = mod.state_dict()
+    assert list(sd) == list(ref) and all(list(sd[k].shape) == ref[k] for k in ref)
+
+
+def test_plan_matches_survey_workload_constants():
+    """76/46 convs, 249.77/166.08 GFLOP, 820.5/499.0 MB activations, 486.9/304.7 MB weights."""
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.topology import build_topology
+    for variant, nconv, gflop, act_mb, w_mb in (("large", 76, 249.76, 820.5, 486.9), ("normal", 46, 166.08, 499.0, 304.7)):
+        layers = Engine(variant).layers(1)
+        topo = build_topology(variant)
+        assert len(layers) == nconv == len(topo.convs)
+        assert abs(sum(l["flops_per_frame"] for l in layers) / 1e9 - gflop) < 0.01
+        assert abs(sum(l["act_bytes_per_frame"] for l in layers) / 1e6 - act_mb) < 0.1
+        assert abs(topo.weight_elems() * 4 / 1e6 - w_mb) < 0.1
+        assert topo.flops_per_frame() == sum(l["flops_per_frame"] for l in layers)
+        for l, c in zip(layers, topo.convs):
+            assert (l["cin"], l["cout"], l["h_in"], l["h_out"], l["stride"]) == (c.cin, c.cout, c.h_in, c.h_out, c.stride)
+            assert bool(l["upsample"]) == c.upsample and bool(l["residual"]) == c.residual and bool(l["concat"]) == c.concat
+        # sub-pixel up-convs issue 4/9 of the algorithmic FLOPs
+        assert sum(l["exec_flops_per_frame"] for l in layers) < sum(l["flops_per_frame"] for l in layers)
+
+
+def test_workspace_reuse_and_growth():
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("large", max_batch=8)
+    keep = Engine("large", max_batch=8, keep_intermediates=True)
+    w1, w8 = e.workspace_bytes(1), e.workspace_bytes(8)
+    assert w1 < keep.workspace_bytes(1) / 2, "liveness reuse should at least halve the arena"
+    assert 6 * w1 < w8 < 9 * w1
+    # every layer output lies inside the arena, 256-byte aligned
+    for l in keep.layers(2):
+        if l["out_offset"] >= 0:
+            assert l["out_offset"] % 256 == 0
+            assert l["out_offset"] + 2 * l["cout"] * l["h_out"] ** 2 * 4 <= keep.workspace_bytes(2)
+
+
+# ---- packer -----------------------------------------------------------------------------------
+def test_pack_weights_matches_numpy_restatement():
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    topo, sd = synth.synthetic("large", ngf=32, num_downs=6, size=128)
+    e = Engine("large", ngf=32, num_downs=6, size=128)
+    e.load_state_dict(sd)
+    blob = e.pack().numpy()
+    f32 = lambda off, n: blob[off:off + 4 * n].view(np.float32)
+    layers = e.layers(1)
+    seen_sub = seen_nine = False
+    for l, c in zip(layers, topo.convs):
+        w = sd[c.weight_key].astype(np.float64)                      # OIHW
+        n = c.cin * c.cout
+        if l["kernel"] == "first_conv":
+            exp = w.transpose(1, 2, 3, 0).reshape(-1)                # [ci][ky][kx][co]
+        elif l["kernel"] == "last_conv":
+            exp = w.transpose(2, 3, 0, 1).reshape(-1)                # [ky][kx][co][ci]
+        elif l["weight_bytes"] == 16 * n * 4:                        # sub-pixel up-conv
+            seen_sub = True
+            grp = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}
+            exp = np.zeros((4, c.cout, 2, 2, c.cin))
+            for py in (0, 1):
+                for px in (0, 1):
+                    for a in (0, 1):
+                        for b in (0, 1):
+                            exp[py * 2 + px, :, a, b, :] = sum(w[:, :, ky, kx] for ky in grp[py][a] for kx in grp[px][b])
+            exp = exp.reshape(-1)
+        else:
+            seen_nine = True
+            exp = w.transpose(0, 2, 3, 1).reshape(-1)                # [co][ky][kx][ci]
+        got = f32(l["w_offset"], exp.size)
+        assert np.array_equal(got, exp.astype(np.float32)), l["name"]
+        if c.bn_key:
+            g, b = sd[c.bn_key + ".weight"].astype(np.float64), sd[c.bn_key + ".bias"].astype(np.float64)
+            m, v = sd[c.bn_key + ".running_mean"].astype(np.float64), sd[c.bn_key + ".running_var"].astype(np.float64)
+            s = g / np.sqrt(v + 1e-5)
+            assert np.array_equal(f32(l["scale_offset"], c.cout), s.astype(np.float32))
+            assert np.array_equal(f32(l["shift_offset"], c.cout), (b - m * s).astype(np.float32))
+        else:
+            assert l["scale_offset"] == -1
+    assert seen_sub and seen_nine
+
+
+def test_pack_refuses_missing_and_unknown_tensors():
+    from livespeechportraits_amd import _native as N, synth
+    from livespeechportraits_amd.engine import Engine
+    topo, sd = synth.synthetic("normal", ngf=32, num_downs=5, size=64)
+    e = Engine("normal", ngf=32, num_downs=5, size=64)
+    partial = dict(sd)
+    del partial["netG.model.model.0.weight"]
+    with pytest.raises(KeyError):
+        e.load_state_dict(partial)                                   # the reference would stay silent (strict=False)
+    e.load_state_dict(partial, strict=False)
+    with pytest.raises(N.Lspf2fError) as ei:
+        e.pack()
+    assert ei.value.code == -3 and "netG.model.model.0.weight" in str(ei.value)
+    with pytest.raises(N.Lspf2fError):
+        N.check(e.lib.lspf2f_set_tensor(e._h, b"netG.bogus", np.zeros(4, np.float32).ctypes.data, 4))
+    bad = dict(sd)
+    bad["netG.model.model.0.weight"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError):
+        e.load_state_dict(bad)
+    extra = e.load_state_dict({("module." + k): v for k, v in sd.items()})   # DataParallel-prefixed keys are accepted
+    assert all(k.endswith("num_batches_tracked") for k in extra)
+    assert e.pack().numel() == e.packed_bytes()
+
+
+# ---- model wrapper (the reference's API surface) -------------------------------------------------
+def test_create_model_and_checkpoint_roundtrip(tmp_path):
+    import livespeechportraits_amd as L
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.topology import build_topology
+    topo = build_topology("normal", ngf=32, num_downs=5, size=64)
+    sd = synth.make_state_dict(topo)
+    ckpt = str(tmp_path / "Feature2Face.pkl")
+    torch.save({"module." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, ckpt)
+    opt = opt_ns(size="normal", ngf=32, n_downsample_G=5, load_epoch=ckpt, checkpoints_dir=str(tmp_path))
+    m = L.create_model(opt)
+    assert type(m).__name__ == "Feature2FaceModel" and m.model_names == ["Feature2Face_G"]
+    m.setup(opt)
+    m.eval()
+    got = m.Feature2Face_G.state_dict()
+    for k, v in sd.items():
+        assert np.array_equal(got[k].numpy(), v), k
+    # save_networks writes '<epoch>_<name>.pkl' that load_networks reads back
+    m.save_networks("7")
+    assert os.path.exists(os.path.join(str(tmp_path), "t", "7_Feature2Face_G.pkl"))
+    # missing checkpoint at inference time -> ValueError (base_model.py:221-223)
+    with pytest.raises(ValueError):
+        L.create_model(opt_ns(size="normal", ngf=32, n_downsample_G=5, load_epoch="nope", checkpoints_dir=str(tmp_path))).setup(
+            opt_ns(load_epoch="nope", checkpoints_dir=str(tmp_path)))
+    # a checkpoint that lacks generator tensors is an error, not silent garbage
+    torch.save({"module.netG.model.model.0.weight": torch.zeros(32, 13, 3, 3)}, ckpt)
+    with pytest.raises(KeyError):
+        m.load_networks(ckpt)
+
+
+def test_inference_has_no_cpu_fallback():
+    import livespeechportraits_amd as L
+    m = L.create_model(opt_ns(size="normal", ngf=32, n_downsample_G=5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.inference(torch.zeros(1, 1, 64, 64), torch.zeros(1, 12, 64, 64))
+    with pytest.raises(NotImplementedError):
+        L.create_model(opt_ns(size="small"))
+    with pytest.raises(NotImplementedError):
+        L.create_model(opt_ns(isTrain=True))
+    with pytest.raises(NotImplementedError):
+        L.create_model(opt_ns(model="audio2feature"))
+
+
+def test_synth_is_deterministic_and_matches_recipe():
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.topology import build_topology
+    topo = build_topology("normal", ngf=32, num_downs=5, size=64)
+    a, b = synth.make_state_dict(topo, 1234), synth.make_state_dict(topo, 1234)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    w = a["netG.model.model.2.block.0.weight"]
+    assert abs(w.std() - 0.02) < 2e-3 and abs(w.mean()) < 2e-3
+    v = a["netG.model.model.2.block.1.running_var"]
+    assert v.min() >= 0.9 and v.max() <= 1.6
+    feat, cand = synth.make_inputs(2, 64)
+    assert set(np.unique(feat)) <= {0.0, 1.0} and 0.01 < feat.mean() < 0.06
+    assert cand.min() >= -1 and cand.max() < 1
+    assert float(synth.uniform01(4, 7)[0]) == float(synth.uniform01(1, 7)[0])
