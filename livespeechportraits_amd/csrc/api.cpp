@@ -208,8 +208,9 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     o->tile_m = l.bm; o->tile_n = l.bn; o->split_k = l.splits; o->k_group = l.group;
     o->flops_per_frame = h->plan.layer_flops(l);
     o->act_bytes_per_frame = h->plan.layer_act_bytes(l);
-    o->weight_bytes = (int64_t)l.cout * l.cin * (l.up4 ? 16 : 9) * 4;
-    o->exec_flops_per_frame = l.up4 ? o->flops_per_frame * 4 / 9 : o->flops_per_frame;
+    const bool sub = l.up4 || l.kind == kLastConv;   // sub-pixel form: 16/9 weight bytes, 4/9 FLOPs
+    o->weight_bytes = (int64_t)l.cout * l.cin * (sub ? 16 : 9) * 4;
+    o->exec_flops_per_frame = sub ? o->flops_per_frame * 4 / 9 : o->flops_per_frame;
     o->w_offset = l.w_off; o->scale_offset = l.scale_off; o->shift_offset = l.shift_off;
     o->out_offset = l.out >= 0 ? (int64_t)h->plan.tensors[l.out].offset : -1;
     return LSPF2F_OK;
@@ -367,7 +368,7 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
     int bm = tile_m, bn = tile_n, sp = split_k;
     if (!bm || !bn || !sp) {
         int a, b, c, g;
-        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / 32, up4 ? 4 : 1, &a, &b, &c, &g);
+        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / 32, up4 ? 4 : 1, upsample == 1, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; }
         if (!sp) sp = c;
     }
@@ -405,12 +406,12 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
     int bm = tile_m, bn = tile_n, sp = split_k, grp = k_group;
     {
         int a, b, c, g;
-        choose_tiling(p.M, cout, p.ktiles_total, p.up4 ? 4 : 1, &a, &b, &c, &g);
+        choose_tiling(p.M, cout, p.ktiles_total, p.up4 ? 4 : 1, p.up != 0, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; if (!grp) grp = g; }
         if (!sp) sp = c;
         if (!grp) grp = 1;
     }
-    if (!igemm_group_supported(bm, bn, grp)) return fail(LSPF2F_ERR_UNSUPPORTED, "tile shape / k_group not instantiated");
+    if (!igemm_group_supported(bm, bn, grp, p.up != 0)) return fail(LSPF2F_ERR_UNSUPPORTED, "tile shape / k_group not instantiated");
     if (sp < 1 || sp > p.ktiles_total) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "bad split_k");
     p.ktiles_per_split = (p.ktiles_total + sp - 1) / sp;
     sp = (p.ktiles_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
@@ -420,6 +421,7 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
             return fail(LSPF2F_ERR_STATE, "split-K scratch missing or too small");
         p.partial = static_cast<float *>(scratch);
     }
+    if (const char *env = std::getenv("LSP_HIP_DBG")) p.dbg = std::atoi(env);   // ablation knob, tools only
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     e = launch_igemm(p, bm, bn, grp, s);
     if (e == hipSuccess && sp > 1) e = launch_splitk_reduce(p, s);

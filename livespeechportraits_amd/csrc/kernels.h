@@ -5,6 +5,30 @@
 
 namespace lspf2f {
 
+// Exact unsigned 32-bit division by a launch-invariant divisor (Granlund-Montgomery round-up
+// method): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(n, m).  ~5 VALU ops instead of the ~40 of
+// a hardware-emulated integer divide in every workgroup's prologue.
+struct FastDiv {
+    unsigned m = 0, s1 = 0, s2 = 0;
+    static FastDiv make(unsigned d)
+    {
+        FastDiv f;
+        unsigned l = 0;
+        while ((1ull << l) < d) ++l;                       // ceil(log2 d)
+        f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+        f.s1 = l < 1 ? l : 1;
+        f.s2 = l > 0 ? l - 1 : 0;
+        return f;
+    }
+#ifdef __HIPCC__
+    __device__ __forceinline__ unsigned div(unsigned n) const
+    {
+        const unsigned t = __umulhi(n, m);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+#endif
+};
+
 // One fused 3x3 convolution as an implicit GEMM:  M = B*Ho*Wo output pixels, N = Cout,
 // K = 9*Cin ordered (ky, kx, ci) with ci running over src0's channels then src1's.
 struct IgemmParams {
@@ -25,6 +49,8 @@ struct IgemmParams {
     int ktiles_total;           // taps*Cin/32 (taps = 9, or 4 for up4)
     int ktiles_per_split;
     int splits;
+    FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
+    int dbg;                    // ablation bits for tools/ (0 in production): 1 no refetch, 2 no LDS restage, 4 no barrier, 8 no buffer flip
 };
 
 struct TileConfig { int bm, bn; };
@@ -35,7 +61,7 @@ static const int kNumTileConfigs = sizeof(kTileConfigs) / sizeof(kTileConfigs[0]
 bool igemm_tile_supported(int bm, int bn);
 hipError_t igemm_init();  // raises the dynamic-LDS limit of the big-tile instantiations
 // g = K-tiles per pipeline step: 1 (all shapes), 2 (128x64, 64x64), 4 (64x64, 32x64)
-bool igemm_group_supported(int bm, int bn, int g);
+bool igemm_group_supported(int bm, int bn, int g, bool up);
 hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t s);
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s);
 
@@ -52,7 +78,7 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
 // Last layer: Upsample x2 -> Conv 3x3 s1 p1 over cat([src0, src1]) -> tanh, NHWC in, NCHW out.
 struct LastConvParams {
     const float *src0, *src1;  // NHWC [B][Hs][Ws][C0|C1]
-    const float *w;            // [(tap*Cout + co)][Cin]
+    const float *w;            // sub-pixel form [4 parities][Cout][2][2][Cin] (taps pre-summed)
     float *out;                // NCHW [B][Cout][2Hs][2Ws]
     int B, Hs, Ws, C0, C1, Cout;
     int apply_tanh;

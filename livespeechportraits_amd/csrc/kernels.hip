@@ -13,9 +13,15 @@
 // :575-579 (tanh); BatchNorm eval folding validated in SURVEY.md 8c.
 #include "kernels.h"
 
+#ifndef LSPF2F_SWP
+#define LSPF2F_SWP 1   // 1: LDS fragment reads issued one step ahead of the MFMAs
+#endif
+
 namespace lspf2f {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned kOOB = 0x80000000u;   // voffset beyond any num_records: buffer load returns 0
 
 static constexpr int BK = 32;    // K-tile (floats); Cin % 32 == 0 so a K-tile never straddles a tap
 static constexpr int LDK = 36;   // LDS row pitch in floats: 144 B makes the 16 rows of a
@@ -24,7 +30,8 @@ static constexpr int LDK = 36;   // LDS row pitch in floats: 144 B makes the 16 
 // G = K-tiles staged per pipeline step (one barrier per G tiles, G tiles of global loads in
 // flight per thread).  G = 1 for long K loops; G = 4 turns a short split-K range (<= 4 tiles)
 // into a single load -> LDS -> MFMA pass, which is what the latency-bound <= 8x8 levels need.
-template <int BM, int BN, int WGM, int WGN, int G>
+// UP = the 9-tap nearest-x2 gather form (only the small, weight-streaming up-convs use it).
+template <int BM, int BN, int WGM, int WGN, int G, bool UP>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams p)
 {
     constexpr int NT = 64 * WGM * WGN;
@@ -63,71 +70,96 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     const int lq = (tid & 7) * 4;
 
     // ---- per-thread im2col row descriptors (fixed for the whole K loop) ----
-    int a_pix[PA];   // b*Hs*Ws, or -1 when the row is past M
-    int a_oy[PA], a_ox[PA];
+    // a_pix0: pixel index of tap (0,0) (may be "negative" at the border -- only used when the
+    // tap's validity bit is set); a_mask: bit t = tap t reads inside the (virtually upsampled)
+    // source; rows past M have mask 0.  All gathers are buffer loads whose voffset is forced
+    // out of range for invalid taps, so padding costs no branch and no select: the hardware
+    // returns zeros.
+    const int tw = p.up4 ? 2 : 3;                       // taps per row
+    const int ntap = tw * tw;
+    const int hlim = UP ? 2 * p.Hs : p.Hs;
+    const int wlim = UP ? 2 * p.Ws : p.Ws;
     const int rw = p.up4 ? p.Ws : p.Wo;                 // extent of the M index space
     const int rhw = p.up4 ? p.Hs * p.Ws : p.Ho * p.Wo;
+    int a_pix0[PA], a_oy[PA], a_ox[PA];
+    unsigned a_mask[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int m = m0 + i * RPP + lrow;
+        a_mask[i] = 0; a_pix0[i] = 0; a_oy[i] = 0; a_ox[i] = 0;
         if (m < p.M) {
-            const int b = m / rhw;
+            // exact division by the launch-invariant extents via precomputed multipliers
+            const int b = (int)p.div_rhw.div((unsigned)m);
             const int r = m - b * rhw;
-            const int oy = r / rw;
-            a_oy[i] = oy * p.stride - 1 + py;
-            a_ox[i] = (r - oy * rw) * p.stride - 1 + px;
-            a_pix[i] = b * p.Hs * p.Ws;
-        } else {
-            a_pix[i] = -1; a_oy[i] = 0; a_ox[i] = 0;
+            const int oy = (int)p.div_rw.div((unsigned)r);
+            const int y0 = oy * p.stride - 1 + py;
+            const int x0 = (r - oy * rw) * p.stride - 1 + px;
+            a_oy[i] = y0; a_ox[i] = x0;
+            a_pix0[i] = UP ? b * p.Hs * p.Ws : b * p.Hs * p.Ws + y0 * p.Ws + x0;
+            unsigned mask = 0, bit = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if (ky >= tw) break;
+                const bool oky = (unsigned)(y0 + ky) < (unsigned)hlim;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    if (kx >= tw) break;
+                    mask |= (unsigned)(oky & ((unsigned)(x0 + kx) < (unsigned)wlim)) << bit;
+                    ++bit;
+                }
+            }
+            a_mask[i] = mask;
         }
     }
-    const int hlim = p.up ? 2 * p.Hs : p.Hs;
-    const int wlim = p.up ? 2 * p.Ws : p.Ws;
-    const int tw = p.up4 ? 2 : 3;                       // taps per row
-    const int K = tw * tw * p.Cin;
+    const int K = ntap * p.Cin;
     const float *wbase = p.w + (size_t)par * p.Cout * K;
-    const float *wrow[PB];
+    unsigned b_off[PB];                                  // byte offset of this thread's weight row, or OOB
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int n = n0 + i * RPP + lrow;
-        wrow[i] = (n < p.Cout) ? wbase + (size_t)n * K + lq : nullptr;
+        b_off[i] = (n < p.Cout) ? (unsigned)(n * K + lq) * 4u : kOOB;
     }
+    const unsigned plane = (unsigned)(p.B * p.Hs * p.Ws) * 4u;
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, p.Cout * K * 4, 0x00020000);
 
-    // K-tile cursor of the NEXT tile to fetch: tap = ky*3+kx, c = channel offset inside the
+    // K-tile cursor of the NEXT tile to fetch: tap = ky*tw+kx, c = channel offset inside the
     // concatenated input
     int tap = (kt_begin * BK) / p.Cin;
     int c = kt_begin * BK - tap * p.Cin;
+    int ky = tap / tw, kx = tap - ky * tw;
 
-    float4 ra[G][PA], rb[G][PB];
-    // fetch K-tiles kt .. kt+G-1 into registers (tiles at or past kt_end are zero)
+    u32x4 ra[G][PA], rb[G][PB];
+    // fetch K-tiles kt .. kt+G-1 into registers (tiles at or past kt_end read as zero)
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (kt + g < kt_end) {
-                const int ky = tap / tw, kx = tap - ky * tw;
-                const float *src; int cs, cc;
-                if (c < p.C0) { src = p.src0; cs = p.C0; cc = c; }
-                else          { src = p.src1; cs = p.C1; cc = c - p.C0; }
+            const bool live = kt + g < kt_end;
+            const bool first = c < p.C0;
+            const float *sp = first ? p.src0 : p.src1;
+            const int cs = first ? p.C0 : p.C1;
+            const int soff = (first ? c : c - p.C0) * 4;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sp), 0, (int)(plane * (unsigned)cs), 0x00020000);
+            const int tapdelta = ky * p.Ws + kx;
+            const unsigned csb = (unsigned)cs * 4u;
 #pragma unroll
-                for (int i = 0; i < PA; ++i) {
-                    const int uy = a_oy[i] + ky, ux = a_ox[i] + kx;
-                    const bool ok = (a_pix[i] >= 0) & (uy >= 0) & (uy < hlim) & (ux >= 0) & (ux < wlim);
-                    const int iy = p.up ? (uy >> 1) : uy, ix = p.up ? (ux >> 1) : ux;
-                    ra[g][i] = ok ? *reinterpret_cast<const float4 *>(
-                                        src + (size_t)(a_pix[i] + iy * p.Ws + ix) * cs + cc + lq)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = live && ((a_mask[i] >> tap) & 1u);
+                const int pix = UP ? a_pix0[i] + ((a_oy[i] + ky) >> 1) * p.Ws + ((a_ox[i] + kx) >> 1)
+                                   : a_pix0[i] + tapdelta;
+                const unsigned voff = ok ? (unsigned)pix * csb + (unsigned)lq * 4u : kOOB;
+                ra[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+            }
 #pragma unroll
-                for (int i = 0; i < PB; ++i)
-                    rb[g][i] = wrow[i] ? *reinterpret_cast<const float4 *>(wrow[i] + (size_t)(kt + g) * BK)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < PB; ++i)
+                rb[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, live ? b_off[i] : kOOB, (kt + g) * (BK * 4), 0);
+            if (live) {
                 c += BK;
-                if (c == p.Cin) { c = 0; ++tap; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < PA; ++i) ra[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < PB; ++i) rb[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c == p.Cin) {
+                    c = 0; ++tap; ++kx;
+                    if (kx == tw) { kx = 0; ++ky; }
+                }
             }
         }
     };
@@ -137,10 +169,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
             float *A = As + (buf * G + g) * TILE_A, *Bq = Bs + (buf * G + g) * TILE_B;
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                *reinterpret_cast<float4 *>(A + (i * RPP + lrow) * LDK + lq) = ra[g][i];
+                *reinterpret_cast<u32x4 *>(A + (i * RPP + lrow) * LDK + lq) = ra[g][i];
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                *reinterpret_cast<float4 *>(Bq + (i * RPP + lrow) * LDK + lq) = rb[g][i];
+                *reinterpret_cast<u32x4 *>(Bq + (i * RPP + lrow) * LDK + lq) = rb[g][i];
         }
     };
 
@@ -156,49 +188,73 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     // The MFMA's k index (l>>5) then pairs k and k+4 -- any K permutation is fine as long as
     // A and B use the same one.
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    auto compute = [&](int buf) {
+    // One "fragment step" = 8 k of one K-tile: TM + TN ds_read_b128, then TM*TN*4 MFMAs.  Fragment
+    // registers are double-buffered so the LDS reads of step s+1 are issued BEFORE the MFMAs of step s
+    // (an in-order wave otherwise exposes the full LDS latency once per step).
+    constexpr int S = G * (BK / 8);            // fragment steps per pipeline step
+    float4 fa[2][TM], fb[2][TN];
+    auto read_frag = [&](int buf, int s, int set) {
+        const int g = s / (BK / 8), kb = s % (BK / 8);
+        const float *A = As + (buf * G + g) * TILE_A + (wm * TM * 32 + frow) * LDK + fk + kb * 8;
+        const float *Bq = Bs + (buf * G + g) * TILE_B + (wn * TN * 32 + frow) * LDK + fk + kb * 8;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float *A = As + (buf * G + g) * TILE_A + (wm * TM * 32 + frow) * LDK + fk;
-            const float *Bq = Bs + (buf * G + g) * TILE_B + (wn * TN * 32 + frow) * LDK + fk;
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(A + i * 32 * LDK);
 #pragma unroll
-            for (int kb = 0; kb < BK / 8; ++kb) {
-                float4 a[TM], b[TN];
+        for (int j = 0; j < TN; ++j) fb[set][j] = *reinterpret_cast<const float4 *>(Bq + j * 32 * LDK);
+    };
+    auto mfma_frag = [&](int set) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(A + i * 32 * LDK + kb * 8);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(Bq + j * 32 * LDK + kb * 8);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                    }
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].x, fb[set][j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].y, fb[set][j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].z, fb[set][j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].w, fb[set][j].w, acc[i][j], 0, 0, 0);
             }
-        }
     };
 
-    // ---- main loop: register prefetch of step s+1 while step s is multiplied out of LDS ----
-    if (kt_begin < kt_end) {
+    // ---- main loop.  Per pipeline step (G K-tiles in LDS buffer `cur`):
+    //   global loads of step t+1 -> registers | fragment steps 0..S-2 (LDS reads one step ahead)
+    //   | registers -> LDS buffer cur^1 (its latency hides behind the last MFMA block)
+    //   | last MFMA block | barrier | first fragment read of step t+1 (hidden behind the next fetch).
+    if (kt_begin < kt_end && !(p.dbg & 32)) {
         fetch(kt_begin);
         stage(0);
         __syncthreads();
         int cur = 0;
+        read_frag(0, 0, 0);
         for (int kt = kt_begin; kt < kt_end; kt += G) {
             const bool more = kt + G < kt_end;
-            if (more) fetch(kt + G);
-            compute(cur);
-            if (more) stage(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
+            if (!(p.dbg & 1)) fetch(kt + G);   // past-the-end tiles are all-OOB loads: no traffic, no branch
+#if LSPF2F_SWP
+#pragma unroll
+            for (int s = 0; s < S - 1; ++s) {
+                read_frag(cur, s + 1, (s + 1) & 1);
+                mfma_frag(s & 1);
+            }
+            if (more && !(p.dbg & 2)) stage(cur ^ 1);
+            mfma_frag((S - 1) & 1);
+            if (!(p.dbg & 4)) __syncthreads();
+            if (!(p.dbg & 8)) cur ^= 1;
+            if (more) read_frag(cur, 0, 0);
+#else
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s) read_frag(cur, s, s & 1);
+                mfma_frag(s & 1);
+            }
+            if (more && !(p.dbg & 2)) stage(cur ^ 1);
+            if (!(p.dbg & 4)) __syncthreads();
+            if (!(p.dbg & 8)) cur ^= 1;
+            if (more) read_frag(cur, 0, 0);
+#endif
         }
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int ccol = lane & 31, crow = 4 * (lane >> 5);
+    if (p.dbg & 16) return;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + ccol;
@@ -213,9 +269,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
                 if (m >= p.M) continue;
                 size_t orow = (size_t)m;          // output pixel index (NHWC row)
                 if (p.up4) {
-                    const int b = m / rhw;
+                    const int b = (int)p.div_rhw.div((unsigned)m);
                     const int rr = m - b * rhw;
-                    const int y = rr / rw, x = rr - y * rw;
+                    const int y = (int)p.div_rw.div((unsigned)rr), x = rr - y * rw;
                     orow = ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
                 }
                 float v = acc[i][j][r];
@@ -281,7 +337,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
     reinterpret_cast<float4 *>(p.out)[i] = s;
 }
 
-template <int BM, int BN, int WGM, int WGN, int G>
+template <int BM, int BN, int WGM, int WGN, int G, bool UP>
 static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
 {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
@@ -290,12 +346,12 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
     const size_t smem = p.ktiles_per_split > G ? smem_max : smem_max / 2;
     static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
     if (smem_max > 64 * 1024 && !attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<BM, BN, WGM, WGN, G>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<BM, BN, WGM, WGN, G, UP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN, G>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
+    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN, G, UP>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
                        smem, s, p);
     return hipGetLastError();
 }
@@ -307,8 +363,9 @@ bool igemm_tile_supported(int bm, int bn)
     return false;
 }
 
-bool igemm_group_supported(int bm, int bn, int g)
+bool igemm_group_supported(int bm, int bn, int g, bool up)
 {
+    if (up) return (bm == 64 && bn == 64 && (g == 1 || g == 4)) || (bm == 32 && bn == 64 && g == 4);
     if (g == 1) return igemm_tile_supported(bm, bn);
     if (g == 2) return (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
     if (g == 4) return (bm == 64 && bn == 64) || (bm == 32 && bn == 64);
@@ -317,24 +374,36 @@ bool igemm_group_supported(int bm, int bn, int g)
 
 hipError_t igemm_init() { return hipSuccess; }
 
-hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
+hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStream_t s)
 {
+    IgemmParams p = p_in;
+    p.div_rhw = FastDiv::make((unsigned)(p.up4 ? p.Hs * p.Ws : p.Ho * p.Wo));
+    p.div_rw = FastDiv::make((unsigned)(p.up4 ? p.Ws : p.Wo));
+    // 2 GiB per tensor: buffer-load offsets are 32-bit with the top bit reserved as the OOB marker
+    const size_t lim = 0x7fffffffull;
+    if ((size_t)p.B * p.Hs * p.Ws * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > lim) return hipErrorInvalidValue;
+    if (p.up) {
+        if (bm == 64 && bn == 64 && g == 1) return launch_igemm_t<64, 64, 2, 2, 1, true>(p, s);
+        if (bm == 64 && bn == 64 && g == 4) return launch_igemm_t<64, 64, 2, 2, 4, true>(p, s);
+        if (bm == 32 && bn == 64 && g == 4) return launch_igemm_t<32, 64, 1, 2, 4, true>(p, s);
+        return hipErrorInvalidValue;
+    }
     if (g == 4) {
-        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 4>(p, s);
-        if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 4>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 4, false>(p, s);
+        if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 4, false>(p, s);
         return hipErrorInvalidValue;
     }
     if (g == 2) {
-        if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 2>(p, s);
-        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 2>(p, s);
+        if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 2, false>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 2, false>(p, s);
         return hipErrorInvalidValue;
     }
-    if (bm == 128 && bn == 128) return launch_igemm_t<128, 128, 2, 2, 1>(p, s);
-    if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 1>(p, s);
-    if (bm == 64 && bn == 128) return launch_igemm_t<64, 128, 2, 2, 1>(p, s);
-    if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 1>(p, s);
-    if (bm == 32 && bn == 128) return launch_igemm_t<32, 128, 1, 4, 1>(p, s);
-    if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 1>(p, s);
+    if (bm == 128 && bn == 128) return launch_igemm_t<128, 128, 2, 2, 1, false>(p, s);
+    if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 1, false>(p, s);
+    if (bm == 64 && bn == 128) return launch_igemm_t<64, 128, 2, 2, 1, false>(p, s);
+    if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 1, false>(p, s);
+    if (bm == 32 && bn == 128) return launch_igemm_t<32, 128, 1, 4, 1, false>(p, s);
+    if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 1, false>(p, s);
     return hipErrorInvalidValue;
 }
 
@@ -348,7 +417,9 @@ hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
 // ------------------------------------------------------------------------------------------
 // First layer.  One thread = one output pixel x 32 output channels (blockIdx.y picks the
 // channel slab).  Lanes run along ox, so the stride-2 NCHW reads of a wave cover one contiguous
-// 512-B span per (ci, ky) that all three kx taps share; weights are broadcast from LDS.
+// 512-B span per (ci, ky) that all three kx taps share; weights are broadcast from LDS.  All 9
+// taps of a channel are loaded before any FMA (9 independent loads in flight per lane; the
+// one-load-per-tap form was latency-bound at ~50 us).
 // Reference: cat (feature2face_model.py:231) + Conv2d(13, ngf, 3, 2, 1, bias=False) + ReLU
 // (networks.py:594, :603, :619 `down = [downconv, downrelu]`).
 __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
@@ -370,6 +441,16 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
     const int r = (int)(gid - (long)b * Ho * Wo);
     const int oy = r / Wo, ox = r - oy * Wo;
 
+    // tap offsets / validity are the same for every channel
+    int toff[9];
+    bool tok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+        tok[t] = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+        toff[t] = tok[t] ? iy * p.W + ix : 0;
+    }
+
     float acc[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc[j] = 0.f;
@@ -380,21 +461,17 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
         const float *src = (ci < p.feat_nc)
             ? p.feat + ((size_t)b * p.feat_nc + ci) * plane
             : p.cand + ((size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc + (ci - p.feat_nc)) * plane;
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy + ky - 1;
-#pragma unroll 1
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = 2 * ox + kx - 1;
-                const bool ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-                const float v = ok ? src[(size_t)iy * p.W + ix] : 0.f;
-                const float4 *wr = reinterpret_cast<const float4 *>(wsm + (ci * 9 + ky * 3 + kx) * 32);
+        float v[9];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 w4 = wr[j];
-                    acc[4 * j + 0] += v * w4.x; acc[4 * j + 1] += v * w4.y;
-                    acc[4 * j + 2] += v * w4.z; acc[4 * j + 3] += v * w4.w;
-                }
+        for (int t = 0; t < 9; ++t) v[t] = tok[t] ? src[toff[t]] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 *wr = reinterpret_cast<const float4 *>(wsm + (ci * 9 + t) * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 w4 = wr[j];
+                acc[4 * j + 0] += v[t] * w4.x; acc[4 * j + 1] += v[t] * w4.y;
+                acc[4 * j + 2] += v[t] * w4.z; acc[4 * j + 3] += v[t] * w4.w;
             }
         }
     }
@@ -415,55 +492,65 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------
-// Last layer.  One thread = one output pixel, all CO (<= 4) output channels; reads the
-// half-resolution NHWC sources directly (the x2 nearest upsample is the (y>>1, x>>1) gather,
-// the concat is two base pointers), weights broadcast from LDS, tanh, NCHW store (lanes run
-// along x => coalesced 256-B stores per channel plane).
+// Last layer, sub-pixel form.  Upsample(x2, nearest) + Conv3x3 over cat([src0, src1]) + tanh:
+// output parity (py, px) only sees a 2x2 neighbourhood of the half-resolution source, so the
+// packer pre-sums the aliasing taps (plan.cpp) and each output pixel costs 4 taps instead of 9.
+// One thread = one output pixel, all CO (<= 4) channels.  Threads are ordered parity-major
+// (b, py, px, y, x) with x fastest, so a wave reads 64 consecutive source pixels and all its lanes
+// use the same weights (LDS broadcast); the concat is two base pointers; NCHW store.
 // Reference: nn.Upsample(2,'nearest') + Conv2d(2*ngf, 3, 3, 1, 1, bias=False) (networks.py:610-611)
 // + torch.tanh (networks.py:577).
 template <int CO>
 __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [9][CO][Cin]
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 parities][CO][2][2][Cin]
     const int cin = p.C0 + p.C1;
-    for (int i = threadIdx.x; i < 9 * CO * cin; i += blockDim.x) wsm[i] = p.w[i];
+    for (int i = threadIdx.x; i < 16 * CO * cin; i += blockDim.x) wsm[i] = p.w[i];
     __syncthreads();
 
     const int H = 2 * p.Hs, W = 2 * p.Ws;
+    const long per_par = (long)p.Hs * p.Ws;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)p.B * H * W) return;
-    const int b = (int)(gid / ((long)H * W));
-    const int r = (int)(gid - (long)b * H * W);
-    const int y = r / W, x = r - y * W;
+    if (gid >= (long)p.B * 4 * per_par) return;
+    const int b = (int)(gid / (4 * per_par));
+    long rem = gid - (long)b * 4 * per_par;
+    const int par = (int)(rem / per_par);
+    rem -= (long)par * per_par;
+    const int y = (int)(rem / p.Ws), x = (int)(rem - (long)y * p.Ws);
+    const int py = par >> 1, px = par & 1;
 
     float acc[CO];
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[co] = 0.f;
 
-    for (int ky = 0; ky < 3; ++ky) {
-        const int uy = y + ky - 1;
-        if (uy < 0 || uy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ux = x + kx - 1;
-            if (ux < 0 || ux >= W) continue;
-            const size_t pix = ((size_t)b * p.Hs + (uy >> 1)) * p.Ws + (ux >> 1);
-            const float *wt = wsm + (ky * 3 + kx) * CO * cin;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int sy = y + a - 1 + py;
+        if (sy < 0 || sy >= p.Hs) continue;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int sx = x + bb - 1 + px;
+            if (sx < 0 || sx >= p.Ws) continue;
+            const size_t pix = ((size_t)b * p.Hs + sy) * p.Ws + sx;
+            const float *wt = wsm + ((par * CO) * 4 + a * 2 + bb) * cin;      // + co*4*cin
             const float4 *s0 = reinterpret_cast<const float4 *>(p.src0 + pix * p.C0);
+#pragma unroll 4
             for (int c4 = 0; c4 < p.C0 / 4; ++c4) {
                 const float4 v = s0[c4];
 #pragma unroll
                 for (int co = 0; co < CO; ++co) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * cin + c4 * 4);
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * 4 * cin + c4 * 4);
                     acc[co] += v.x * w4.x + v.y * w4.y + v.z * w4.z + v.w * w4.w;
                 }
             }
             if (p.C1) {
                 const float4 *s1 = reinterpret_cast<const float4 *>(p.src1 + pix * p.C1);
+#pragma unroll 4
                 for (int c4 = 0; c4 < p.C1 / 4; ++c4) {
                     const float4 v = s1[c4];
 #pragma unroll
                     for (int co = 0; co < CO; ++co) {
-                        const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * cin + p.C0 + c4 * 4);
+                        const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * 4 * cin + p.C0 + c4 * 4);
                         acc[co] += v.x * w4.x + v.y * w4.y + v.z * w4.z + v.w * w4.w;
                     }
                 }
@@ -472,14 +559,14 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
     }
 #pragma unroll
     for (int co = 0; co < CO; ++co)
-        p.out[(((size_t)b * CO + co) * H + y) * W + x] = p.apply_tanh ? tanhf(acc[co]) : acc[co];
+        p.out[(((size_t)b * CO + co) * H + 2 * y + py) * W + 2 * x + px] = p.apply_tanh ? tanhf(acc[co]) : acc[co];
 }
 
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
     const long total = (long)p.B * 4 * p.Hs * p.Ws;
     const dim3 grid((unsigned)((total + 255) / 256));
-    const size_t smem = (size_t)9 * p.Cout * (p.C0 + p.C1) * sizeof(float);
+    const size_t smem = (size_t)16 * p.Cout * (p.C0 + p.C1) * sizeof(float);
     switch (p.Cout) {
     case 1: hipLaunchKernelGGL(last_conv<1>, grid, dim3(256), smem, s, p); break;
     case 2: hipLaunchKernelGGL(last_conv<2>, grid, dim3(256), smem, s, p); break;

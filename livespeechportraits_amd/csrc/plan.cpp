@@ -10,8 +10,9 @@ static const double kBnEps = 1e-5;   // nn.BatchNorm2d default (networks.py neve
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-void choose_tiling(int M, int N, int ktiles, int par, int *bm_out, int *bn_out, int *splits_out, int *group_out)
+void choose_tiling(int M, int N, int ktiles, int par, bool up9, int *bm_out, int *bn_out, int *splits_out, int *group_out)
 {
+    // up9: the 9-tap upsample gather form is instantiated for 64x64 (G = 1, 4) and 32x64 (G = 4) only
     // par = independent GEMM slices per launch (4 output parities in sub-pixel up-conv form)
     // Candidates, largest first.  MFMA-bound fp32: big tiles cut L2->LDS traffic, but the chip has
     // 256 CUs and wants >= ~2 workgroups per CU, so shrink the tile (then split K) until the
@@ -29,6 +30,7 @@ void choose_tiling(int M, int N, int ktiles, int par, int *bm_out, int *bn_out, 
         for (int i = 0; i < 4; ++i) {
             const int bm = cand[i][0], bn = cand[i][1];
             if (bn > 64 && N < 128) continue;      // N <= 64: only the bn = 64 shapes
+            if (up9 && i != 3) continue;
             if (bm > 64 && M <= 64) continue;
             const long tiles = (long)par * ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
             best = i; best_tiles = tiles;          // ends on 64x64 (+ split-K) if nothing is wide enough
@@ -201,7 +203,7 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
         // small levels keep the 9-tap gather form.
         l.up4 = l.kind == kIgemm && l.up && l.ho >= kUp4MinExtent;
         if (l.up4) l.up = false;
-        off += (size_t)l.cout * l.cin * (l.up4 ? 16 : 9) * sizeof(float);
+        off += (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9) * sizeof(float);
         if (!l.bnkey.empty()) {
             off = align_up(off, 256);
             l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
@@ -290,7 +292,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             int bm, bn, splits, group;
             const int Mout = batch * l.ho * l.ho;
             const int M = l.up4 ? batch * l.hs * l.hs : Mout;
-            choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / 32, l.up4 ? 4 : 1, &bm, &bn, &splits, &group);
+            choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / 32, l.up4 ? 4 : 1, l.up, &bm, &bn, &splits, &group);
             if (tiled) { (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group; }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }
@@ -330,7 +332,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
         const float *W = get(l.wkey).data.data();           // OIHW
         float *dst = reinterpret_cast<float *>(base + l.w_off);
         const int cin = l.cin, cout = l.cout;
-        if (l.kind == kIgemm && l.up4) {
+        if ((l.kind == kIgemm && l.up4) || l.kind == kLastConv) {
             // sub-pixel form of Upsample(x2, nearest) + Conv3x3: output parity (py, px) only ever
             // sees 2x2 distinct source pixels, so the 3x3 taps that alias onto the same source
             // pixel are pre-summed (in double, rounded once):
@@ -362,12 +364,6 @@ std::string Plan::pack(void *blob, size_t bytes) const
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < 9; ++t)
                         dst[((size_t)ci * 9 + t) * cout + co] = W[((size_t)co * cin + ci) * 9 + t];
-        } else {
-            // [tap][co][ci]
-            for (int co = 0; co < cout; ++co)
-                for (int ci = 0; ci < cin; ++ci)
-                    for (int t = 0; t < 9; ++t)
-                        dst[((size_t)t * cout + co) * cin + ci] = W[((size_t)co * cin + ci) * 9 + t];
         }
         if (!l.bnkey.empty()) {
             // eval-mode BatchNorm2d folded to y = x*scale + shift, applied AFTER accumulation

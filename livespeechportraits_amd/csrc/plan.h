@@ -73,7 +73,7 @@ struct Plan {
 };
 
 // tile / split-K heuristic shared by the planner and lspf2f_conv3x3
-void choose_tiling(int M, int N, int ktiles, int par, int *bm, int *bn, int *splits, int *group);
+void choose_tiling(int M, int N, int ktiles, int par, bool up9, int *bm, int *bn, int *splits, int *group);
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 
 }  // namespace lspf2f

@@ -98,7 +98,8 @@ CASES = [
 ]
 for tm, tn in [(128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64)]:
     CASES.append((1, 64, 32, 160, 20, 1, False, True, True, True, (tm, tn), 1))   # ragged everything
-    CASES.append((1, 96, 0, 128, 12, 1, True, True, False, True, (tm, tn), 3))    # forced split-K
+    up_ok = (tm, tn) == (64, 64)   # the 9-tap gather form is instantiated for 64x64 / 32x64(g4) only
+    CASES.append((1, 96, 0, 128, 12, 1, up_ok, True, False, True, (tm, tn), 3))   # forced split-K
     CASES.append((2, 64, 0, 64, 18, 2, False, False, False, False, (tm, tn), 2))
 
 
@@ -107,7 +108,7 @@ for tm, tn in [(128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64)]:
 GROUP_CASES = []
 for (tm, tn), g in [((128, 64), 2), ((64, 64), 2), ((64, 64), 4), ((32, 64), 4)]:
     GROUP_CASES.append((1, 64, 32, 96, 10, 1, False, True, True, True, (tm, tn), 1, g))   # 27 tiles, 1 split
-    GROUP_CASES.append((1, 64, 0, 64, 6, 1, True, True, False, True, (tm, tn), 5, g))     # 18 tiles / 5 splits = 4,4,4,4,2
+    GROUP_CASES.append((1, 64, 0, 64, 6, 1, g == 4, True, False, True, (tm, tn), 5, g))   # 18 tiles / 5 splits = 4,4,4,4,2
     GROUP_CASES.append((1, 128, 0, 64, 4, 2, False, False, False, False, (tm, tn), 9, g))  # 36 tiles / 9 = 4 each: single step
 
 

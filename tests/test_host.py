@@ -115,9 +115,7 @@ def test_pack_weights_matches_numpy_restatement():
         n = c.cin * c.cout
         if l["kernel"] == "first_conv":
             exp = w.transpose(1, 2, 3, 0).reshape(-1)                # [ci][ky][kx][co]
-        elif l["kernel"] == "last_conv":
-            exp = w.transpose(2, 3, 0, 1).reshape(-1)                # [ky][kx][co][ci]
-        elif l["weight_bytes"] == 16 * n * 4:                        # sub-pixel up-conv
+        elif l["weight_bytes"] == 16 * n * 4:                        # sub-pixel up-conv (incl. the last layer)
             seen_sub = True
             grp = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}
             exp = np.zeros((4, c.cout, 2, 2, c.cin))
