@@ -13,6 +13,8 @@
 // :575-579 (tanh); BatchNorm eval folding validated in SURVEY.md 8c.
 #include "kernels.h"
 
+#include <cstdlib>
+
 #ifndef LSPF2F_SWP
 #define LSPF2F_SWP 1   // 1: LDS fragment reads issued one step ahead of the MFMAs
 #endif
@@ -456,14 +458,25 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
     for (int j = 0; j < 32; ++j) acc[j] = 0.f;
 
     const size_t plane = (size_t)p.H * p.W;
-#pragma unroll 1
-    for (int ci = 0; ci < cin; ++ci) {
-        const float *src = (ci < p.feat_nc)
+    auto plane_of = [&](int ci) -> const float * {
+        return (ci < p.feat_nc)
             ? p.feat + ((size_t)b * p.feat_nc + ci) * plane
             : p.cand + ((size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc + (ci - p.feat_nc)) * plane;
-        float v[9];
+    };
+    // the 9 taps of channel ci+1 are in flight while channel ci is multiplied
+    float v[9], vn[9];
+    {
+        const float *src = plane_of(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) v[t] = tok[t] ? src[toff[t]] : 0.f;
+    }
+#pragma unroll 1
+    for (int ci = 0; ci < cin; ++ci) {
+        if (ci + 1 < cin) {
+            const float *src = plane_of(ci + 1);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) vn[t] = tok[t] ? src[toff[t]] : 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float4 *wr = reinterpret_cast<const float4 *>(wsm + (ci * 9 + t) * 32);
@@ -474,6 +487,8 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
                 acc[4 * j + 2] += v[t] * w4.z; acc[4 * j + 3] += v[t] * w4.w;
             }
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = vn[t];
     }
     float4 *o = reinterpret_cast<float4 *>(p.out + (size_t)gid * p.Cout + co0);
 #pragma unroll
@@ -562,19 +577,158 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
         p.out[(((size_t)b * CO + co) * H + 2 * y + py) * W + 2 * x + px] = p.apply_tanh ? tanhf(acc[co]) : acc[co];
 }
 
+// Fast path of the last layer for C0 == C1 <= 64*NCH: the 16 lanes of a DPP row share one output
+// pixel and split its input channels (lane j owns channels 4j..4j+3 of every 64-channel slab), so a
+// wave's load of 4 neighbouring pixels is one contiguous 1-KB read, the 4-tap x CO weights of the
+// wave's parity live in registers for the whole kernel, and the channel reduction is 4 DPP row
+// rotations per output.  Waves are persistent over pixel quads of ONE parity (wave id & 3).
+template <int CO, int NCH>
+__global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, sub = lane >> 4;               // channel slot, pixel within the quad
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int par = wave & 3, py = par >> 1, px = par & 1;
+    const int cin = p.C0 + p.C1;
+    const int H = 2 * p.Hs, W = 2 * p.Ws;
+
+    // weights of this parity: w[src][chunk][tap][co] as float4 over the lane's 4 channels
+    float4 w[2][NCH][4][CO];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = (c * 16 + j) * 4;                 // channel inside the source
+            const bool okc = ch < (sidx ? p.C1 : p.C0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int co = 0; co < CO; ++co)
+                    w[sidx][c][t][co] = okc
+                        ? *reinterpret_cast<const float4 *>(p.w + ((size_t)(par * CO + co) * 4 + t) * cin + (sidx ? p.C0 : 0) + ch)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+
+    // Each wave owns a contiguous run of pixel quads of its parity (coordinates advance
+    // incrementally: no per-iteration division) and keeps the NEXT quad's 8*NCH loads in flight
+    // while it multiplies the current one (the per-quad chain load -> FMA -> DPP -> store is
+    // otherwise latency-bound).
+    const int qpr = (p.Ws + 3) / 4;                          // quads per source row
+    const unsigned nquads = (unsigned)p.B * p.Hs * qpr;
+    const unsigned wpp = (unsigned)nwaves >> 2;              // waves per parity
+    const unsigned chunk = (nquads + wpp - 1) / wpp;
+    unsigned q = (unsigned)(wave >> 2) * chunk;
+    const unsigned qend = q + chunk < nquads ? q + chunk : nquads;
+    if (q >= qend) return;
+    int b = (int)(q / ((unsigned)p.Hs * qpr));
+    int y, xq;
+    { const unsigned r = q - (unsigned)b * p.Hs * qpr; y = (int)(r / qpr); xq = (int)(r - (unsigned)y * qpr); }
+
+    const float *__restrict__ s0 = p.src0;
+    const float *__restrict__ s1 = p.src1;
+    float *__restrict__ outp = p.out;
+
+    float4 v[2][2][4][NCH];                                  // [buffer][src][tap][chunk]
+    auto issue = [&](int buf, int bq, int yq, int xqq) {
+        const int x = xqq * 4 + sub;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sy = yq + (t >> 1) - 1 + py, sx = x + (t & 1) - 1 + px;
+            const bool ok = (x < p.Ws) & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
+            const size_t pix = ok ? ((size_t)bq * p.Hs + sy) * p.Ws + sx : 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = (c * 16 + j) * 4;
+                v[buf][0][t][c] = (ok && ch < p.C0) ? *reinterpret_cast<const float4 *>(s0 + pix * p.C0 + ch)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[buf][1][t][c] = (ok && ch < p.C1) ? *reinterpret_cast<const float4 *>(s1 + pix * p.C1 + ch)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto consume = [&](int buf, int bq, int yq, int xqq) {
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float4 x4 = v[buf][sidx][t][c];
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float4 ww = w[sidx][c][t][co];
+                        acc[co] += x4.x * ww.x + x4.y * ww.y + x4.z * ww.z + x4.w * ww.w;
+                    }
+                }
+        // sum over the 16 channel slots of the row: rotate-and-add (row_ror 8, 4, 2, 1)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float r = acc[co];
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x128, 0xf, 0xf, false));
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x124, 0xf, 0xf, false));
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x122, 0xf, 0xf, false));
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x121, 0xf, 0xf, false));
+            acc[co] = r;
+        }
+        const int x = xqq * 4 + sub;
+        if (j < CO && x < p.Ws) {
+            float r = acc[0];
+#pragma unroll
+            for (int co = 1; co < CO; ++co) r = (j == co) ? acc[co] : r;
+            outp[(((size_t)bq * CO + j) * H + 2 * yq + py) * W + 2 * x + px] = p.apply_tanh ? tanhf(r) : r;
+        }
+    };
+    auto advance = [&](int &bq, int &yq, int &xqq) {
+        if (++xqq == qpr) { xqq = 0; if (++yq == p.Hs) { yq = 0; ++bq; } }
+    };
+
+    issue(0, b, y, xq);
+    for (; q < qend; q += 2) {
+        int b1 = b, y1 = y, x1 = xq;
+        advance(b1, y1, x1);
+        const bool has1 = q + 1 < qend;
+        if (has1) issue(1, b1, y1, x1);
+        consume(0, b, y, xq);
+        int b2 = b1, y2 = y1, x2 = x1;
+        advance(b2, y2, x2);
+        if (q + 2 < qend) issue(0, b2, y2, x2);
+        if (has1) consume(1, b1, y1, x1);
+        b = b2; y = y2; xq = x2;
+    }
+}
+
+template <int CO>
+static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
+{
+    const long quads = (long)p.B * p.Hs * ((p.Ws + 3) / 4);
+    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 128 && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
+        // 4 parities x quads wave-iterations; 4 waves per block, parity = wave & 3
+        long blocks = (quads + 7) / 8;                      // ~8 quads per wave
+        if (blocks > 512) blocks = 512;                     // 2 blocks (8 waves) per CU, all resident
+        if (blocks < 1) blocks = 1;
+        if (p.C0 <= 64) hipLaunchKernelGGL((last_conv_rows<CO, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((last_conv_rows<CO, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    const long total = (long)p.B * 4 * p.Hs * p.Ws;
+    const size_t smem = (size_t)16 * p.Cout * (p.C0 + p.C1) * sizeof(float);
+    hipLaunchKernelGGL(last_conv<CO>, dim3((unsigned)((total + 255) / 256)), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
-    const long total = (long)p.B * 4 * p.Hs * p.Ws;
-    const dim3 grid((unsigned)((total + 255) / 256));
-    const size_t smem = (size_t)16 * p.Cout * (p.C0 + p.C1) * sizeof(float);
     switch (p.Cout) {
-    case 1: hipLaunchKernelGGL(last_conv<1>, grid, dim3(256), smem, s, p); break;
-    case 2: hipLaunchKernelGGL(last_conv<2>, grid, dim3(256), smem, s, p); break;
-    case 3: hipLaunchKernelGGL(last_conv<3>, grid, dim3(256), smem, s, p); break;
-    case 4: hipLaunchKernelGGL(last_conv<4>, grid, dim3(256), smem, s, p); break;
+    case 1: return launch_last_conv_co<1>(p, s);
+    case 2: return launch_last_conv_co<2>(p, s);
+    case 3: return launch_last_conv_co<3>(p, s);
+    case 4: return launch_last_conv_co<4>(p, s);
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 }  // namespace lspf2f
