@@ -23,16 +23,65 @@ namespace lspf2f {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS ring depth of the igemm pipeline (2; 3 if built with -DLSPF2F_STAGES=3 and it leaves >= 2 workgroups per CU)
+#ifndef LSPF2F_STAGES
+#define LSPF2F_STAGES 2   // measured: ring depth 3 is ~1 % slower than 2 on MI355X (DMA latency is not the limiter)
+#endif
+__host__ __device__ constexpr int igemm_stages(int bm, int bn, int g)
+{
+    return (LSPF2F_STAGES >= 3 && 3 * g * (bm + bn) * 128 <= 80 * 1024) ? 3 : 2;
+}
 static constexpr unsigned kOOB = 0x80000000u;   // voffset beyond any num_records: buffer load returns 0
 
 static constexpr int BK = 32;    // K-tile (floats); Cin % 32 == 0 so a K-tile never straddles a tap
-static constexpr int LDK = 36;   // LDS row pitch in floats: 144 B makes the 16 rows of a
-                                 // ds_read_b128 lane group hit 16 distinct 16-B bank slots
+static constexpr int LDK = 32;   // LDS row pitch in floats (128 B, unpadded: the tile is written by LDS-DMA,
+                                 // whose destination is lane-linear).  Bank conflicts are avoided by an XOR
+                                 // swizzle instead: 16-B slot s of row r holds k-quad s ^ ((r >> 1) & 7), which
+                                 // puts the 16 rows of every ds_read_b128 lane group on 16 distinct bank slots.
 
 // G = K-tiles staged per pipeline step (one barrier per G tiles, G tiles of global loads in
 // flight per thread).  G = 1 for long K loops; G = 4 turns a short split-K range (<= 4 tiles)
 // into a single load -> LDS -> MFMA pass, which is what the latency-bound <= 8x8 levels need.
 // UP = the 9-tap nearest-x2 gather form (only the small, weight-streaming up-convs use it).
+// buffer resource descriptor (raw buffer, stride 0) from wave-uniform values
+__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// One LDS-DMA piece: 64 lanes x 16 B -> LDS[lds_addr + lane*16]; out-of-range voffset lands as zeros.
+// Issued from inline asm on purpose: a compiler-visible LDS-DMA makes hipcc wait vmcnt(0) before the
+// next ds_read (it cannot disambiguate LDS addresses), which serialises the copy with the MFMAs.  The
+// kernel waits for its DMAs itself (dma_wait) right before the barrier that publishes the buffer.
+// M0 is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 srd, int soff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 4\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+                 : "memory");
+}
+// wait until at most N of this wave's DMA pieces are still in flight (they complete in order)
+template <int N>
+__device__ __forceinline__ void dma_wait()
+{
+    __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs issued so far ABOVE the wait (they cover the copy)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int BM, int BN, int WGM, int WGN, int G, bool UP>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams p)
 {
@@ -45,7 +94,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // double-buffered unless the whole K range fits one step
-    const int nbuf = p.ktiles_per_split > G ? 2 : 1;
+    // LDS ring of NS pipeline steps (1 when the whole K range fits one step).  With LDS-DMA a deeper
+    // ring costs no registers, so the copy of step t+2 is in flight while step t is multiplied.
+    constexpr int NS = igemm_stages(BM, BN, G);
+    const int nbuf = p.ktiles_per_split > G ? NS : 1;
     float *As = smem;                          // [nbuf][G][BM][LDK]
     float *Bs = smem + nbuf * G * TILE_A;      // [nbuf][G][BN][LDK]
 
@@ -69,7 +121,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
 
     const int lrow = tid >> 3;
-    const int lq = (tid & 7) * 4;
+    // staging: thread = (row lrow of each 8-row wave stripe, 16-B slot tid&7); it fetches the k-quad that
+    // belongs in its slot
+    const int lq = ((tid & 7) ^ ((lrow >> 1) & 7)) * 4;
 
     // ---- per-thread im2col row descriptors (fixed for the whole K loop) ----
     // a_pix0: pixel index of tap (0,0) (may be "negative" at the border -- only used when the
@@ -122,8 +176,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
         b_off[i] = (n < p.Cout) ? (unsigned)(n * K + lq) * 4u : kOOB;
     }
     const unsigned plane = (unsigned)(p.B * p.Hs * p.Ws) * 4u;
-    const __amdgpu_buffer_rsrc_t rsw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, p.Cout * K * 4, 0x00020000);
+    const i32x4 rsw = make_srd(wbase, (unsigned)(p.Cout * K) * 4u);
 
     // K-tile cursor of the NEXT tile to fetch: tap = ky*tw+kx, c = channel offset inside the
     // concatenated input
@@ -131,9 +184,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     int c = kt_begin * BK - tap * p.Cin;
     int ky = tap / tw, kx = tap - ky * tw;
 
-    u32x4 ra[G][PA], rb[G][PB];
-    // fetch K-tiles kt .. kt+G-1 into registers (tiles at or past kt_end read as zero)
-    auto fetch = [&](int kt) {
+    // Stage K-tiles kt .. kt+G-1 into LDS buffer `buf` with buffer_load ... lds (LDS-DMA): no staging
+    // registers, no ds_write; invalid taps / ragged rows use an out-of-range voffset and land as zeros
+    // (tools/probes/lds_dma_probe.hip verifies both properties on gfx950).  One instruction moves the
+    // 8 rows x 128 B stripe of this wave: destination = wave-uniform base + lane * 16.
+    typedef __attribute__((address_space(3))) float lds_float;
+    const int wstripe = __builtin_amdgcn_readfirstlane((tid >> 6) * 8);   // first row of this wave's stripe in a pass
+    const unsigned lds_a = (unsigned)(unsigned long long)(lds_float *)As;   // LDS byte addresses
+    const unsigned lds_b = (unsigned)(unsigned long long)(lds_float *)Bs;
+    auto fetch = [&](int kt, int buf) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const bool live = kt + g < kt_end;
@@ -141,21 +200,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
             const float *sp = first ? p.src0 : p.src1;
             const int cs = first ? p.C0 : p.C1;
             const int soff = (first ? c : c - p.C0) * 4;
-            const __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sp), 0, (int)(plane * (unsigned)cs), 0x00020000);
+            const i32x4 rs = make_srd(sp, plane * (unsigned)cs);
             const int tapdelta = ky * p.Ws + kx;
             const unsigned csb = (unsigned)cs * 4u;
+            const unsigned A = lds_a + (unsigned)(((buf * G + g) * TILE_A + wstripe * LDK) * 4);
+            const unsigned Bq = lds_b + (unsigned)(((buf * G + g) * TILE_B + wstripe * LDK) * 4);
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 const bool ok = live && ((a_mask[i] >> tap) & 1u);
                 const int pix = UP ? a_pix0[i] + ((a_oy[i] + ky) >> 1) * p.Ws + ((a_ox[i] + kx) >> 1)
                                    : a_pix0[i] + tapdelta;
                 const unsigned voff = ok ? (unsigned)pix * csb + (unsigned)lq * 4u : kOOB;
-                ra[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+                dma16(A + i * RPP * LDK * 4, voff, rs, soff);
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                rb[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, live ? b_off[i] : kOOB, (kt + g) * (BK * 4), 0);
+                dma16(Bq + i * RPP * LDK * 4, live ? b_off[i] : kOOB, rsw, (kt + g) * (BK * 4));
             if (live) {
                 c += BK;
                 if (c == p.Cin) {
@@ -163,18 +223,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
                     if (kx == tw) { kx = 0; ++ky; }
                 }
             }
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float *A = As + (buf * G + g) * TILE_A, *Bq = Bs + (buf * G + g) * TILE_B;
-#pragma unroll
-            for (int i = 0; i < PA; ++i)
-                *reinterpret_cast<u32x4 *>(A + (i * RPP + lrow) * LDK + lq) = ra[g][i];
-#pragma unroll
-            for (int i = 0; i < PB; ++i)
-                *reinterpret_cast<u32x4 *>(Bq + (i * RPP + lrow) * LDK + lq) = rb[g][i];
         }
     };
 
@@ -189,7 +237,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     // fragment addressing: lane l supplies row (l&31), k-quad (l>>5) of each 8-wide k group.
     // The MFMA's k index (l>>5) then pairs k and k+4 -- any K permutation is fine as long as
     // A and B use the same one.
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    const int frow = lane & 31;
+    const int fsw = (lane >> 5) ^ ((frow >> 1) & 7);   // (k-quad low bit) ^ row swizzle; tile offsets are multiples of 32 rows
     // One "fragment step" = 8 k of one K-tile: TM + TN ds_read_b128, then TM*TN*4 MFMAs.  Fragment
     // registers are double-buffered so the LDS reads of step s+1 are issued BEFORE the MFMAs of step s
     // (an in-order wave otherwise exposes the full LDS latency once per step).
@@ -197,8 +246,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     float4 fa[2][TM], fb[2][TN];
     auto read_frag = [&](int buf, int s, int set) {
         const int g = s / (BK / 8), kb = s % (BK / 8);
-        const float *A = As + (buf * G + g) * TILE_A + (wm * TM * 32 + frow) * LDK + fk + kb * 8;
-        const float *Bq = Bs + (buf * G + g) * TILE_B + (wn * TN * 32 + frow) * LDK + fk + kb * 8;
+        const int qoff = ((kb * 2) ^ fsw) * 4;         // swizzled slot of k-quad kb*2 + (lane>>5)
+        const float *A = As + (buf * G + g) * TILE_A + (wm * TM * 32 + frow) * LDK + qoff;
+        const float *Bq = Bs + (buf * G + g) * TILE_B + (wn * TN * 32 + frow) * LDK + qoff;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(A + i * 32 * LDK);
 #pragma unroll
@@ -221,36 +271,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     //   | registers -> LDS buffer cur^1 (its latency hides behind the last MFMA block)
     //   | last MFMA block | barrier | first fragment read of step t+1 (hidden behind the next fetch).
     if (kt_begin < kt_end && !(p.dbg & 32)) {
-        fetch(kt_begin);
-        stage(0);
+        constexpr int PIECES = G * (PA + PB);      // DMA instructions this wave issues per step
+        const int nsteps = (kt_end - kt_begin + G - 1) / G;
+        fetch(kt_begin, 0);
+        if (NS > 2 && nsteps > 1) fetch(kt_begin + G, 1);
+        if (NS > 2 && nsteps > 1) dma_wait<PIECES>(); else dma_wait<0>();
         __syncthreads();
         int cur = 0;
         read_frag(0, 0, 0);
-        for (int kt = kt_begin; kt < kt_end; kt += G) {
-            const bool more = kt + G < kt_end;
-            if (!(p.dbg & 1)) fetch(kt + G);   // past-the-end tiles are all-OOB loads: no traffic, no branch
-#if LSPF2F_SWP
+        for (int t = 0; t < nsteps; ++t) {
+            // ring slot (cur + NS-1) % NS was last read in step t-1; every wave has passed that barrier
+            const int ahead = t + NS - 1;
+            const bool issue = ahead < nsteps && !(p.dbg & 1);
+            int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
+            if (issue) fetch(kt_begin + ahead * G, slot);
 #pragma unroll
             for (int s = 0; s < S - 1; ++s) {
                 read_frag(cur, s + 1, (s + 1) & 1);
                 mfma_frag(s & 1);
             }
-            if (more && !(p.dbg & 2)) stage(cur ^ 1);
             mfma_frag((S - 1) & 1);
+            // step t+1 must have landed: everything but the pieces issued in THIS iteration
+            if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
             if (!(p.dbg & 4)) __syncthreads();
-            if (!(p.dbg & 8)) cur ^= 1;
-            if (more) read_frag(cur, 0, 0);
-#else
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (s) read_frag(cur, s, s & 1);
-                mfma_frag(s & 1);
-            }
-            if (more && !(p.dbg & 2)) stage(cur ^ 1);
-            if (!(p.dbg & 4)) __syncthreads();
-            if (!(p.dbg & 8)) cur ^= 1;
-            if (more) read_frag(cur, 0, 0);
-#endif
+            if (!(p.dbg & 8)) { if (++cur == NS) cur = 0; }
+            if (t + 1 < nsteps) read_frag(cur, 0, 0);
         }
     }
 
@@ -344,8 +389,9 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
 {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
     const int npar = p.up4 ? 4 : 1;
-    constexpr size_t smem_max = (size_t)2 * G * (BM + BN) * LDK * sizeof(float);
-    const size_t smem = p.ktiles_per_split > G ? smem_max : smem_max / 2;
+    constexpr size_t smem_one = (size_t)G * (BM + BN) * LDK * sizeof(float);
+    constexpr size_t smem_max = smem_one * igemm_stages(BM, BN, G);
+    const size_t smem = p.ktiles_per_split > G ? smem_max : smem_one;
     static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
     if (smem_max > 64 * 1024 && !attr_done) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<BM, BN, WGM, WGN, G, UP>),
