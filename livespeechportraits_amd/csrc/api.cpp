@@ -193,7 +193,7 @@ static const char *kernel_name(const LayerDesc &l)
     switch (l.kind) {
     case kFirstConv: return "first_conv";
     case kLastConv: return "last_conv";
-    default: return l.splits > 1 ? "igemm3x3_f32+splitk_reduce" : "igemm3x3_f32";
+    default: return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3_f32+splitk_reduce" : "igemm3x3_f32");
     }
 }
 
@@ -236,6 +236,13 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.out = out;
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out;
         e = launch_last_conv(p, s);
+    } else if (l.smallm) {
+        SmallMParams p{};
+        p.src = tptr(l.src0); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.Cin = l.cin; p.Cout = l.cout;
+        p.stride = l.stride; p.up = l.up; p.relu = l.relu; p.M = batch * l.ho * l.ho;
+        e = launch_smallm(p, s);
     } else {
         IgemmParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off);
@@ -391,6 +398,20 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
     if ((scale == nullptr) != (shift == nullptr)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "scale and shift come together");
     hipError_t e = ensure_init();
     if (e != hipSuccess) return hipfail(e, "kernel attribute setup");
+    {
+        // tile 1x1 forces the tiny-M single-launch kernel; tile 0x0 lets the planner's rule pick it
+        SmallMParams q{};
+        q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
+        q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs); q.Wo = q.Ho;
+        q.Cin = c0; q.Cout = cout; q.stride = stride; q.up = upsample == 1; q.relu = relu; q.M = batch * q.Ho * q.Wo;
+        const bool want = (tile_m == 1 && tile_n == 1) || (tile_m == 0 && tile_n == 0 && split_k == 0);
+        if (want && c1 == 0 && upsample != 2 && smallm_supported(q)) {
+            e = launch_smallm(q, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (tiny-M) launch");
+            return LSPF2F_OK;
+        }
+        if (tile_m == 1 && tile_n == 1) return fail(LSPF2F_ERR_UNSUPPORTED, "tiny-M kernel does not support this shape");
+    }
     IgemmParams p{};
     p.src0 = src0; p.src1 = c1 ? src1 : nullptr; p.w = w_packed; p.scale = scale; p.shift = shift;
     p.residual = residual; p.out = out;

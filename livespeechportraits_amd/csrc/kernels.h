@@ -65,6 +65,19 @@ bool igemm_group_supported(int bm, int bn, int g, bool up);
 hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t s);
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s);
 
+// Tiny-M single-source conv (M <= 16 output pixels, whole input <= 64 KB): one launch, no split-K.
+struct SmallMParams {
+    const float *src;            // NHWC [B][Hs][Ws][Cin]
+    const float *w;              // [Cout][9][Cin]
+    const float *scale, *shift;  // [Cout] or nullptr
+    const float *residual;       // [M][Cout] or nullptr
+    float *out;                  // [M][Cout]
+    int B, Hs, Ws, Ho, Wo, Cin, Cout;
+    int stride, up, relu, M;
+};
+bool smallm_supported(const SmallMParams &p);
+hipError_t launch_smallm(const SmallMParams &p, hipStream_t s);
+
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
 struct FirstConvParams {
     const float *feat;   // [B][feat_nc][H][W]

@@ -293,7 +293,12 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             const int Mout = batch * l.ho * l.ho;
             const int M = l.up4 ? batch * l.hs * l.hs : Mout;
             choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / 32, l.up4 ? 4 : 1, l.up, &bm, &bn, &splits, &group);
-            if (tiled) { (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group; }
+            const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
+            if (smallm) { bm = bn = 1; splits = 1; group = 1; }
+            if (tiled) {
+                (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
+                (*tiled)[li].smallm = smallm;
+            }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }
     }

@@ -38,6 +38,7 @@ struct LayerDesc {
     int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
     // per-batch tiling decision
     int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
+    bool smallm = false;   // executed by the single-launch tiny-M kernel (M <= 16) instead of the igemm
 };
 
 struct ParamDesc {         // an expected state-dict entry
@@ -74,6 +75,11 @@ struct Plan {
 
 // tile / split-K heuristic shared by the planner and lspf2f_conv3x3
 void choose_tiling(int M, int N, int ktiles, int par, bool up9, int *bm, int *bn, int *splits, int *group);
+// tiny-M kernel eligibility (mirrors smallm_supported() in kernels.hip)
+inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes)
+{
+    return M <= 16 && c1 == 0 && cin % 256 == 0 && 9 * (cin / 4) <= 5 * 256 && in_bytes <= 64 * 1024 && cout % 2 == 0;
+}
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 
 }  // namespace lspf2f

@@ -129,6 +129,44 @@ def test_conv3x3_k_groups(cfg, gpu_device):
     assert (got - ref).abs().max().item() <= 2e-5
 
 
+TINY_CASES = [
+    # b, cin, cout, hs, stride, up, bn, res, relu     (tile 1x1 = the single-launch tiny-M kernel)
+    (1, 512, 512, 4, 1, False, True, True, True),     # L6 res conv b
+    (1, 512, 512, 2, 1, False, True, False, True),    # L7 res conv a (2x2: every tap row/col hits padding)
+    (1, 512, 512, 4, 2, False, False, False, True),   # L7.down (4 -> 2, no BN)
+    (1, 512, 512, 2, 1, True, True, False, True),     # L7.up (9-tap nearest-x2 gather, 2 -> 4)
+    (2, 256, 64, 2, 1, False, True, True, False),     # batch folded into M (8 pixels), Cin 256, no ReLU
+    (4, 256, 96, 2, 1, False, False, False, False),   # M = 16 exactly, Cout not a multiple of 64
+    (1, 256, 36, 1, 1, True, True, False, True),      # 1x1 source upsampled to 2x2
+]
+
+
+@pytest.mark.parametrize("cfg", TINY_CASES, ids=lambda c: "b%d_c%d_o%d_h%d_s%d_up%d_bn%d_res%d_relu%d" % c)
+def test_conv3x3_tiny_m_kernel(cfg, gpu_device):
+    b, cin, cout, hs, stride, up, bn, res, relu = cfg
+    x0 = rnd(b, cin, hs, hs, seed=31)
+    w = rnd(cout, cin, 3, 3, seed=33) * 0.05
+    scale = rnd(cout, seed=34) * 0.5 + 1.0 if bn else None
+    shift = rnd(cout, seed=35) * 0.1 if bn else None
+    ho = 2 * hs if up else (hs + stride - 1) // stride
+    r = rnd(b, cout, ho, ho, seed=36) if res else None
+    got = run_conv(gpu_device, x0, None, w, scale, shift, r, stride, int(up), relu, (1, 1))
+    ref = ref_conv(x0, None, w, scale, shift, r, stride, up, relu)
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2e-5
+    # the MFMA path computes the same thing
+    mf = run_conv(gpu_device, x0, None, w, scale, shift, r, stride, int(up), relu, (32, 64), 0, 4)
+    assert (got - mf).abs().max().item() <= 2e-5
+
+
+def test_conv3x3_tiny_m_rejects_unsupported(gpu_device):
+    from livespeechportraits_amd import _native as N
+    with pytest.raises(N.Lspf2fError):      # 8x8 output = 64 pixels > 16
+        run_conv(gpu_device, rnd(1, 256, 8, 8), None, rnd(64, 256, 3, 3), None, None, None, 1, 0, False, (1, 1))
+    with pytest.raises(N.Lspf2fError):      # Cin not a multiple of 256
+        run_conv(gpu_device, rnd(1, 128, 2, 2), None, rnd(64, 128, 3, 3), None, None, None, 1, 0, False, (1, 1))
+
+
 SUBPIXEL_CASES = [
     # b, c0, c1, cout, hs, tile, split, group
     (1, 64, 64, 64, 16, (0, 0), 0, 0),        # concat up-conv, planner's choice
