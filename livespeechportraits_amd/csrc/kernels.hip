@@ -299,36 +299,55 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
         }
     }
 
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int ccol = lane & 31, crow = 4 * (lane >> 5);
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5),
+    // i.e. a lane owns 16 rows of ONE column -- storing that directly means 4-byte accesses.  Each
+    // wave instead transposes its 32x32 tile through a private 4.5-KB LDS patch (the K-loop buffers
+    // are free after the last barrier) so every lane ends up with 4 consecutive channels of a row:
+    // float4 residual loads / stores, 8 lanes per 128-B row segment, 4 instead of 16 memory
+    // instructions per tile.  Same-wave LDS traffic needs no barrier (a wave's DS ops execute in order).
     if (p.dbg & 16) return;
+    constexpr int EP = 36;                                   // patch row pitch (floats), keeps rows 16-B aligned
+    float *patch = smem + wave * (32 * EP);
+    const int ccol = lane & 31, crow = 4 * (lane >> 5);
+    const int erow = lane >> 3, ecol = (lane & 7) * 4;      // this lane's (row within 8-row pass, first channel)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + ccol;
-        if (n >= p.Cout) continue;
-        float sc = 1.f, sh = 0.f;
-        if (p.splits == 1 && p.scale) { sc = p.scale[n]; sh = p.shift[n]; }
+        const int nb = n0 + (wn * TN + j) * 32;              // first channel of the tile
+        const int n = nb + ecol;
+        const bool nok = n < p.Cout;                         // Cout % 4 == 0: a float4 is all-in or all-out
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.splits == 1 && p.scale && nok) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + n);
+            sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + crow;
-                if (m >= p.M) continue;
-                size_t orow = (size_t)m;          // output pixel index (NHWC row)
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + crow) * EP + ccol] = acc[i][j][r];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + erow;
+                float4 v = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                if (m >= p.M || !nok) continue;
+                size_t orow = (size_t)m;                     // output pixel index (NHWC row)
                 if (p.up4) {
                     const int b = (int)p.div_rhw.div((unsigned)m);
                     const int rr = m - b * rhw;
                     const int y = (int)p.div_rw.div((unsigned)rr), x = rr - y * rw;
                     orow = ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
                 }
-                float v = acc[i][j][r];
                 if (p.splits > 1) {
-                    p.partial[((size_t)z * p.Mout + orow) * p.Cout + n] = v;
+                    *reinterpret_cast<float4 *>(p.partial + ((size_t)z * p.Mout + orow) * p.Cout + n) = v;
                 } else {
-                    v = v * sc + sh;
-                    if (p.residual) v += p.residual[orow * p.Cout + n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[orow * p.Cout + n] = v;
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (p.residual) {
+                        const float4 rv = *reinterpret_cast<const float4 *>(p.residual + orow * p.Cout + n);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4 *>(p.out + orow * p.Cout + n) = v;
                 }
             }
         }
@@ -391,7 +410,9 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
     const int npar = p.up4 ? 4 : 1;
     constexpr size_t smem_one = (size_t)G * (BM + BN) * LDK * sizeof(float);
     constexpr size_t smem_max = smem_one * igemm_stages(BM, BN, G);
-    const size_t smem = p.ktiles_per_split > G ? smem_max : smem_one;
+    constexpr size_t smem_patch = (size_t)WGM * WGN * 32 * 36 * sizeof(float);   // epilogue transpose patches
+    size_t smem = p.ktiles_per_split > G ? smem_max : smem_one;
+    if (smem < smem_patch) smem = smem_patch;
     static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
     if (smem_max > 64 * 1024 && !attr_done) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<BM, BN, WGM, WGN, G, UP>),
