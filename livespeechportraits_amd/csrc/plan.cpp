@@ -12,48 +12,37 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 void choose_tiling(int M, int N, int ktiles, int par, bool up9, int *bm_out, int *bn_out, int *splits_out, int *group_out)
 {
-    // up9: the 9-tap upsample gather form is instantiated for 64x64 (G = 1, 4) and 32x64 (G = 4) only
     // par = independent GEMM slices per launch (4 output parities in sub-pixel up-conv form)
-    // Candidates, largest first.  MFMA-bound fp32: big tiles cut L2->LDS traffic, but the chip has
-    // 256 CUs and wants >= ~2 workgroups per CU, so shrink the tile (then split K) until the
-    // launch is wide enough.
-    static const int cand[][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}};
+    // up9: the 9-tap upsample gather form is instantiated for 64x64 (G = 1, 4) and 32x64 (G = 4) only
+    //
+    // Rules distilled from tools/tune_conv.py sweeps on MI355X (profiles/r01_tune_*.txt).  The kernel is
+    // MFMA-bound and its throughput is flat (+-5 %) across tile shapes, so what matters is having
+    // >= ~2 workgroups per CU (256 CUs): 64x128 when that still leaves >= 384 workgroups, else 64x64,
+    // else 64x64 + split-K up to ~512 workgroups with >= 4 K-tiles per split.  128-row tiles never won.
     const int want = 384;
-    int best = -1;
-    long best_tiles = 0;
+    int bm = 64, bn = 64, splits = 1, group = 1;
     if (M <= 32) {
-        // <= 4x4 spatial at batch 1: pure weight streaming; the 2-wave 32x64 shape gives the most
-        // workgroups per weight byte
-        best = 4;
-        best_tiles = (long)par * ((N + 63) / 64);
+        // <= 4x4 spatial at batch 1 that the tiny-M kernel did not take: weight streaming, 4 K-tiles per
+        // workgroup fetched in one step
+        bm = 32; bn = 64; group = 4;
+        splits = std::max(1, (ktiles + 3) / 4);
+    } else if (M <= 64) {
+        group = 4;
+        splits = std::max(1, (ktiles + 3) / 4);
     } else {
-        for (int i = 0; i < 4; ++i) {
-            const int bm = cand[i][0], bn = cand[i][1];
-            if (bn > 64 && N < 128) continue;      // N <= 64: only the bn = 64 shapes
-            if (up9 && i != 3) continue;
-            if (bm > 64 && M <= 64) continue;
-            const long tiles = (long)par * ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-            best = i; best_tiles = tiles;          // ends on 64x64 (+ split-K) if nothing is wide enough
-            if (tiles >= want) break;
+        const long t128 = (long)par * ((M + 63) / 64) * ((N + 127) / 128);
+        const long t64 = (long)par * ((M + 63) / 64) * ((N + 63) / 64);
+        long tiles = t64;
+        if (!up9 && N >= 128 && t128 >= want) { bn = 128; tiles = t128; }
+        if (tiles < want) {
+            splits = (int)((512 + tiles - 1) / tiles);
+            splits = std::min(splits, std::max(1, ktiles / 4));   // keep >= 4 K-tiles per split
+            const int per = (ktiles + splits - 1) / splits;      // make every split non-empty
+            splits = (ktiles + per - 1) / per;
         }
     }
-    int splits = 1;
-    if (best_tiles < want) {
-        splits = (int)((512 + best_tiles - 1) / best_tiles);
-        const int max_splits = std::max(1, ktiles / 4);   // keep >= 4 K-tiles per split
-        splits = std::min(splits, max_splits);
-        // make every split non-empty
-        const int per = (ktiles + splits - 1) / splits;
-        splits = (ktiles + per - 1) / per;
-    }
-    int group = 1;
-    if (M <= 64) {
-        // latency-bound weight streaming: 4 K-tiles per workgroup, fetched in one step
-        splits = std::max(1, (ktiles + 3) / 4);
-        group = 4;
-    }
-    *bm_out = cand[best][0];
-    *bn_out = cand[best][1];
+    *bm_out = bm;
+    *bn_out = bn;
     *splits_out = splits;
     *group_out = group;
 }
