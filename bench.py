@@ -121,10 +121,20 @@ def main():
                     l["split_k"], gf, m * 1e3, gf / m if m > 0 else 0))
             f.write("# sum %.3f ms; igemm family %.3f ms = %.2f TFLOP/s\n" % (acc.sum(), ig_ms, achieved))
 
+    # HBM traffic of the same launch set from the committed PMC passes (offline: rocprofv3 --pmc cannot
+    # run inside this process); only quoted for the workload it was measured on
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_large_b1.json")
+    if a.variant == "large" and B == 1 and a.size == 512 and os.path.exists(pmc_path):
+        pj = json.load(open(pmc_path))["per_forward_bytes"]["conv_family"]
+        traffic = int(pj["fetch_x2"] + pj["write"])
+        traffic_src = "profiles/r01_pmc_large_b1.json (FETCH_SIZE x2 + WRITE_SIZE per forward, rocprofv3 --pmc)"
+
     roofline = {
         "bound": "mfma", "kernel": "igemm3x3_f32 family incl. split-K reduce and tiny-M conv (all %d conv layers of one frame batch except first/last)" % len(ig),
         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes": int(sum(layers[i]["act_bytes_per_frame"] for i in ig) * B + sum(layers[i]["weight_bytes"] for i in ig)),
         "flops_per_launch_set": ig_flops, "ms_per_launch_set": round(ig_ms, 4),
         "executed": {"tflops": round(executed, 2), "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                      "note": "MFMA FLOPs actually issued: the sub-pixel up-convs need 4/9 of the algorithmic count"},
