@@ -130,6 +130,15 @@ int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes);
 int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch,
                    float *out_dev, int batch, void *hip_stream);
 
+/* Same forward with the reference's frame post-processing fused into the last kernel.
+ * Replaces: util.tensor2im(pred_fake[0]) (util/util.py:19-42, called at demo.py:268), i.e.
+ * (x + 1) / 2 * 255 -> clip [0,255] -> uint8, CHW -> HWC -- computed on the device, so the per-frame
+ * D2H copy shrinks from 3 MiB fp32 to 0.75 MiB and the numpy pass disappears.
+ *   out_u8_dev [batch][H][W][output_nc] uint8 (may be NULL); out_dev as in lspf2f_forward (may be
+ *   NULL when out_u8_dev is given). */
+int lspf2f_forward_ex(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch,
+                      float *out_dev, unsigned char *out_u8_dev, int batch, void *hip_stream);
+
 /* ---- introspection (tests, bench, profiling) ---------------------------------------------- */
 
 typedef struct lspf2f_layer_info {

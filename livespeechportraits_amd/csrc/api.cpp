@@ -17,11 +17,11 @@
 using namespace lspf2f;
 
 struct GraphKey {
-    const void *feat, *cand, *out, *ws, *blob;
+    const void *feat, *cand, *out, *out_u8, *ws, *blob;
     int cand_batch, batch;
     bool operator==(const GraphKey &o) const
     {
-        return feat == o.feat && cand == o.cand && out == o.out && ws == o.ws && blob == o.blob &&
+        return feat == o.feat && cand == o.cand && out == o.out && out_u8 == o.out_u8 && ws == o.ws && blob == o.blob &&
                cand_batch == o.cand_batch && batch == o.batch;
     }
 };
@@ -219,7 +219,7 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
 }  // extern "C"
 
 static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, const float *cand, int cand_batch,
-                     float *out, int batch, hipStream_t s)
+                     float *out, unsigned char *out_u8, int batch, hipStream_t s)
 {
     const Plan &P = h->plan;
     auto tptr = [&](int t) -> float * { return t < 0 ? nullptr : reinterpret_cast<float *>(h->ws + P.tensors[t].offset); };
@@ -234,7 +234,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
     } else if (l.kind == kLastConv) {
         LastConvParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.out = out;
-        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out;
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out; p.out_u8 = out_u8;
         e = launch_last_conv(p, s);
     } else if (l.smallm) {
         SmallMParams p{};
@@ -289,7 +289,14 @@ extern "C" {
 int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch, float *out_dev,
                    int batch, void *hip_stream)
 {
-    int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev, batch);
+    return lspf2f_forward_ex(h, feat_dev, cand_dev, cand_batch, out_dev, nullptr, batch, hip_stream);
+}
+
+int lspf2f_forward_ex(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch, float *out_dev,
+                      unsigned char *out_u8_dev, int batch, void *hip_stream)
+{
+    if (!out_dev && !out_u8_dev) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "at least one of out_dev / out_u8_dev is required");
+    int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev ? out_dev : reinterpret_cast<float *>(out_u8_dev), batch);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
 
@@ -304,13 +311,13 @@ int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_de
     }
     if (eager) {
         for (const auto &l : h->plan.layers) {
-            rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, batch, s);
+            rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch, s);
             if (rc) return rc;
         }
         return LSPF2F_OK;
     }
 
-    GraphKey key{feat_dev, cand_dev, out_dev, h->ws, h->blob, cand_batch, batch};
+    GraphKey key{feat_dev, cand_dev, out_dev, out_u8_dev, h->ws, h->blob, cand_batch, batch};
     CachedGraph *g = nullptr;
     for (auto &c : h->graphs)
         if (c.exec && c.key == key) { g = &c; break; }
@@ -325,7 +332,7 @@ int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_de
         hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) return hipfail(e, "hipStreamBeginCapture");
         for (const auto &l : h->plan.layers) {
-            rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, batch, h->cap_stream);
+            rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch, h->cap_stream);
             if (rc) break;
         }
         e = hipStreamEndCapture(h->cap_stream, &g->graph);
@@ -353,7 +360,7 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
         if (hipEventCreate(&e) != hipSuccess) return fail(LSPF2F_ERR_HIP, "hipEventCreate failed");
     (void)hipEventRecord(ev[0], s);
     for (int i = 0; i < n && !rc; ++i) {
-        rc = run_layer(h, h->plan.layers[i], feat_dev, cand_dev, cand_batch, out_dev, batch, s);
+        rc = run_layer(h, h->plan.layers[i], feat_dev, cand_dev, cand_batch, out_dev, nullptr, batch, s);
         (void)hipEventRecord(ev[i + 1], s);
     }
     const hipError_t e = hipStreamSynchronize(s);

@@ -95,6 +95,7 @@ struct LastConvParams {
     float *out;                // NCHW [B][Cout][2Hs][2Ws]
     int B, Hs, Ws, C0, C1, Cout;
     int apply_tanh;
+    unsigned char *out_u8;     // optional HWC uint8 frame [B][2Hs][2Ws][Cout] = tensor2im(out); out may then be nullptr
 };
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);
 

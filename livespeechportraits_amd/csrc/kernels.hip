@@ -708,6 +708,15 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// util.tensor2im (reference util/util.py:19-42) on one value: (x + 1) / 2 * 255 in float32, clip to
+// [0, 255], truncate to uint8 -- the same operation order as the numpy expression it replaces.
+__device__ __forceinline__ unsigned char to_u8(float v)
+{
+    float t = (v + 1.0f) / 2.0f * 255.0f;
+    t = fminf(fmaxf(t, 0.0f), 255.0f);
+    return (unsigned char)t;
+}
+
 // ------------------------------------------------------------------------------------------
 // Last layer, sub-pixel form.  Upsample(x2, nearest) + Conv3x3 over cat([src0, src1]) + tanh:
 // output parity (py, px) only sees a 2x2 neighbourhood of the half-resolution source, so the
@@ -776,7 +785,11 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
     }
 #pragma unroll
     for (int co = 0; co < CO; ++co)
-        p.out[(((size_t)b * CO + co) * H + 2 * y + py) * W + 2 * x + px] = p.apply_tanh ? tanhf(acc[co]) : acc[co];
+    {
+        const float v = p.apply_tanh ? tanhf(acc[co]) : acc[co];
+        if (p.out) p.out[(((size_t)b * CO + co) * H + 2 * y + py) * W + 2 * x + px] = v;
+        if (p.out_u8) p.out_u8[(((size_t)b * H + 2 * y + py) * W + 2 * x + px) * CO + co] = to_u8(v);
+    }
 }
 
 // Fast path of the last layer for C0 == C1 <= 64*NCH: the 16 lanes of a DPP row share one output
@@ -881,7 +894,9 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
             float r = acc[0];
 #pragma unroll
             for (int co = 1; co < CO; ++co) r = (j == co) ? acc[co] : r;
-            outp[(((size_t)bq * CO + j) * H + 2 * yq + py) * W + 2 * x + px] = p.apply_tanh ? tanhf(r) : r;
+            r = p.apply_tanh ? tanhf(r) : r;
+            if (outp) outp[(((size_t)bq * CO + j) * H + 2 * yq + py) * W + 2 * x + px] = r;
+            if (p.out_u8) p.out_u8[(((size_t)bq * H + 2 * yq + py) * W + 2 * x + px) * CO + j] = to_u8(r);
         }
     };
     auto advance = [&](int &bq, int &yq, int &xqq) {

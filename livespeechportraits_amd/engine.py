@@ -154,6 +154,24 @@ class Engine:
                                         ctypes.c_void_p(stream)))
         return out
 
+    def forward_image(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: Optional[torch.Tensor] = None,
+                      also_float: bool = False):
+        """Forward + the reference's util.tensor2im (util/util.py:19-42) fused into the last kernel:
+        returns uint8 frames [B,H,W,3] (HWC, what demo.py:268 hands to the JPEG writer), and the
+        fp32 NCHW tensor as well when ``also_float``."""
+        b = self._check_inputs(feat, cand)
+        feat = feat.contiguous()
+        cand = cand.contiguous() if cand is not None else None
+        if out_u8 is None:
+            out_u8 = torch.empty((b, self.size, self.size, self.output_nc), dtype=torch.uint8, device=self.device)
+        out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device) if also_float else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self.lib.lspf2f_forward_ex(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
+                                           cand.shape[0] if cand is not None else 0,
+                                           out.data_ptr() if out is not None else None, out_u8.data_ptr(), b,
+                                           ctypes.c_void_p(stream)))
+        return (out_u8, out) if also_float else out_u8
+
     def forward_timed(self, feat, cand, out=None):
         b = self._check_inputs(feat, cand)
         if out is None:

@@ -37,6 +37,16 @@ class Feature2FaceModel(BaseModel):
         with torch.no_grad():
             return self._g().render(feature_map, cand_image)
 
+    def inference_image(self, feature_map, cand_image):
+        """inference() followed by util.tensor2im, fused on the device: uint8 [B,H,W,3] frames
+        (``util.tensor2im(pred_fake[0])`` of demo.py:268 is ``inference_image(...)[0].cpu().numpy()``)."""
+        with torch.no_grad():
+            g = self._g().netG
+            if feature_map.device.type != "cuda":
+                raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
+            e = g._engine_for(feature_map.shape[-1], feature_map.shape[0], feature_map.device)
+            return e.forward_image(feature_map.float(), cand_image.float() if cand_image is not None else None)
+
     # the reference's abstract training hooks (base_model.py:70-86); kept so callers that probe
     # for them get a clear message instead of an AttributeError
     def set_input(self, data=None, data_info=None):

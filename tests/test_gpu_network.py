@@ -115,3 +115,22 @@ def test_full_size_batch8_properties(gpu_device):
     assert err <= TIGHT
     # the other frames differ (distinct feature maps) but stay in range
     assert (out[1] - out[0]).abs().max().item() > 1e-3
+
+
+def test_fused_tensor2im_uint8_output(gpu_device):
+    """util.tensor2im fused into the last kernel.  uint8 HWC frames must equal the
+    oracle's tensor2im of OUR fp32 output bit-for-bit, and the reference golden's within one grey level."""
+    from oracle.tensor2im_oracle import tensor2im
+    meta, arrays, topo, sd, feat, cand = golden_problem("normal_512")
+    e = make_engine(topo, sd, gpu_device, 1)
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+    u8, f32 = e.forward_image(f, c, also_float=True)
+    assert u8.shape == (1, 512, 512, 3) and u8.dtype == torch.uint8
+    only = e.forward_image(f, c)                       # uint8-only path (no fp32 store at all)
+    assert torch.equal(only, u8)
+    assert torch.equal(f32, e.forward(f, c))
+    want = tensor2im(f32[0].cpu().numpy())
+    assert np.array_equal(u8[0].cpu().numpy(), want)
+    ref = tensor2im(arrays["out"][0])
+    d = np.abs(u8[0].cpu().numpy().astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3

@@ -68,3 +68,28 @@ def test_oracle_is_not_reachable_from_the_product():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "f2f_oracle" not in src, f
+
+
+def test_tensor2im_oracle_matches_reference_function():
+    """oracle/tensor2im_oracle.py against the reference's own util.tensor2im when the reference tree is
+    present (build container); always against a hand-computed known-answer vector."""
+    import os
+    import sys
+    import types
+    from oracle.tensor2im_oracle import tensor2im
+    x = np.array([-1.0, -0.999, -0.5, 0.0, 0.0039, 0.5, 0.999, 1.0, 1.5, -2.0, 0.2, -0.2], np.float32)
+    chw = np.stack([x.reshape(3, 4)] * 3)
+    got = tensor2im(chw)
+    assert got.shape == (3, 4, 3) and got.dtype == np.uint8
+    exp = np.clip((x.astype(np.float32) + 1) / 2.0 * 255.0, 0, 255).astype(np.uint8)
+    assert np.array_equal(got[:, :, 0].reshape(-1), exp)
+    assert list(exp[[0, 3, 7, 8, 9]]) == [0, 127, 255, 255, 0]
+    if os.path.isdir("/root/reference/util"):
+        sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+        sys.path.insert(0, "/root/reference")
+        try:
+            from util import util as ref_util
+        finally:
+            sys.path.pop(0)
+        rnd = np.random.default_rng(3).uniform(-1.2, 1.2, (3, 17, 19)).astype(np.float32)
+        assert np.array_equal(ref_util.tensor2im(torch.from_numpy(rnd)), tensor2im(rnd))
