@@ -172,6 +172,23 @@ def main():
         dt = time.perf_counter() - t1
         extra = {"batch8_frames_per_s": round(8 * n8 / dt, 2),
                  "batch8_tflops": round(topo.flops_per_frame() * 8 * n8 / dt / 1e12, 2)}
+        # PCIe-inclusive rate of a demo.py-style loop (never `value`): per frame, H2D of a host feature map
+        # (1 MiB, pinned), forward with fused tensor2im, D2H of the uint8 frame (0.75 MiB), synchronised
+        hfeat = torch.from_numpy(feat_np).pin_memory()
+        hout = torch.empty((1, a.size, a.size, 3), dtype=torch.uint8).pin_memory()
+        dfeat = torch.empty_like(feat)
+        du8 = torch.empty((1, a.size, a.size, 3), dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            dfeat.copy_(hfeat, non_blocking=True); eng.forward_image(dfeat, cand, du8); hout.copy_(du8, non_blocking=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        nl = 100
+        for _ in range(nl):
+            dfeat.copy_(hfeat, non_blocking=True)
+            eng.forward_image(dfeat, cand, du8)
+            hout.copy_(du8, non_blocking=True)
+            torch.cuda.synchronize()
+        extra["pcie_inclusive_frames_per_s_batch1_uint8"] = round(nl / (time.perf_counter() - t2), 2)
 
     line = {
         "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",

@@ -130,6 +130,15 @@ int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes);
 int lspf2f_forward(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch,
                    float *out_dev, int batch, void *hip_stream);
 
+/* Optional: pre-compute the candidate stack's contribution to the first convolution.
+ * demo.py:89-95 builds img_candidates once per person and passes the same tensor to every
+ * inference() call (demo.py:266); 12 of the first layer's 13 input channels are therefore constant.
+ * After this call, lspf2f_forward*() may be given cand_dev == NULL: the first layer then only
+ * convolves the feature-map channel and adds the cached partial sums (kept in the first
+ * (H/2)*(W/2)*ngf*4 bytes of the workspace, so re-binding the workspace or the weights drops it).
+ * cand_dev: [1][input_nc-feat_nc][H][W]; NULL clears the cache.  Enqueued on hip_stream. */
+int lspf2f_set_candidates(lspf2f_handle *h, const float *cand_dev, void *hip_stream);
+
 /* Same forward with the reference's frame post-processing fused into the last kernel.
  * Replaces: util.tensor2im(pred_fake[0]) (util/util.py:19-42, called at demo.py:268), i.e.
  * (x + 1) / 2 * 255 -> clip [0,255] -> uint8, CHW -> HWC -- computed on the device, so the per-frame

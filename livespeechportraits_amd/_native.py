@@ -67,6 +67,7 @@ SIGNATURES = {
     "lspf2f_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "lspf2f_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lspf2f_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "lspf2f_set_candidates": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lspf2f_forward_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "lspf2f_num_layers": (c_int, [c_void_p]),
     "lspf2f_plan_batch": (c_int, [c_void_p, c_int]),

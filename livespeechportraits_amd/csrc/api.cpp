@@ -48,6 +48,7 @@ struct lspf2f_handle {
     size_t ws_size = 0;
     bool packed = false;
     bool use_graph = true;
+    const void *cand_cached = nullptr;   // candidate stack whose first-conv contribution sits in the workspace cache
     hipStream_t cap_stream = nullptr;
     std::vector<CachedGraph> graphs;
     size_t next_victim = 0;
@@ -158,6 +159,7 @@ int lspf2f_bind_weights(lspf2f_handle *h, const void *dev_blob, size_t bytes)
     if (bytes < h->plan.blob_bytes) return fail(LSPF2F_ERR_SHAPE, "packed weight arena too small");
     if ((uintptr_t)dev_blob % 256) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "weight arena must be 256-byte aligned");
     h->drop_graphs();
+    h->cand_cached = nullptr;
     h->blob = static_cast<const char *>(dev_blob);
     h->blob_size = bytes;
     return LSPF2F_OK;
@@ -174,6 +176,7 @@ int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes)
     if (!h || !dev_workspace) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if ((uintptr_t)dev_workspace % 256) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
     h->drop_graphs();
+    h->cand_cached = nullptr;
     h->ws = static_cast<char *>(dev_workspace);
     h->ws_size = bytes;
     return LSPF2F_OK;
@@ -230,7 +233,23 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.feat = feat; p.cand = cand; p.w = bptr(l.w_off); p.out = tptr(l.out);
         p.B = batch; p.H = l.hs; p.W = l.hs; p.feat_nc = P.feat_nc; p.cand_nc = P.input_nc - P.feat_nc;
         p.cand_batch = cand_batch; p.Cout = l.cout;
-        e = launch_first_conv(p, s);
+        p.ci_begin = 0; p.ci_end = P.input_nc; p.base = nullptr; p.relu = 1;
+        float *cache = reinterpret_cast<float *>(h->ws);
+        const bool shared = p.cand_nc > 0 && P.feat_nc > 0 && (cand == nullptr || (cand_batch == 1 && batch > 1));
+        if (shared) {
+            // candidate stack shared by the whole batch: its contribution is computed once (or taken
+            // from lspf2f_set_candidates' cache when cand == NULL), each frame then adds its own
+            // feature-map channels
+            if (cand != nullptr) {
+                FirstConvParams c = p;
+                c.B = 1; c.cand_batch = 1; c.ci_begin = P.feat_nc; c.out = cache; c.relu = 0;
+                e = launch_first_conv(c, s);
+            }
+            p.ci_end = P.feat_nc; p.base = cache;
+            if (e == hipSuccess) e = launch_first_conv(p, s);
+        } else {
+            e = launch_first_conv(p, s);
+        }
     } else if (l.kind == kLastConv) {
         LastConvParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.out = out;
@@ -271,8 +290,9 @@ static int check_forward_args(lspf2f_handle *h, const float *feat, const float *
     if (!h || !feat || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (batch < 1 || batch > h->cfg.max_batch) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "batch out of range (max_batch)");
     const int cand_nc = h->plan.input_nc - h->plan.feat_nc;
-    if (cand_nc > 0 && !cand) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "cand_image is required (input_nc > feat_nc)");
-    if (cand_nc > 0 && cand_batch != 1 && cand_batch != batch)
+    if (cand_nc > 0 && !cand && !h->cand_cached)
+        return fail(LSPF2F_ERR_INVALID_ARGUMENT, "cand_image is required (input_nc > feat_nc) unless lspf2f_set_candidates() was called");
+    if (cand_nc > 0 && cand && cand_batch != 1 && cand_batch != batch)
         return fail(LSPF2F_ERR_SHAPE, "cand_batch must be 1 (broadcast) or equal to batch");
     if (!h->blob) return fail(LSPF2F_ERR_STATE, "weights not bound (lspf2f_bind_weights)");
     if (!h->ws) return fail(LSPF2F_ERR_STATE, "workspace not bound (lspf2f_bind_workspace)");
@@ -344,6 +364,26 @@ int lspf2f_forward_ex(lspf2f_handle *h, const float *feat_dev, const float *cand
     }
     const hipError_t e = hipGraphLaunch(g->exec, s);
     if (e != hipSuccess) return hipfail(e, "hipGraphLaunch");
+    return LSPF2F_OK;
+}
+
+int lspf2f_set_candidates(lspf2f_handle *h, const float *cand_dev, void *hip_stream)
+{
+    if (!h) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null handle");
+    if (!cand_dev) { h->cand_cached = nullptr; return LSPF2F_OK; }
+    const Plan &P = h->plan;
+    if (P.input_nc == P.feat_nc || P.feat_nc == 0) return fail(LSPF2F_ERR_UNSUPPORTED, "no candidate channels to cache");
+    if (!h->blob || !h->ws) return fail(LSPF2F_ERR_STATE, "bind weights and workspace first");
+    if (h->ws_size < P.cand_cache_bytes()) return fail(LSPF2F_ERR_STATE, "workspace too small");
+    const LayerDesc &l = P.layers[0];
+    FirstConvParams c{};
+    c.feat = nullptr; c.cand = cand_dev; c.w = reinterpret_cast<const float *>(h->blob + l.w_off);
+    c.out = reinterpret_cast<float *>(h->ws);
+    c.B = 1; c.H = l.hs; c.W = l.hs; c.feat_nc = P.feat_nc; c.cand_nc = P.input_nc - P.feat_nc; c.cand_batch = 1;
+    c.Cout = l.cout; c.ci_begin = P.feat_nc; c.ci_end = P.input_nc; c.base = nullptr; c.relu = 0;
+    const hipError_t e = launch_first_conv(c, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return hipfail(e, "lspf2f_set_candidates launch");
+    h->cand_cached = cand_dev;
     return LSPF2F_OK;
 }
 

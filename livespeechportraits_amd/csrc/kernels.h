@@ -85,6 +85,9 @@ struct FirstConvParams {
     const float *w;      // [(ci*9 + ky*3 + kx)][Cout]
     float *out;          // NHWC [B][H/2][W/2][Cout]
     int B, H, W, feat_nc, cand_nc, cand_batch, Cout;
+    int ci_begin, ci_end;   // input-channel range of this pass ([0, feat_nc+cand_nc) = the whole layer)
+    const float *base;      // optional pre-activation partial sums [1][H/2][W/2][Cout] to start from
+    int relu;
 };
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
 

@@ -629,12 +629,15 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
 __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];   // [K][32]
-    const int cin = p.feat_nc + p.cand_nc;
-    const int K = cin * 9;
+    // channel range of this pass: the whole input, or -- when the candidate stack is shared by the batch --
+    // only the candidate channels (pass 1, once: writes the pre-activation partial sums `base`) or only
+    // the feature-map channels (pass 2, per frame: starts from `base`, applies ReLU)
+    const int cbeg = p.ci_begin, cin = p.ci_end;
+    const int K = (cin - cbeg) * 9;
     const int co0 = blockIdx.y * 32;
     for (int i = threadIdx.x; i < K * 32; i += blockDim.x) {
         const int k = i >> 5, j = i & 31;
-        wsm[i] = p.w[(size_t)k * p.Cout + co0 + j];
+        wsm[i] = p.w[(size_t)(cbeg * 9 + k) * p.Cout + co0 + j];
     }
     __syncthreads();
 
@@ -656,8 +659,18 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
     }
 
     float acc[32];
+    if (p.base) {
+        // base is [1][Ho][Wo][Cout] (shared by every frame of the batch)
+        const float4 *bp = reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + co0);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 8; ++j) {
+            const float4 t = bp[j];
+            acc[4 * j] = t.x; acc[4 * j + 1] = t.y; acc[4 * j + 2] = t.z; acc[4 * j + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    }
 
     const size_t plane = (size_t)p.H * p.W;
     auto plane_of = [&](int ci) -> const float * {
@@ -668,12 +681,12 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
     // the 9 taps of channel ci+1 are in flight while channel ci is multiplied
     float v[9], vn[9];
     {
-        const float *src = plane_of(0);
+        const float *src = plane_of(cbeg);
 #pragma unroll
         for (int t = 0; t < 9; ++t) v[t] = tok[t] ? src[toff[t]] : 0.f;
     }
 #pragma unroll 1
-    for (int ci = 0; ci < cin; ++ci) {
+    for (int ci = cbeg; ci < cin; ++ci) {
         if (ci + 1 < cin) {
             const float *src = plane_of(ci + 1);
 #pragma unroll
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float4 *wr = reinterpret_cast<const float4 *>(wsm + (ci * 9 + t) * 32);
+            const float4 *wr = reinterpret_cast<const float4 *>(wsm + ((ci - cbeg) * 9 + t) * 32);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float4 w4 = wr[j];
@@ -695,14 +708,67 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
     float4 *o = reinterpret_cast<float4 *>(p.out + (size_t)gid * p.Cout + co0);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        o[j] = make_float4(fmaxf(acc[4 * j], 0.f), fmaxf(acc[4 * j + 1], 0.f),
-                           fmaxf(acc[4 * j + 2], 0.f), fmaxf(acc[4 * j + 3], 0.f));
+        o[j] = p.relu ? make_float4(fmaxf(acc[4 * j], 0.f), fmaxf(acc[4 * j + 1], 0.f),
+                                    fmaxf(acc[4 * j + 2], 0.f), fmaxf(acc[4 * j + 3], 0.f))
+                      : make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+}
+
+// Feature-map-only pass of the first layer (the candidate share comes in through `base`): pure streaming,
+// ~1 FLOP/byte.  16 lanes share a pixel and own 4 output channels each, so a wave reads and writes
+// 4 pixels x Cout*4 B contiguously (Cout = 64: exactly 1 KB per instruction); the 9 x feat_nc tap values
+// are broadcast loads, the lane's weights stay in registers.
+template <int FN>
+__global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
+{
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const int lpp = p.Cout / 4;                              // lanes per pixel (16 for ngf 64, 8 for ngf 32)
+    const int ppw = 64 / lpp;                                // pixels per wave
+    const int lane = threadIdx.x & 63;
+    const int j = lane % lpp, sub = lane / lpp;
+    float4 w[FN][9];
+#pragma unroll
+    for (int ci = 0; ci < FN; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            w[ci][t] = *reinterpret_cast<const float4 *>(p.w + (size_t)(ci * 9 + t) * p.Cout + j * 4);
+    const long npix = (long)p.B * Ho * Wo;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const size_t plane = (size_t)p.H * p.W;
+    for (long g = wave * ppw + sub; g < npix; g += nwaves * ppw) {
+        const int b = (int)(g / (Ho * Wo));
+        const int r = (int)(g - (long)b * Ho * Wo);
+        const int oy = r / Wo, ox = r - oy * Wo;
+        float4 acc = *reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + j * 4);
+#pragma unroll
+        for (int ci = 0; ci < FN; ++ci) {
+            const float *src = p.feat + ((size_t)b * p.feat_nc + ci) * plane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const float v = ok ? src[(size_t)iy * p.W + ix] : 0.f;
+                acc.x += v * w[ci][t].x; acc.y += v * w[ci][t].y; acc.z += v * w[ci][t].z; acc.w += v * w[ci][t].w;
+            }
+        }
+        if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<float4 *>(p.out + (size_t)g * p.Cout + j * 4) = acc;
+    }
 }
 
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
 {
+    if (p.base && p.ci_begin == 0 && p.ci_end == 1 && p.feat_nc == 1 && 64 % (p.Cout / 4) == 0 && p.Cout <= 256) {
+        const long npix = (long)p.B * (p.H / 2) * (p.W / 2);
+        const int ppw = 64 / (p.Cout / 4);
+        long blocks = (npix / ppw + 3) / 4;                  // one pixel group per wave ...
+        if (blocks > 4096) blocks = 4096;                    // ... up to 16 blocks per CU, then grid-stride
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(first_conv_feat<1>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     const long total = (long)p.B * (p.H / 2) * (p.W / 2);
-    const int K = (p.feat_nc + p.cand_nc) * 9;
+    const int K = (p.ci_end - p.ci_begin) * 9;
     hipLaunchKernelGGL(first_conv, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
                        (size_t)K * 32 * sizeof(float), s, p);
     return hipGetLastError();
@@ -794,12 +860,15 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
 
 // Fast path of the last layer for C0 == C1 <= 64*NCH: the 16 lanes of a DPP row share one output
 // pixel and split its input channels (lane j owns channels 4j..4j+3 of every 64-channel slab), so a
-// wave's load of 4 neighbouring pixels is one contiguous 1-KB read, the 4-tap x CO weights of the
-// wave's parity live in registers for the whole kernel, and the channel reduction is 4 DPP row
-// rotations per output.  Waves are persistent over pixel quads of ONE parity (wave id & 3).
+// wave's load of 4 neighbouring pixels is one contiguous 1-KB read and the channel reduction is 4 DPP
+// row rotations per output.  Each wave walks a contiguous run of pixel quads of ONE output parity
+// (wave id & 3); that parity's 4-tap x CO weights sit in LDS (conflict-free: a row's 16 lanes read 16
+// consecutive float4, the 4 rows broadcast), which keeps the kernel at ~64 VGPRs = 8 waves/SIMD --
+// the loop is a load -> FMA -> DPP -> store chain and needs the occupancy to hide its latency.
 template <int CO, int NCH>
 __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 parities][2 src][NCH][4 taps][CO][16 lanes] float4
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, sub = lane >> 4;               // channel slot, pixel within the quad
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -808,27 +877,23 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
     const int cin = p.C0 + p.C1;
     const int H = 2 * p.Hs, W = 2 * p.Ws;
 
-    // weights of this parity: w[src][chunk][tap][co] as float4 over the lane's 4 channels
-    float4 w[2][NCH][4][CO];
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int ch = (c * 16 + j) * 4;                 // channel inside the source
-            const bool okc = ch < (sidx ? p.C1 : p.C0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int co = 0; co < CO; ++co)
-                    w[sidx][c][t][co] = okc
-                        ? *reinterpret_cast<const float4 *>(p.w + ((size_t)(par * CO + co) * 4 + t) * cin + (sidx ? p.C0 : 0) + ch)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    constexpr int WPP = 2 * NCH * 4 * CO * 16;              // float4 per parity
+    for (int i = threadIdx.x; i < 4 * WPP; i += blockDim.x) {
+        int r = i;
+        const int jj = r & 15; r >>= 4;
+        const int co = r % CO; r /= CO;
+        const int t = r & 3; r >>= 2;
+        const int c = r % NCH; r /= NCH;
+        const int sidx = r & 1, pr = r >> 1;
+        const int ch = (c * 16 + jj) * 4;
+        const bool okc = ch < (sidx ? p.C1 : p.C0);
+        reinterpret_cast<float4 *>(wsm)[i] = okc
+            ? *reinterpret_cast<const float4 *>(p.w + ((size_t)(pr * CO + co) * 4 + t) * cin + (sidx ? p.C0 : 0) + ch)
+            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float4 *wpar = reinterpret_cast<const float4 *>(wsm) + par * WPP + j;   // + ((sidx*NCH + c)*4 + t)*CO*16 + co*16
 
-    // Each wave owns a contiguous run of pixel quads of its parity (coordinates advance
-    // incrementally: no per-iteration division) and keeps the NEXT quad's 8*NCH loads in flight
-    // while it multiplies the current one (the per-quad chain load -> FMA -> DPP -> store is
-    // otherwise latency-bound).
     const int qpr = (p.Ws + 3) / 4;                          // quads per source row
     const unsigned nquads = (unsigned)p.B * p.Hs * qpr;
     const unsigned wpp = (unsigned)nwaves >> 2;              // waves per parity
@@ -844,38 +909,37 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
     const float *__restrict__ s1 = p.src1;
     float *__restrict__ outp = p.out;
 
-    float4 v[2][2][4][NCH];                                  // [buffer][src][tap][chunk]
-    auto issue = [&](int buf, int bq, int yq, int xqq) {
-        const int x = xqq * 4 + sub;
+    for (; q < qend; ++q) {
+        asm volatile("" ::: "memory");   // keep the weight reads in LDS (LICM would pin 96 VGPRs)
+        const int x = xq * 4 + sub;
+        float4 v[2][4][NCH];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int sy = yq + (t >> 1) - 1 + py, sx = x + (t & 1) - 1 + px;
+            const int sy = y + (t >> 1) - 1 + py, sx = x + (t & 1) - 1 + px;
             const bool ok = (x < p.Ws) & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
-            const size_t pix = ok ? ((size_t)bq * p.Hs + sy) * p.Ws + sx : 0;
+            const size_t pix = ok ? ((size_t)b * p.Hs + sy) * p.Ws + sx : 0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int ch = (c * 16 + j) * 4;
-                v[buf][0][t][c] = (ok && ch < p.C0) ? *reinterpret_cast<const float4 *>(s0 + pix * p.C0 + ch)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-                v[buf][1][t][c] = (ok && ch < p.C1) ? *reinterpret_cast<const float4 *>(s1 + pix * p.C1 + ch)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[0][t][c] = (ok && ch < p.C0) ? *reinterpret_cast<const float4 *>(s0 + pix * p.C0 + ch)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[1][t][c] = (ok && ch < p.C1) ? *reinterpret_cast<const float4 *>(s1 + pix * p.C1 + ch)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-    };
-    auto consume = [&](int buf, int bq, int yq, int xqq) {
         float acc[CO];
 #pragma unroll
         for (int co = 0; co < CO; ++co) acc[co] = 0.f;
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const float4 x4 = v[buf][sidx][t][c];
+                for (int t = 0; t < 4; ++t) {
+                    const float4 x4 = v[sidx][t][c];
 #pragma unroll
                     for (int co = 0; co < CO; ++co) {
-                        const float4 ww = w[sidx][c][t][co];
+                        const float4 ww = wpar[(((sidx * NCH + c) * 4 + t) * CO + co) * 16];
                         acc[co] += x4.x * ww.x + x4.y * ww.y + x4.z * ww.z + x4.w * ww.w;
                     }
                 }
@@ -889,32 +953,15 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
             r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x121, 0xf, 0xf, false));
             acc[co] = r;
         }
-        const int x = xqq * 4 + sub;
         if (j < CO && x < p.Ws) {
             float r = acc[0];
 #pragma unroll
             for (int co = 1; co < CO; ++co) r = (j == co) ? acc[co] : r;
             r = p.apply_tanh ? tanhf(r) : r;
-            if (outp) outp[(((size_t)bq * CO + j) * H + 2 * yq + py) * W + 2 * x + px] = r;
-            if (p.out_u8) p.out_u8[(((size_t)bq * H + 2 * yq + py) * W + 2 * x + px) * CO + j] = to_u8(r);
+            if (outp) outp[(((size_t)b * CO + j) * H + 2 * y + py) * W + 2 * x + px] = r;
+            if (p.out_u8) p.out_u8[(((size_t)b * H + 2 * y + py) * W + 2 * x + px) * CO + j] = to_u8(r);
         }
-    };
-    auto advance = [&](int &bq, int &yq, int &xqq) {
-        if (++xqq == qpr) { xqq = 0; if (++yq == p.Hs) { yq = 0; ++bq; } }
-    };
-
-    issue(0, b, y, xq);
-    for (; q < qend; q += 2) {
-        int b1 = b, y1 = y, x1 = xq;
-        advance(b1, y1, x1);
-        const bool has1 = q + 1 < qend;
-        if (has1) issue(1, b1, y1, x1);
-        consume(0, b, y, xq);
-        int b2 = b1, y2 = y1, x2 = x1;
-        advance(b2, y2, x2);
-        if (q + 2 < qend) issue(0, b2, y2, x2);
-        if (has1) consume(1, b1, y1, x1);
-        b = b2; y = y2; xq = x2;
+        if (++xq == qpr) { xq = 0; if (++y == p.Hs) { y = 0; ++b; } }
     }
 }
 
@@ -924,11 +971,13 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
     const long quads = (long)p.B * p.Hs * ((p.Ws + 3) / 4);
     if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 128 && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
         // 4 parities x quads wave-iterations; 4 waves per block, parity = wave & 3
-        long blocks = (quads + 7) / 8;                      // ~8 quads per wave
-        if (blocks > 512) blocks = 512;                     // 2 blocks (8 waves) per CU, all resident
+        long blocks = (quads + 3) / 4;                      // >= ~4 quads per wave
+        if (blocks > 2048) blocks = 2048;                   // 8 blocks (32 waves) per CU, all resident
         if (blocks < 1) blocks = 1;
-        if (p.C0 <= 64) hipLaunchKernelGGL((last_conv_rows<CO, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((last_conv_rows<CO, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        const int nch = p.C0 <= 64 ? 1 : 2;
+        const size_t smem = (size_t)4 * 2 * nch * 4 * CO * 16 * sizeof(float4);
+        if (nch == 1) hipLaunchKernelGGL((last_conv_rows<CO, 1>), dim3((unsigned)blocks), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((last_conv_rows<CO, 2>), dim3((unsigned)blocks), dim3(256), smem, s, p);
         return hipGetLastError();
     }
     const long total = (long)p.B * 4 * p.Hs * p.Ws;

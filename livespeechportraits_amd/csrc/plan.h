@@ -63,6 +63,9 @@ struct Plan {
     size_t act_bytes = 0;       // activation arena
     size_t partial_bytes = 0;   // split-K scratch
     size_t partial_offset = 0;
+    // persistent region at workspace offset 0: pre-activation contribution of the candidate channels to the
+    // first conv, [H/2][W/2][ngf] fp32 (constant per person: demo.py:89-95 builds img_candidates once)
+    size_t cand_cache_bytes() const { return ((size_t)(size / 2) * (size / 2) * ngf * sizeof(float) + 255) / 256 * 256; }
 
     std::string build(int variant, int input_nc, int feat_nc, int output_nc, int ngf, int num_downs,
                       int size, bool keep);   // returns "" or an error message

@@ -35,6 +35,10 @@ class Engine:
         h = ctypes.c_void_p()
         N.check(self.lib.lspf2f_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
+        # candidate-stack cache (lspf2f_set_candidates): off by default so that a bare Engine never reuses
+        # work across calls; Feature2FaceModel turns it on (the stack is constant per person)
+        self.auto_cand_cache = False
+        self._cand_key = None
         self._blob_dev: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self.device: Optional[torch.device] = None
@@ -110,11 +114,13 @@ class Engine:
         self.device = blob.device
         self._blob_dev = blob
         N.check(self.lib.lspf2f_bind_weights(self._h, blob.data_ptr(), blob.numel()))
+        self._cand_key = None
         self._ensure_workspace(self.max_batch)
 
     def _ensure_workspace(self, batch: int) -> None:
         need = int(self.lib.lspf2f_workspace_bytes(self._h, batch))
         if self._ws is None or self._ws.numel() < need:
+            self._cand_key = None
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
             N.check(self.lib.lspf2f_bind_workspace(self._h, self._ws.data_ptr(), self._ws.numel()))
 
@@ -142,6 +148,35 @@ class Engine:
                 raise ValueError("cand_image must be [1 or B,%d,%d,%d], got %s" % (cand_nc, s, s, tuple(cand.shape)))
         return b
 
+    def set_candidates(self, cand: Optional[torch.Tensor]) -> None:
+        """Pre-compute the candidate stack's contribution to the first conv (12 of its 13 input
+        channels are constant per person -- demo.py:89-95).  ``forward(feat, cand)`` with the SAME,
+        unmodified tensor then skips that work; ``None`` clears the cache."""
+        if cand is None:
+            N.check(self.lib.lspf2f_set_candidates(self._h, None, None))
+            self._cand_key = None
+            return
+        s, cand_nc = self.size, self.input_nc - self.feat_nc
+        if tuple(cand.shape) != (1, cand_nc, s, s) or cand.dtype != torch.float32 or not cand.is_contiguous():
+            raise ValueError("set_candidates wants a contiguous float32 [1,%d,%d,%d] tensor" % (cand_nc, s, s))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self.lib.lspf2f_set_candidates(self._h, cand.data_ptr(), ctypes.c_void_p(stream)))
+        self._cand_key = (id(cand), cand.data_ptr(), cand._version)
+        self._cand_ref = cand       # keep it alive: the key contains its id()
+
+    def _cand_arg(self, cand: Optional[torch.Tensor]):
+        """(pointer, batch) to hand to the library: NULL when the cached contribution applies."""
+        if cand is None:
+            return None, 0
+        if self.auto_cand_cache and cand.shape[0] == 1 and cand.is_contiguous():
+            key = (id(cand), cand.data_ptr(), cand._version)
+            if key != self._cand_key:
+                self.set_candidates(cand)
+            return None, 1
+        if self._cand_key is not None and (id(cand), cand.data_ptr(), cand._version) == self._cand_key:
+            return None, 1
+        return cand.data_ptr(), cand.shape[0]
+
     def forward(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         b = self._check_inputs(feat, cand)
         feat = feat.contiguous()
@@ -149,9 +184,8 @@ class Engine:
         if out is None:
             out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        N.check(self.lib.lspf2f_forward(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
-                                        cand.shape[0] if cand is not None else 0, out.data_ptr(), b,
-                                        ctypes.c_void_p(stream)))
+        cptr, cb = self._cand_arg(cand)
+        N.check(self.lib.lspf2f_forward(self._h, feat.data_ptr(), cptr, cb, out.data_ptr(), b, ctypes.c_void_p(stream)))
         return out
 
     def forward_image(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: Optional[torch.Tensor] = None,
@@ -166,8 +200,8 @@ class Engine:
             out_u8 = torch.empty((b, self.size, self.size, self.output_nc), dtype=torch.uint8, device=self.device)
         out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device) if also_float else None
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        N.check(self.lib.lspf2f_forward_ex(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
-                                           cand.shape[0] if cand is not None else 0,
+        cptr, cb = self._cand_arg(cand)
+        N.check(self.lib.lspf2f_forward_ex(self._h, feat.data_ptr(), cptr, cb,
                                            out.data_ptr() if out is not None else None, out_u8.data_ptr(), b,
                                            ctypes.c_void_p(stream)))
         return (out_u8, out) if also_float else out_u8

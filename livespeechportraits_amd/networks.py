@@ -13,6 +13,7 @@ Key layout restated from (not copied from) the reference:
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -94,6 +95,7 @@ class Feature2FaceGenerator(nn.Module):
                 e.bind(self._blob)        # blob layout does not depend on size / batch
             else:
                 self._dirty = True
+            e.auto_cand_cache = os.environ.get("LSP_HIP_CAND_CACHE", "1") != "0"
             self._engine = e
         if self._dirty or e.device != device:
             sd = {"netG." + k: v for k, v in self.state_dict().items()}
