@@ -965,10 +965,136 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
     }
 }
 
+// Last layer, sliding-window form (C0 == C1 <= 64).  The rows kernel above re-reads every source pixel
+// 16x (4 taps x 4 parities) through L1, which bounds it at ~1 TB/s of useful traffic.  Here a 16-lane
+// group (lane = 4 input channels of each source) walks along one source row keeping the 3x3 source
+// neighbourhood in registers: per step it loads ONE new column (3 rows x 2 sources) and emits all four
+// output parities of that source pixel -- 1.5 loads per output instead of 8 -- with the pre-summed
+// sub-pixel weights read conflict-free from LDS and the channel sum done by DPP row rotations.
+template <int CO>
+__global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, int seg)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 par][2 src][4 taps][CO][16 lanes] float4
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const int cin = p.C0 + p.C1;
+    const int H = 2 * p.Hs, W = 2 * p.Ws;
+    constexpr int WTOT = 4 * 2 * 4 * CO * 16;
+    for (int i = threadIdx.x; i < WTOT; i += blockDim.x) {
+        int r = i;
+        const int jj = r & 15; r >>= 4;
+        const int co = r % CO; r /= CO;
+        const int t = r & 3; r >>= 2;
+        const int sidx = r & 1, pr = r >> 1;
+        const int ch = jj * 4;
+        reinterpret_cast<float4 *>(wsm)[i] = ch < (sidx ? p.C1 : p.C0)
+            ? *reinterpret_cast<const float4 *>(p.w + ((size_t)(pr * CO + co) * 4 + t) * cin + (sidx ? p.C0 : 0) + ch)
+            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float4 *wl = reinterpret_cast<const float4 *>(wsm) + j;
+
+    // one 16-lane group = one (frame, source row, column segment)
+    const int nseg = (p.Ws + seg - 1) / seg;
+    const long ngroups = (long)p.B * p.Hs * nseg;
+    const long group = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    if (group >= ngroups) return;          // whole 16-lane rows retire together (DPP rows stay intact)
+    const int b = (int)(group / ((long)p.Hs * nseg));
+    const int rr = (int)(group - (long)b * p.Hs * nseg);
+    const int y = rr / nseg, x0 = (rr - y * nseg) * seg;
+    const int x1 = x0 + seg < p.Ws ? x0 + seg : p.Ws;
+    const bool chan_ok = j * 4 < p.C0;
+
+    const float *__restrict__ s0 = p.src0;
+    const float *__restrict__ s1 = p.src1;
+    auto load_col = [&](int x, float4 (&col)[3][2]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int sy = y + r - 1;
+            const bool ok = chan_ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
+            const size_t pix = ok ? ((size_t)b * p.Hs + sy) * p.Ws + x : 0;
+            col[r][0] = ok ? *reinterpret_cast<const float4 *>(s0 + pix * p.C0 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            col[r][1] = ok ? *reinterpret_cast<const float4 *>(s1 + pix * p.C1 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 win[3][3][2];                       // [column x-1, x, x+1][row y-1, y, y+1][source]
+    float4 nxt[3][2];
+    load_col(x0 - 1, win[0]);
+    load_col(x0, win[1]);
+    load_col(x0 + 1, win[2]);
+    for (int x = x0; x < x1; ++x) {
+        asm volatile("" ::: "memory");         // keep the weights in LDS (see last_conv_rows)
+        if (x + 1 < x1) load_col(x + 2, nxt);  // next step's column flies while this step computes
+        float acc[4][CO];
+#pragma unroll
+        for (int par = 0; par < 4; ++par)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[par][co] = 0.f;
+#pragma unroll
+        for (int par = 0; par < 4; ++par) {
+            const int py = par >> 1, px = par & 1;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 v = win[(t & 1) + px][(t >> 1) + py][sidx];
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float4 ww = wl[(((par * 2 + sidx) * 4 + t) * CO + co) * 16];
+                        acc[par][co] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+                    }
+                }
+        }
+#pragma unroll
+        for (int par = 0; par < 4; ++par) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                float r = acc[par][co];
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x128, 0xf, 0xf, false));
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x124, 0xf, 0xf, false));
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x122, 0xf, 0xf, false));
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x121, 0xf, 0xf, false));
+                acc[par][co] = r;
+            }
+        }
+        if (j < CO) {
+#pragma unroll
+            for (int par = 0; par < 4; ++par) {
+                float r = acc[par][0];
+#pragma unroll
+                for (int co = 1; co < CO; ++co) r = (j == co) ? acc[par][co] : r;
+                r = p.apply_tanh ? tanhf(r) : r;
+                const int Y = 2 * y + (par >> 1), X = 2 * x + (par & 1);
+                if (p.out) p.out[(((size_t)b * CO + j) * H + Y) * W + X] = r;
+                if (p.out_u8) p.out_u8[(((size_t)b * H + Y) * W + X) * CO + j] = to_u8(r);
+            }
+        }
+        // slide the window
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                win[0][r][sidx] = win[1][r][sidx];
+                win[1][r][sidx] = win[2][r][sidx];
+                win[2][r][sidx] = nxt[r][sidx];
+            }
+    }
+}
+
 template <int CO>
 static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
 {
     const long quads = (long)p.B * p.Hs * ((p.Ws + 3) / 4);
+    // measured on MI355X (512x512 output): batch 1 rows 43 us / strip 55 us; batch 8 rows 270 us / strip 221 us
+    const bool big = (long)p.B * p.Hs * p.Ws >= 4 * 65536;
+    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 64 && (big || std::getenv("LSP_HIP_LASTCONV_STRIP")) &&
+        !std::getenv("LSP_HIP_LASTCONV_ROWS") && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
+        // sliding-window kernel; segment length trades window priming (2 extra columns) for parallelism
+        const int seg = 32;
+        const long groups = (long)p.B * p.Hs * ((p.Ws + seg - 1) / seg);
+        const size_t smem = (size_t)4 * 2 * 4 * CO * 16 * sizeof(float4);
+        hipLaunchKernelGGL(last_conv_strip<CO>, dim3((unsigned)((groups + 15) / 16)), dim3(256), smem, s, p, seg);
+        return hipGetLastError();
+    }
     if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 128 && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
         // 4 parities x quads wave-iterations; 4 waves per block, parity = wave & 3
         long blocks = (quads + 3) / 4;                      // >= ~4 quads per wave

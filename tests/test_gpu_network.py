@@ -164,3 +164,15 @@ def test_shared_candidate_paths_agree(gpu_device):
     assert (changed - ref).abs().max().item() <= 2e-6
     assert (changed - shared).abs().max().item() > 1e-4
     e.set_candidates(None)
+
+
+@pytest.mark.parametrize("env", ["LSP_HIP_LASTCONV_STRIP", "LSP_HIP_LASTCONV_ROWS", "LSP_HIP_LASTCONV_GENERIC"])
+def test_every_last_conv_variant_matches_golden(env, gpu_device, monkeypatch):
+    """The last layer has three kernels (sliding-window, channel-parallel rows, generic); the planner picks by
+    size, so each is forced once here and checked against the reference golden."""
+    monkeypatch.setenv(env, "1")
+    for case in ("large_s128_b2", "normal_512"):
+        meta, arrays, topo, sd, feat, cand = golden_problem(case)
+        e = make_engine(topo, sd, gpu_device, meta["batch"])
+        out = e.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device))
+        assert np.abs(out.cpu().numpy() - arrays["out"]).max() <= TIGHT
