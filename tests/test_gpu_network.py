@@ -176,3 +176,37 @@ def test_every_last_conv_variant_matches_golden(env, gpu_device, monkeypatch):
         e = make_engine(topo, sd, gpu_device, meta["batch"])
         out = e.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device))
         assert np.abs(out.cpu().numpy() - arrays["out"]).max() <= TIGHT
+
+
+def test_drop_in_model_api_end_to_end(gpu_device, tmp_path):
+    """The reference's own call sequence (demo.py:168-172, :266): create_model(opt) -> setup(opt) (loads a
+    DataParallel-prefixed .pkl) -> eval() -> inference(feature_map, cand_image), on the GPU, against the golden."""
+    import argparse
+    import livespeechportraits_amd as L
+    meta, arrays, topo, sd, feat, cand = golden_problem("large_s128_b2")
+    ckpt = str(tmp_path / "Feature2Face.pkl")
+    torch.save({"module." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, ckpt)
+    opt = argparse.Namespace(model="feature2face", gpu_ids=[0], isTrain=False, size=meta["variant"], ngf=meta["ngf"],
+                             n_downsample_G=meta["num_downs"], fp16=0, checkpoints_dir=str(tmp_path), name="t",
+                             load_epoch=ckpt, verbose=False)
+    model = L.create_model(opt)
+    model.setup(opt)
+    model.eval()
+    assert list(model.Feature2Face_G.state_dict())[0].startswith("module.netG.")       # DataParallel-style keys
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+    out = model.inference(f, c)                      # cand batch 1, feature batch 2
+    assert out.shape == (2, 3, 128, 128) and out.dtype == torch.float32 and out.device == f.device
+    assert np.abs(out.cpu().numpy() - arrays["out"]).max() <= TIGHT
+    again = model.inference(f, c)                    # second call goes through the candidate cache
+    assert torch.equal(again, out)
+    one = model.inference(f[:1].contiguous(), c)     # demo.py's batch-1 call pattern
+    assert np.abs(one.cpu().numpy() - arrays["out"][:1]).max() <= TIGHT
+    # G also accepts the concatenated tensor the reference's netG is called with
+    cat = torch.cat([f, c.expand(2, -1, -1, -1)], 1)
+    assert np.abs(model._g()(cat).cpu().numpy() - arrays["out"]).max() <= TIGHT
+    u8 = model.inference_image(f, c)
+    assert u8.shape == (2, 128, 128, 3) and u8.dtype == torch.uint8
+    # new weights are picked up (load_state_dict marks the packed blob dirty)
+    sd2 = {k: (v * 0.5 if v.dtype == np.float32 and v.ndim == 4 else v) for k, v in sd.items()}
+    model._g().load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd2.items()})
+    assert (model.inference(f, c) - out).abs().max().item() > 1e-3
