@@ -32,12 +32,14 @@ struct FastDiv {
 // One fused 3x3 convolution as an implicit GEMM:  M = B*Ho*Wo output pixels, N = Cout,
 // K = 9*Cin ordered (ky, kx, ci) with ci running over src0's channels then src1's.
 struct IgemmParams {
-    const float *src0, *src1;   // NHWC [B][Hs][Ws][C0|C1]; src1 == nullptr when C1 == 0
-    const float *w;             // [Cout][9*Cin]
+    // activations / weights are fp32 (dtype 0) or bf16 (dtype 1: bf16 storage, fp32 accumulate / epilogue)
+    const void *src0, *src1;    // NHWC [B][Hs][Ws][C0|C1]; src1 == nullptr when C1 == 0
+    const void *w;              // [Cout][9*Cin]
     const float *scale, *shift; // [Cout] folded BatchNorm, or nullptr (identity)
-    const float *residual;      // NHWC [M][Cout] or nullptr
-    float *out;                 // NHWC [M][Cout]
-    float *partial;             // split-K scratch [splits][M][Cout] (splits > 1)
+    const void *residual;       // NHWC [M][Cout] or nullptr
+    void *out;                  // NHWC [M][Cout]
+    float *partial;             // split-K scratch [splits][M][Cout] (splits > 1), always fp32
+    int dtype;                  // 0 = fp32, 1 = bf16
     int B, Hs, Ws, Ho, Wo;
     int C0, C1, Cin, Cout;
     int stride;                 // 1 | 2
@@ -46,7 +48,7 @@ struct IgemmParams {
     int relu;
     int M;                      // GEMM rows per launch slice (up4: B*Hs*Ws per parity, else B*Ho*Wo)
     int Mout;                   // output pixels B*Ho*Wo
-    int ktiles_total;           // taps*Cin/32 (taps = 9, or 4 for up4)
+    int ktiles_total;           // taps*Cin/(32|64): a K-tile is 128 B of channels (taps = 9, or 4 for up4)
     int ktiles_per_split;
     int splits;
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
@@ -67,11 +69,12 @@ hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s);
 
 // Tiny-M single-source conv (M <= 16 output pixels, whole input <= 64 KB): one launch, no split-K.
 struct SmallMParams {
-    const float *src;            // NHWC [B][Hs][Ws][Cin]
-    const float *w;              // [Cout][9][Cin]
+    const void *src;             // NHWC [B][Hs][Ws][Cin]            (fp32 or bf16, see dtype)
+    const void *w;               // [Cout][9][Cin]
     const float *scale, *shift;  // [Cout] or nullptr
-    const float *residual;       // [M][Cout] or nullptr
-    float *out;                  // [M][Cout]
+    const void *residual;        // [M][Cout] or nullptr
+    void *out;                   // [M][Cout]
+    int dtype;                   // 0 = fp32, 1 = bf16
     int B, Hs, Ws, Ho, Wo, Cin, Cout;
     int stride, up, relu, M;
 };
@@ -83,7 +86,8 @@ struct FirstConvParams {
     const float *feat;   // [B][feat_nc][H][W]
     const float *cand;   // [cand_batch][cand_nc][H][W] or nullptr
     const float *w;      // [(ci*9 + ky*3 + kx)][Cout]
-    float *out;          // NHWC [B][H/2][W/2][Cout]
+    void *out;           // NHWC [B][H/2][W/2][Cout], fp32 or bf16 (dtype)
+    int dtype;
     int B, H, W, feat_nc, cand_nc, cand_batch, Cout;
     int ci_begin, ci_end;   // input-channel range of this pass ([0, feat_nc+cand_nc) = the whole layer)
     const float *base;      // optional pre-activation partial sums [1][H/2][W/2][Cout] to start from
@@ -93,7 +97,8 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
 
 // Last layer: Upsample x2 -> Conv 3x3 s1 p1 over cat([src0, src1]) -> tanh, NHWC in, NCHW out.
 struct LastConvParams {
-    const float *src0, *src1;  // NHWC [B][Hs][Ws][C0|C1]
+    const void *src0, *src1;   // NHWC [B][Hs][Ws][C0|C1], fp32 or bf16 (dtype); weights stay fp32
+    int dtype;
     const float *w;            // sub-pixel form [4 parities][Cout][2][2][Cin] (taps pre-summed)
     float *out;                // NCHW [B][Cout][2Hs][2Ws]
     int B, Hs, Ws, C0, C1, Cout;

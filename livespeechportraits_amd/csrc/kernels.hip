@@ -24,6 +24,34 @@ namespace lspf2f {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;               // bf16 storage (round-to-nearest-even on store)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+// 4 consecutive channels of an activation row: load / store as float4 regardless of the storage type
+template <typename T> __device__ __forceinline__ float4 load4(const T *p);
+template <> __device__ __forceinline__ float4 load4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t *p)
+{
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v)
+{
+    uint2 u;
+    u.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2 *>(p) = u;
+}
 
 // LDS ring depth of the igemm pipeline (2; 3 if built with -DLSPF2F_STAGES=3 and it leaves >= 2 workgroups per CU)
 #ifndef LSPF2F_STAGES
@@ -82,9 +110,14 @@ __device__ __forceinline__ void dma_wait()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int G, bool UP>
-__global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams p)
+// T = storage type of activations and weights: float (exact fp32 MFMA, v_mfma_f32_32x32x2_f32) or bf16_t
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate and epilogue).  A K-tile is always 128 B of channels (32 fp32 /
+// 64 bf16), so the LDS geometry, the DMA pieces and the swizzle are identical for both.
+template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP>
+__global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
 {
+    constexpr int EB = (int)sizeof(T);               // element bytes
+    constexpr int BKE = 128 / EB;                    // channels per K-tile
     constexpr int NT = 64 * WGM * WGN;
     constexpr int RPP = NT / 8;            // tile rows staged per pass (8 threads x float4 = one 32-float row)
     constexpr int PA = BM / RPP, PB = BN / RPP;
@@ -123,7 +156,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
     const int lrow = tid >> 3;
     // staging: thread = (row lrow of each 8-row wave stripe, 16-B slot tid&7); it fetches the k-quad that
     // belongs in its slot
-    const int lq = ((tid & 7) ^ ((lrow >> 1) & 7)) * 4;
+    const int lqb = ((tid & 7) ^ ((lrow >> 1) & 7)) * 16;   // byte offset of the k-slot this thread fetches
 
     // ---- per-thread im2col row descriptors (fixed for the whole K loop) ----
     // a_pix0: pixel index of tap (0,0) (may be "negative" at the border -- only used when the
@@ -168,20 +201,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
         }
     }
     const int K = ntap * p.Cin;
-    const float *wbase = p.w + (size_t)par * p.Cout * K;
+    const T *wbase = static_cast<const T *>(p.w) + (size_t)par * p.Cout * K;
     unsigned b_off[PB];                                  // byte offset of this thread's weight row, or OOB
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int n = n0 + i * RPP + lrow;
-        b_off[i] = (n < p.Cout) ? (unsigned)(n * K + lq) * 4u : kOOB;
+        b_off[i] = (n < p.Cout) ? (unsigned)(n * K) * (unsigned)EB + (unsigned)lqb : kOOB;
     }
-    const unsigned plane = (unsigned)(p.B * p.Hs * p.Ws) * 4u;
-    const i32x4 rsw = make_srd(wbase, (unsigned)(p.Cout * K) * 4u);
+    const unsigned plane = (unsigned)(p.B * p.Hs * p.Ws) * (unsigned)EB;
+    const i32x4 rsw = make_srd(wbase, (unsigned)(p.Cout * K) * (unsigned)EB);
 
     // K-tile cursor of the NEXT tile to fetch: tap = ky*tw+kx, c = channel offset inside the
     // concatenated input
-    int tap = (kt_begin * BK) / p.Cin;
-    int c = kt_begin * BK - tap * p.Cin;
+    int tap = (kt_begin * BKE) / p.Cin;
+    int c = kt_begin * BKE - tap * p.Cin;
     int ky = tap / tw, kx = tap - ky * tw;
 
     // Stage K-tiles kt .. kt+G-1 into LDS buffer `buf` with buffer_load ... lds (LDS-DMA): no staging
@@ -197,12 +230,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
         for (int g = 0; g < G; ++g) {
             const bool live = kt + g < kt_end;
             const bool first = c < p.C0;
-            const float *sp = first ? p.src0 : p.src1;
+            const void *sp = first ? p.src0 : p.src1;
             const int cs = first ? p.C0 : p.C1;
-            const int soff = (first ? c : c - p.C0) * 4;
+            const int soff = (first ? c : c - p.C0) * EB;
             const i32x4 rs = make_srd(sp, plane * (unsigned)cs);
             const int tapdelta = ky * p.Ws + kx;
-            const unsigned csb = (unsigned)cs * 4u;
+            const unsigned csb = (unsigned)cs * (unsigned)EB;
             const unsigned A = lds_a + (unsigned)(((buf * G + g) * TILE_A + wstripe * LDK) * 4);
             const unsigned Bq = lds_b + (unsigned)(((buf * G + g) * TILE_B + wstripe * LDK) * 4);
 #pragma unroll
@@ -210,14 +243,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
                 const bool ok = live && ((a_mask[i] >> tap) & 1u);
                 const int pix = UP ? a_pix0[i] + ((a_oy[i] + ky) >> 1) * p.Ws + ((a_ox[i] + kx) >> 1)
                                    : a_pix0[i] + tapdelta;
-                const unsigned voff = ok ? (unsigned)pix * csb + (unsigned)lq * 4u : kOOB;
+                const unsigned voff = ok ? (unsigned)pix * csb + (unsigned)lqb : kOOB;
                 dma16(A + i * RPP * LDK * 4, voff, rs, soff);
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i)
                 dma16(Bq + i * RPP * LDK * 4, live ? b_off[i] : kOOB, rsw, (kt + g) * (BK * 4));
             if (live) {
-                c += BK;
+                c += BKE;
                 if (c == p.Cin) {
                     c = 0; ++tap; ++kx;
                     if (kx == tw) { kx = 0; ++ky; }
@@ -259,10 +292,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].x, fb[set][j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].y, fb[set][j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].z, fb[set][j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].w, fb[set][j].w, acc[i][j], 0, 0, 0);
+                if constexpr (EB == 4) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].x, fb[set][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].y, fb[set][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].z, fb[set][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].w, fb[set][j].w, acc[i][j], 0, 0, 0);
+                } else {
+                    // the 16-B slot is 8 consecutive bf16 channels = this lane's K = 8*(lane>>5) .. +7 operand
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
+                                                                        __builtin_bit_cast(bf16x8, fb[set][j]),
+                                                                        acc[i][j], 0, 0, 0);
+                }
             }
     };
 
@@ -343,11 +383,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
                 } else {
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                     if (p.residual) {
-                        const float4 rv = *reinterpret_cast<const float4 *>(p.residual + orow * p.Cout + n);
+                        const float4 rv = load4(static_cast<const T *>(p.residual) + orow * p.Cout + n);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *reinterpret_cast<float4 *>(p.out + orow * p.Cout + n) = v;
+                    store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
                 }
             }
         }
@@ -357,6 +397,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3_f32(const IgemmParams
 // out = epilogue(sum_z partial[z]).  Block = 64 float4 columns x 4 z-lanes: z-lane y adds
 // partials y, y+4, y+8, ... (ascending), then the four lane sums are added in lane order --
 // a fixed summation tree, so results are bit-reproducible run to run.
+template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
 {
     __shared__ float4 red[3][64];
@@ -396,14 +437,14 @@ __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
         s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
     }
     if (p.residual) {
-        const float4 r = reinterpret_cast<const float4 *>(p.residual)[i];
+        const float4 r = load4(static_cast<const T *>(p.residual) + (size_t)i * 4);
         s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
     }
     if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-    reinterpret_cast<float4 *>(p.out)[i] = s;
+    store4(static_cast<T *>(p.out) + (size_t)i * 4, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int G, bool UP>
+template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP>
 static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
 {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
@@ -415,12 +456,12 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
     if (smem < smem_patch) smem = smem_patch;
     static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
     if (smem_max > 64 * 1024 && !attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3_f32<BM, BN, WGM, WGN, G, UP>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3<T, BM, BN, WGM, WGN, G, UP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm3x3_f32<BM, BN, WGM, WGN, G, UP>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
+    hipLaunchKernelGGL((igemm3x3<T, BM, BN, WGM, WGN, G, UP>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
                        smem, s, p);
     return hipGetLastError();
 }
@@ -443,6 +484,34 @@ bool igemm_group_supported(int bm, int bn, int g, bool up)
 
 hipError_t igemm_init() { return hipSuccess; }
 
+template <typename T>
+static hipError_t launch_igemm_typed(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
+{
+    if (p.up) {
+        if (bm == 64 && bn == 64 && g == 1) return launch_igemm_t<T, 64, 64, 2, 2, 1, true>(p, s);
+        if (bm == 64 && bn == 64 && g == 4) return launch_igemm_t<T, 64, 64, 2, 2, 4, true>(p, s);
+        if (bm == 32 && bn == 64 && g == 4) return launch_igemm_t<T, 32, 64, 1, 2, 4, true>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (g == 4) {
+        if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 4, false>(p, s);
+        if (bm == 32 && bn == 64) return launch_igemm_t<T, 32, 64, 1, 2, 4, false>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (g == 2) {
+        if (bm == 128 && bn == 64) return launch_igemm_t<T, 128, 64, 2, 2, 2, false>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 2, false>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (bm == 128 && bn == 128) return launch_igemm_t<T, 128, 128, 2, 2, 1, false>(p, s);
+    if (bm == 128 && bn == 64) return launch_igemm_t<T, 128, 64, 2, 2, 1, false>(p, s);
+    if (bm == 64 && bn == 128) return launch_igemm_t<T, 64, 128, 2, 2, 1, false>(p, s);
+    if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 1, false>(p, s);
+    if (bm == 32 && bn == 128) return launch_igemm_t<T, 32, 128, 1, 4, 1, false>(p, s);
+    if (bm == 32 && bn == 64) return launch_igemm_t<T, 32, 64, 1, 2, 1, false>(p, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStream_t s)
 {
     IgemmParams p = p_in;
@@ -450,36 +519,17 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
     p.div_rw = FastDiv::make((unsigned)(p.up4 ? p.Ws : p.Wo));
     // 2 GiB per tensor: buffer-load offsets are 32-bit with the top bit reserved as the OOB marker
     const size_t lim = 0x7fffffffull;
-    if ((size_t)p.B * p.Hs * p.Ws * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > lim) return hipErrorInvalidValue;
-    if (p.up) {
-        if (bm == 64 && bn == 64 && g == 1) return launch_igemm_t<64, 64, 2, 2, 1, true>(p, s);
-        if (bm == 64 && bn == 64 && g == 4) return launch_igemm_t<64, 64, 2, 2, 4, true>(p, s);
-        if (bm == 32 && bn == 64 && g == 4) return launch_igemm_t<32, 64, 1, 2, 4, true>(p, s);
-        return hipErrorInvalidValue;
-    }
-    if (g == 4) {
-        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 4, false>(p, s);
-        if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 4, false>(p, s);
-        return hipErrorInvalidValue;
-    }
-    if (g == 2) {
-        if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 2, false>(p, s);
-        if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 2, false>(p, s);
-        return hipErrorInvalidValue;
-    }
-    if (bm == 128 && bn == 128) return launch_igemm_t<128, 128, 2, 2, 1, false>(p, s);
-    if (bm == 128 && bn == 64) return launch_igemm_t<128, 64, 2, 2, 1, false>(p, s);
-    if (bm == 64 && bn == 128) return launch_igemm_t<64, 128, 2, 2, 1, false>(p, s);
-    if (bm == 64 && bn == 64) return launch_igemm_t<64, 64, 2, 2, 1, false>(p, s);
-    if (bm == 32 && bn == 128) return launch_igemm_t<32, 128, 1, 4, 1, false>(p, s);
-    if (bm == 32 && bn == 64) return launch_igemm_t<32, 64, 1, 2, 1, false>(p, s);
-    return hipErrorInvalidValue;
+    const size_t eb = p.dtype == 1 ? 2 : 4;
+    if ((size_t)p.B * p.Hs * p.Ws * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * eb > lim) return hipErrorInvalidValue;
+    if ((p.C0 * eb) % 128 || (p.C1 * eb) % 128) return hipErrorInvalidValue;   // a K-tile is 128 B of channels
+    return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
 }
 
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
 {
     const size_t total4 = (size_t)p.Mout * p.Cout / 4;
-    hipLaunchKernelGGL(splitk_reduce, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
+    if (p.dtype == 1) hipLaunchKernelGGL(splitk_reduce<bf16_t>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(splitk_reduce<float>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -491,7 +541,7 @@ hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
 // all 256 CUs stream weight rows (issued first, one latency), the whole input tensor (<= 64 KB)
 // is staged in LDS, each thread multiplies its K-slice for all pixels on the VALU, and the block
 // reduces through LDS in a fixed order.  Same packed weights [Cout][tap][Cin] as the igemm.
-template <int NC>
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
 {
     constexpr int MM = 16;                                 // max output pixels (batch folded in)
@@ -512,14 +562,14 @@ __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
         for (int j = 0; j < NJ; ++j) {
             const int k4 = tid + 256 * j;
             wv[nc][j] = (k4 < K4 && n0 + nc < p.Cout)
-                ? reinterpret_cast<const float4 *>(p.w + (size_t)(n0 + nc) * 9 * p.Cin)[k4]
+                ? load4(static_cast<const T *>(p.w) + (size_t)(n0 + nc) * 9 * p.Cin + (size_t)k4 * 4)
                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     // 2. input tensor -> LDS, (m, tap) -> source pixel table
     const int npix = p.B * p.Hs * p.Ws;
     const int nin4 = npix * C4;
     for (int i = tid; i < nin4; i += 256)
-        reinterpret_cast<float4 *>(act)[i] = reinterpret_cast<const float4 *>(p.src)[i];
+        reinterpret_cast<float4 *>(act)[i] = load4(static_cast<const T *>(p.src) + (size_t)i * 4);   // LDS copy is fp32
     for (int i = tid; i < C4; i += 256) reinterpret_cast<float4 *>(act)[nin4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < MM * 9) {
         const int t = tid / MM, m = tid - t * MM;
@@ -587,9 +637,13 @@ __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
         if (part == 0 && m < p.M && n < p.Cout) {
             float v = sum;
             if (p.scale) v = v * p.scale[n] + p.shift[n];
-            if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+            if (p.residual) {
+                if constexpr (sizeof(T) == 4) v += static_cast<const float *>(p.residual)[(size_t)m * p.Cout + n];
+                else v += bf2f(static_cast<const bf16_t *>(p.residual)[(size_t)m * p.Cout + n]);
+            }
             if (p.relu) v = fmaxf(v, 0.f);
-            p.out[(size_t)m * p.Cout + n] = v;
+            if constexpr (sizeof(T) == 4) static_cast<float *>(p.out)[(size_t)m * p.Cout + n] = v;
+            else static_cast<bf16_t *>(p.out)[(size_t)m * p.Cout + n] = f2bf(v);
         }
     }
 }
@@ -609,12 +663,16 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     const size_t smem = 160 * 4 + (act_bytes > red_bytes ? act_bytes : red_bytes);
     static bool attr_done = false;
     if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<NC>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv3x3_smallm<NC>, dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
+    if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL((conv3x3_smallm<float, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 
@@ -626,6 +684,7 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
 // one-load-per-tap form was latency-bound at ~50 us).
 // Reference: cat (feature2face_model.py:231) + Conv2d(13, ngf, 3, 2, 1, bias=False) + ReLU
 // (networks.py:594, :603, :619 `down = [downconv, downrelu]`).
+template <typename T>
 __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];   // [K][32]
@@ -705,19 +764,19 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
 #pragma unroll
         for (int t = 0; t < 9; ++t) v[t] = vn[t];
     }
-    float4 *o = reinterpret_cast<float4 *>(p.out + (size_t)gid * p.Cout + co0);
+    T *o = static_cast<T *>(p.out) + (size_t)gid * p.Cout + co0;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        o[j] = p.relu ? make_float4(fmaxf(acc[4 * j], 0.f), fmaxf(acc[4 * j + 1], 0.f),
-                                    fmaxf(acc[4 * j + 2], 0.f), fmaxf(acc[4 * j + 3], 0.f))
-                      : make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+        store4(o + 4 * j, p.relu ? make_float4(fmaxf(acc[4 * j], 0.f), fmaxf(acc[4 * j + 1], 0.f),
+                                               fmaxf(acc[4 * j + 2], 0.f), fmaxf(acc[4 * j + 3], 0.f))
+                                 : make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]));
 }
 
 // Feature-map-only pass of the first layer (the candidate share comes in through `base`): pure streaming,
 // ~1 FLOP/byte.  16 lanes share a pixel and own 4 output channels each, so a wave reads and writes
 // 4 pixels x Cout*4 B contiguously (Cout = 64: exactly 1 KB per instruction); the 9 x feat_nc tap values
 // are broadcast loads, the lane's weights stay in registers.
-template <int FN>
+template <typename T, int FN>
 __global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
 {
     const int Ho = p.H / 2, Wo = p.W / 2;
@@ -752,7 +811,7 @@ __global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
             }
         }
         if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        *reinterpret_cast<float4 *>(p.out + (size_t)g * p.Cout + j * 4) = acc;
+        store4(static_cast<T *>(p.out) + (size_t)g * p.Cout + j * 4, acc);
     }
 }
 
@@ -764,13 +823,18 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
         long blocks = (npix / ppw + 3) / 4;                  // one pixel group per wave ...
         if (blocks > 4096) blocks = 4096;                    // ... up to 16 blocks per CU, then grid-stride
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(first_conv_feat<1>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.dtype == 1) hipLaunchKernelGGL((first_conv_feat<bf16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((first_conv_feat<float, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         return hipGetLastError();
     }
     const long total = (long)p.B * (p.H / 2) * (p.W / 2);
     const int K = (p.ci_end - p.ci_begin) * 9;
-    hipLaunchKernelGGL(first_conv, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
-                       (size_t)K * 32 * sizeof(float), s, p);
+    if (p.dtype == 1 && p.out != nullptr && !(p.relu == 0 && p.base == nullptr && p.ci_begin > 0))
+        hipLaunchKernelGGL(first_conv<bf16_t>, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
+                           (size_t)K * 32 * sizeof(float), s, p);
+    else   // fp32 activations, or the candidate-share pass (its cache is always fp32)
+        hipLaunchKernelGGL(first_conv<float>, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
+                           (size_t)K * 32 * sizeof(float), s, p);
     return hipGetLastError();
 }
 
@@ -792,7 +856,7 @@ __device__ __forceinline__ unsigned char to_u8(float v)
 // use the same weights (LDS broadcast); the concat is two base pointers; NCHW store.
 // Reference: nn.Upsample(2,'nearest') + Conv2d(2*ngf, 3, 3, 1, 1, bias=False) (networks.py:610-611)
 // + torch.tanh (networks.py:577).
-template <int CO>
+template <typename T, int CO>
 __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 parities][CO][2][2][Cin]
@@ -825,10 +889,10 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
             if (sx < 0 || sx >= p.Ws) continue;
             const size_t pix = ((size_t)b * p.Hs + sy) * p.Ws + sx;
             const float *wt = wsm + ((par * CO) * 4 + a * 2 + bb) * cin;      // + co*4*cin
-            const float4 *s0 = reinterpret_cast<const float4 *>(p.src0 + pix * p.C0);
+            const T *s0 = static_cast<const T *>(p.src0) + pix * p.C0;
 #pragma unroll 4
             for (int c4 = 0; c4 < p.C0 / 4; ++c4) {
-                const float4 v = s0[c4];
+                const float4 v = load4(s0 + c4 * 4);
 #pragma unroll
                 for (int co = 0; co < CO; ++co) {
                     const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * 4 * cin + c4 * 4);
@@ -836,10 +900,10 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
                 }
             }
             if (p.C1) {
-                const float4 *s1 = reinterpret_cast<const float4 *>(p.src1 + pix * p.C1);
+                const T *s1 = static_cast<const T *>(p.src1) + pix * p.C1;
 #pragma unroll 4
                 for (int c4 = 0; c4 < p.C1 / 4; ++c4) {
-                    const float4 v = s1[c4];
+                    const float4 v = load4(s1 + c4 * 4);
 #pragma unroll
                     for (int co = 0; co < CO; ++co) {
                         const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * 4 * cin + p.C0 + c4 * 4);
@@ -865,7 +929,7 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
 // (wave id & 3); that parity's 4-tap x CO weights sit in LDS (conflict-free: a row's 16 lanes read 16
 // consecutive float4, the 4 rows broadcast), which keeps the kernel at ~64 VGPRs = 8 waves/SIMD --
 // the loop is a load -> FMA -> DPP -> store chain and needs the occupancy to hide its latency.
-template <int CO, int NCH>
+template <typename T, int CO, int NCH>
 __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 parities][2 src][NCH][4 taps][CO][16 lanes] float4
@@ -905,8 +969,8 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
     int y, xq;
     { const unsigned r = q - (unsigned)b * p.Hs * qpr; y = (int)(r / qpr); xq = (int)(r - (unsigned)y * qpr); }
 
-    const float *__restrict__ s0 = p.src0;
-    const float *__restrict__ s1 = p.src1;
+    const T *__restrict__ s0 = static_cast<const T *>(p.src0);
+    const T *__restrict__ s1 = static_cast<const T *>(p.src1);
     float *__restrict__ outp = p.out;
 
     for (; q < qend; ++q) {
@@ -921,9 +985,9 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int ch = (c * 16 + j) * 4;
-                v[0][t][c] = (ok && ch < p.C0) ? *reinterpret_cast<const float4 *>(s0 + pix * p.C0 + ch)
+                v[0][t][c] = (ok && ch < p.C0) ? load4(s0 + pix * p.C0 + ch)
                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-                v[1][t][c] = (ok && ch < p.C1) ? *reinterpret_cast<const float4 *>(s1 + pix * p.C1 + ch)
+                v[1][t][c] = (ok && ch < p.C1) ? load4(s1 + pix * p.C1 + ch)
                                                : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -971,7 +1035,7 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
 // neighbourhood in registers: per step it loads ONE new column (3 rows x 2 sources) and emits all four
 // output parities of that source pixel -- 1.5 loads per output instead of 8 -- with the pre-summed
 // sub-pixel weights read conflict-free from LDS and the channel sum done by DPP row rotations.
-template <int CO>
+template <typename T, int CO>
 __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, int seg)
 {
     extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 par][2 src][4 taps][CO][16 lanes] float4
@@ -1004,16 +1068,16 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
     const int x1 = x0 + seg < p.Ws ? x0 + seg : p.Ws;
     const bool chan_ok = j * 4 < p.C0;
 
-    const float *__restrict__ s0 = p.src0;
-    const float *__restrict__ s1 = p.src1;
+    const T *__restrict__ s0 = static_cast<const T *>(p.src0);
+    const T *__restrict__ s1 = static_cast<const T *>(p.src1);
     auto load_col = [&](int x, float4 (&col)[3][2]) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int sy = y + r - 1;
             const bool ok = chan_ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
             const size_t pix = ok ? ((size_t)b * p.Hs + sy) * p.Ws + x : 0;
-            col[r][0] = ok ? *reinterpret_cast<const float4 *>(s0 + pix * p.C0 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            col[r][1] = ok ? *reinterpret_cast<const float4 *>(s1 + pix * p.C1 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            col[r][0] = ok ? load4(s0 + pix * p.C0 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            col[r][1] = ok ? load4(s1 + pix * p.C1 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     float4 win[3][3][2];                       // [column x-1, x, x+1][row y-1, y, y+1][source]
@@ -1080,7 +1144,7 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
     }
 }
 
-template <int CO>
+template <typename T, int CO>
 static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
 {
     const long quads = (long)p.B * p.Hs * ((p.Ws + 3) / 4);
@@ -1092,7 +1156,7 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
         const int seg = 32;
         const long groups = (long)p.B * p.Hs * ((p.Ws + seg - 1) / seg);
         const size_t smem = (size_t)4 * 2 * 4 * CO * 16 * sizeof(float4);
-        hipLaunchKernelGGL(last_conv_strip<CO>, dim3((unsigned)((groups + 15) / 16)), dim3(256), smem, s, p, seg);
+        hipLaunchKernelGGL((last_conv_strip<T, CO>), dim3((unsigned)((groups + 15) / 16)), dim3(256), smem, s, p, seg);
         return hipGetLastError();
     }
     if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 128 && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
@@ -1102,23 +1166,32 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
         if (blocks < 1) blocks = 1;
         const int nch = p.C0 <= 64 ? 1 : 2;
         const size_t smem = (size_t)4 * 2 * nch * 4 * CO * 16 * sizeof(float4);
-        if (nch == 1) hipLaunchKernelGGL((last_conv_rows<CO, 1>), dim3((unsigned)blocks), dim3(256), smem, s, p);
-        else hipLaunchKernelGGL((last_conv_rows<CO, 2>), dim3((unsigned)blocks), dim3(256), smem, s, p);
+        if (nch == 1) hipLaunchKernelGGL((last_conv_rows<T, CO, 1>), dim3((unsigned)blocks), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((last_conv_rows<T, CO, 2>), dim3((unsigned)blocks), dim3(256), smem, s, p);
         return hipGetLastError();
     }
     const long total = (long)p.B * 4 * p.Hs * p.Ws;
     const size_t smem = (size_t)16 * p.Cout * (p.C0 + p.C1) * sizeof(float);
-    hipLaunchKernelGGL(last_conv<CO>, dim3((unsigned)((total + 255) / 256)), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((last_conv<T, CO>), dim3((unsigned)((total + 255) / 256)), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
+    if (p.dtype == 1) {
+        switch (p.Cout) {
+        case 1: return launch_last_conv_co<bf16_t, 1>(p, s);
+        case 2: return launch_last_conv_co<bf16_t, 2>(p, s);
+        case 3: return launch_last_conv_co<bf16_t, 3>(p, s);
+        case 4: return launch_last_conv_co<bf16_t, 4>(p, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (p.Cout) {
-    case 1: return launch_last_conv_co<1>(p, s);
-    case 2: return launch_last_conv_co<2>(p, s);
-    case 3: return launch_last_conv_co<3>(p, s);
-    case 4: return launch_last_conv_co<4>(p, s);
+    case 1: return launch_last_conv_co<float, 1>(p, s);
+    case 2: return launch_last_conv_co<float, 2>(p, s);
+    case 3: return launch_last_conv_co<float, 3>(p, s);
+    case 4: return launch_last_conv_co<float, 4>(p, s);
     default: return hipErrorInvalidValue;
     }
 }
