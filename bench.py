@@ -22,6 +22,7 @@ import torch         # noqa: E402
 import torch.distributed as dist   # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (not the 2:1-sparse marketing figure)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -33,6 +34,8 @@ def main():
     ap.add_argument("--variant", default="large", choices=["large", "normal"])
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = the parity configuration (default); bf16 = BASELINE.json configs[2] storage path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--layers", default=None, help="write the per-layer timing table to this file")
@@ -53,7 +56,8 @@ def main():
 
     topo = build_topology(a.variant, size=a.size)
     B = a.batch
-    eng = Engine(a.variant, size=a.size, max_batch=max(B, 8 if not a.no_extra and world == 1 else B))
+    eng = Engine(a.variant, size=a.size, max_batch=max(B, 8 if not a.no_extra and world == 1 else B), dtype=a.dtype)
+    peak = PEAK_F32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     sd = synth.make_state_dict(topo, 1234) if rank == 0 else None
     D.setup_engine(eng, sd, dev)          # pack on rank 0, ONE RCCL broadcast, bind everywhere
 
@@ -125,21 +129,21 @@ def main():
     # run inside this process); only quoted for the workload it was measured on
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_large_b1.json")
-    if a.variant == "large" and B == 1 and a.size == 512 and os.path.exists(pmc_path):
+    if a.variant == "large" and B == 1 and a.size == 512 and a.dtype == "f32" and os.path.exists(pmc_path):
         pj = json.load(open(pmc_path))["per_forward_bytes"]["conv_family"]
         traffic = int(pj["fetch_x2"] + pj["write"])
         traffic_src = "profiles/r01_pmc_large_b1.json (FETCH_SIZE x2 + WRITE_SIZE per forward, rocprofv3 --pmc)"
 
     roofline = {
         "bound": "mfma", "kernel": "igemm3x3_f32 family incl. split-K reduce and tiny-M conv (all %d conv layers of one frame batch except first/last)" % len(ig),
-        "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes": int(sum(layers[i]["act_bytes_per_frame"] for i in ig) * B + sum(layers[i]["weight_bytes"] for i in ig)),
         "flops_per_launch_set": ig_flops, "ms_per_launch_set": round(ig_ms, 4),
-        "executed": {"tflops": round(executed, 2), "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+        "executed": {"tflops": round(executed, 2), "frac": round(executed / peak, 4),
                      "note": "MFMA FLOPs actually issued: the sub-pixel up-convs need 4/9 of the algorithmic count"},
         "whole_forward": {"achieved": round(flops_step / (ev_ms * 1e-3) / 1e12, 2),
-                          "frac": round(flops_step / (ev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                          "frac": round(flops_step / (ev_ms * 1e-3) / 1e12 / peak, 4),
                           "ms_device": round(ev_ms, 4)},
     }
 
@@ -193,9 +197,10 @@ def main():
     line = {
         "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s generator (%s), batch %d per GPU, %dx%d, fp32, synthetic weights+inputs"
-                               % (a.variant, "May" if a.variant == "large" else "Obama1", B, a.size, a.size),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "%s generator (%s), batch %d per GPU, %dx%d, %s, synthetic weights+inputs"
+                               % (a.variant, "May" if a.variant == "large" else "Obama1", B, a.size, a.size,
+                                  "fp32" if a.dtype == "f32" else "bf16 storage / fp32 accumulate (parity-unpinned: tolerance declared in tests)"),
                    "global_batch": world * B, "parallelism": "dp%d (frames sharded, one RCCL weight broadcast)" % world,
                    "gflop_per_frame": round(topo.flops_per_frame() / 1e9, 2)},
         "roofline": roofline, "cpu_baseline": cpu_baseline,

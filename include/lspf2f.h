@@ -49,7 +49,10 @@ typedef enum lspf2f_variant {
 } lspf2f_variant;
 
 typedef enum lspf2f_dtype {
-    LSPF2F_DTYPE_F32 = 0        /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+    LSPF2F_DTYPE_F32 = 0,       /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity configuration */
+    LSPF2F_DTYPE_BF16 = 1       /* bf16 activations + conv weights in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate and
+                                   epilogue; API tensors stay fp32.  The reference has no bf16 path (only fp16 autocast,
+                                   feature2face_G.py:28-30): compared against the fp32 oracle with a declared tolerance */
 } lspf2f_dtype;
 
 /* flags for lspf2f_config.flags */
@@ -185,15 +188,17 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
  *   stride in {1,2}; upsample: 0 none; 1 nearest x2 before the conv (9-tap gather form, stride 1);
  *   2 the same op in sub-pixel form: w_packed is [4 parities][cout][2][2][c0+c1] with the
  *   aliasing 3x3 taps pre-summed (see plan.cpp pack()).
+ *   dtype: lspf2f_dtype of src0/src1/w_packed/residual/out (scale/shift are always fp32; bf16 needs
+ *   c0, c1 % 64 == 0).
  *   tile_m/tile_n/split_k/k_group = 0 selects the planner's choice (k_group = K-tiles fetched
  *   per pipeline step: 1, 2 or 4); scratch is needed when split_k != 1
  *   (size from lspf2f_conv3x3_scratch_bytes). */
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride,
-                                    int upsample, int tile_m, int tile_n, int split_k, int k_group);
-int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, const float *scale,
-                   const float *shift, const float *residual, float *out, int batch, int hs, int ws,
+                                    int upsample, int tile_m, int tile_n, int split_k, int k_group, int dtype);
+int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, const float *scale,
+                   const float *shift, const void *residual, void *out, int batch, int hs, int ws,
                    int c0, int c1, int cout, int stride, int upsample, int relu, int tile_m,
-                   int tile_n, int split_k, int k_group, void *scratch, size_t scratch_bytes,
+                   int tile_n, int split_k, int k_group, int dtype, void *scratch, size_t scratch_bytes,
                    void *hip_stream);
 
 #ifdef __cplusplus

@@ -21,6 +21,7 @@ ERR_NAMES = {
     -5: "STATE", -6: "HIP", -7: "NO_DEVICE",
 }
 VARIANT_IDS = {"normal": 0, "large": 1}
+DTYPE_IDS = {"f32": 0, "bf16": 1}
 FLAG_KEEP_INTERMEDIATES = 1
 
 
@@ -74,8 +75,8 @@ SIGNATURES = {
     "lspf2f_layer_info_get": (c_int, [c_void_p, c_int, POINTER(LayerInfo)]),
     "lspf2f_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                      POINTER(c_float)]),
-    "lspf2f_conv3x3_scratch_bytes": (c_size_t, [c_int] * 12),
-    "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 13 + [c_void_p, c_size_t, c_void_p]),
+    "lspf2f_conv3x3_scratch_bytes": (c_size_t, [c_int] * 13),
+    "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -88,7 +88,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
 {
     if (!cfg || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (cfg->abi_version != LSPF2F_ABI_VERSION) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "ABI version mismatch");
-    if (cfg->dtype != LSPF2F_DTYPE_F32) return fail(LSPF2F_ERR_UNSUPPORTED, "only LSPF2F_DTYPE_F32 is implemented");
+    if (cfg->dtype != LSPF2F_DTYPE_F32 && cfg->dtype != LSPF2F_DTYPE_BF16) return fail(LSPF2F_ERR_UNSUPPORTED, "unknown dtype");
     if (cfg->height != cfg->width) return fail(LSPF2F_ERR_UNSUPPORTED, "frames must be square (loadSize x loadSize)");
     if (cfg->max_batch < 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "max_batch must be >= 1");
     lspf2f_handle *h = new (std::nothrow) lspf2f_handle();
@@ -96,7 +96,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     h->cfg = *cfg;
     const std::string e = h->plan.build(cfg->variant, cfg->input_nc, cfg->feat_nc, cfg->output_nc, cfg->ngf,
                                         cfg->num_downs, cfg->height,
-                                        (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0);
+                                        (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0, cfg->dtype);
     if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
@@ -212,7 +212,7 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     o->flops_per_frame = h->plan.layer_flops(l);
     o->act_bytes_per_frame = h->plan.layer_act_bytes(l);
     const bool sub = l.up4 || l.kind == kLastConv;   // sub-pixel form: 16/9 weight bytes, 4/9 FLOPs
-    o->weight_bytes = (int64_t)l.cout * l.cin * (sub ? 16 : 9) * 4;
+    o->weight_bytes = (int64_t)l.cout * l.cin * (sub ? 16 : 9) * (int64_t)(h->plan.layer_weights_typed(l) ? h->plan.elt() : 4);
     o->exec_flops_per_frame = sub ? o->flops_per_frame * 4 / 9 : o->flops_per_frame;
     o->w_offset = l.w_off; o->scale_offset = l.scale_off; o->shift_offset = l.shift_off;
     o->out_offset = l.out >= 0 ? (int64_t)h->plan.tensors[l.out].offset : -1;
@@ -232,7 +232,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         FirstConvParams p{};
         p.feat = feat; p.cand = cand; p.w = bptr(l.w_off); p.out = tptr(l.out);
         p.B = batch; p.H = l.hs; p.W = l.hs; p.feat_nc = P.feat_nc; p.cand_nc = P.input_nc - P.feat_nc;
-        p.cand_batch = cand_batch; p.Cout = l.cout;
+        p.cand_batch = cand_batch; p.Cout = l.cout; p.dtype = P.dtype;
         p.ci_begin = 0; p.ci_end = P.input_nc; p.base = nullptr; p.relu = 1;
         float *cache = reinterpret_cast<float *>(h->ws);
         const bool shared = p.cand_nc > 0 && P.feat_nc > 0 && (cand == nullptr || (cand_batch == 1 && batch > 1));
@@ -253,14 +253,14 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
     } else if (l.kind == kLastConv) {
         LastConvParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.out = out;
-        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out; p.out_u8 = out_u8;
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out; p.out_u8 = out_u8; p.dtype = P.dtype;
         e = launch_last_conv(p, s);
     } else if (l.smallm) {
         SmallMParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.residual = tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.Cin = l.cin; p.Cout = l.cout;
-        p.stride = l.stride; p.up = l.up; p.relu = l.relu; p.M = batch * l.ho * l.ho;
+        p.stride = l.stride; p.up = l.up; p.relu = l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
         e = launch_smallm(p, s);
     } else {
         IgemmParams p{};
@@ -274,7 +274,8 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.up4 = l.up4;
         p.Mout = batch * l.ho * l.ho;
         p.M = l.up4 ? batch * l.hs * l.hs : p.Mout;
-        p.ktiles_total = (l.up4 ? 4 : 9) * l.cin / 32;
+        p.dtype = P.dtype;
+        p.ktiles_total = (l.up4 ? 4 : 9) * l.cin / P.ktile_channels();
         p.splits = l.splits;
         p.ktiles_per_split = (p.ktiles_total + l.splits - 1) / l.splits;
         e = launch_igemm(p, l.bm, l.bn, l.group, s);
@@ -412,8 +413,9 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
 }
 
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride, int upsample,
-                                    int tile_m, int tile_n, int split_k, int k_group)
+                                    int tile_m, int tile_n, int split_k, int k_group, int dtype)
 {
+    const int ktc = dtype == 1 ? 64 : 32;
     (void)ws;
     const int ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
     const int Mout = batch * ho * ho;
@@ -422,7 +424,7 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
     int bm = tile_m, bn = tile_n, sp = split_k;
     if (!bm || !bn || !sp) {
         int a, b, c, g;
-        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / 32, up4 ? 4 : 1, upsample == 1, &a, &b, &c, &g);
+        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / ktc, up4 ? 4 : 1, upsample == 1, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; }
         if (!sp) sp = c;
     }
@@ -430,15 +432,17 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
     return sp > 1 ? (size_t)sp * Mout * cout * sizeof(float) : 0;
 }
 
-int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, const float *scale,
-                   const float *shift, const float *residual, float *out, int batch, int hs, int ws, int c0,
+int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, const float *scale,
+                   const float *shift, const void *residual, void *out, int batch, int hs, int ws, int c0,
                    int c1, int cout, int stride, int upsample, int relu, int tile_m, int tile_n, int split_k,
-                   int k_group, void *scratch, size_t scratch_bytes, void *hip_stream)
+                   int k_group, int dtype, void *scratch, size_t scratch_bytes, void *hip_stream)
 {
+    if (dtype != 0 && dtype != 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "dtype must be 0 (fp32) or 1 (bf16)");
+    const int ktc = dtype == 1 ? 64 : 32;
     if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
-    if ((c0 % 32) || (c1 % 32) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1))
-        return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32");
+    if ((c0 % ktc) || (c1 % ktc) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1))
+        return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (fp32) / 64 (bf16)");
     if (cout % 4) return fail(LSPF2F_ERR_UNSUPPORTED, "cout must be a multiple of 4");
     if (stride != 1 && stride != 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "stride must be 1 or 2");
     if (upsample && stride != 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "upsample requires stride 1");
@@ -451,6 +455,7 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
         q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
         q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs); q.Wo = q.Ho;
         q.Cin = c0; q.Cout = cout; q.stride = stride; q.up = upsample == 1; q.relu = relu; q.M = batch * q.Ho * q.Wo;
+        q.dtype = dtype;
         const bool want = (tile_m == 1 && tile_n == 1) || (tile_m == 0 && tile_n == 0 && split_k == 0);
         if (want && c1 == 0 && upsample != 2 && smallm_supported(q)) {
             e = launch_smallm(q, static_cast<hipStream_t>(hip_stream));
@@ -470,7 +475,8 @@ int lspf2f_conv3x3(const float *src0, const float *src1, const float *w_packed, 
     p.up = upsample == 1; p.up4 = upsample == 2;
     p.Mout = batch * p.Ho * p.Wo;
     p.M = p.up4 ? batch * hs * ws : p.Mout;
-    p.ktiles_total = (p.up4 ? 4 : 9) * p.Cin / 32;
+    p.dtype = dtype;
+    p.ktiles_total = (p.up4 ? 4 : 9) * p.Cin / ktc;
     int bm = tile_m, bn = tile_n, sp = split_k, grp = k_group;
     {
         int a, b, c, g;

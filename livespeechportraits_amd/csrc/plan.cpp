@@ -166,8 +166,11 @@ struct Builder {
 }  // namespace
 
 std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc_, int ngf_, int num_downs_,
-                        int size_, bool keep)
+                        int size_, bool keep, int dtype_)
 {
+    if (dtype_ != 0 && dtype_ != 1) return "dtype must be 0 (fp32) or 1 (bf16)";
+    if (dtype_ == 1 && ngf_ % 64 != 0) return "bf16 needs ngf % 64 == 0 (a K-tile is 64 bf16 channels)";
+    dtype = dtype_;
     if (variant_ != 0 && variant_ != 1)
         return "variant must be 0 (normal) or 1 (large); the 'small' U-Net (networks.py:680-769) is not supported";
     if (ngf_ <= 0 || ngf_ % 32 != 0) return "ngf must be a positive multiple of 32 (MFMA K-tile = 32 channels)";
@@ -192,7 +195,7 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
         // small levels keep the 9-tap gather form.
         l.up4 = l.kind == kIgemm && l.up && l.ho >= kUp4MinExtent;
         if (l.up4) l.up = false;
-        off += (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9) * sizeof(float);
+        off += (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9) * (layer_weights_typed(l) ? elt() : sizeof(float));
         if (!l.bnkey.empty()) {
             off = align_up(off, 256);
             l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
@@ -211,7 +214,7 @@ int64_t Plan::layer_act_bytes(const LayerDesc &l) const
 {
     int64_t e = (int64_t)l.cin * l.hs * l.hs + (int64_t)l.cout * l.ho * l.ho;
     if (l.residual) e += (int64_t)l.cout * l.ho * l.ho;
-    return e * 4;
+    return e * (int64_t)elt();
 }
 
 namespace {
@@ -264,7 +267,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
     Arena a;
     std::vector<size_t> off(p.tensors.size(), 0);
     auto bytes_of = [&](const TensorDesc &t) {
-        return align_up((size_t)t.c * t.h * t.h * (size_t)batch * sizeof(float), 256);
+        return align_up((size_t)t.c * t.h * t.h * (size_t)batch * p.elt(), 256);
     };
     size_t partial = 0;
     for (int li = 0; li < (int)p.layers.size(); ++li) {
@@ -281,7 +284,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             int bm, bn, splits, group;
             const int Mout = batch * l.ho * l.ho;
             const int M = l.up4 ? batch * l.hs * l.hs : Mout;
-            choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / 32, l.up4 ? 4 : 1, l.up, &bm, &bn, &splits, &group);
+            choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, &bm, &bn, &splits, &group);
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             if (tiled) {
@@ -324,7 +327,12 @@ std::string Plan::pack(void *blob, size_t bytes) const
     auto get = [&](const std::string &k) -> const ParamDesc & { return params[param_index.at(k)]; };
     for (const auto &l : layers) {
         const float *W = get(l.wkey).data.data();           // OIHW
+        // igemm-family weights are stored in the plan's dtype; staged in fp32 then narrowed (RNE) if bf16
+        const bool narrow = dtype == 1 && layer_weights_typed(l);
+        const size_t wcount = (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9);
+        std::vector<float> stage_buf;
         float *dst = reinterpret_cast<float *>(base + l.w_off);
+        if (narrow) { stage_buf.resize(wcount); dst = stage_buf.data(); }
         const int cin = l.cin, cout = l.cout;
         if ((l.kind == kIgemm && l.up4) || l.kind == kLastConv) {
             // sub-pixel form of Upsample(x2, nearest) + Conv3x3: output parity (py, px) only ever
@@ -358,6 +366,15 @@ std::string Plan::pack(void *blob, size_t bytes) const
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < 9; ++t)
                         dst[((size_t)ci * 9 + t) * cout + co] = W[((size_t)co * cin + ci) * 9 + t];
+        }
+        if (narrow) {
+            uint16_t *d16 = reinterpret_cast<uint16_t *>(base + l.w_off);
+            for (size_t i = 0; i < wcount; ++i) {
+                uint32_t u;
+                std::memcpy(&u, &stage_buf[i], 4);
+                u += 0x7fffu + ((u >> 16) & 1u);             // round to nearest even
+                d16[i] = (uint16_t)(u >> 16);
+            }
         }
         if (!l.bnkey.empty()) {
             // eval-mode BatchNorm2d folded to y = x*scale + shift, applied AFTER accumulation

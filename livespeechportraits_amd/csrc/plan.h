@@ -52,6 +52,10 @@ struct ParamDesc {         // an expected state-dict entry
 struct Plan {
     int variant = 1, nres = 2, input_nc = 13, feat_nc = 1, output_nc = 3, ngf = 64, num_downs = 8, size = 512;
     bool keep_intermediates = false;
+    int dtype = 0;             // 0: fp32 activations + weights; 1: bf16 storage (fp32 accumulate), first/last-layer weights fp32
+    size_t elt() const { return dtype == 1 ? 2 : 4; }
+    int ktile_channels() const { return dtype == 1 ? 64 : 32; }   // a K-tile is 128 B of channels
+    bool layer_weights_typed(const LayerDesc &l) const { return l.kind == kIgemm; }   // else fp32
     std::vector<LayerDesc> layers;
     std::vector<TensorDesc> tensors;
     std::vector<ParamDesc> params;
@@ -68,7 +72,7 @@ struct Plan {
     size_t cand_cache_bytes() const { return ((size_t)(size / 2) * (size / 2) * ngf * sizeof(float) + 255) / 256 * 256; }
 
     std::string build(int variant, int input_nc, int feat_nc, int output_nc, int ngf, int num_downs,
-                      int size, bool keep);   // returns "" or an error message
+                      int size, bool keep, int dtype = 0);   // returns "" or an error message
     void plan_batch(int batch);
     size_t workspace_bytes(int batch) const;   // without mutating the current plan
     std::string pack(void *blob, size_t bytes) const;   // "" or error

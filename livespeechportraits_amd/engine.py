@@ -22,15 +22,18 @@ from . import _native as N
 class Engine:
     def __init__(self, variant: str = "large", input_nc: int = 13, feat_nc: int = 1,
                  output_nc: int = 3, ngf: int = 64, num_downs: int = 8, size: int = 512,
-                 max_batch: int = 1, keep_intermediates: bool = False):
+                 max_batch: int = 1, keep_intermediates: bool = False, dtype: str = "f32"):
         if variant not in N.VARIANT_IDS:
             raise ValueError("opt.size must be 'normal' or 'large' for the HIP renderer "
                              "(got %r; the 'small' U-Net is not on the shipped path)" % (variant,))
+        if dtype not in N.DTYPE_IDS:
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
         self.lib = N.load()
         self.variant, self.input_nc, self.feat_nc, self.output_nc = variant, input_nc, feat_nc, output_nc
         self.ngf, self.num_downs, self.size, self.max_batch = ngf, num_downs, size, max_batch
         cfg = N.Config(N.ABI_VERSION, N.VARIANT_IDS[variant], input_nc, feat_nc, output_nc, ngf,
-                       num_downs, size, size, max_batch, 0,
+                       num_downs, size, size, max_batch, N.DTYPE_IDS[dtype],
                        N.FLAG_KEEP_INTERMEDIATES if keep_intermediates else 0)
         h = ctypes.c_void_p()
         N.check(self.lib.lspf2f_create(ctypes.byref(cfg), ctypes.byref(h)))
@@ -241,6 +244,7 @@ class Engine:
         for l in self.layers(batch):
             if l["name"] == name and l["out_offset"] >= 0:
                 n = batch * l["h_out"] * l["h_out"] * l["cout"]
-                raw = self._ws[l["out_offset"]: l["out_offset"] + 4 * n]
-                return raw.view(torch.float32).view(batch, l["h_out"], l["h_out"], l["cout"])
+                tdt, eb = (torch.bfloat16, 2) if self.dtype == "bf16" else (torch.float32, 4)
+                raw = self._ws[l["out_offset"]: l["out_offset"] + eb * n]
+                return raw.view(tdt).view(batch, l["h_out"], l["h_out"], l["cout"])
         raise KeyError(name)

@@ -14,34 +14,35 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), split_k=0, k_group=0):
+def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), split_k=0, k_group=0, dtype=0):
     """x0/x1: NCHW cpu tensors; w OIHW. Returns NCHW cpu tensor computed by the HIP kernel."""
     from livespeechportraits_amd import _native as N
     lib = N.load()
     b, c0, hs, ws = x0.shape
     c1 = x1.shape[1] if x1 is not None else 0
     cout = w.shape[0]
-    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev).to(tdt)
     d0 = nhwc(x0)
     d1 = nhwc(x1) if x1 is not None else None
     if up == 2:
-        wp = pack_subpixel(w).to(dev)                        # [parity][co][a][b][ci]
+        wp = pack_subpixel(w).to(dev).to(tdt)                # [parity][co][a][b][ci]
     else:
-        wp = w.permute(0, 2, 3, 1).contiguous().to(dev)      # [co][ky][kx][ci]
+        wp = w.permute(0, 2, 3, 1).contiguous().to(dev).to(tdt)   # [co][ky][kx][ci]
     dsc = scale.to(dev) if scale is not None else None
     dsh = shift.to(dev) if shift is not None else None
     ho = 2 * hs if up else (hs + stride - 1) // stride
     dres = nhwc(res) if res is not None else None
-    out = torch.full((b, ho, ho, cout), float("nan"), device=dev)
-    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, int(up), tile[0], tile[1], split_k, k_group)
+    out = torch.full((b, ho, ho, cout), float("nan"), device=dev, dtype=tdt)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, int(up), tile[0], tile[1], split_k, k_group, dtype)
     scratch = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     rc = lib.lspf2f_conv3x3(p(d0), p(d1), p(wp), p(dsc), p(dsh), p(dres), p(out), b, hs, ws, c0, c1, cout,
-                            stride, int(up), int(relu), tile[0], tile[1], split_k, k_group, p(scratch), scratch.numel(),
+                            stride, int(up), int(relu), tile[0], tile[1], split_k, k_group, dtype, p(scratch), scratch.numel(),
                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     N.check(rc)
     torch.cuda.synchronize()
-    return out.permute(0, 3, 1, 2).contiguous().cpu()
+    return out.float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
 def pack_subpixel(w):
@@ -233,3 +234,54 @@ def test_conv3x3_rejects_bad_arguments(gpu_device):
     w = rnd(64, 48, 3, 3)
     with pytest.raises(N.Lspf2fError):
         run_conv(gpu_device, x, None, w, None, None, None, 1, False, False)
+
+
+def bf16r(t):
+    """round to bf16 and back (what the bf16 path stores in HBM)"""
+    return t.to(torch.bfloat16).float() if t is not None else None
+
+
+BF16_CASES = [
+    # b, c0, c1, cout, hs, stride, up(0/1/2), res, tile, split, group
+    (1, 64, 0, 64, 32, 1, 0, True, (0, 0), 0, 0),
+    (2, 64, 64, 128, 16, 1, 2, False, (0, 0), 0, 0),       # sub-pixel concat up-conv
+    (1, 128, 0, 256, 16, 2, 0, False, (64, 128), 1, 1),
+    (1, 512, 0, 512, 4, 1, 0, True, (1, 1), 0, 0),         # tiny-M kernel
+    (1, 512, 0, 512, 2, 1, 1, False, (32, 64), 0, 4),      # 9-tap upsample gather, split-K + reduce
+    (1, 256, 0, 192, 12, 1, 0, True, (64, 64), 3, 2),      # ragged, split-K, K groups
+]
+
+
+@pytest.mark.parametrize("cfg", BF16_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_s%d_up%d_res%d_t%dx%d_k%d_g%d" % (
+    c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8][0], c[8][1], c[9], c[10]))
+def test_conv3x3_bf16_storage(cfg, gpu_device):
+    """bf16 activations/weights in HBM, fp32 accumulate + epilogue.  Reference = the same conv on the
+    bf16-ROUNDED operands in fp64, output rounded to bf16: the kernel may differ by one bf16 ulp of the
+    result (fp32 accumulation order), i.e. 2^-8 relative."""
+    b, c0, c1, cout, hs, stride, up, res, tile, split, g = cfg
+    x0 = bf16r(rnd(b, c0, hs, hs, seed=41))
+    x1 = bf16r(rnd(b, c1, hs, hs, seed=42)) if c1 else None
+    w = rnd(cout, c0 + c1, 3, 3, seed=43) * 0.05
+    scale, shift = rnd(cout, seed=44) * 0.5 + 1.0, rnd(cout, seed=45) * 0.1
+    ho = 2 * hs if up else (hs + stride - 1) // stride
+    r = bf16r(rnd(b, cout, ho, ho, seed=46)) if res else None
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, up, True, tile, split, g, dtype=1)
+    wq = bf16r(pack_subpixel(w)) if up == 2 else bf16r(w)
+    if up == 2:   # reference for the folded weights: run the 4 parity convs explicitly
+        x = x0 if x1 is None else torch.cat([x0, x1], 1)
+        xp = F.pad(x.double(), (1, 1, 1, 1))
+        ref = torch.zeros(b, cout, 2 * hs, 2 * hs, dtype=torch.float64)
+        for py in (0, 1):
+            for px in (0, 1):
+                acc = 0
+                for a in (0, 1):
+                    for bb in (0, 1):
+                        patch = xp[:, :, a + py: a + py + hs, bb + px: bb + px + hs]
+                        acc = acc + torch.einsum("bchw,oc->bohw", patch, wq[py * 2 + px, :, a, bb, :].double())
+                ref[:, :, py::2, px::2] = acc
+        ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).float()
+    else:
+        ref = ref_conv(x0, x1, wq, scale, shift, r, stride, bool(up), True)
+    assert torch.isfinite(got).all()
+    tol = (ref.abs() * 2.0 ** -8 + 1e-3)
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()

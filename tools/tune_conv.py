@@ -32,6 +32,7 @@ SHAPES = [
     ("512>128@64up", 256, 256, 128, 64, 1, 2),
     ("256>64@128up", 128, 128, 64, 128, 1, 2),
 ]
+DT = 0
 TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64)]
 
 
@@ -40,7 +41,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
+    global DT
+    DT = 1 if a.dtype == "bf16" else 0
+    tdt = torch.bfloat16 if DT else torch.float32
     lib = N.load()
     dev = torch.device("cuda:0")
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -50,15 +55,15 @@ def main():
         if a.only and a.only not in name:
             continue
         b = a.batch
-        x0 = torch.rand(b, hs, hs, c0, device=dev) - 0.5
-        x1 = torch.rand(b, hs, hs, c1, device=dev) - 0.5 if c1 else None
-        w = (torch.rand(cout, (16 if up == 2 else 9) * (c0 + c1), device=dev) - 0.5) * 0.05
+        x0 = (torch.rand(b, hs, hs, c0, device=dev) - 0.5).to(tdt)
+        x1 = (torch.rand(b, hs, hs, c1, device=dev) - 0.5).to(tdt) if c1 else None
+        w = ((torch.rand(cout, (16 if up == 2 else 9) * (c0 + c1), device=dev) - 0.5) * 0.05).to(tdt)
         sc = torch.rand(cout, device=dev) + 0.5
         sh = torch.rand(cout, device=dev)
         ho = 2 * hs if up else hs // stride
-        out = torch.empty(b, ho, ho, cout, device=dev)
+        out = torch.empty(b, ho, ho, cout, device=dev, dtype=tdt)
         M = b * ho * ho
-        kt = (4 if up == 2 else 9) * (c0 + c1) // 32
+        kt = (4 if up == 2 else 9) * (c0 + c1) // (64 if DT else 32)
         par = 4 if up == 2 else 1
         flops = 2.0 * M * cout * 9 * (c0 + c1)
         res = []
@@ -69,7 +74,7 @@ def main():
             for sp in (1, 2, 3, 4, 6, 8, 12, 16, 18, 24, 36, 48, 72):
                 if sp > kt // 4 or tiles * sp > 8192 or (tiles * sp < 96 and sp < kt // 2):
                     continue
-                sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, stride, up, tm, tn, sp, 1)
+                sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, stride, up, tm, tn, sp, 1, DT)
                 if sb == 0 and sp > 1:
                     continue
                 scratch = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
@@ -81,7 +86,7 @@ def main():
 
                     def run():
                         N.check(lib.lspf2f_conv3x3(P(x0), P(x1), P(w), P(sc), P(sh), None, P(out), b, hs, hs, c0, c1,
-                                                   cout, stride, up, 1, tm, tn, sp, g, P(scratch), scratch.numel(),
+                                                   cout, stride, up, 1, tm, tn, sp, g, DT, P(scratch), scratch.numel(),
                                                    stream))
                     try:
                         for _ in range(3):
