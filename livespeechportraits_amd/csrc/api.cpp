@@ -424,7 +424,7 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
     int bm = tile_m, bn = tile_n, sp = split_k;
     if (!bm || !bn || !sp) {
         int a, b, c, g;
-        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / ktc, up4 ? 4 : 1, upsample == 1, &a, &b, &c, &g);
+        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / ktc, up4 ? 4 : 1, upsample == 1, dtype, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; }
         if (!sp) sp = c;
     }
@@ -480,7 +480,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     int bm = tile_m, bn = tile_n, sp = split_k, grp = k_group;
     {
         int a, b, c, g;
-        choose_tiling(p.M, cout, p.ktiles_total, p.up4 ? 4 : 1, p.up != 0, &a, &b, &c, &g);
+        choose_tiling(p.M, cout, p.ktiles_total, p.up4 ? 4 : 1, p.up != 0, dtype, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; if (!grp) grp = g; }
         if (!sp) sp = c;
         if (!grp) grp = 1;

@@ -10,7 +10,7 @@ static const double kBnEps = 1e-5;   // nn.BatchNorm2d default (networks.py neve
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-void choose_tiling(int M, int N, int ktiles, int par, bool up9, int *bm_out, int *bn_out, int *splits_out, int *group_out)
+void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *bm_out, int *bn_out, int *splits_out, int *group_out)
 {
     // par = independent GEMM slices per launch (4 output parities in sub-pixel up-conv form)
     // up9: the 9-tap upsample gather form is instantiated for 64x64 (G = 1, 4) and 32x64 (G = 4) only
@@ -34,7 +34,15 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int *bm_out, int
         const long t64 = (long)par * ((M + 63) / 64) * ((N + 63) / 64);
         long tiles = t64;
         if (!up9 && N >= 128 && t128 >= want) { bn = 128; tiles = t128; }
-        if (tiles < want) {
+        if (dtype == 1 && !up9) {
+            // bf16: an MFMA step is 16x shorter, so the per-K-tile overhead (DMA issue, barrier) dominates
+            // and the biggest tile that still gives every CU a workgroup wins by 10-35 %
+            // (profiles/r01_tune_conv_bf16_b8.txt): 128 rows x (128 | 64) columns
+            const int wn = N >= 128 ? 128 : 64;
+            const long tbig = (long)par * ((M + 127) / 128) * ((N + wn - 1) / wn);
+            if (tbig >= 256) { bm = 128; bn = wn; tiles = tbig; }
+        }
+        if (tiles < (bm == 128 ? 512 : want)) {
             splits = (int)((512 + tiles - 1) / tiles);
             splits = std::min(splits, std::max(1, ktiles / 4));   // keep >= 4 K-tiles per split
             const int per = (ktiles + splits - 1) / splits;      // make every split non-empty
@@ -284,7 +292,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             int bm, bn, splits, group;
             const int Mout = batch * l.ho * l.ho;
             const int M = l.up4 ? batch * l.hs * l.hs : Mout;
-            choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, &bm, &bn, &splits, &group);
+            choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, p.dtype, &bm, &bn, &splits, &group);
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             if (tiled) {
