@@ -247,3 +247,27 @@ def test_bf16_rejects_unsupported_width():
     from livespeechportraits_amd.engine import Engine
     with pytest.raises(N.Lspf2fError):
         Engine("normal", ngf=32, num_downs=5, size=64, dtype="bf16")   # K-tile = 64 bf16 channels
+
+
+def test_batched_render_loop_on_gpu(gpu_device, tmp_path):
+    """demo.py's frame loop, batched, through the real model (uint8 frames, shared
+    candidates, overlapped D2H) == the per-frame batch-1 path."""
+    import argparse
+    import livespeechportraits_amd as L
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.render_loop import render_frames
+    meta, _, topo, sd, _, cand = golden_problem("large_s128_b2")
+    opt = argparse.Namespace(model="feature2face", gpu_ids=[0], isTrain=False, size=meta["variant"], ngf=meta["ngf"],
+                             n_downsample_G=meta["num_downs"], fp16=0, checkpoints_dir=str(tmp_path), name="t",
+                             load_epoch="none", verbose=False)
+    model = L.create_model(opt)
+    model._g().load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    model.eval()
+    feats, _ = synth.make_inputs(7, topo.size, seed=5, cand_batch=1)
+    c = torch.from_numpy(cand).to(gpu_device)
+    frames = render_frames(model, (torch.from_numpy(f) for f in feats), c, batch=3)
+    assert len(frames) == 7 and frames[0].shape == (topo.size, topo.size, 3)
+    for i in (0, 3, 6):
+        one = model.inference_image(torch.from_numpy(feats[i:i + 1]).to(gpu_device), c)[0].cpu().numpy()
+        d = np.abs(one.astype(np.int16) - frames[i].astype(np.int16))
+        assert d.max() <= 1            # batch-1 and batch-3 tilings sum in a different order: <= 1 grey level

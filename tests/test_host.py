@@ -222,3 +222,24 @@ def test_synth_is_deterministic_and_matches_recipe():
     assert set(np.unique(feat)) <= {0.0, 1.0} and 0.01 < feat.mean() < 0.06
     assert cand.min() >= -1 and cand.max() < 1
     assert float(synth.uniform01(4, 7)[0]) == float(synth.uniform01(1, 7)[0])
+
+
+def test_batched_render_loop_bookkeeping():
+    """render_frames chunks the frame stream, keeps order, handles a ragged last batch (CPU, stand-in model)."""
+    from livespeechportraits_amd.render_loop import batched, render_frames
+    assert [len(c) for c in batched(range(11), 4)] == [4, 4, 3]
+
+    class Fake:
+        calls = []
+        def inference_image(self, maps, cand):
+            Fake.calls.append(maps.shape[0])
+            return (maps[:, 0, :, :, None] * 10).to(torch.uint8).expand(-1, -1, -1, 3).contiguous()
+
+    maps = [torch.full((1, 4, 4), float(i)) for i in range(7)]
+    got = render_frames(Fake(), iter(maps), torch.zeros(1, 12, 4, 4), batch=3)
+    assert Fake.calls == [3, 3, 1] and len(got) == 7
+    assert [int(f[0, 0, 0]) for f in got] == [10 * i for i in range(7)]
+    assert got[0].shape == (4, 4, 3) and got[0].dtype == np.uint8
+    seen = []
+    render_frames(Fake(), iter(maps), torch.zeros(1, 12, 4, 4), batch=4, on_frame=lambda i, a: seen.append((i, int(a[0, 0, 0]))))
+    assert seen == [(i, 10 * i) for i in range(7)]
