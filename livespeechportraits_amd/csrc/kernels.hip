@@ -1096,6 +1096,16 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
 #pragma unroll
         for (int par = 0; par < 4; ++par) {
             const int py = par >> 1, px = par & 1;
+            // all 8*CO weight reads of this parity are issued as one batch (one LDS latency per parity instead of
+            // one per use: PMC showed 64 % of the wave time in s_waitcnt with just-in-time reads)
+            float4 wq[2][4][CO];
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) wq[sidx][t][co] = wl[(((par * 2 + sidx) * 4 + t) * CO + co) * 16];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx)
 #pragma unroll
@@ -1103,7 +1113,7 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
                     const float4 v = win[(t & 1) + px][(t >> 1) + py][sidx];
 #pragma unroll
                     for (int co = 0; co < CO; ++co) {
-                        const float4 ww = wl[(((par * 2 + sidx) * 4 + t) * CO + co) * 16];
+                        const float4 ww = wq[sidx][t][co];
                         acc[par][co] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
                     }
                 }
