@@ -1,0 +1,532 @@
+// gfx950: the two layers at the API edge.  First: cat([feature_map, cand_image]) -> Conv 3x3 s2 -> ReLU reading
+// the NCHW fp32 API tensors; last: Upsample x2 + Conv 3x3 over the concat + tanh (+ fused util.tensor2im) writing
+// NCHW fp32 and/or HWC uint8.  DESIGN.md section 4.3.
+#include "device_common.h"
+#include "kernels.h"
+
+#include <cstdlib>
+
+namespace lspf2f {
+
+// ------------------------------------------------------------------------------------------
+// First layer.  One thread = one output pixel x 32 output channels (blockIdx.y picks the
+// channel slab).  Lanes run along ox, so the stride-2 NCHW reads of a wave cover one contiguous
+// 512-B span per (ci, ky) that all three kx taps share; weights are broadcast from LDS.  All 9
+// taps of a channel are loaded before any FMA (9 independent loads in flight per lane; the
+// one-load-per-tap form was latency-bound at ~50 us).
+// Reference: cat (feature2face_model.py:231) + Conv2d(13, ngf, 3, 2, 1, bias=False) + ReLU
+// (networks.py:594, :603, :619 `down = [downconv, downrelu]`).
+template <typename T>
+__global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [K][32]
+    // channel range of this pass: the whole input, or -- when the candidate stack is shared by the batch --
+    // only the candidate channels (pass 1, once: writes the pre-activation partial sums `base`) or only
+    // the feature-map channels (pass 2, per frame: starts from `base`, applies ReLU)
+    const int cbeg = p.ci_begin, cin = p.ci_end;
+    const int K = (cin - cbeg) * 9;
+    const int co0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < K * 32; i += blockDim.x) {
+        const int k = i >> 5, j = i & 31;
+        wsm[i] = p.w[(size_t)(cbeg * 9 + k) * p.Cout + co0 + j];
+    }
+    __syncthreads();
+
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)p.B * Ho * Wo) return;
+    const int b = (int)(gid / (Ho * Wo));
+    const int r = (int)(gid - (long)b * Ho * Wo);
+    const int oy = r / Wo, ox = r - oy * Wo;
+
+    // tap offsets / validity are the same for every channel
+    int toff[9];
+    bool tok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+        tok[t] = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+        toff[t] = tok[t] ? iy * p.W + ix : 0;
+    }
+
+    float acc[32];
+    if (p.base) {
+        // base is [1][Ho][Wo][Cout] (shared by every frame of the batch)
+        const float4 *bp = reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + co0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 t = bp[j];
+            acc[4 * j] = t.x; acc[4 * j + 1] = t.y; acc[4 * j + 2] = t.z; acc[4 * j + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    }
+
+    const size_t plane = (size_t)p.H * p.W;
+    auto plane_of = [&](int ci) -> const float * {
+        return (ci < p.feat_nc)
+            ? p.feat + ((size_t)b * p.feat_nc + ci) * plane
+            : p.cand + ((size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc + (ci - p.feat_nc)) * plane;
+    };
+    // the 9 taps of channel ci+1 are in flight while channel ci is multiplied
+    float v[9], vn[9];
+    {
+        const float *src = plane_of(cbeg);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = tok[t] ? src[toff[t]] : 0.f;
+    }
+#pragma unroll 1
+    for (int ci = cbeg; ci < cin; ++ci) {
+        if (ci + 1 < cin) {
+            const float *src = plane_of(ci + 1);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) vn[t] = tok[t] ? src[toff[t]] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 *wr = reinterpret_cast<const float4 *>(wsm + ((ci - cbeg) * 9 + t) * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 w4 = wr[j];
+                acc[4 * j + 0] += v[t] * w4.x; acc[4 * j + 1] += v[t] * w4.y;
+                acc[4 * j + 2] += v[t] * w4.z; acc[4 * j + 3] += v[t] * w4.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = vn[t];
+    }
+    T *o = static_cast<T *>(p.out) + (size_t)gid * p.Cout + co0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        store4(o + 4 * j, p.relu ? make_float4(fmaxf(acc[4 * j], 0.f), fmaxf(acc[4 * j + 1], 0.f),
+                                               fmaxf(acc[4 * j + 2], 0.f), fmaxf(acc[4 * j + 3], 0.f))
+                                 : make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]));
+}
+
+// Feature-map-only pass of the first layer (the candidate share comes in through `base`): pure streaming,
+// ~1 FLOP/byte.  16 lanes share a pixel and own 4 output channels each, so a wave reads and writes
+// 4 pixels x Cout*4 B contiguously (Cout = 64: exactly 1 KB per instruction); the 9 x feat_nc tap values
+// are broadcast loads, the lane's weights stay in registers.
+template <typename T, int FN>
+__global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
+{
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const int lpp = p.Cout / 4;                              // lanes per pixel (16 for ngf 64, 8 for ngf 32)
+    const int ppw = 64 / lpp;                                // pixels per wave
+    const int lane = threadIdx.x & 63;
+    const int j = lane % lpp, sub = lane / lpp;
+    float4 w[FN][9];
+#pragma unroll
+    for (int ci = 0; ci < FN; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            w[ci][t] = *reinterpret_cast<const float4 *>(p.w + (size_t)(ci * 9 + t) * p.Cout + j * 4);
+    const long npix = (long)p.B * Ho * Wo;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const size_t plane = (size_t)p.H * p.W;
+    for (long g = wave * ppw + sub; g < npix; g += nwaves * ppw) {
+        const int b = (int)(g / (Ho * Wo));
+        const int r = (int)(g - (long)b * Ho * Wo);
+        const int oy = r / Wo, ox = r - oy * Wo;
+        float4 acc = *reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + j * 4);
+#pragma unroll
+        for (int ci = 0; ci < FN; ++ci) {
+            const float *src = p.feat + ((size_t)b * p.feat_nc + ci) * plane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const float v = ok ? src[(size_t)iy * p.W + ix] : 0.f;
+                acc.x += v * w[ci][t].x; acc.y += v * w[ci][t].y; acc.z += v * w[ci][t].z; acc.w += v * w[ci][t].w;
+            }
+        }
+        if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        store4(static_cast<T *>(p.out) + (size_t)g * p.Cout + j * 4, acc);
+    }
+}
+
+hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
+{
+    if (p.base && p.ci_begin == 0 && p.ci_end == 1 && p.feat_nc == 1 && 64 % (p.Cout / 4) == 0 && p.Cout <= 256) {
+        const long npix = (long)p.B * (p.H / 2) * (p.W / 2);
+        const int ppw = 64 / (p.Cout / 4);
+        long blocks = (npix / ppw + 3) / 4;                  // one pixel group per wave ...
+        if (blocks > 4096) blocks = 4096;                    // ... up to 16 blocks per CU, then grid-stride
+        if (blocks < 1) blocks = 1;
+        if (p.dtype == 1) hipLaunchKernelGGL((first_conv_feat<bf16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((first_conv_feat<float, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    const long total = (long)p.B * (p.H / 2) * (p.W / 2);
+    const int K = (p.ci_end - p.ci_begin) * 9;
+    if (p.dtype == 1 && p.out != nullptr && !(p.relu == 0 && p.base == nullptr && p.ci_begin > 0))
+        hipLaunchKernelGGL(first_conv<bf16_t>, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
+                           (size_t)K * 32 * sizeof(float), s, p);
+    else   // fp32 activations, or the candidate-share pass (its cache is always fp32)
+        hipLaunchKernelGGL(first_conv<float>, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
+                           (size_t)K * 32 * sizeof(float), s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Last layer, sub-pixel form.  Upsample(x2, nearest) + Conv3x3 over cat([src0, src1]) + tanh:
+// output parity (py, px) only sees a 2x2 neighbourhood of the half-resolution source, so the
+// packer pre-sums the aliasing taps (plan.cpp) and each output pixel costs 4 taps instead of 9.
+// One thread = one output pixel, all CO (<= 4) channels.  Threads are ordered parity-major
+// (b, py, px, y, x) with x fastest, so a wave reads 64 consecutive source pixels and all its lanes
+// use the same weights (LDS broadcast); the concat is two base pointers; NCHW store.
+// Reference: nn.Upsample(2,'nearest') + Conv2d(2*ngf, 3, 3, 1, 1, bias=False) (networks.py:610-611)
+// + torch.tanh (networks.py:577).
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 parities][CO][2][2][Cin]
+    const int cin = p.C0 + p.C1;
+    for (int i = threadIdx.x; i < 16 * CO * cin; i += blockDim.x) wsm[i] = p.w[i];
+    __syncthreads();
+
+    const int H = 2 * p.Hs, W = 2 * p.Ws;
+    const long per_par = (long)p.Hs * p.Ws;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)p.B * 4 * per_par) return;
+    const int b = (int)(gid / (4 * per_par));
+    long rem = gid - (long)b * 4 * per_par;
+    const int par = (int)(rem / per_par);
+    rem -= (long)par * per_par;
+    const int y = (int)(rem / p.Ws), x = (int)(rem - (long)y * p.Ws);
+    const int py = par >> 1, px = par & 1;
+
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int sy = y + a - 1 + py;
+        if (sy < 0 || sy >= p.Hs) continue;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int sx = x + bb - 1 + px;
+            if (sx < 0 || sx >= p.Ws) continue;
+            const size_t pix = ((size_t)b * p.Hs + sy) * p.Ws + sx;
+            const float *wt = wsm + ((par * CO) * 4 + a * 2 + bb) * cin;      // + co*4*cin
+            const T *s0 = static_cast<const T *>(p.src0) + pix * p.C0;
+#pragma unroll 4
+            for (int c4 = 0; c4 < p.C0 / 4; ++c4) {
+                const float4 v = load4(s0 + c4 * 4);
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * 4 * cin + c4 * 4);
+                    acc[co] += v.x * w4.x + v.y * w4.y + v.z * w4.z + v.w * w4.w;
+                }
+            }
+            if (p.C1) {
+                const T *s1 = static_cast<const T *>(p.src1) + pix * p.C1;
+#pragma unroll 4
+                for (int c4 = 0; c4 < p.C1 / 4; ++c4) {
+                    const float4 v = load4(s1 + c4 * 4);
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(wt + co * 4 * cin + p.C0 + c4 * 4);
+                        acc[co] += v.x * w4.x + v.y * w4.y + v.z * w4.z + v.w * w4.w;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+    {
+        const float v = p.apply_tanh ? tanhf(acc[co]) : acc[co];
+        if (p.out) p.out[(((size_t)b * CO + co) * H + 2 * y + py) * W + 2 * x + px] = v;
+        if (p.out_u8) p.out_u8[(((size_t)b * H + 2 * y + py) * W + 2 * x + px) * CO + co] = to_u8(v);
+    }
+}
+
+// Fast path of the last layer for C0 == C1 <= 64*NCH: the 16 lanes of a DPP row share one output
+// pixel and split its input channels (lane j owns channels 4j..4j+3 of every 64-channel slab), so a
+// wave's load of 4 neighbouring pixels is one contiguous 1-KB read and the channel reduction is 4 DPP
+// row rotations per output.  Each wave walks a contiguous run of pixel quads of ONE output parity
+// (wave id & 3); that parity's 4-tap x CO weights sit in LDS (conflict-free: a row's 16 lanes read 16
+// consecutive float4, the 4 rows broadcast), which keeps the kernel at ~64 VGPRs = 8 waves/SIMD --
+// the loop is a load -> FMA -> DPP -> store chain and needs the occupancy to hide its latency.
+template <typename T, int CO, int NCH>
+__global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 parities][2 src][NCH][4 taps][CO][16 lanes] float4
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, sub = lane >> 4;               // channel slot, pixel within the quad
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int par = wave & 3, py = par >> 1, px = par & 1;
+    const int cin = p.C0 + p.C1;
+    const int H = 2 * p.Hs, W = 2 * p.Ws;
+
+    constexpr int WPP = 2 * NCH * 4 * CO * 16;              // float4 per parity
+    for (int i = threadIdx.x; i < 4 * WPP; i += blockDim.x) {
+        int r = i;
+        const int jj = r & 15; r >>= 4;
+        const int co = r % CO; r /= CO;
+        const int t = r & 3; r >>= 2;
+        const int c = r % NCH; r /= NCH;
+        const int sidx = r & 1, pr = r >> 1;
+        const int ch = (c * 16 + jj) * 4;
+        const bool okc = ch < (sidx ? p.C1 : p.C0);
+        reinterpret_cast<float4 *>(wsm)[i] = okc
+            ? *reinterpret_cast<const float4 *>(p.w + ((size_t)(pr * CO + co) * 4 + t) * cin + (sidx ? p.C0 : 0) + ch)
+            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float4 *wpar = reinterpret_cast<const float4 *>(wsm) + par * WPP + j;   // + ((sidx*NCH + c)*4 + t)*CO*16 + co*16
+
+    const int qpr = (p.Ws + 3) / 4;                          // quads per source row
+    const unsigned nquads = (unsigned)p.B * p.Hs * qpr;
+    const unsigned wpp = (unsigned)nwaves >> 2;              // waves per parity
+    const unsigned chunk = (nquads + wpp - 1) / wpp;
+    unsigned q = (unsigned)(wave >> 2) * chunk;
+    const unsigned qend = q + chunk < nquads ? q + chunk : nquads;
+    if (q >= qend) return;
+    int b = (int)(q / ((unsigned)p.Hs * qpr));
+    int y, xq;
+    { const unsigned r = q - (unsigned)b * p.Hs * qpr; y = (int)(r / qpr); xq = (int)(r - (unsigned)y * qpr); }
+
+    const T *__restrict__ s0 = static_cast<const T *>(p.src0);
+    const T *__restrict__ s1 = static_cast<const T *>(p.src1);
+    float *__restrict__ outp = p.out;
+
+    for (; q < qend; ++q) {
+        asm volatile("" ::: "memory");   // keep the weight reads in LDS (LICM would pin 96 VGPRs)
+        const int x = xq * 4 + sub;
+        float4 v[2][4][NCH];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sy = y + (t >> 1) - 1 + py, sx = x + (t & 1) - 1 + px;
+            const bool ok = (x < p.Ws) & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
+            const size_t pix = ok ? ((size_t)b * p.Hs + sy) * p.Ws + sx : 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = (c * 16 + j) * 4;
+                v[0][t][c] = (ok && ch < p.C0) ? load4(s0 + pix * p.C0 + ch)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[1][t][c] = (ok && ch < p.C1) ? load4(s1 + pix * p.C1 + ch)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 x4 = v[sidx][t][c];
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float4 ww = wpar[(((sidx * NCH + c) * 4 + t) * CO + co) * 16];
+                        acc[co] += x4.x * ww.x + x4.y * ww.y + x4.z * ww.z + x4.w * ww.w;
+                    }
+                }
+        // sum over the 16 channel slots of the row: rotate-and-add (row_ror 8, 4, 2, 1)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float r = acc[co];
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x128, 0xf, 0xf, false));
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x124, 0xf, 0xf, false));
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x122, 0xf, 0xf, false));
+            r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x121, 0xf, 0xf, false));
+            acc[co] = r;
+        }
+        if (j < CO && x < p.Ws) {
+            float r = acc[0];
+#pragma unroll
+            for (int co = 1; co < CO; ++co) r = (j == co) ? acc[co] : r;
+            r = p.apply_tanh ? tanhf(r) : r;
+            if (outp) outp[(((size_t)b * CO + j) * H + 2 * y + py) * W + 2 * x + px] = r;
+            if (p.out_u8) p.out_u8[(((size_t)b * H + 2 * y + py) * W + 2 * x + px) * CO + j] = to_u8(r);
+        }
+        if (++xq == qpr) { xq = 0; if (++y == p.Hs) { y = 0; ++b; } }
+    }
+}
+
+// Last layer, sliding-window form (C0 == C1 <= 64).  The rows kernel above re-reads every source pixel
+// 16x (4 taps x 4 parities) through L1, which bounds it at ~1 TB/s of useful traffic.  Here a 16-lane
+// group (lane = 4 input channels of each source) walks along one source row keeping the 3x3 source
+// neighbourhood in registers: per step it loads ONE new column (3 rows x 2 sources) and emits all four
+// output parities of that source pixel -- 1.5 loads per output instead of 8 -- with the pre-summed
+// sub-pixel weights read conflict-free from LDS and the channel sum done by DPP row rotations.
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, int seg)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [4 par][2 src][4 taps][CO][16 lanes] float4
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const int cin = p.C0 + p.C1;
+    const int H = 2 * p.Hs, W = 2 * p.Ws;
+    constexpr int WTOT = 4 * 2 * 4 * CO * 16;
+    for (int i = threadIdx.x; i < WTOT; i += blockDim.x) {
+        int r = i;
+        const int jj = r & 15; r >>= 4;
+        const int co = r % CO; r /= CO;
+        const int t = r & 3; r >>= 2;
+        const int sidx = r & 1, pr = r >> 1;
+        const int ch = jj * 4;
+        reinterpret_cast<float4 *>(wsm)[i] = ch < (sidx ? p.C1 : p.C0)
+            ? *reinterpret_cast<const float4 *>(p.w + ((size_t)(pr * CO + co) * 4 + t) * cin + (sidx ? p.C0 : 0) + ch)
+            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float4 *wl = reinterpret_cast<const float4 *>(wsm) + j;
+
+    // one 16-lane group = one (frame, source row, column segment)
+    const int nseg = (p.Ws + seg - 1) / seg;
+    const long ngroups = (long)p.B * p.Hs * nseg;
+    const long group = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    if (group >= ngroups) return;          // whole 16-lane rows retire together (DPP rows stay intact)
+    const int b = (int)(group / ((long)p.Hs * nseg));
+    const int rr = (int)(group - (long)b * p.Hs * nseg);
+    const int y = rr / nseg, x0 = (rr - y * nseg) * seg;
+    const int x1 = x0 + seg < p.Ws ? x0 + seg : p.Ws;
+    const bool chan_ok = j * 4 < p.C0;
+
+    const T *__restrict__ s0 = static_cast<const T *>(p.src0);
+    const T *__restrict__ s1 = static_cast<const T *>(p.src1);
+    auto load_col = [&](int x, float4 (&col)[3][2]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int sy = y + r - 1;
+            const bool ok = chan_ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
+            const size_t pix = ok ? ((size_t)b * p.Hs + sy) * p.Ws + x : 0;
+            col[r][0] = ok ? load4(s0 + pix * p.C0 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            col[r][1] = ok ? load4(s1 + pix * p.C1 + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 win[3][3][2];                       // [column x-1, x, x+1][row y-1, y, y+1][source]
+    float4 nxt[3][2];
+    load_col(x0 - 1, win[0]);
+    load_col(x0, win[1]);
+    load_col(x0 + 1, win[2]);
+    for (int x = x0; x < x1; ++x) {
+        asm volatile("" ::: "memory");         // keep the weights in LDS (see last_conv_rows)
+        if (x + 1 < x1) load_col(x + 2, nxt);  // next step's column flies while this step computes
+        float acc[4][CO];
+#pragma unroll
+        for (int par = 0; par < 4; ++par)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[par][co] = 0.f;
+#pragma unroll
+        for (int par = 0; par < 4; ++par) {
+            const int py = par >> 1, px = par & 1;
+            // all 8*CO weight reads of this parity are issued as one batch (one LDS latency per parity instead of
+            // one per use: PMC showed 64 % of the wave time in s_waitcnt with just-in-time reads)
+            float4 wq[2][4][CO];
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) wq[sidx][t][co] = wl[(((par * 2 + sidx) * 4 + t) * CO + co) * 16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 v = win[(t & 1) + px][(t >> 1) + py][sidx];
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float4 ww = wq[sidx][t][co];
+                        acc[par][co] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+                    }
+                }
+        }
+#pragma unroll
+        for (int par = 0; par < 4; ++par) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                float r = acc[par][co];
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x128, 0xf, 0xf, false));
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x124, 0xf, 0xf, false));
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x122, 0xf, 0xf, false));
+                r += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r), 0x121, 0xf, 0xf, false));
+                acc[par][co] = r;
+            }
+        }
+        if (j < CO) {
+#pragma unroll
+            for (int par = 0; par < 4; ++par) {
+                float r = acc[par][0];
+#pragma unroll
+                for (int co = 1; co < CO; ++co) r = (j == co) ? acc[par][co] : r;
+                r = p.apply_tanh ? tanhf(r) : r;
+                const int Y = 2 * y + (par >> 1), X = 2 * x + (par & 1);
+                if (p.out) p.out[(((size_t)b * CO + j) * H + Y) * W + X] = r;
+                if (p.out_u8) p.out_u8[(((size_t)b * H + Y) * W + X) * CO + j] = to_u8(r);
+            }
+        }
+        // slide the window
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                win[0][r][sidx] = win[1][r][sidx];
+                win[1][r][sidx] = win[2][r][sidx];
+                win[2][r][sidx] = nxt[r][sidx];
+            }
+    }
+}
+
+template <typename T, int CO>
+static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
+{
+    const long quads = (long)p.B * p.Hs * ((p.Ws + 3) / 4);
+    // measured on MI355X (512x512 output): batch 1 rows 43 us / strip 55 us; batch 8 rows 270 us / strip 221 us
+    const bool big = (long)p.B * p.Hs * p.Ws >= 4 * 65536;
+    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 64 && (big || std::getenv("LSP_HIP_LASTCONV_STRIP")) &&
+        !std::getenv("LSP_HIP_LASTCONV_ROWS") && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
+        // sliding-window kernel; segment length trades window priming (2 extra columns) for parallelism
+        const int seg = 32;
+        const long groups = (long)p.B * p.Hs * ((p.Ws + seg - 1) / seg);
+        const size_t smem = (size_t)4 * 2 * 4 * CO * 16 * sizeof(float4);
+        hipLaunchKernelGGL((last_conv_strip<T, CO>), dim3((unsigned)((groups + 15) / 16)), dim3(256), smem, s, p, seg);
+        return hipGetLastError();
+    }
+    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 128 && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
+        // 4 parities x quads wave-iterations; 4 waves per block, parity = wave & 3
+        long blocks = (quads + 3) / 4;                      // >= ~4 quads per wave
+        if (blocks > 2048) blocks = 2048;                   // 8 blocks (32 waves) per CU, all resident
+        if (blocks < 1) blocks = 1;
+        const int nch = p.C0 <= 64 ? 1 : 2;
+        const size_t smem = (size_t)4 * 2 * nch * 4 * CO * 16 * sizeof(float4);
+        if (nch == 1) hipLaunchKernelGGL((last_conv_rows<T, CO, 1>), dim3((unsigned)blocks), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((last_conv_rows<T, CO, 2>), dim3((unsigned)blocks), dim3(256), smem, s, p);
+        return hipGetLastError();
+    }
+    const long total = (long)p.B * 4 * p.Hs * p.Ws;
+    const size_t smem = (size_t)16 * p.Cout * (p.C0 + p.C1) * sizeof(float);
+    hipLaunchKernelGGL((last_conv<T, CO>), dim3((unsigned)((total + 255) / 256)), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
+{
+    if (p.dtype == 1) {
+        switch (p.Cout) {
+        case 1: return launch_last_conv_co<bf16_t, 1>(p, s);
+        case 2: return launch_last_conv_co<bf16_t, 2>(p, s);
+        case 3: return launch_last_conv_co<bf16_t, 3>(p, s);
+        case 4: return launch_last_conv_co<bf16_t, 4>(p, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    switch (p.Cout) {
+    case 1: return launch_last_conv_co<float, 1>(p, s);
+    case 2: return launch_last_conv_co<float, 2>(p, s);
+    case 3: return launch_last_conv_co<float, 3>(p, s);
+    case 4: return launch_last_conv_co<float, 4>(p, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace lspf2f

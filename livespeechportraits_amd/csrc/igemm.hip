@@ -1,0 +1,495 @@
+// gfx950 (MI355X / CDNA4): the fused 3x3 convolution as an implicit GEMM on the matrix cores, plus the
+// deterministic split-K reduction.  See DESIGN.md section 4.1.
+//
+//  igemm3x3<T,...>   im2col gather (stride 1|2, sub-pixel or 9-tap nearest-x2 upsample, optional second source =
+//                    the never-materialised torch.cat) -> LDS-DMA staging -> MFMA (fp32: v_mfma_f32_32x32x2_f32,
+//                    bf16: v_mfma_f32_32x32x16_bf16) -> epilogue (folded BatchNorm scale/shift, residual add, ReLU)
+//                    or fp32 split-K partials.
+//  splitk_reduce<T>  fixed-order reduction of the partials + the same epilogue.
+//
+// Reference semantics: models/networks.py:592-640 (level layout), :650-675 (ResidualBlock); BatchNorm eval
+// folding validated in SURVEY.md 8c.
+#include "device_common.h"
+#include "kernels.h"
+
+
+#ifndef LSPF2F_SWP
+#define LSPF2F_SWP 1   // 1: LDS fragment reads issued one step ahead of the MFMAs
+#endif
+
+
+namespace lspf2f {
+
+static constexpr unsigned kOOB = 0x80000000u;   // voffset beyond any num_records: buffer load returns 0
+
+static constexpr int BK = 32;    // K-tile (floats); Cin % 32 == 0 so a K-tile never straddles a tap
+static constexpr int LDK = 32;   // LDS row pitch in floats (128 B, unpadded: the tile is written by LDS-DMA,
+                                 // whose destination is lane-linear).  Bank conflicts are avoided by an XOR
+                                 // swizzle instead: 16-B slot s of row r holds k-quad s ^ ((r >> 1) & 7), which
+                                 // puts the 16 rows of every ds_read_b128 lane group on 16 distinct bank slots.
+
+// G = K-tiles staged per pipeline step (one barrier per G tiles, G tiles of global loads in
+// flight per thread).  G = 1 for long K loops; G = 4 turns a short split-K range (<= 4 tiles)
+// into a single load -> LDS -> MFMA pass, which is what the latency-bound <= 8x8 levels need.
+// UP = the 9-tap nearest-x2 gather form (only the small, weight-streaming up-convs use it).
+// buffer resource descriptor (raw buffer, stride 0) from wave-uniform values
+__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// One LDS-DMA piece: 64 lanes x 16 B -> LDS[lds_addr + lane*16]; out-of-range voffset lands as zeros.
+// Issued from inline asm on purpose: a compiler-visible LDS-DMA makes hipcc wait vmcnt(0) before the
+// next ds_read (it cannot disambiguate LDS addresses), which serialises the copy with the MFMAs.  The
+// kernel waits for its DMAs itself (dma_wait) right before the barrier that publishes the buffer.
+// M0 is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 srd, int soff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 4\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+                 : "memory");
+}
+// wait until at most N of this wave's DMA pieces are still in flight (they complete in order)
+template <int N>
+__device__ __forceinline__ void dma_wait()
+{
+    __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs issued so far ABOVE the wait (they cover the copy)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// T = storage type of activations and weights: float (exact fp32 MFMA, v_mfma_f32_32x32x2_f32) or bf16_t
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate and epilogue).  A K-tile is always 128 B of channels (32 fp32 /
+// 64 bf16), so the LDS geometry, the DMA pieces and the swizzle are identical for both.
+template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP>
+__global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
+{
+    constexpr int EB = (int)sizeof(T);               // element bytes
+    constexpr int BKE = 128 / EB;                    // channels per K-tile
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int RPP = NT / 8;            // tile rows staged per pass (8 threads x float4 = one 32-float row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    constexpr int TILE_A = BM * LDK, TILE_B = BN * LDK;
+    static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // double-buffered unless the whole K range fits one step
+    // LDS ring of NS pipeline steps (1 when the whole K range fits one step).  With LDS-DMA a deeper
+    // ring costs no registers, so the copy of step t+2 is in flight while step t is multiplied.
+    constexpr int NS = igemm_stages(BM, BN, G);
+    const int nbuf = p.ktiles_per_split > G ? NS : 1;
+    float *As = smem;                          // [nbuf][G][BM][LDK]
+    float *Bs = smem + nbuf * G * TILE_A;      // [nbuf][G][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // up4 (sub-pixel form of Upsample x2 + Conv3x3): blockIdx.x also enumerates the 4 output
+    // parities (py, px); each is a 2x2-tap conv over the LOW-res source with pre-summed weights,
+    // M counts low-res positions, and row m lands on output pixel (2y+py, 2x+px).
+    const int ntn = (p.Cout + BN - 1) / BN;
+    int bx = blockIdx.x, par = 0;
+    if (p.up4) { par = bx & 3; bx >>= 2; }
+    const int py = par >> 1, px = par & 1;
+    const int mt = bx / ntn, nt = bx - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.y;
+    const int kt_begin = z * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
+    if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
+
+    const int lrow = tid >> 3;
+    // staging: thread = (row lrow of each 8-row wave stripe, 16-B slot tid&7); it fetches the k-quad that
+    // belongs in its slot
+    const int lqb = ((tid & 7) ^ ((lrow >> 1) & 7)) * 16;   // byte offset of the k-slot this thread fetches
+
+    // ---- per-thread im2col row descriptors (fixed for the whole K loop) ----
+    // a_pix0: pixel index of tap (0,0) (may be "negative" at the border -- only used when the
+    // tap's validity bit is set); a_mask: bit t = tap t reads inside the (virtually upsampled)
+    // source; rows past M have mask 0.  All gathers are buffer loads whose voffset is forced
+    // out of range for invalid taps, so padding costs no branch and no select: the hardware
+    // returns zeros.
+    const int tw = p.up4 ? 2 : 3;                       // taps per row
+    const int ntap = tw * tw;
+    const int hlim = UP ? 2 * p.Hs : p.Hs;
+    const int wlim = UP ? 2 * p.Ws : p.Ws;
+    const int rw = p.up4 ? p.Ws : p.Wo;                 // extent of the M index space
+    const int rhw = p.up4 ? p.Hs * p.Ws : p.Ho * p.Wo;
+    int a_pix0[PA], a_oy[PA], a_ox[PA];
+    unsigned a_mask[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + i * RPP + lrow;
+        a_mask[i] = 0; a_pix0[i] = 0; a_oy[i] = 0; a_ox[i] = 0;
+        if (m < p.M) {
+            // exact division by the launch-invariant extents via precomputed multipliers
+            const int b = (int)p.div_rhw.div((unsigned)m);
+            const int r = m - b * rhw;
+            const int oy = (int)p.div_rw.div((unsigned)r);
+            const int y0 = oy * p.stride - 1 + py;
+            const int x0 = (r - oy * rw) * p.stride - 1 + px;
+            a_oy[i] = y0; a_ox[i] = x0;
+            a_pix0[i] = UP ? b * p.Hs * p.Ws : b * p.Hs * p.Ws + y0 * p.Ws + x0;
+            unsigned mask = 0, bit = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if (ky >= tw) break;
+                const bool oky = (unsigned)(y0 + ky) < (unsigned)hlim;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    if (kx >= tw) break;
+                    mask |= (unsigned)(oky & ((unsigned)(x0 + kx) < (unsigned)wlim)) << bit;
+                    ++bit;
+                }
+            }
+            a_mask[i] = mask;
+        }
+    }
+    const int K = ntap * p.Cin;
+    const T *wbase = static_cast<const T *>(p.w) + (size_t)par * p.Cout * K;
+    unsigned b_off[PB];                                  // byte offset of this thread's weight row, or OOB
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + i * RPP + lrow;
+        b_off[i] = (n < p.Cout) ? (unsigned)(n * K) * (unsigned)EB + (unsigned)lqb : kOOB;
+    }
+    const unsigned plane = (unsigned)(p.B * p.Hs * p.Ws) * (unsigned)EB;
+    const i32x4 rsw = make_srd(wbase, (unsigned)(p.Cout * K) * (unsigned)EB);
+
+    // K-tile cursor of the NEXT tile to fetch: tap = ky*tw+kx, c = channel offset inside the
+    // concatenated input
+    int tap = (kt_begin * BKE) / p.Cin;
+    int c = kt_begin * BKE - tap * p.Cin;
+    int ky = tap / tw, kx = tap - ky * tw;
+
+    // Stage K-tiles kt .. kt+G-1 into LDS buffer `buf` with buffer_load ... lds (LDS-DMA): no staging
+    // registers, no ds_write; invalid taps / ragged rows use an out-of-range voffset and land as zeros
+    // (tools/probes/lds_dma_probe.hip verifies both properties on gfx950).  One instruction moves the
+    // 8 rows x 128 B stripe of this wave: destination = wave-uniform base + lane * 16.
+    typedef __attribute__((address_space(3))) float lds_float;
+    const int wstripe = __builtin_amdgcn_readfirstlane((tid >> 6) * 8);   // first row of this wave's stripe in a pass
+    const unsigned lds_a = (unsigned)(unsigned long long)(lds_float *)As;   // LDS byte addresses
+    const unsigned lds_b = (unsigned)(unsigned long long)(lds_float *)Bs;
+    auto fetch = [&](int kt, int buf) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool live = kt + g < kt_end;
+            const bool first = c < p.C0;
+            const void *sp = first ? p.src0 : p.src1;
+            const int cs = first ? p.C0 : p.C1;
+            const int soff = (first ? c : c - p.C0) * EB;
+            const i32x4 rs = make_srd(sp, plane * (unsigned)cs);
+            const int tapdelta = ky * p.Ws + kx;
+            const unsigned csb = (unsigned)cs * (unsigned)EB;
+            const unsigned A = lds_a + (unsigned)(((buf * G + g) * TILE_A + wstripe * LDK) * 4);
+            const unsigned Bq = lds_b + (unsigned)(((buf * G + g) * TILE_B + wstripe * LDK) * 4);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = live && ((a_mask[i] >> tap) & 1u);
+                const int pix = UP ? a_pix0[i] + ((a_oy[i] + ky) >> 1) * p.Ws + ((a_ox[i] + kx) >> 1)
+                                   : a_pix0[i] + tapdelta;
+                const unsigned voff = ok ? (unsigned)pix * csb + (unsigned)lqb : kOOB;
+                dma16(A + i * RPP * LDK * 4, voff, rs, soff);
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                dma16(Bq + i * RPP * LDK * 4, live ? b_off[i] : kOOB, rsw, (kt + g) * (BK * 4));
+            if (live) {
+                c += BKE;
+                if (c == p.Cin) {
+                    c = 0; ++tap; ++kx;
+                    if (kx == tw) { kx = 0; ++ky; }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: lane l supplies row (l&31), k-quad (l>>5) of each 8-wide k group.
+    // The MFMA's k index (l>>5) then pairs k and k+4 -- any K permutation is fine as long as
+    // A and B use the same one.
+    const int frow = lane & 31;
+    const int fsw = (lane >> 5) ^ ((frow >> 1) & 7);   // (k-quad low bit) ^ row swizzle; tile offsets are multiples of 32 rows
+    // One "fragment step" = 8 k of one K-tile: TM + TN ds_read_b128, then TM*TN*4 MFMAs.  Fragment
+    // registers are double-buffered so the LDS reads of step s+1 are issued BEFORE the MFMAs of step s
+    // (an in-order wave otherwise exposes the full LDS latency once per step).
+    constexpr int S = G * (BK / 8);            // fragment steps per pipeline step
+    float4 fa[2][TM], fb[2][TN];
+    auto read_frag = [&](int buf, int s, int set) {
+        const int g = s / (BK / 8), kb = s % (BK / 8);
+        const int qoff = ((kb * 2) ^ fsw) * 4;         // swizzled slot of k-quad kb*2 + (lane>>5)
+        const float *A = As + (buf * G + g) * TILE_A + (wm * TM * 32 + frow) * LDK + qoff;
+        const float *Bq = Bs + (buf * G + g) * TILE_B + (wn * TN * 32 + frow) * LDK + qoff;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(A + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[set][j] = *reinterpret_cast<const float4 *>(Bq + j * 32 * LDK);
+    };
+    auto mfma_frag = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (EB == 4) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].x, fb[set][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].y, fb[set][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].z, fb[set][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].w, fb[set][j].w, acc[i][j], 0, 0, 0);
+                } else {
+                    // the 16-B slot is 8 consecutive bf16 channels = this lane's K = 8*(lane>>5) .. +7 operand
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
+                                                                        __builtin_bit_cast(bf16x8, fb[set][j]),
+                                                                        acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+
+    // ---- main loop.  Per pipeline step (G K-tiles in LDS buffer `cur`):
+    //   global loads of step t+1 -> registers | fragment steps 0..S-2 (LDS reads one step ahead)
+    //   | registers -> LDS buffer cur^1 (its latency hides behind the last MFMA block)
+    //   | last MFMA block | barrier | first fragment read of step t+1 (hidden behind the next fetch).
+    if (kt_begin < kt_end && !(p.dbg & 32)) {
+        constexpr int PIECES = G * (PA + PB);      // DMA instructions this wave issues per step
+        const int nsteps = (kt_end - kt_begin + G - 1) / G;
+        fetch(kt_begin, 0);
+        if (NS > 2 && nsteps > 1) fetch(kt_begin + G, 1);
+        if (NS > 2 && nsteps > 1) dma_wait<PIECES>(); else dma_wait<0>();
+        __syncthreads();
+        int cur = 0;
+        read_frag(0, 0, 0);
+        for (int t = 0; t < nsteps; ++t) {
+            // ring slot (cur + NS-1) % NS was last read in step t-1; every wave has passed that barrier
+            const int ahead = t + NS - 1;
+            const bool issue = ahead < nsteps && !(p.dbg & 1);
+            int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
+            if (issue) fetch(kt_begin + ahead * G, slot);
+#pragma unroll
+            for (int s = 0; s < S - 1; ++s) {
+                read_frag(cur, s + 1, (s + 1) & 1);
+                mfma_frag(s & 1);
+            }
+            mfma_frag((S - 1) & 1);
+            // step t+1 must have landed: everything but the pieces issued in THIS iteration
+            if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
+            if (!(p.dbg & 4)) __syncthreads();
+            if (!(p.dbg & 8)) { if (++cur == NS) cur = 0; }
+            if (t + 1 < nsteps) read_frag(cur, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5),
+    // i.e. a lane owns 16 rows of ONE column -- storing that directly means 4-byte accesses.  Each
+    // wave instead transposes its 32x32 tile through a private 4.5-KB LDS patch (the K-loop buffers
+    // are free after the last barrier) so every lane ends up with 4 consecutive channels of a row:
+    // float4 residual loads / stores, 8 lanes per 128-B row segment, 4 instead of 16 memory
+    // instructions per tile.  Same-wave LDS traffic needs no barrier (a wave's DS ops execute in order).
+    if (p.dbg & 16) return;
+    constexpr int EP = 36;                                   // patch row pitch (floats), keeps rows 16-B aligned
+    float *patch = smem + wave * (32 * EP);
+    const int ccol = lane & 31, crow = 4 * (lane >> 5);
+    const int erow = lane >> 3, ecol = (lane & 7) * 4;      // this lane's (row within 8-row pass, first channel)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + (wn * TN + j) * 32;              // first channel of the tile
+        const int n = nb + ecol;
+        const bool nok = n < p.Cout;                         // Cout % 4 == 0: a float4 is all-in or all-out
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.splits == 1 && p.scale && nok) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + n);
+            sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + crow) * EP + ccol] = acc[i][j][r];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + erow;
+                float4 v = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                if (m >= p.M || !nok) continue;
+                size_t orow = (size_t)m;                     // output pixel index (NHWC row)
+                if (p.up4) {
+                    const int b = (int)p.div_rhw.div((unsigned)m);
+                    const int rr = m - b * rhw;
+                    const int y = (int)p.div_rw.div((unsigned)rr), x = rr - y * rw;
+                    orow = ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
+                }
+                if (p.splits > 1) {
+                    *reinterpret_cast<float4 *>(p.partial + ((size_t)z * p.Mout + orow) * p.Cout + n) = v;
+                } else {
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (p.residual) {
+                        const float4 rv = load4(static_cast<const T *>(p.residual) + orow * p.Cout + n);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
+                }
+            }
+        }
+    }
+}
+
+// out = epilogue(sum_z partial[z]).  Block = 64 float4 columns x 4 z-lanes: z-lane y adds
+// partials y, y+4, y+8, ... (ascending), then the four lane sums are added in lane order --
+// a fixed summation tree, so results are bit-reproducible run to run.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
+{
+    __shared__ float4 red[3][64];
+    const unsigned total4 = (unsigned)(((size_t)p.Mout * p.Cout) >> 2);
+    const unsigned x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const unsigned i = blockIdx.x * 64u + x;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4) {
+        const float4 *pp = reinterpret_cast<const float4 *>(p.partial) + i;
+        int zz = (int)y;
+        for (; zz + 12 < p.splits; zz += 16) {
+            const float4 t0 = pp[(size_t)zz * total4], t1 = pp[(size_t)(zz + 4) * total4];
+            const float4 t2 = pp[(size_t)(zz + 8) * total4], t3 = pp[(size_t)(zz + 12) * total4];
+            s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+            s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+            s.x += t2.x; s.y += t2.y; s.z += t2.z; s.w += t2.w;
+            s.x += t3.x; s.y += t3.y; s.z += t3.z; s.w += t3.w;
+        }
+        for (; zz < p.splits; zz += 4) {
+            const float4 t = pp[(size_t)zz * total4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+    }
+    if (y) red[y - 1][x] = s;
+    __syncthreads();
+    if (y || i >= total4) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 t = red[k][x];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const unsigned n = (i * 4u) % (unsigned)p.Cout;
+    if (p.scale) {
+        const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
+        const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y;
+        s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
+    }
+    if (p.residual) {
+        const float4 r = load4(static_cast<const T *>(p.residual) + (size_t)i * 4);
+        s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+    }
+    if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    store4(static_cast<T *>(p.out) + (size_t)i * 4, s);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP>
+static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
+{
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
+    const int npar = p.up4 ? 4 : 1;
+    constexpr size_t smem_one = (size_t)G * (BM + BN) * LDK * sizeof(float);
+    constexpr size_t smem_max = smem_one * igemm_stages(BM, BN, G);
+    constexpr size_t smem_patch = (size_t)WGM * WGN * 32 * 36 * sizeof(float);   // epilogue transpose patches
+    size_t smem = p.ktiles_per_split > G ? smem_max : smem_one;
+    if (smem < smem_patch) smem = smem_patch;
+    static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
+    if (smem_max > 64 * 1024 && !attr_done) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3<T, BM, BN, WGM, WGN, G, UP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm3x3<T, BM, BN, WGM, WGN, G, UP>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
+                       smem, s, p);
+    return hipGetLastError();
+}
+
+bool igemm_tile_supported(int bm, int bn)
+{
+    for (int i = 0; i < kNumTileConfigs; ++i)
+        if (kTileConfigs[i].bm == bm && kTileConfigs[i].bn == bn) return true;
+    return false;
+}
+
+bool igemm_group_supported(int bm, int bn, int g, bool up)
+{
+    if (up) return (bm == 64 && bn == 64 && (g == 1 || g == 4)) || (bm == 32 && bn == 64 && g == 4);
+    if (g == 1) return igemm_tile_supported(bm, bn);
+    if (g == 2) return (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
+    if (g == 4) return (bm == 64 && bn == 64) || (bm == 32 && bn == 64);
+    return false;
+}
+
+hipError_t igemm_init() { return hipSuccess; }
+
+template <typename T>
+static hipError_t launch_igemm_typed(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
+{
+    if (p.up) {
+        if (bm == 64 && bn == 64 && g == 1) return launch_igemm_t<T, 64, 64, 2, 2, 1, true>(p, s);
+        if (bm == 64 && bn == 64 && g == 4) return launch_igemm_t<T, 64, 64, 2, 2, 4, true>(p, s);
+        if (bm == 32 && bn == 64 && g == 4) return launch_igemm_t<T, 32, 64, 1, 2, 4, true>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (g == 4) {
+        if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 4, false>(p, s);
+        if (bm == 32 && bn == 64) return launch_igemm_t<T, 32, 64, 1, 2, 4, false>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (g == 2) {
+        if (bm == 128 && bn == 64) return launch_igemm_t<T, 128, 64, 2, 2, 2, false>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 2, false>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (bm == 128 && bn == 128) return launch_igemm_t<T, 128, 128, 2, 2, 1, false>(p, s);
+    if (bm == 128 && bn == 64) return launch_igemm_t<T, 128, 64, 2, 2, 1, false>(p, s);
+    if (bm == 64 && bn == 128) return launch_igemm_t<T, 64, 128, 2, 2, 1, false>(p, s);
+    if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 1, false>(p, s);
+    if (bm == 32 && bn == 128) return launch_igemm_t<T, 32, 128, 1, 4, 1, false>(p, s);
+    if (bm == 32 && bn == 64) return launch_igemm_t<T, 32, 64, 1, 2, 1, false>(p, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStream_t s)
+{
+    IgemmParams p = p_in;
+    p.div_rhw = FastDiv::make((unsigned)(p.up4 ? p.Hs * p.Ws : p.Ho * p.Wo));
+    p.div_rw = FastDiv::make((unsigned)(p.up4 ? p.Ws : p.Wo));
+    // 2 GiB per tensor: buffer-load offsets are 32-bit with the top bit reserved as the OOB marker
+    const size_t lim = 0x7fffffffull;
+    const size_t eb = p.dtype == 1 ? 2 : 4;
+    if ((size_t)p.B * p.Hs * p.Ws * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * eb > lim) return hipErrorInvalidValue;
+    if ((p.C0 * eb) % 128 || (p.C1 * eb) % 128) return hipErrorInvalidValue;   // a K-tile is 128 B of channels
+    return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
+}
+
+hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
+{
+    const size_t total4 = (size_t)p.Mout * p.Cout / 4;
+    if (p.dtype == 1) hipLaunchKernelGGL(splitk_reduce<bf16_t>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(splitk_reduce<float>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace lspf2f

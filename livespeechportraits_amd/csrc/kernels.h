@@ -1,4 +1,4 @@
-// Host-visible launch interface of the gfx950 kernels (kernels.hip).  Internal to liblspf2f.so.
+// Host-visible launch interface of the gfx950 kernels (igemm.hip, small_layers.hip, edge_layers.hip).  Internal to liblspf2f.so.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

@@ -82,7 +82,7 @@ struct Plan {
 
 // tile / split-K heuristic shared by the planner and lspf2f_conv3x3
 void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *bm, int *bn, int *splits, int *group);
-// tiny-M kernel eligibility (mirrors smallm_supported() in kernels.hip)
+// tiny-M kernel eligibility (mirrors smallm_supported() in small_layers.hip)
 inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes)
 {
     return M <= 16 && c1 == 0 && cin % 256 == 0 && 9 * (cin / 4) <= 5 * 256 && in_bytes <= 64 * 1024 && cout % 2 == 0;

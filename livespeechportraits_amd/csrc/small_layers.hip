@@ -1,0 +1,150 @@
+// gfx950: single-launch convolution for the <= 4x4 levels (pure weight streaming).  DESIGN.md section 4.2.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace lspf2f {
+
+// ------------------------------------------------------------------------------------------
+// Tiny-M convolution (<= 16 output pixels in the whole batch: the 4x4 and 2x2 levels at batch 1).
+// These layers are pure weight streaming (9.4 MB of weights for <= 0.08 GFLOP) and were paying two
+// launches each (split-K igemm + reduce, ~14 us).  Here one launch does the whole layer: every
+// workgroup owns NC output channels over the FULL K, so no cross-workgroup reduction exists;
+// all 256 CUs stream weight rows (issued first, one latency), the whole input tensor (<= 64 KB)
+// is staged in LDS, each thread multiplies its K-slice for all pixels on the VALU, and the block
+// reduces through LDS in a fixed order.  Same packed weights [Cout][tap][Cin] as the igemm.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
+{
+    constexpr int MM = 16;                                 // max output pixels (batch folded in)
+    constexpr int NJ = 5;                                  // K/4 <= 5*256 float4 per weight row (Cin <= 512... 568)
+    constexpr int RS = 264;                                // reduction row pitch (floats)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    int *pixtab = reinterpret_cast<int *>(sm);             // [9][MM] source pixel of (tap, m); padding -> the zero pixel
+    float *act = sm + 160;                                 // [B*Hs*Ws + 1][Cin] (last pixel = zeros); later red[MM*NC][RS]
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * NC;
+    const int C4 = p.Cin >> 2, K4 = 9 * C4;
+
+    // 1. weights of this workgroup's channels: issue first
+    float4 wv[NC][NJ];
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k4 = tid + 256 * j;
+            wv[nc][j] = (k4 < K4 && n0 + nc < p.Cout)
+                ? load4(static_cast<const T *>(p.w) + (size_t)(n0 + nc) * 9 * p.Cin + (size_t)k4 * 4)
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    // 2. input tensor -> LDS, (m, tap) -> source pixel table
+    const int npix = p.B * p.Hs * p.Ws;
+    const int nin4 = npix * C4;
+    for (int i = tid; i < nin4; i += 256)
+        reinterpret_cast<float4 *>(act)[i] = load4(static_cast<const T *>(p.src) + (size_t)i * 4);   // LDS copy is fp32
+    for (int i = tid; i < C4; i += 256) reinterpret_cast<float4 *>(act)[nin4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < MM * 9) {
+        const int t = tid / MM, m = tid - t * MM;
+        int pix = npix;                                    // zero pixel: padding taps and rows past M
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, r = m - b * hw;
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            const int uy = oy * p.stride + t / 3 - 1, ux = ox * p.stride + t % 3 - 1;
+            const int hl = p.up ? 2 * p.Hs : p.Hs, wl = p.up ? 2 * p.Ws : p.Ws;
+            if (uy >= 0 && uy < hl && ux >= 0 && ux < wl)
+                pix = (b * p.Hs + (p.up ? uy >> 1 : uy)) * p.Ws + (p.up ? ux >> 1 : ux);
+        }
+        pixtab[tid] = pix;
+    }
+    __syncthreads();
+
+    // 3. this thread's K-slice times every pixel.  k4 = tid + 256 j; a wave's 64 consecutive float4 stay
+    //    inside one tap (Cin % 256 == 0), so the tap and the pixel validity are wave-uniform.
+    float acc[MM][NC];
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc) acc[m][nc] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int k4 = tid + 256 * j;
+        if (k4 >= K4) continue;
+        const int tap = k4 / C4, c4 = k4 - tap * C4;
+        // branch-free: 4 table reads, then 16 independent pixel reads, then the FMAs
+        int pix[MM];
+#pragma unroll
+        for (int q = 0; q < MM / 4; ++q) {
+            const int4 t4 = reinterpret_cast<const int4 *>(pixtab + tap * MM)[q];
+            pix[4 * q] = t4.x; pix[4 * q + 1] = t4.y; pix[4 * q + 2] = t4.z; pix[4 * q + 3] = t4.w;
+        }
+        float4 a[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) a[m] = reinterpret_cast<const float4 *>(act)[pix[m] * C4 + c4];
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) {
+                const float4 w4 = wv[nc][j];
+                acc[m][nc] += a[m].x * w4.x + a[m].y * w4.y + a[m].z * w4.z + a[m].w * w4.w;
+            }
+    }
+    __syncthreads();                                       // everyone is done with act
+    // 4. block reduction: red[o][tid], then 8 threads per output sum 32 interleaved values each
+    float *red = act;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc) red[(m * NC + nc) * RS + tid] = acc[m][nc];
+    __syncthreads();
+    if (tid < MM * NC * 8) {
+        const int o = tid >> 3, part = tid & 7;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) sum += red[o * RS + i * 8 + part];
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        const int m = o / NC, n = n0 + o % NC;
+        if (part == 0 && m < p.M && n < p.Cout) {
+            float v = sum;
+            if (p.scale) v = v * p.scale[n] + p.shift[n];
+            if (p.residual) {
+                if constexpr (sizeof(T) == 4) v += static_cast<const float *>(p.residual)[(size_t)m * p.Cout + n];
+                else v += bf2f(static_cast<const bf16_t *>(p.residual)[(size_t)m * p.Cout + n]);
+            }
+            if (p.relu) v = fmaxf(v, 0.f);
+            if constexpr (sizeof(T) == 4) static_cast<float *>(p.out)[(size_t)m * p.Cout + n] = v;
+            else static_cast<bf16_t *>(p.out)[(size_t)m * p.Cout + n] = f2bf(v);
+        }
+    }
+}
+
+bool smallm_supported(const SmallMParams &p)
+{
+    const size_t act_bytes = (size_t)p.B * p.Hs * p.Ws * p.Cin * 4;
+    return p.M <= 16 && p.Cin % 256 == 0 && 9 * (p.Cin / 4) <= 5 * 256 && act_bytes <= 64 * 1024 && p.Cout % 2 == 0;
+}
+
+hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
+{
+    if (!smallm_supported(p)) return hipErrorInvalidValue;
+    constexpr int NC = 2;
+    const size_t act_bytes = ((size_t)p.B * p.Hs * p.Ws + 1) * p.Cin * 4;
+    const size_t red_bytes = (size_t)16 * NC * 264 * 4;
+    const size_t smem = 160 * 4 + (act_bytes > red_bytes ? act_bytes : red_bytes);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL((conv3x3_smallm<float, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace lspf2f
