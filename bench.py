@@ -135,7 +135,7 @@ def main():
         traffic_src = "profiles/r01_pmc_large_b1.json (FETCH_SIZE x2 + WRITE_SIZE per forward, rocprofv3 --pmc)"
 
     roofline = {
-        "bound": "mfma", "kernel": "igemm3x3_f32 family incl. split-K reduce and tiny-M conv (all %d conv layers of one frame batch except first/last)" % len(ig),
+        "bound": "mfma", "kernel": "igemm3x3 family incl. split-K reduce and tiny-M conv (all %d conv layers of one frame batch except first/last)" % len(ig),
         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes": int(sum(layers[i]["act_bytes_per_frame"] for i in ig) * B + sum(layers[i]["weight_bytes"] for i in ig)),

@@ -196,7 +196,7 @@ static const char *kernel_name(const LayerDesc &l)
     switch (l.kind) {
     case kFirstConv: return "first_conv";
     case kLastConv: return "last_conv";
-    default: return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3_f32+splitk_reduce" : "igemm3x3_f32");
+    default: return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3+splitk_reduce" : "igemm3x3");
     }
 }
 
