@@ -353,9 +353,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     }
 }
 
-// out = epilogue(sum_z partial[z]).  Block = 64 float4 columns x 4 z-lanes: z-lane y adds
-// partials y, y+4, y+8, ... (ascending), then the four lane sums are added in lane order --
-// a fixed summation tree, so results are bit-reproducible run to run.
+// out = epilogue(sum_z partial[z]) -- shared tail of both reduce kernels
+template <typename T>
+__device__ __forceinline__ void reduce_epilogue(const IgemmParams &p, unsigned i, float4 s)
+{
+    const unsigned n = (i * 4u) % (unsigned)p.Cout;
+    if (p.scale) {
+        const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
+        const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y;
+        s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
+    }
+    if (p.residual) {
+        const float4 r = load4(static_cast<const T *>(p.residual) + (size_t)i * 4);
+        s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+    }
+    if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    store4(static_cast<T *>(p.out) + (size_t)i * 4, s);
+}
+
+// Many splits (the <= 16x16 levels): block = 64 float4 columns x 4 z-lanes: z-lane y adds partials
+// y, y+4, y+8, ... (ascending), then the four lane sums are added in lane order -- a fixed summation
+// tree, so results are bit-reproducible run to run.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
 {
@@ -388,19 +407,25 @@ __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
         const float4 t = red[k][x];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    const unsigned n = (i * 4u) % (unsigned)p.Cout;
-    if (p.scale) {
-        const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n);
-        const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n);
-        s.x = s.x * sc.x + sh.x; s.y = s.y * sc.y + sh.y;
-        s.z = s.z * sc.z + sh.z; s.w = s.w * sc.w + sh.w;
-    }
-    if (p.residual) {
-        const float4 r = load4(static_cast<const T *>(p.residual) + (size_t)i * 4);
-        s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
-    }
-    if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-    store4(static_cast<T *>(p.out) + (size_t)i * 4, s);
+    reduce_epilogue<T>(p, i, s);
+}
+
+// Few splits (2..4: the mid levels, megabytes of partials): one float4 per thread, all partial loads in
+// flight at once, no LDS, no barrier -- a pure streaming pass.  z ascending.
+template <typename T, int NS>
+__global__ __launch_bounds__(256) void splitk_reduce_few(const IgemmParams p)
+{
+    const unsigned total4 = (unsigned)(((size_t)p.Mout * p.Cout) >> 2);
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total4) return;
+    const float4 *pp = reinterpret_cast<const float4 *>(p.partial) + i;
+    float4 t[NS];
+#pragma unroll
+    for (int z = 0; z < NS; ++z) t[z] = pp[(size_t)z * total4];
+    float4 s = t[0];
+#pragma unroll
+    for (int z = 1; z < NS; ++z) { s.x += t[z].x; s.y += t[z].y; s.z += t[z].z; s.w += t[z].w; }
+    reduce_epilogue<T>(p, i, s);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP>
@@ -484,12 +509,23 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
     return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
 }
 
-hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
+template <typename T>
+static hipError_t launch_splitk_reduce_t(const IgemmParams &p, hipStream_t s)
 {
     const size_t total4 = (size_t)p.Mout * p.Cout / 4;
-    if (p.dtype == 1) hipLaunchKernelGGL(splitk_reduce<bf16_t>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(splitk_reduce<float>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p);
+    const dim3 few((unsigned)((total4 + 255) / 256));
+    switch (p.splits) {
+    case 2: hipLaunchKernelGGL((splitk_reduce_few<T, 2>), few, dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((splitk_reduce_few<T, 3>), few, dim3(256), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((splitk_reduce_few<T, 4>), few, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p); break;
+    }
     return hipGetLastError();
+}
+
+hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
+{
+    return p.dtype == 1 ? launch_splitk_reduce_t<bf16_t>(p, s) : launch_splitk_reduce_t<float>(p, s);
 }
 
 }  // namespace lspf2f
