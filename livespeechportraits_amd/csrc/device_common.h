@@ -9,6 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float v2f __attribute__((ext_vector_type(2)));   // pairs for v_pk_fma_f32
 typedef unsigned short bf16_t;               // bf16 storage (round-to-nearest-even on store)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }

@@ -411,11 +411,13 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
     for (int x = x0; x < x1; ++x) {
         asm volatile("" ::: "memory");         // keep the weights in LDS (see last_conv_rows)
         if (x + 1 < x1) load_col(x + 2, nxt);  // next step's column flies while this step computes
-        float acc[4][CO];
+        // accumulate in float2 lanes so that the dot products compile to v_pk_fma_f32 (2 FMAs per VALU slot);
+        // the pair is summed once at the end
+        v2f acc2[4][CO];
 #pragma unroll
         for (int par = 0; par < 4; ++par)
 #pragma unroll
-            for (int co = 0; co < CO; ++co) acc[par][co] = 0.f;
+            for (int co = 0; co < CO; ++co) acc2[par][co] = v2f{0.f, 0.f};
 #pragma unroll
         for (int par = 0; par < 4; ++par) {
             const int py = par >> 1, px = par & 1;
@@ -437,10 +439,16 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
 #pragma unroll
                     for (int co = 0; co < CO; ++co) {
                         const float4 ww = wq[sidx][t][co];
-                        acc[par][co] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+                        acc2[par][co] += v2f{v.x, v.y} * v2f{ww.x, ww.y};
+                        acc2[par][co] += v2f{v.z, v.w} * v2f{ww.z, ww.w};
                     }
                 }
         }
+        float acc[4][CO];
+#pragma unroll
+        for (int par = 0; par < 4; ++par)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[par][co] = acc2[par][co].x + acc2[par][co].y;
 #pragma unroll
         for (int par = 0; par < 4; ++par) {
 #pragma unroll
