@@ -11,6 +11,7 @@
 // folding validated in SURVEY.md 8c.
 #include "device_common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 
 #ifndef LSPF2F_SWP
@@ -102,12 +103,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     // parities (py, px); each is a 2x2-tap conv over the LOW-res source with pre-summed weights,
     // M counts low-res positions, and row m lands on output pixel (2y+py, 2x+px).
     const int ntn = (p.Cout + BN - 1) / BN;
-    int bx = blockIdx.x, par = 0;
+    // XCD-aware order: the dispatcher deals workgroups round-robin over the 8 XCDs (private L2s),
+    // so logical tile ids are handed out in 8 contiguous chunks -- one XCD works on one band of
+    // image rows (m-major: activations fetched once, weights by every XCD) or on one band of
+    // output channels / K-splits (n-major, weight-heavy layers: weights fetched once).
+    unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (p.xcd) {
+        const unsigned total = gridDim.x * gridDim.y, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const int z = (int)(lin / gridDim.x);
+    int bx = (int)(lin - (unsigned)z * gridDim.x), par = 0;
     if (p.up4) { par = bx & 3; bx >>= 2; }
     const int py = par >> 1, px = par & 1;
-    const int mt = bx / ntn, nt = bx - mt * ntn;
+    int mt, nt;
+    if (p.xcd == 2) { const int ntm = (p.M + BM - 1) / BM; nt = bx / ntm; mt = bx - nt * ntm; }
+    else { mt = bx / ntn; nt = bx - mt * ntn; }
     const int m0 = mt * BM, n0 = nt * BN;
-    const int z = blockIdx.y;
     const int kt_begin = z * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split;
     if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
@@ -506,6 +518,12 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
     const size_t eb = p.dtype == 1 ? 2 : 4;
     if ((size_t)p.B * p.Hs * p.Ws * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * eb > lim) return hipErrorInvalidValue;
     if ((p.C0 * eb) % 128 || (p.C1 * eb) % 128) return hipErrorInvalidValue;   // a K-tile is 128 B of channels
+    {   // XCD chunking: partition the larger operand across the 8 L2s (LSP_HIP_XCD=0/1/2 overrides, tools only)
+        static const int forced = std::getenv("LSP_HIP_XCD") ? std::atoi(std::getenv("LSP_HIP_XCD")) : -1;
+        const size_t act = (size_t)p.B * p.Hs * p.Ws * p.Cin * eb;
+        const size_t wgt = (size_t)(p.up4 ? 16 : 9) * p.Cin * p.Cout * eb;
+        p.xcd = forced >= 0 ? forced : (wgt > act ? 2 : 1);
+    }
     return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
 }
 

@@ -52,6 +52,7 @@ struct IgemmParams {
     int ktiles_per_split;
     int splits;
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
+    int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
     int dbg;                    // ablation bits for tools/ (0 in production): 1 no refetch, 2 no LDS restage, 4 no barrier, 8 no buffer flip
 };
 

@@ -15,6 +15,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("root")
     ap.add_argument("--forwards", type=int, default=8, help="forwards in each PMC run (warmup+steps+5 timed passes)")
+    ap.add_argument("--json", default=None, help="also write per-forward HBM-side bytes per kernel family (read by bench.py)")
+    ap.add_argument("--label", default="bench.py large batch 1 fp32")
     a = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
@@ -41,6 +43,17 @@ def main():
               % (k[:44], calls[k] / a.forwards, f, 2 * f, w, 100 * hit / max(hit + miss, 1), mf,
                  d.get("SQ_LDS_BANK_CONFLICT", 0) / a.forwards, d.get("SQ_LDS_UNALIGNED_STALL", 0) / a.forwards))
     print("# total per forward: fetch %.1f MB (x2 %.1f MB), write %.1f MB" % (tot_f, 2 * tot_f, tot_w))
+    if a.json:
+        import json
+        fam = {"conv_family": ("igemm3x3", "splitk_reduce", "conv3x3_smallm"), "first_conv": ("first_conv",), "last_conv": ("last_conv",)}
+        out = {}
+        for name, prefixes in fam.items():
+            fr = sum(d.get("FETCH_SIZE", 0) for k, d in agg.items() if k.startswith(prefixes)) * 1024 / a.forwards
+            wr = sum(d.get("WRITE_SIZE", 0) for k, d in agg.items() if k.startswith(prefixes)) * 1024 / a.forwards
+            out[name] = {"fetch_raw": fr, "fetch_x2": 2 * fr, "write": wr}
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), %s, %d forwards per pass; tools/collect_profiles.sh + tools/pmc_summary.py --json" % (a.label, a.forwards),
+                   "correction": "FETCH_SIZE doubled for 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected",
+                   "per_forward_bytes": out}, open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
