@@ -1,4 +1,4 @@
-"""ctypes binding of liblspf2f.so (include/lspf2f.h).
+"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h).
 
 There is deliberately no fallback: if the shared library is missing or does not
 load, importing the hot path raises -- a GPU box must never silently run
@@ -79,6 +79,39 @@ SIGNATURES = {
     "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p, c_size_t, c_void_p]),
 }
 
+
+
+class A2HConfig(Structure):
+    """lspa2h_config (include/lspa2h.h)"""
+    _fields_ = [(n, c_int32) for n in ("abi_version", "residual_layers", "residual_blocks", "residual_channels",
+                                       "dilation_channels", "skip_channels", "kernel_size", "input_channels",
+                                       "cond_channels", "hidden_size", "ncenter", "ndim", "loss",
+                                       "max_audio_frames")] + [("flags", c_uint32)]
+
+
+A2H_ABI_VERSION = 1
+A2H_LOSS_IDS = {"GMM": 0, "L2": 1}
+_GEN_ARGS = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int, c_void_p]
+# every symbol include/lspa2h.h declares
+A2H_SIGNATURES = {
+    "lspa2h_create": (c_int, [POINTER(A2HConfig), POINTER(c_void_p)]),
+    "lspa2h_destroy": (c_int, [c_void_p]),
+    "lspa2h_last_error": (c_char_p, []),
+    "lspa2h_abi_version": (c_int, []),
+    "lspa2h_receptive_field": (c_int, [c_void_p]),
+    "lspa2h_num_tensors": (c_int, [c_void_p]),
+    "lspa2h_tensor_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_size_t)]),
+    "lspa2h_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "lspa2h_packed_bytes": (c_size_t, [c_void_p]),
+    "lspa2h_pack_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspa2h_bind_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspa2h_workspace_bytes": (c_size_t, [c_void_p]),
+    "lspa2h_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspa2h_generate": (c_int, _GEN_ARGS),
+    "lspa2h_generate_timed": (c_int, _GEN_ARGS + [POINTER(c_float), POINTER(c_float)]),
+    "lspa2h_debug_cond": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int)]),
+}
+
 _lib = None
 
 
@@ -96,7 +129,7 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e)) from e
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
@@ -106,6 +139,9 @@ def load() -> ctypes.CDLL:
     if lib.lspf2f_abi_version() != ABI_VERSION:
         raise NativeLibraryError("ABI version mismatch: library %d, binding %d"
                                  % (lib.lspf2f_abi_version(), ABI_VERSION))
+    if lib.lspa2h_abi_version() != A2H_ABI_VERSION:
+        raise NativeLibraryError("lspa2h ABI version mismatch: library %d, binding %d"
+                                 % (lib.lspa2h_abi_version(), A2H_ABI_VERSION))
     _lib = lib
     return lib
 
@@ -114,3 +150,15 @@ def check(rc: int) -> None:
     if rc != OK:
         msg = load().lspf2f_last_error()
         raise Lspf2fError(rc, msg.decode() if msg else "")
+
+
+class Lspa2hError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lspa2h error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check_a2h(rc: int) -> None:
+    if rc != OK:
+        msg = load().lspa2h_last_error()
+        raise Lspa2hError(rc, msg.decode() if msg else "")

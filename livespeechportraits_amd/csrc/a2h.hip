@@ -1,0 +1,677 @@
+// Head-pose generator (include/lspa2h.h): the autoregressive WaveNet of the reference's
+// Audio2HeadposeModel.generate_sequences (models/audio2headpose_model.py:133-187), gfx950 only.
+//
+// Two kernels:
+//   a2h_gemm     fp32 MFMA GEMM with a per-column affine (+LeakyReLU) epilogue: the audio_downsample MLP
+//                (models/audio2headpose.py:16-21, BatchNorm1d folded) and ALL layers' cond_filter/cond_gate
+//                1x1 convs (models/networks.py:277-287) for every audio frame at once -- none of it depends
+//                on the sampled poses, so it leaves the sequential loop.
+//   a2h_stream   ONE persistent workgroup runs every time step of the loop: start convs, the gated residual
+//                layers evaluated incrementally (per-layer dilation queues in LDS), end convs, GMM sampling,
+//                feedback.  The step-to-step dependence goes through the 12 sampled values, so there is no
+//                parallelism across steps or layers; the kernel is a chain of 256x256 / 384x128 mat-vecs
+//                whose weights (6.4 MB per step) stream from L2 in kernel-specific packed layouts, one
+//                coalesced 1-KB wave load per instruction, double-buffered in registers across the barriers.
+#include "../../include/lspa2h.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace lspa2h {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RC = 128;        // residual == dilation channels
+constexpr int SC = 256;        // skip channels
+constexpr int NT = 512;        // threads of the stream workgroup
+constexpr int MAX_LAYERS = 32;
+constexpr int MAX_OUT = 64;    // (2*ndim+1)*ncenter
+constexpr float LRELU = 0.2f;  // nn.LeakyReLU(0.2), networks.py:147
+
+// ------------------------------------------------------------------------------------------------ GEMM
+struct GemmParams {
+    const float *A;      // [M][K]
+    const float *W;      // [N][K]   (nn.Linear / 1x1 Conv1d weight layout)
+    const float *scale;  // [N] or null (=1)
+    const float *shift;  // [N]
+    float *C;            // [M][N]
+    int M, N, K;
+    int leaky;
+};
+
+// C = act((A W^T) * scale + shift).  64x64 tile, 4 waves (2x2) of one 32x32 MFMA accumulator, K step 32.
+// N % 64 == 0 and K % 32 == 0 (checked by the launcher); M is ragged.
+__global__ __launch_bounds__(256) void a2h_gemm(GemmParams p)
+{
+    constexpr int LD = 36;
+    __shared__ float As[64 * LD];
+    __shared__ float Bs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lrow = tid >> 3, lq = (tid & 7) * 4;   // staging: 32 rows x 8 float4 per pass, 2 passes
+    for (int k0 = 0; k0 < p.K; k0 += 32) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = pass * 32 + lrow;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < p.M) a = *reinterpret_cast<const float4 *>(p.A + (size_t)(m0 + r) * p.K + k0 + lq);
+            const float4 b = *reinterpret_cast<const float4 *>(p.W + (size_t)(n0 + r) * p.K + k0 + lq);
+            *reinterpret_cast<float4 *>(As + r * LD + lq) = a;
+            *reinterpret_cast<float4 *>(Bs + r * LD + lq) = b;
+        }
+        __syncthreads();
+        const float *ap = As + (wm * 32 + (lane & 31)) * LD + (lane >> 5);
+        const float *bp = Bs + (wn * 32 + (lane & 31)) * LD + (lane >> 5);
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = acc[r] * sc + sh;
+        if (p.leaky) v = v > 0.f ? v : LRELU * v;
+        p.C[(size_t)m * p.N + n] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- stream
+struct StreamParams {
+    // packed weights (device blob)
+    const float *start1_w, *start1_b;   // [128][ndim], [128]
+    const float *blob; unsigned blob_bytes;  // packed matrices below are byte offsets into it
+    unsigned start2_w; const float *start2_b;   // packed 8 x 512 float4, [128]
+    unsigned fg_w;                      // per layer: packed 32 x 512 float4 (65536 floats)
+    unsigned rs_w;                      // per layer: packed 24 x 512 float4 (49152 floats)
+    const float *rs_b;                  // per layer: [384] residual bias (128) + skip bias (256)
+    unsigned end1_w; const float *end1_b;       // packed 8 x 512 float4, [64]
+    const float *end2_w, *end2_b;       // [nout][nout], [nout]
+    // per-call tensors
+    const float *proj;                  // [n_audio][layers*256]: cond projections + conv biases, packed row order
+    const float *pre, *noise, *expq;
+    float *out;
+    int layers, ndim, ncenter, nout, loss;
+    int field;                          // receptive field R
+    int nframe, frame_future;
+    float sigma_scale;
+    int dil[MAX_LAYERS];                // dilation of layer l (power of two)
+    int qoff[MAX_LAYERS];               // first queue row of layer l
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over aligned groups of 4 / 8 lanes; every lane of the group gets the total
+__device__ __forceinline__ float sum4(float v) { return dpp_add<0x4E>(dpp_add<0xB1>(v)); }          // quad_perm xor1, xor2
+__device__ __forceinline__ float sum8(float v) { return dpp_add<0x141>(sum4(v)); }                    // + row_half_mirror
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU * v; }
+
+// float4 loads [B, E) of a packed matrix that starts `off` bytes into the blob: instruction i reads float4
+// (i*512 + tid) -> 1 KB contiguous per wave.  Buffer loads: one VGPR (tid*16) addresses all of them, the
+// per-instruction part sits in an SGPR (64-bit global addresses would cost two VGPRs per load in flight).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int B, int E, int N>
+__device__ __forceinline__ void load_packed(float4 (&w)[N], __amdgpu_buffer_rsrc_t blob, unsigned off, int voff)
+{
+#pragma unroll
+    for (int i = B; i < E; ++i)
+        w[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(blob, voff, (int)(off + (unsigned)i * NT * 16u), 0));
+}
+__device__ __forceinline__ float dot4(float4 w, float4 v, float acc)
+{
+    acc = fmaf(w.x, v.x, acc); acc = fmaf(w.y, v.y, acc); acc = fmaf(w.z, v.z, acc); acc = fmaf(w.w, v.w, acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(NT) void a2h_stream(StreamParams p)
+{
+    extern __shared__ float smem[];
+    float *xbuf = smem;                  // [128] current layer input
+    float *zbuf = xbuf + RC;             // [128] gated activation
+    float *tbuf = zbuf + RC;             // [128] start_conv1 output
+    float *sbuf = tbuf + RC;             // [256] lrelu(skip sum)
+    float *r1 = sbuf + SC;               // [64]  end_conv_1 output (lrelu applied)
+    float *r2 = r1 + MAX_OUT;            // [64]  end_conv_2 output
+    float *inb = r2 + MAX_OUT;           // [16]  WaveNet input of this step (head pose)
+    float *queue = inb + 16;             // [sum of dilations][128]
+    const int tid = threadIdx.x;
+
+    int qrows = 0;
+    for (int l = 0; l < p.layers; ++l) qrows += p.dil[l];
+    for (int i = tid; i < qrows * RC; i += NT) queue[i] = 0.f;
+    if (tid < 16) inb[tid] = tid < p.ndim ? p.pre[tid] : 0.f;
+
+    const int nsteps = p.field - 1 + p.nframe;
+    const int fu = tid >> 3, fpart = tid & 7;        // fg item: channels fu and fu+64, 32-column part
+    const int rq = tid >> 2, rpart = tid & 3;        // rs item: rows rq, 128+rq, 256+rq, 32-column part
+    const unsigned fg_stride = 32 * NT * 16, rs_stride = 24 * NT * 16;   // bytes per layer
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void *)p.blob, 0, (int)p.blob_bytes, 0x00020000);
+    const int voff = tid * 16;
+    const int projN = p.layers * 256;
+
+    // Weight registers.  F + R together are 87 % of the CU's register file, so the next mat-vec's weights
+    // cannot all be in flight while the current set is live: half of the next set is requested before a
+    // set is consumed, the other half as soon as its registers are free.
+    float4 F[32], R[24];
+    load_packed<0, 32>(F, blob, p.fg_w, voff);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        int arow = s + p.frame_future - (p.field - 1);
+        arow = arow < 0 ? 0 : arow;                  // the reference prepends field-1 copies of audio row 0
+        const float *projrow = p.proj + (size_t)arow * projN;
+        // ---- start convs (networks.py:198-199): 1x1, bias, LeakyReLU
+        if (tid < RC) {
+            float a = p.start1_b[tid];
+            for (int k = 0; k < p.ndim; ++k) a = fmaf(p.start1_w[tid * p.ndim + k], inb[k], a);
+            tbuf[tid] = lrelu(a);
+        }
+        __syncthreads();
+        {
+            float4 w[8];
+            load_packed<0, 8>(w, blob, p.start2_w, voff);
+            const float4 *v = reinterpret_cast<const float4 *>(tbuf + rpart * 32);
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a = dot4(w[q], v[q], a);
+            a = sum4(a);
+            if (rpart == 0) xbuf[rq] = lrelu(a + p.start2_b[rq]);
+        }
+        float skip0 = 0.f, skip1 = 0.f;              // skip rows rq and 128+rq (leader lanes)
+        __syncthreads();
+
+        for (int l = 0; l < p.layers; ++l) {
+            const int d = p.dil[l];
+            float *qslot = queue + (size_t)(p.qoff[l] + (s & (d - 1))) * RC;   // holds x[t-d]; overwritten with x[t]
+            const unsigned rsw = p.rs_w + (unsigned)l * rs_stride;
+            load_packed<0, 16>(R, blob, rsw, voff);                                    // in flight during the fg mat-vec
+            float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fpart == 0) pb = *reinterpret_cast<const float4 *>(projrow + l * 256 + fu * 4);
+            // ---- filter/gate dilated convs + cond (networks.py:303-314): 256 rows x [x[t-d] ; x[t]]
+            {
+                const float4 *v = reinterpret_cast<const float4 *>((fpart < 4 ? qslot + fpart * 32 : xbuf + (fpart - 4) * 32));
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 x = v[q];
+                    a0 = dot4(F[q], x, a0); a1 = dot4(F[8 + q], x, a1); a2 = dot4(F[16 + q], x, a2); a3 = dot4(F[24 + q], x, a3);
+                }
+                asm volatile("" ::: "memory");                  // keep the late half late: its registers are not free earlier
+                load_packed<16, 24>(R, blob, rsw, voff);
+                a0 = sum8(a0); a1 = sum8(a1); a2 = sum8(a2); a3 = sum8(a3);
+                if (fpart == 0) {   // tanh(filter) * sigmoid(gate), networks.py:317-319
+                    zbuf[fu] = tanhf(a0 + pb.x) * (1.f / (1.f + expf(-(a1 + pb.y))));
+                    zbuf[fu + 64] = tanhf(a2 + pb.z) * (1.f / (1.f + expf(-(a3 + pb.w))));
+                }
+            }
+            __syncthreads();
+            // next fg weights (next layer, or layer 0 of the next step) stream in during the rs mat-vec
+            const unsigned fgw = p.fg_w + (unsigned)(l + 1 == p.layers ? 0 : l + 1) * fg_stride;
+            load_packed<0, 16>(F, blob, fgw, voff);
+            // ---- residual + skip 1x1 convs (networks.py:322-323)
+            {
+                const float4 *v = reinterpret_cast<const float4 *>(zbuf + rpart * 32);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 z = v[q];
+                    a0 = dot4(R[q], z, a0); a1 = dot4(R[8 + q], z, a1); a2 = dot4(R[16 + q], z, a2);
+                }
+                asm volatile("" ::: "memory");
+                load_packed<16, 32>(F, blob, fgw, voff);
+                a0 = sum4(a0); a1 = sum4(a1); a2 = sum4(a2);
+                if (rpart == 0) {
+                    const float *b = p.rs_b + l * 384;
+                    const float x = xbuf[rq];
+                    qslot[rq] = x;                       // every reader of x[t-d] is past the barrier above
+                    xbuf[rq] = a0 + b[rq] + x;           // residual = residual_conv(x) + input
+                    skip0 += a1 + b[128 + rq];
+                    skip1 += a2 + b[256 + rq];
+                }
+            }
+            __syncthreads();
+        }
+
+        const int frame = s - (p.field - 1);
+        if (frame < 0) continue;                         // still filling the first receptive field
+        // ---- end convs (networks.py:207-208) on the summed skips
+        if (rpart == 0) { sbuf[rq] = lrelu(skip0); sbuf[128 + rq] = lrelu(skip1); }
+        __syncthreads();
+        {
+            float4 w[8];
+            load_packed<0, 8>(w, blob, p.end1_w, voff);
+            const float4 *v = reinterpret_cast<const float4 *>(sbuf + fpart * 32);
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a = dot4(w[q], v[q], a);
+            a = sum8(a);
+            if (fpart == 0) r1[fu] = lrelu(a + p.end1_b[fu]);
+        }
+        __syncthreads();
+        if (tid < p.nout) {
+            float a = p.end2_b[tid];
+            for (int k = 0; k < p.nout; ++k) a = fmaf(p.end2_w[tid * p.nout + k], r1[k], a);
+            r2[tid] = a;
+        }
+        __syncthreads();
+        // ---- Sample_GMM (losses.py:68-112) / L2 passthrough
+        if (tid < p.ndim) {
+            float v;
+            if (p.loss == LSPA2H_LOSS_L2) {
+                v = r2[tid];
+            } else {
+                int idx = 0;
+                if (p.ncenter > 1) {   // softmax -> prob / Exp(1) draw -> argmax  (torch.multinomial, one sample)
+                    float mx = r2[0];
+                    for (int k = 1; k < p.ncenter; ++k) mx = fmaxf(mx, r2[k]);
+                    float den = 0.f;
+                    for (int k = 0; k < p.ncenter; ++k) den += expf(r2[k] - mx);
+                    float best = -1.f;
+                    for (int k = 0; k < p.ncenter; ++k) {
+                        const float val = (expf(r2[k] - mx) / den) / p.expq[(size_t)frame * p.ncenter + k];
+                        if (val > best) { best = val; idx = k; }
+                    }
+                }
+                const float mu = r2[p.ncenter + idx * p.ndim + tid];
+                const float sigma = expf(-r2[p.ncenter + p.ncenter * p.ndim + idx * p.ndim + tid]) * p.sigma_scale;
+                const float nz = p.noise ? p.noise[(size_t)frame * p.ndim + tid] : 0.f;
+                v = nz * sigma + mu;
+            }
+            p.out[(size_t)frame * p.ndim + tid] = v;
+            inb[tid] = v;                                // history_headpose <- cat(history[1:], pred), :186
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+static int hipfail(hipError_t e, const char *what) { return fail(LSPA2H_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+
+struct TensorSlot {
+    std::string key;
+    std::vector<size_t> shape;
+    size_t numel = 0;
+    std::vector<float> data;
+    bool set = false;
+};
+
+}  // namespace lspa2h
+
+using namespace lspa2h;
+
+struct lspa2h_handle {
+    lspa2h_config cfg{};
+    int layers = 0, nout = 0, field = 0;
+    std::vector<int> dil, qoff;
+    int qrows = 0;
+    std::vector<TensorSlot> tensors;
+    std::map<std::string, int> index;
+    // blob offsets (floats)
+    size_t o_mlp0_w, o_mlp0_scale, o_mlp0_shift, o_mlp1_w, o_mlp1_b, o_proj_w, o_proj_b;
+    size_t o_start1_w, o_start1_b, o_start2_w, o_start2_b, o_fg_w, o_rs_w, o_rs_b, o_end1_w, o_end1_b, o_end2_w, o_end2_b;
+    size_t blob_floats = 0;
+    const float *blob = nullptr;
+    size_t blob_bytes = 0;
+    float *ws = nullptr;
+    size_t ws_bytes = 0;
+    bool packed = false;
+    bool attr_done = false;
+    int last_rows = 0;
+
+    void add(const std::string &key, std::vector<size_t> shape)
+    {
+        TensorSlot t;
+        t.key = key; t.shape = shape; t.numel = 1;
+        for (size_t s : shape) t.numel *= s;
+        index[key] = (int)tensors.size();
+        tensors.push_back(std::move(t));
+    }
+    const std::vector<float> &T(const std::string &key) const { return tensors[index.at(key)].data; }
+};
+
+static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+extern "C" {
+
+const char *lspa2h_last_error(void) { return g_err.c_str(); }
+int lspa2h_abi_version(void) { return LSPA2H_ABI_VERSION; }
+
+int lspa2h_create(const lspa2h_config *cfg, lspa2h_handle **out)
+{
+    if (!cfg || !out) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    if (cfg->abi_version != LSPA2H_ABI_VERSION) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "abi_version mismatch");
+    if (cfg->residual_channels != RC || cfg->dilation_channels != RC || cfg->skip_channels != SC || cfg->kernel_size != 2)
+        return fail(LSPA2H_ERR_UNSUPPORTED, "kernels are built for residual/dilation 128, skip 256, kernel_size 2 (the reference defaults)");
+    if (cfg->residual_layers < 1 || cfg->residual_layers > 10 || cfg->residual_blocks < 1 ||
+        cfg->residual_layers * cfg->residual_blocks > MAX_LAYERS)
+        return fail(LSPA2H_ERR_UNSUPPORTED, "residual_layers in 1..10 and layers*blocks <= 32");
+    if (cfg->ndim < 1 || cfg->ndim > 16 || cfg->ncenter < 1 || cfg->ncenter > 8) return fail(LSPA2H_ERR_UNSUPPORTED, "ndim <= 16, ncenter <= 8");
+    if (cfg->input_channels != cfg->ndim) return fail(LSPA2H_ERR_SHAPE, "input_channels must equal ndim (samples are fed back as history)");
+    if (cfg->loss != LSPA2H_LOSS_GMM && cfg->loss != LSPA2H_LOSS_L2) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "loss");
+    if (cfg->cond_channels != cfg->hidden_size || cfg->hidden_size % 64 || cfg->hidden_size < 64)
+        return fail(LSPA2H_ERR_SHAPE, "cond_channels must equal hidden_size, a multiple of 64");
+    if (cfg->max_audio_frames < 1) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "max_audio_frames");
+    lspa2h_handle *h = new (std::nothrow) lspa2h_handle;
+    if (!h) return fail(LSPA2H_ERR_STATE, "out of host memory");
+    h->cfg = *cfg;
+    h->layers = cfg->residual_layers * cfg->residual_blocks;
+    h->nout = cfg->loss == LSPA2H_LOSS_GMM ? (2 * cfg->ndim + 1) * cfg->ncenter : cfg->ndim;
+    if (h->nout > MAX_OUT) { delete h; return fail(LSPA2H_ERR_UNSUPPORTED, "(2*ndim+1)*ncenter must be <= 64"); }
+    h->field = 1;
+    for (int b = 0; b < cfg->residual_blocks; ++b)
+        for (int i = 0; i < cfg->residual_layers; ++i) {
+            h->dil.push_back(1 << i);
+            h->qoff.push_back(h->qrows);
+            h->qrows += 1 << i;
+            h->field += 1 << i;     // kernel_size 2: additional_scope doubles per layer (networks.py:150-166)
+        }
+    const size_t lds = (size_t)(RC * 3 + SC + 2 * MAX_OUT + 16 + (size_t)h->qrows * RC) * sizeof(float);
+    if (lds > 160 * 1024) { delete h; return fail(LSPA2H_ERR_UNSUPPORTED, "dilation queues exceed the 160 KB LDS of one CU"); }
+
+    const size_t H = cfg->hidden_size, nd = cfg->ndim, no = h->nout;
+    h->add("audio_downsample.0.weight", {H, 2 * H});
+    h->add("audio_downsample.0.bias", {H});
+    h->add("audio_downsample.1.weight", {H});
+    h->add("audio_downsample.1.bias", {H});
+    h->add("audio_downsample.1.running_mean", {H});
+    h->add("audio_downsample.1.running_var", {H});
+    h->add("audio_downsample.3.weight", {H, H});
+    h->add("audio_downsample.3.bias", {H});
+    h->add("WaveNet.start_conv1.weight", {RC, nd, 1});
+    h->add("WaveNet.start_conv1.bias", {RC});
+    h->add("WaveNet.start_conv2.weight", {RC, RC, 1});
+    h->add("WaveNet.start_conv2.bias", {RC});
+    for (int l = 0; l < h->layers; ++l) {
+        const std::string p = "WaveNet.residual_blocks." + std::to_string(l) + ".";
+        h->add(p + "filter_conv.weight", {RC, RC, 2});
+        h->add(p + "filter_conv.bias", {RC});
+        h->add(p + "gate_conv.weight", {RC, RC, 2});
+        h->add(p + "gate_conv.bias", {RC});
+        h->add(p + "residual_conv.weight", {RC, RC, 1});
+        h->add(p + "residual_conv.bias", {RC});
+        h->add(p + "skip_conv.weight", {SC, RC, 1});
+        h->add(p + "skip_conv.bias", {SC});
+        h->add(p + "cond_filter_conv.weight", {RC, H, 1});
+        h->add(p + "cond_filter_conv.bias", {RC});
+        h->add(p + "cond_gate_conv.weight", {RC, H, 1});
+        h->add(p + "cond_gate_conv.bias", {RC});
+    }
+    h->add("WaveNet.end_conv_1.weight", {no, SC, 1});
+    h->add("WaveNet.end_conv_1.bias", {no});
+    h->add("WaveNet.end_conv_2.weight", {no, no, 1});
+    h->add("WaveNet.end_conv_2.bias", {no});
+
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o = align64(o + n); return at; };
+    const size_t L = h->layers;
+    h->o_mlp0_w = take(H * 2 * H); h->o_mlp0_scale = take(H); h->o_mlp0_shift = take(H);
+    h->o_mlp1_w = take(H * H); h->o_mlp1_b = take(H);
+    h->o_proj_w = take(L * 256 * H); h->o_proj_b = take(L * 256);
+    h->o_start1_w = take(RC * nd); h->o_start1_b = take(RC);
+    h->o_start2_w = take(8 * NT * 4); h->o_start2_b = take(RC);
+    h->o_fg_w = take(L * 32 * NT * 4); h->o_rs_w = take(L * 24 * NT * 4); h->o_rs_b = take(L * 384);
+    h->o_end1_w = take(8 * NT * 4); h->o_end1_b = take(MAX_OUT);
+    h->o_end2_w = take(no * no); h->o_end2_b = take(no);
+    h->blob_floats = o;
+    *out = h;
+    return LSPA2H_OK;
+}
+
+int lspa2h_destroy(lspa2h_handle *h) { delete h; return LSPA2H_OK; }
+int lspa2h_receptive_field(const lspa2h_handle *h) { return h ? h->field : fail(LSPA2H_ERR_INVALID_ARGUMENT, "null handle"); }
+int lspa2h_num_tensors(const lspa2h_handle *h) { return h ? (int)h->tensors.size() : fail(LSPA2H_ERR_INVALID_ARGUMENT, "null handle"); }
+
+int lspa2h_tensor_info(const lspa2h_handle *h, int index, const char **key, size_t *numel)
+{
+    if (!h || index < 0 || index >= (int)h->tensors.size()) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "tensor index out of range");
+    if (key) *key = h->tensors[index].key.c_str();
+    if (numel) *numel = h->tensors[index].numel;
+    return LSPA2H_OK;
+}
+
+int lspa2h_set_tensor(lspa2h_handle *h, const char *key, const float *host_data, size_t numel)
+{
+    if (!h || !key || !host_data) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return fail(LSPA2H_ERR_INVALID_ARGUMENT, std::string("unknown tensor key: ") + key);
+    TensorSlot &t = h->tensors[it->second];
+    if (numel != t.numel) return fail(LSPA2H_ERR_SHAPE, std::string("wrong element count for ") + key);
+    t.data.assign(host_data, host_data + numel);
+    t.set = true;
+    h->packed = false;
+    return LSPA2H_OK;
+}
+
+size_t lspa2h_packed_bytes(const lspa2h_handle *h) { return h ? h->blob_floats * sizeof(float) : 0; }
+
+int lspa2h_pack_weights(lspa2h_handle *h, void *host_dst, size_t bytes)
+{
+    if (!h || !host_dst) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes < h->blob_floats * sizeof(float)) return fail(LSPA2H_ERR_SHAPE, "destination smaller than lspa2h_packed_bytes()");
+    for (const TensorSlot &t : h->tensors)
+        if (!t.set) return fail(LSPA2H_ERR_STATE, "tensor not set: " + t.key);   // the reference's strict=False would be silent
+    float *d = static_cast<float *>(host_dst);
+    std::memset(d, 0, h->blob_floats * sizeof(float));
+    const int H = h->cfg.hidden_size, nd = h->cfg.ndim, no = h->nout, L = h->layers;
+
+    std::memcpy(d + h->o_mlp0_w, h->T("audio_downsample.0.weight").data(), sizeof(float) * (size_t)H * 2 * H);
+    {   // Linear bias + eval BatchNorm1d (eps 1e-5) folded: y = (xW^T) * s + ((b - mean) * s + beta)
+        const auto &b = h->T("audio_downsample.0.bias"), &g = h->T("audio_downsample.1.weight"), &be = h->T("audio_downsample.1.bias");
+        const auto &mu = h->T("audio_downsample.1.running_mean"), &var = h->T("audio_downsample.1.running_var");
+        for (int i = 0; i < H; ++i) {
+            const double s = (double)g[i] / std::sqrt((double)var[i] + 1e-5);
+            d[h->o_mlp0_scale + i] = (float)s;
+            d[h->o_mlp0_shift + i] = (float)(((double)b[i] - (double)mu[i]) * s + (double)be[i]);
+        }
+    }
+    std::memcpy(d + h->o_mlp1_w, h->T("audio_downsample.3.weight").data(), sizeof(float) * (size_t)H * H);
+    std::memcpy(d + h->o_mlp1_b, h->T("audio_downsample.3.bias").data(), sizeof(float) * H);
+    std::memcpy(d + h->o_start1_w, h->T("WaveNet.start_conv1.weight").data(), sizeof(float) * RC * nd);
+    std::memcpy(d + h->o_start1_b, h->T("WaveNet.start_conv1.bias").data(), sizeof(float) * RC);
+    std::memcpy(d + h->o_start2_b, h->T("WaveNet.start_conv2.bias").data(), sizeof(float) * RC);
+    {   // start2: thread t = (row t>>2, part t&3), float4 q of its 32 columns at (q*512 + t)
+        const auto &w = h->T("WaveNet.start_conv2.weight");
+        for (int t = 0; t < NT; ++t)
+            for (int q = 0; q < 8; ++q)
+                for (int e = 0; e < 4; ++e)
+                    d[h->o_start2_w + ((size_t)q * NT + t) * 4 + e] = w[(size_t)(t >> 2) * RC + (t & 3) * 32 + q * 4 + e];
+    }
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "WaveNet.residual_blocks." + std::to_string(l) + ".";
+        const auto &fw = h->T(p + "filter_conv.weight"), &gw = h->T(p + "gate_conv.weight");
+        const auto &fb = h->T(p + "filter_conv.bias"), &gb = h->T(p + "gate_conv.bias");
+        const auto &cfw = h->T(p + "cond_filter_conv.weight"), &cgw = h->T(p + "cond_gate_conv.weight");
+        const auto &cfb = h->T(p + "cond_filter_conv.bias"), &cgb = h->T(p + "cond_gate_conv.bias");
+        // fg: thread t = (u = t>>3, part = t&7); item j: 0 filter[u], 1 gate[u], 2 filter[u+64], 3 gate[u+64];
+        // column c of [x[t-d] ; x[t]]: c < 128 -> tap 0 (the zero-padded side, networks.py:303), else tap 1
+        float *fg = d + h->o_fg_w + (size_t)l * 32 * NT * 4;
+        for (int t = 0; t < NT; ++t)
+            for (int j = 0; j < 4; ++j) {
+                const int ch = (t >> 3) + (j >> 1) * 64;
+                const auto &w = (j & 1) ? gw : fw;
+                for (int q = 0; q < 8; ++q)
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = (t & 7) * 32 + q * 4 + e;
+                        const int tap = c >= RC, ci = c & (RC - 1);
+                        fg[((size_t)(j * 8 + q) * NT + t) * 4 + e] = w[((size_t)ch * RC + ci) * 2 + tap];
+                    }
+            }
+        // cond projection rows in the same (u, j) order; their bias carries both conv biases
+        for (int u = 0; u < 64; ++u)
+            for (int j = 0; j < 4; ++j) {
+                const int ch = u + (j >> 1) * 64, row = l * 256 + u * 4 + j;
+                const auto &w = (j & 1) ? cgw : cfw;
+                std::memcpy(d + h->o_proj_w + (size_t)row * H, w.data() + (size_t)ch * H, sizeof(float) * H);
+                d[h->o_proj_b + row] = (j & 1) ? cgb[ch] + gb[ch] : cfb[ch] + fb[ch];
+            }
+        // rs: thread t = (rq = t>>2, part = t&3); item j: row j*128 + rq of [residual_conv ; skip_conv]
+        const auto &rw = h->T(p + "residual_conv.weight"), &sw = h->T(p + "skip_conv.weight");
+        float *rs = d + h->o_rs_w + (size_t)l * 24 * NT * 4;
+        for (int t = 0; t < NT; ++t)
+            for (int j = 0; j < 3; ++j)
+                for (int q = 0; q < 8; ++q)
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = (t & 3) * 32 + q * 4 + e, r = t >> 2;
+                        rs[((size_t)(j * 8 + q) * NT + t) * 4 + e] = j == 0 ? rw[(size_t)r * RC + c] : sw[(size_t)((j - 1) * 128 + r) * RC + c];
+                    }
+        std::memcpy(d + h->o_rs_b + (size_t)l * 384, h->T(p + "residual_conv.bias").data(), sizeof(float) * RC);
+        std::memcpy(d + h->o_rs_b + (size_t)l * 384 + RC, h->T(p + "skip_conv.bias").data(), sizeof(float) * SC);
+    }
+    {   // end1: thread t = (row t>>3, part t&7); rows >= nout stay zero
+        const auto &w = h->T("WaveNet.end_conv_1.weight");
+        for (int t = 0; t < NT; ++t)
+            if ((t >> 3) < no)
+                for (int q = 0; q < 8; ++q)
+                    for (int e = 0; e < 4; ++e)
+                        d[h->o_end1_w + ((size_t)q * NT + t) * 4 + e] = w[(size_t)(t >> 3) * SC + (t & 7) * 32 + q * 4 + e];
+        std::memcpy(d + h->o_end1_b, h->T("WaveNet.end_conv_1.bias").data(), sizeof(float) * no);
+    }
+    std::memcpy(d + h->o_end2_w, h->T("WaveNet.end_conv_2.weight").data(), sizeof(float) * (size_t)no * no);
+    std::memcpy(d + h->o_end2_b, h->T("WaveNet.end_conv_2.bias").data(), sizeof(float) * no);
+    h->packed = true;
+    return LSPA2H_OK;
+}
+
+int lspa2h_bind_weights(lspa2h_handle *h, const void *packed_dev, size_t bytes)
+{
+    if (!h || !packed_dev) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes < h->blob_floats * sizeof(float)) return fail(LSPA2H_ERR_SHAPE, "blob smaller than lspa2h_packed_bytes()");
+    if ((uintptr_t)packed_dev & 15) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "blob must be 16-byte aligned");
+    h->blob = static_cast<const float *>(packed_dev);
+    h->blob_bytes = bytes;
+    return LSPA2H_OK;
+}
+
+size_t lspa2h_workspace_bytes(const lspa2h_handle *h)
+{
+    if (!h) return 0;
+    const size_t rows = h->cfg.max_audio_frames, H = h->cfg.hidden_size;
+    return (align64(rows * H) * 2 + align64(rows * (size_t)h->layers * 256)) * sizeof(float);
+}
+
+int lspa2h_bind_workspace(lspa2h_handle *h, void *workspace_dev, size_t bytes)
+{
+    if (!h || !workspace_dev) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes < lspa2h_workspace_bytes(h)) return fail(LSPA2H_ERR_SHAPE, "workspace smaller than lspa2h_workspace_bytes()");
+    if ((uintptr_t)workspace_dev & 15) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
+    h->ws = static_cast<float *>(workspace_dev);
+    h->ws_bytes = bytes;
+    return LSPA2H_OK;
+}
+
+static int launch_gemm(const float *A, const float *W, const float *scale, const float *shift, float *C, int M, int N, int K,
+                       int leaky, hipStream_t s)
+{
+    if (N % 64 || K % 32) return fail(LSPA2H_ERR_SHAPE, "gemm needs N % 64 == 0 and K % 32 == 0");
+    GemmParams p{A, W, scale, shift, C, M, N, K, leaky};
+    hipLaunchKernelGGL(a2h_gemm, dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, p);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LSPA2H_OK : hipfail(e, "a2h_gemm launch");
+}
+
+static int generate_impl(lspa2h_handle *h, const float *audio_dev, int n_audio, const float *pre_dev, const float *noise_dev,
+                         const float *expq_dev, float sigma_scale, int frame_future, float *out_dev, int nframe, hipStream_t s,
+                         hipEvent_t mid)
+{
+    if (!h || !audio_dev || !pre_dev || !out_dev) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->blob) return fail(LSPA2H_ERR_STATE, "weights not bound (lspa2h_bind_weights)");
+    if (!h->ws) return fail(LSPA2H_ERR_STATE, "workspace not bound (lspa2h_bind_workspace)");
+    if (n_audio < 1 || n_audio > h->cfg.max_audio_frames) return fail(LSPA2H_ERR_SHAPE, "n_audio out of range (max_audio_frames)");
+    if (frame_future < 0 || nframe < 1 || nframe != n_audio - frame_future)
+        return fail(LSPA2H_ERR_SHAPE, "nframe must equal n_audio - frame_future and be >= 1");
+    if (h->cfg.loss == LSPA2H_LOSS_GMM && h->cfg.ncenter > 1 && !expq_dev)
+        return fail(LSPA2H_ERR_INVALID_ARGUMENT, "expq_dev is required when ncenter > 1");
+    const int H = h->cfg.hidden_size, L = h->layers;
+    const size_t rows = h->cfg.max_audio_frames;
+    float *hid = h->ws, *cond = hid + align64(rows * H), *proj = cond + align64(rows * H);
+    const float *b = h->blob;
+    int rc;
+    // audio_downsample: Linear(2H->H) + BatchNorm1d(eval) + LeakyReLU(0.2) + Linear(H->H)   (audio2headpose.py:16-21)
+    if ((rc = launch_gemm(audio_dev, b + h->o_mlp0_w, b + h->o_mlp0_scale, b + h->o_mlp0_shift, hid, n_audio, H, 2 * H, 1, s))) return rc;
+    if ((rc = launch_gemm(hid, b + h->o_mlp1_w, nullptr, b + h->o_mlp1_b, cond, n_audio, H, H, 0, s))) return rc;
+    // every layer's cond_filter_conv / cond_gate_conv on every frame (networks.py:310-311)
+    if ((rc = launch_gemm(cond, b + h->o_proj_w, nullptr, b + h->o_proj_b, proj, n_audio, L * 256, H, 0, s))) return rc;
+    if (mid) (void)hipEventRecord(mid, s);
+    h->last_rows = n_audio;
+
+    StreamParams p{};
+    p.start1_w = b + h->o_start1_w; p.start1_b = b + h->o_start1_b;
+    p.blob = b; p.blob_bytes = (unsigned)(h->blob_floats * sizeof(float));
+    p.start2_w = (unsigned)(h->o_start2_w * 4); p.start2_b = b + h->o_start2_b;
+    p.fg_w = (unsigned)(h->o_fg_w * 4); p.rs_w = (unsigned)(h->o_rs_w * 4); p.rs_b = b + h->o_rs_b;
+    p.end1_w = (unsigned)(h->o_end1_w * 4); p.end1_b = b + h->o_end1_b;
+    p.end2_w = b + h->o_end2_w; p.end2_b = b + h->o_end2_b;
+    p.proj = proj; p.pre = pre_dev; p.noise = noise_dev; p.expq = expq_dev; p.out = out_dev;
+    p.layers = L; p.ndim = h->cfg.ndim; p.ncenter = h->cfg.ncenter; p.nout = h->nout; p.loss = h->cfg.loss;
+    p.field = h->field; p.nframe = nframe; p.frame_future = frame_future; p.sigma_scale = sigma_scale;
+    for (int l = 0; l < L; ++l) { p.dil[l] = h->dil[l]; p.qoff[l] = h->qoff[l]; }
+    const size_t lds = (size_t)(RC * 3 + SC + 2 * MAX_OUT + 16 + (size_t)h->qrows * RC) * sizeof(float);
+    if (!h->attr_done) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&a2h_stream),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hipfail(e, "hipFuncSetAttribute(a2h_stream)");
+        h->attr_done = true;
+    }
+    hipLaunchKernelGGL(a2h_stream, dim3(1), dim3(NT), lds, s, p);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LSPA2H_OK : hipfail(e, "a2h_stream launch");
+}
+
+int lspa2h_generate(lspa2h_handle *h, const float *audio_dev, int n_audio, const float *pre_dev, const float *noise_dev,
+                    const float *expq_dev, float sigma_scale, int frame_future, float *out_dev, int nframe, void *stream)
+{
+    return generate_impl(h, audio_dev, n_audio, pre_dev, noise_dev, expq_dev, sigma_scale, frame_future, out_dev, nframe,
+                         static_cast<hipStream_t>(stream), nullptr);
+}
+
+int lspa2h_generate_timed(lspa2h_handle *h, const float *audio_dev, int n_audio, const float *pre_dev, const float *noise_dev,
+                          const float *expq_dev, float sigma_scale, int frame_future, float *out_dev, int nframe, void *stream,
+                          float *precompute_ms, float *loop_ms)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1, e2;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
+        return fail(LSPA2H_ERR_HIP, "hipEventCreate");
+    (void)hipEventRecord(e0, s);
+    int rc = generate_impl(h, audio_dev, n_audio, pre_dev, noise_dev, expq_dev, sigma_scale, frame_future, out_dev, nframe, s, e1);
+    if (rc == LSPA2H_OK) {
+        (void)hipEventRecord(e2, s);
+        const hipError_t e = hipEventSynchronize(e2);
+        if (e != hipSuccess) rc = hipfail(e, "hipEventSynchronize");
+        else {
+            if (precompute_ms) (void)hipEventElapsedTime(precompute_ms, e0, e1);
+            if (loop_ms) (void)hipEventElapsedTime(loop_ms, e1, e2);
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    return rc;
+}
+
+int lspa2h_debug_cond(const lspa2h_handle *h, const float **cond_dev, int *rows, int *cols)
+{
+    if (!h || !h->ws) return fail(LSPA2H_ERR_STATE, "workspace not bound");
+    if (cond_dev) *cond_dev = h->ws + align64((size_t)h->cfg.max_audio_frames * h->cfg.hidden_size);
+    if (rows) *rows = h->last_rows;
+    if (cols) *cols = h->cfg.hidden_size;
+    return LSPA2H_OK;
+}
+
+}  // extern "C"

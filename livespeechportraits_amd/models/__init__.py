@@ -1,5 +1,6 @@
 """``from livespeechportraits_amd.models import create_model`` -- the reference's factory
-(models/__init__.py:29-71) for the one model this package replaces."""
+(models/__init__.py:29-71) for the models this package replaces: feature2face (the renderer) and
+audio2headpose."""
 from __future__ import annotations
 
 import importlib
@@ -8,10 +9,10 @@ from ..base_model import BaseModel
 
 
 def find_model_using_name(model_name: str):
-    if model_name != "feature2face":
-        raise NotImplementedError("livespeechportraits_amd replaces only --model feature2face; "
+    if model_name not in ("feature2face", "audio2headpose"):
+        raise NotImplementedError("livespeechportraits_amd replaces --model feature2face and audio2headpose; "
                                   "%r stays with the reference implementation" % (model_name,))
-    lib = importlib.import_module("livespeechportraits_amd.feature2face_model")
+    lib = importlib.import_module("livespeechportraits_amd.%s_model" % model_name)
     target = model_name.replace("_", "") + "model"
     for name, cls in vars(lib).items():
         if name.lower() == target and isinstance(cls, type) and issubclass(cls, BaseModel):

@@ -140,12 +140,14 @@ def init_weights(net: nn.Module, init_type: str = "normal", init_gain: float = 0
         raise NotImplementedError("only init_type='normal' (the one feature2face_model.py:27 uses)")
     with torch.no_grad():
         for m in net.modules():
-            if isinstance(m, nn.Conv2d):
+            if isinstance(m, (nn.Conv2d, nn.Conv1d, nn.Linear)):   # reference: class name contains 'Conv' or 'Linear'
                 m.weight.normal_(0.0, init_gain)
+                if m.bias is not None:
+                    m.bias.zero_()
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.normal_(1.0, init_gain)
                 m.bias.zero_()
-            if isinstance(m, Feature2FaceGenerator):
+            if hasattr(m, "mark_dirty"):
                 m.mark_dirty()
 
 

@@ -101,3 +101,62 @@ def synthetic(variant: str = "large", ngf: int = 64, num_downs: int = 8, size: i
               seed: int = 1234):
     topo = build_topology(variant, ngf=ngf, num_downs=num_downs, size=size)
     return topo, make_state_dict(topo, seed)
+
+
+# ---- Audio2Headpose ------------------------------------------------------
+A2H_DEFAULTS = dict(residual_layers=7, residual_blocks=2, residual_channels=128, dilation_channels=128,
+                    skip_channels=256, kernel_size=2, input_channels=12, cond_channels=512, hidden_size=512,
+                    ncenter=1, ndim=12, loss="GMM")
+
+
+def a2h_shapes(cfg: Dict) -> Dict[str, Tuple[int, ...]]:
+    """state-dict key -> shape of the reference's Audio2Headpose (models/audio2headpose.py:8-37;
+    key list dumped from the instantiated reference module, see oracle/make_golden_a2h.py)."""
+    H, nd, nc = cfg["hidden_size"], cfg["ndim"], cfg["ncenter"]
+    res, dil, skip, k, cond = cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["kernel_size"], cfg["cond_channels"]
+    out = (2 * nd + 1) * nc if cfg["loss"] == "GMM" else nd
+    s = {"audio_downsample.0.weight": (H, 2 * H), "audio_downsample.0.bias": (H,),
+         "audio_downsample.1.weight": (H,), "audio_downsample.1.bias": (H,),
+         "audio_downsample.1.running_mean": (H,), "audio_downsample.1.running_var": (H,),
+         "audio_downsample.3.weight": (H, H), "audio_downsample.3.bias": (H,),
+         "WaveNet.start_conv1.weight": (res, cfg["input_channels"], 1), "WaveNet.start_conv1.bias": (res,),
+         "WaveNet.start_conv2.weight": (res, res, 1), "WaveNet.start_conv2.bias": (res,)}
+    for i in range(cfg["residual_layers"] * cfg["residual_blocks"]):
+        p = "WaveNet.residual_blocks.%d." % i
+        s.update({p + "filter_conv.weight": (dil, res, k), p + "filter_conv.bias": (dil,),
+                  p + "gate_conv.weight": (dil, res, k), p + "gate_conv.bias": (dil,),
+                  p + "residual_conv.weight": (res, dil, 1), p + "residual_conv.bias": (res,),
+                  p + "skip_conv.weight": (skip, dil, 1), p + "skip_conv.bias": (skip,),
+                  p + "cond_filter_conv.weight": (dil, cond, 1), p + "cond_filter_conv.bias": (dil,),
+                  p + "cond_gate_conv.weight": (dil, cond, 1), p + "cond_gate_conv.bias": (dil,)})
+    s.update({"WaveNet.end_conv_1.weight": (out, skip, 1), "WaveNet.end_conv_1.bias": (out,),
+              "WaveNet.end_conv_2.weight": (out, out, 1), "WaveNet.end_conv_2.bias": (out,)})
+    return s
+
+
+def make_a2h_state_dict(cfg: Dict, seed: int = 4321) -> Dict[str, np.ndarray]:
+    """Weights of std 1/sqrt(fan_in) (the reference's N(0, 0.02) init gives a near-constant network whose
+    feedback path would not be exercised), biases std 0.05, BN statistics perturbed as for the renderer."""
+    sd = {}
+    for key, shape in a2h_shapes(cfg).items():
+        n = int(np.prod(shape))
+        st = _stream(seed, key)
+        if key.endswith("running_var"):
+            v = uniform01(n, st) * np.float32(0.7) + np.float32(0.9)
+        elif key.endswith("running_mean"):
+            v = symmetric(n, 0.05, st)
+        elif len(shape) >= 2:
+            v = symmetric(n, 1.0 / float(np.sqrt(np.prod(shape[1:]))), st)
+        elif key == "audio_downsample.1.weight":
+            v = np.float32(1.0) + symmetric(n, 0.02, st)
+        else:
+            v = symmetric(n, 0.05, st)
+        sd[key] = v.reshape(shape).astype(np.float32)
+    return sd
+
+
+def make_a2h_inputs(n_audio: int, cfg: Dict, seed: int = 17) -> Tuple[np.ndarray, np.ndarray]:
+    """(audio_feats [n_audio, 2*hidden], pre_headpose [ndim]) -- APC-feature-like values of std 0.5."""
+    audio = symmetric(n_audio * 2 * cfg["hidden_size"], 0.5, _stream(seed, "a2h.audio")).reshape(n_audio, -1)
+    pre = symmetric(cfg["ndim"], 0.1, _stream(seed, "a2h.pre"))
+    return audio.astype(np.float32), pre.astype(np.float32)

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""ORACLE tooling -- freeze head-pose sequences of the REAL reference into tests/golden/a2h_*.npz.
+
+Runs only in the build container (needs /root/reference).  For every case it
+  1. builds the deterministic synthetic state dict and inputs (livespeechportraits_amd.synth),
+  2. instantiates the reference's own Audio2HeadposeModel on CPU (models/audio2headpose_model.py:13-27),
+     loads the weights and calls its generate_sequences() under torch.manual_seed(seed) -- the per-frame
+     sliding-window loop with Sample_GMM drawing from the CPU generator (:133-187, losses.py:68-112),
+  3. re-draws that random stream with livespeechportraits_amd.audio2headpose_model.draw_gmm_noise under the
+     same seed and asserts oracle/a2h_oracle.py::generate_sequences reproduces the reference BIT-EXACTLY
+     (same ops, same order, same draws) and that the float64 streaming evaluation agrees to ~1e-5,
+  4. writes the reference output and the draws to tests/golden/a2h_<case>.npz (+ the key->shape map).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from livespeechportraits_amd import synth                                        # noqa: E402
+from livespeechportraits_amd.audio2headpose_model import draw_gmm_noise          # noqa: E402
+from oracle import a2h_oracle                                                     # noqa: E402
+
+# name -> (config overrides, nframe, frame_future, sigma_scale, seed)
+CASES = {
+    "default_n48": ({}, 48, 15, 0.3, 77),            # demo.py:212 settings (sigma 0.3, frame_future 15)
+    "default_n300": ({}, 300, 15, 0.3, 78),          # long horizon: error growth through the feedback
+    "nc2_l4b1": (dict(residual_layers=4, residual_blocks=1, ncenter=2), 40, 3, 0.5, 79),
+    "l2_l5b2": (dict(residual_layers=5, residual_blocks=2, loss="L2"), 32, 0, 0.0, 80),
+}
+
+
+def ref_opt(cfg, frame_future):
+    return argparse.Namespace(
+        gpu_ids=[], isTrain=False, checkpoints_dir="/tmp", name="a2h", load_epoch="none", verbose=False,
+        feature_decoder="WaveNet", loss=cfg["loss"], A2H_GMM_ndim=cfg["ndim"], A2H_GMM_ncenter=cfg["ncenter"],
+        APC_hidden_size=cfg["hidden_size"], A2H_wavenet_residual_layers=cfg["residual_layers"],
+        A2H_wavenet_residual_blocks=cfg["residual_blocks"], A2H_wavenet_residual_channels=cfg["residual_channels"],
+        A2H_wavenet_dilation_channels=cfg["dilation_channels"], A2H_wavenet_skip_channels=cfg["skip_channels"],
+        A2H_wavenet_kernel_size=cfg["kernel_size"], time_frame_length=1, A2H_wavenet_use_bias=True,
+        A2H_wavenet_input_channels=cfg["input_channels"], A2H_wavenet_cond_channels=cfg["cond_channels"],
+        frame_future=frame_future, model="audio2headpose", task="Audio2Headpose")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden_a2h.py needs /root/reference (build container only)")
+    for name in ("torchvision", "torchvision.models", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, REF)
+    from models.audio2headpose_model import Audio2HeadposeModel              # the reference class
+
+    for name, (over, nframe, ff, sigma, seed) in CASES.items():
+        if a.only and a.only != name:
+            continue
+        cfg = dict(synth.A2H_DEFAULTS, **over)
+        sd = synth.make_a2h_state_dict(cfg, seed=4321)
+        audio, pre = synth.make_a2h_inputs(nframe + ff, cfg, seed=17)
+        opt = ref_opt(cfg, ff)
+        model = Audio2HeadposeModel(opt)
+        net = model.Audio2Headpose
+        ref_keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+        mine = {k: list(v.shape) for k, v in sd.items()}
+        assert {k: v for k, v in ref_keys.items() if not k.endswith("num_batches_tracked")} == mine, "key/shape map differs"
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        model.eval()
+        opt.A2H_receptive_field = net.WaveNet.receptive_field
+        assert opt.A2H_receptive_field == a2h_oracle.receptive_field(cfg)
+        torch.manual_seed(seed)
+        t0 = time.time()
+        ref = model.generate_sequences(audio.copy(), pre.copy(), fill_zero=True, sigma_scale=sigma, opt=opt)
+        t_ref = time.time() - t0
+        torch.manual_seed(seed)
+        noise, expq = draw_gmm_noise(nframe, cfg["ncenter"], cfg["ndim"]) if cfg["loss"] == "GMM" else (torch.zeros(nframe, cfg["ndim"]), torch.ones(nframe, cfg["ncenter"]))
+        noise, expq = noise.numpy(), expq.numpy()
+        ora = a2h_oracle.generate_sequences(sd, cfg, audio, pre, noise, expq, sigma, ff)
+        assert np.array_equal(ora, ref), "oracle is not bit-identical to the reference: max-abs %.3e" % np.abs(ora - ref).max()
+        st = a2h_oracle.stream(sd, cfg, audio, pre, noise, expq, sigma, ff)
+        err = np.abs(st - ref).max()
+        print("%-14s nframe %3d  reference %.2f s (%.1f ms/frame, %d threads)  |out| max %.2f std %.2f  oracle bit-exact  stream(f64) max-abs %.2e"
+              % (name, nframe, t_ref, 1e3 * t_ref / nframe, torch.get_num_threads(), np.abs(ref).max(), ref.std(), err))
+        assert err < 5e-4, "streaming evaluation disagrees with the reference"
+        np.savez_compressed(os.path.join(a.out, "a2h_%s.npz" % name), out=ref.astype(np.float32), noise=noise, expq=expq)
+        with open(os.path.join(a.out, "a2h_%s.json" % name), "w") as f:
+            json.dump({"cfg": cfg, "nframe": nframe, "frame_future": ff, "sigma_scale": sigma, "torch_seed": seed,
+                       "weights_seed": 4321, "inputs_seed": 17, "stream_f64_max_abs": float(err),
+                       "reference_cpu_s": t_ref, "reference_cpu_threads": torch.get_num_threads()}, f, indent=1)
+        if name == "default_n48":
+            with open(os.path.join(a.out, "keys_a2h.json"), "w") as f:
+                json.dump(ref_keys, f, indent=0)
+
+
+if __name__ == "__main__":
+    main()
