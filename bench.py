@@ -193,6 +193,7 @@ def main():
             hout.copy_(du8, non_blocking=True)
             torch.cuda.synchronize()
         extra["pcie_inclusive_frames_per_s_batch1_uint8"] = round(nl / (time.perf_counter() - t2), 2)
+        extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
 
     line = {
         "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",
@@ -210,6 +211,49 @@ def main():
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def headpose_extra(dev, cpu_threads):
+    """SURVEY.md 8f rank 3 beside the headline: Audio2HeadposeModel.generate_sequences on the demo clip's length
+    (687 frames + frame_future 15, default network, synthetic weights), device tensors in -> device tensor out.
+    loop_ms = fill_ms + us_per_frame * nframe from two clip lengths; the CPU leg times the reference's
+    sliding-window algorithm (oracle/a2h_oracle.py, kind "port") on a bounded sample."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.a2h_engine import HeadposeEngine
+    cfg, ff = dict(synth.A2H_DEFAULTS), 15
+    sd = synth.make_a2h_state_dict(cfg)
+    eng = HeadposeEngine(max_audio_frames=687 + ff)
+    eng.load_state_dict(sd)
+    eng.bind(dev)
+    med = {}
+    for nframe in (87, 687):
+        audio, pre = synth.make_a2h_inputs(nframe + ff, cfg)
+        au, pr = torch.from_numpy(audio).to(dev), torch.from_numpy(pre).to(dev)
+        noise = torch.from_numpy(synth.symmetric(nframe * 12, 1.0, 5).reshape(nframe, 12)).to(dev)
+        eng.generate_timed(au, pr, noise, None, 0.3, ff)
+        t = sorted(eng.generate_timed(au, pr, noise, None, 0.3, ff)[1:] for _ in range(5))
+        if eng.status() != 0:
+            raise RuntimeError("head-pose kernel hand-off timed out")
+        med[nframe] = t[2]
+    slope = (med[687][1] - med[87][1]) / 600.0
+    out = {"metric": "head poses/s (Audio2Headpose.generate_sequences, 687-frame clip, fp32, synthetic weights)",
+           "value": round(687 / ((med[687][0] + med[687][1]) * 1e-3), 1), "precompute_ms": round(med[687][0], 3),
+           "loop_ms": round(med[687][1], 3), "us_per_frame": round(1e3 * slope, 2),
+           "fill_ms": round(med[87][1] - slope * 87, 3)}
+    if cpu_threads:
+        from oracle import a2h_oracle
+        n = 32
+        audio, pre = synth.make_a2h_inputs(n + ff, cfg)
+        noise = synth.symmetric(n * 12, 1.0, 5).reshape(n, 12)
+        torch.set_num_threads(int(cpu_threads))
+        a2h_oracle.generate_sequences(sd, cfg, audio[:4 + ff], pre, noise, np.ones((n, 1), np.float32), 0.3, ff)   # warm-up
+        t0 = time.perf_counter()
+        a2h_oracle.generate_sequences(sd, cfg, audio, pre, noise, np.ones((n, 1), np.float32), 0.3, ff)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "head poses/s", "cores": int(cpu_threads), "kind": "port",
+                               "sample": "%d frames of oracle/a2h_oracle.generate_sequences: the reference's per-frame 255-wide "
+                                         "re-evaluation (torch %s CPU)" % (n, torch.__version__)}
+    return out
 
 
 if __name__ == "__main__":

@@ -37,6 +37,11 @@ extern "C" {
 #define LSPA2H_ERR_HIP (-4)
 #define LSPA2H_ERR_SHAPE (-5)
 
+/* Run the whole loop in ONE workgroup that streams the weights every step: the first implementation, kept as an
+ * independent second route to the same bits.  Measured on MI355X, default network: 84 us per frame + 20 ms to fill
+ * the first receptive field, against 31.5 us + 0.55 ms for the default layer-pipelined kernel. */
+#define LSPA2H_FLAG_SINGLE_WORKGROUP 1u
+
 #define LSPA2H_LOSS_GMM 0 /* opt.loss == 'GMM': output (2*ndim+1)*ncenter, sampled */
 #define LSPA2H_LOSS_L2 1  /* opt.loss == 'L2' : output ndim, used as is (audio2headpose_model.py:182-183) */
 
@@ -56,7 +61,7 @@ typedef struct lspa2h_config {
     int32_t ndim;              /* A2H_GMM_ndim (12), <= 16 */
     int32_t loss;              /* LSPA2H_LOSS_* */
     int32_t max_audio_frames;  /* largest n_audio lspa2h_generate will see (sizes the workspace) */
-    uint32_t flags;            /* reserved, 0 */
+    uint32_t flags;            /* LSPA2H_FLAG_* */
 } lspa2h_config;
 
 typedef struct lspa2h_handle lspa2h_handle;
@@ -90,6 +95,10 @@ int lspa2h_bind_workspace(lspa2h_handle *h, void *workspace_dev, size_t bytes);
  * nframe must equal n_audio - frame_future.  Asynchronous on `stream` (hipStream_t). */
 int lspa2h_generate(lspa2h_handle *h, const float *audio_dev, int n_audio, const float *pre_dev, const float *noise_dev,
                     const float *expq_dev, float sigma_scale, int frame_future, float *out_dev, int nframe, void *stream);
+
+/* Waits for `stream` and reports whether the last lspa2h_generate completed: *code == 0, or the identifier of the
+ * first inter-workgroup hand-off that timed out (the kernel never spins unbounded; output rows are then undefined). */
+int lspa2h_status(lspa2h_handle *h, void *stream, uint32_t *code);
 
 /* Test / profiling hooks (no reference counterpart). */
 /* down_audio_feats of Audio2Headpose.forward (audio2headpose.py:47): [n_audio][hidden_size], valid after generate */

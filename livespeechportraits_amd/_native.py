@@ -91,6 +91,7 @@ class A2HConfig(Structure):
 
 A2H_ABI_VERSION = 1
 A2H_LOSS_IDS = {"GMM": 0, "L2": 1}
+A2H_FLAG_SINGLE_WORKGROUP = 1
 _GEN_ARGS = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int, c_void_p]
 # every symbol include/lspa2h.h declares
 A2H_SIGNATURES = {
@@ -110,6 +111,7 @@ A2H_SIGNATURES = {
     "lspa2h_generate": (c_int, _GEN_ARGS),
     "lspa2h_generate_timed": (c_int, _GEN_ARGS + [POINTER(c_float), POINTER(c_float)]),
     "lspa2h_debug_cond": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int)]),
+    "lspa2h_status": (c_int, [c_void_p, c_void_p, POINTER(c_uint32)]),
 }
 
 _lib = None

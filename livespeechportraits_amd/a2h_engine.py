@@ -20,13 +20,15 @@ class HeadposeEngine:
     def __init__(self, residual_layers: int = 7, residual_blocks: int = 2, residual_channels: int = 128,
                  dilation_channels: int = 128, skip_channels: int = 256, kernel_size: int = 2,
                  input_channels: int = 12, cond_channels: int = 512, hidden_size: int = 512,
-                 ncenter: int = 1, ndim: int = 12, loss: str = "GMM", max_audio_frames: int = 4096):
+                 ncenter: int = 1, ndim: int = 12, loss: str = "GMM", max_audio_frames: int = 4096,
+                 single_workgroup: bool = False):
         if loss not in N.A2H_LOSS_IDS:
             raise ValueError("loss must be 'GMM' or 'L2', got %r" % (loss,))
         self.lib = N.load()
         self.cfg = N.A2HConfig(N.A2H_ABI_VERSION, residual_layers, residual_blocks, residual_channels, dilation_channels,
                                skip_channels, kernel_size, input_channels, cond_channels, hidden_size, ncenter, ndim,
-                               N.A2H_LOSS_IDS[loss], max_audio_frames, 0)
+                               N.A2H_LOSS_IDS[loss], max_audio_frames,
+                               N.A2H_FLAG_SINGLE_WORKGROUP if single_workgroup else 0)
         self.h = ctypes.c_void_p()
         N.check_a2h(self.lib.lspa2h_create(ctypes.byref(self.cfg), ctypes.byref(self.h)))
         self.ndim, self.ncenter, self.loss = ndim, ncenter, loss
@@ -113,6 +115,14 @@ class HeadposeEngine:
         with torch.cuda.device(audio.device):
             N.check_a2h(self.lib.lspa2h_generate_timed(*args, ctypes.byref(pre_ms), ctypes.byref(loop_ms)))
         return out, pre_ms.value, loop_ms.value
+
+    def status(self, device=None) -> int:
+        """Synchronises the current stream; 0 if the last generate() completed, else the code of the hand-off that timed out."""
+        code = ctypes.c_uint32()
+        dev = device if device is not None else self.blob.device
+        with torch.cuda.device(dev):
+            N.check_a2h(self.lib.lspa2h_status(self.h, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), ctypes.byref(code)))
+        return code.value
 
     def debug_cond(self) -> torch.Tensor:
         """down_audio_feats of the last generate() call (copied out of the workspace)."""

@@ -67,4 +67,7 @@ class Audio2HeadposeModel(BaseModel):
         a = torch.from_numpy(audio).to(dev)
         pre = torch.from_numpy(np.asarray(pre_headpose, dtype=np.float32).reshape(-1)).to(dev)
         out = eng.generate(a, pre, noise, expq, float(sigma_scale), int(frame_future))
+        code = eng.status(dev)
+        if code:
+            raise RuntimeError("head-pose kernel: inter-workgroup hand-off 0x%x timed out" % code)
         return out.cpu().numpy().astype(np.float64)       # the reference fills an np.zeros (float64) array, :149

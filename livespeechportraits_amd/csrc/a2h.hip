@@ -110,6 +110,12 @@ struct StreamParams {
     float sigma_scale;
     int dil[MAX_LAYERS];                // dilation of layer l (power of two)
     int qoff[MAX_LAYERS];               // first queue row of layer l
+    // layer-pipelined kernel only
+    unsigned long long *xbox;           // [layers+1][nsteps][128] granules {epoch, value}: input of layer e / of the head
+    unsigned long long *sbox;           // [layers][nframe][256] granules: skip_conv output of layer l for frame f
+    unsigned *status;                   // 0 ok, else the code of the first hand-off that timed out
+    unsigned epoch;                     // tag of this call (never 0)
+    int stride;                         // only blocks with blockIdx.x % stride == 0 work (8: all on one XCD, for speed only)
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
@@ -300,6 +306,243 @@ __global__ __launch_bounds__(NT) void a2h_stream(StreamParams p)
     }
 }
 
+// -------------------------------------------------------------------------------------------- pipeline
+// Layer-pipelined form of the same loop: block 0 is the head (start convs, end convs, sampling), block 1+l owns
+// residual layer l with ALL its weights resident on the CU (fg: 128 VGPRs, residual + first skip half: 64 VGPRs,
+// second skip half: 64 KB of LDS) next to its dilation queue, so nothing is streamed per step.  The 128-float
+// activation hops from block to block through global memory as 8-byte {value, epoch} granules stored
+// write-through and polled past L1 (sc1): the data is its own flag, no fence, no dependence on dispatch order or
+// XCD placement (cdna_hip_programming.md Guideline 16, form R2).  Skip outputs do not ride the chain: each layer
+// posts its 256 values to the head after it has forwarded the activation, and the head adds them in layer order
+// (the reference's order) while it waits.  Every
+// (edge, step) has its own slot, so there is no flow control and a producer can run arbitrarily far ahead --
+// which is what happens while the first receptive field fills: those steps do not depend on any sample, the
+// head posts them all at once and the layers work on different steps concurrently.
+// All polls are bounded: a lost hand-off ends the kernel with a status code instead of hanging the GPU.
+// Mailboxes are addressed as buffers (SGPR resource + SGPR slot offset + one VGPR lane offset): with 192 VGPRs
+// holding weights there is no room for per-thread 64-bit pointers.  aux 16 = sc1: the store is written through
+// and the load is served by L2/memory, never by this CU's L1 -- what a relaxed agent-scope atomic lowers to.
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int AUX_SC1 = 16;
+
+// granule i of the slot that starts `slot` bytes into the box: ONE aligned 8-byte store {value, epoch}
+__device__ __forceinline__ void put_granule(__amdgpu_buffer_rsrc_t box, unsigned slot, int i, unsigned epoch, float v)
+{
+    u32x2 g; g.x = __float_as_uint(v); g.y = epoch;
+    __builtin_amdgcn_raw_buffer_store_b64(g, box, i * 8, (int)slot, AUX_SC1);
+}
+// every thread i < n waits for granule i of the slot; returns false for the whole block on timeout
+__device__ __forceinline__ bool get_granules(__amdgpu_buffer_rsrc_t box, unsigned slot, int n, unsigned epoch, float *dst,
+                                             unsigned *status, unsigned code)
+{
+    const int tid = threadIdx.x;
+    bool ok = true;
+    if (tid < n) {
+        unsigned spins = 0;
+        for (;;) {
+            const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(box, tid * 8, (int)slot, AUX_SC1);
+            asm volatile("" ::: "memory");               // a fresh load every pass
+            if (g.y == epoch) { dst[tid] = __uint_as_float(g.x); break; }
+            if (++spins > SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(status, RLX_AGENT) != 0)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) atomicCAS(status, 0u, code);
+    }
+    return __syncthreads_and(ok);
+}
+
+__global__ __launch_bounds__(NT) void a2h_pipe(StreamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xbuf = smem;                  // [128]
+    float *zbuf = xbuf + RC;             // [128]
+    float *tbuf = zbuf + RC;             // [128]
+    float *sbuf = tbuf + RC;             // [256]
+    float *r1 = sbuf + SC;               // [64]
+    float *r2 = r1 + MAX_OUT;            // [64]
+    float *inb = r2 + MAX_OUT;           // [16]
+    float *queue = inb + 16;             // [dilation of this layer][128]
+    const int tid = threadIdx.x;
+    if (blockIdx.x % p.stride) return;
+    const int block = blockIdx.x / p.stride;
+    const int nsteps = p.field - 1 + p.nframe;
+    const int fu = tid >> 3, fpart = tid & 7;
+    const int rq = tid >> 2, rpart = tid & 3;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void *)p.blob, 0, (int)p.blob_bytes, 0x00020000);
+    const int voff = tid * 16;
+    const unsigned xedge = (unsigned)nsteps * RC * 8u, sedge = (unsigned)p.nframe * SC * 8u;   // bytes per edge
+    const __amdgpu_buffer_rsrc_t xbox = __builtin_amdgcn_make_buffer_rsrc((void *)p.xbox, 0, (int)(xedge * (unsigned)(p.layers + 1)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sbox = __builtin_amdgcn_make_buffer_rsrc((void *)p.sbox, 0, (int)(sedge * (unsigned)p.layers), 0x00020000);
+
+    if (block == 0) {
+        // ------------------------------------------------------------------ head
+        float4 w2[8], we[8];
+        load_packed<0, 8>(w2, blob, p.start2_w, voff);
+        load_packed<0, 8>(we, blob, p.end1_w, voff);
+        if (tid < 16) inb[tid] = tid < p.ndim ? p.pre[tid] : 0.f;
+        __syncthreads();
+        for (int frame = -1; frame < p.nframe; ++frame) {
+            // frame -1: the constant input of the first `field` steps; frame f >= 0: sample f, then the input of step field+f
+            if (frame >= 0) {
+                const int s = p.field - 1 + frame;
+                bool ok = true;
+                if (tid < SC) {   // skip = sum over layers, in layer order (networks.py:203-204); layer l's values arrive ~one hop apart
+                    float acc = 0.f;
+                    for (int l = 0; l < p.layers && ok; ++l) {
+                        const int slot = (int)((unsigned)l * sedge + (unsigned)frame * (SC * 8u));
+                        for (unsigned spins = 0;;) {
+                            const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(sbox, tid * 8, slot, AUX_SC1);
+                            asm volatile("" ::: "memory");
+                            if (g.y == p.epoch) { acc = l ? acc + __uint_as_float(g.x) : __uint_as_float(g.x); break; }
+                            if (++spins > SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(p.status, RLX_AGENT) != 0)) { ok = false; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    if (!ok) atomicCAS(p.status, 0u, 0x100u + frame);
+                    sbuf[tid] = lrelu(acc);
+                }
+                if (!__syncthreads_and(ok)) return;
+                {   // end convs (networks.py:207-208)
+                    const float4 *v = reinterpret_cast<const float4 *>(sbuf + fpart * 32);
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a = dot4(we[q], v[q], a);
+                    a = sum8(a);
+                    if (fpart == 0) r1[fu] = lrelu(a + p.end1_b[fu]);
+                }
+                __syncthreads();
+                if (tid < p.nout) {
+                    float a = p.end2_b[tid];
+                    for (int k = 0; k < p.nout; ++k) a = fmaf(p.end2_w[tid * p.nout + k], r1[k], a);
+                    r2[tid] = a;
+                }
+                __syncthreads();
+                if (tid < p.ndim) {   // Sample_GMM (losses.py:68-112) / L2 passthrough
+                    float v;
+                    if (p.loss == LSPA2H_LOSS_L2) {
+                        v = r2[tid];
+                    } else {
+                        int idx = 0;
+                        if (p.ncenter > 1) {
+                            float mx = r2[0];
+                            for (int k = 1; k < p.ncenter; ++k) mx = fmaxf(mx, r2[k]);
+                            float den = 0.f;
+                            for (int k = 0; k < p.ncenter; ++k) den += expf(r2[k] - mx);
+                            float best = -1.f;
+                            for (int k = 0; k < p.ncenter; ++k) {
+                                const float val = (expf(r2[k] - mx) / den) / p.expq[(size_t)frame * p.ncenter + k];
+                                if (val > best) { best = val; idx = k; }
+                            }
+                        }
+                        const float mu = r2[p.ncenter + idx * p.ndim + tid];
+                        const float sigma = expf(-r2[p.ncenter + p.ncenter * p.ndim + idx * p.ndim + tid]) * p.sigma_scale;
+                        const float nz = p.noise ? p.noise[(size_t)frame * p.ndim + tid] : 0.f;
+                        v = nz * sigma + mu;
+                    }
+                    p.out[(size_t)frame * p.ndim + tid] = v;
+                    inb[tid] = v;
+                }
+                __syncthreads();
+                if (frame + 1 == p.nframe) break;
+                (void)s;
+            }
+            // start convs (networks.py:198-199) on the pose in inb
+            if (tid < RC) {
+                float a = p.start1_b[tid];
+                for (int k = 0; k < p.ndim; ++k) a = fmaf(p.start1_w[tid * p.ndim + k], inb[k], a);
+                tbuf[tid] = lrelu(a);
+            }
+            __syncthreads();
+            {
+                const float4 *v = reinterpret_cast<const float4 *>(tbuf + rpart * 32);
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a = dot4(w2[q], v[q], a);
+                a = sum4(a);
+                if (rpart == 0) {
+                    const float x0 = lrelu(a + p.start2_b[rq]);
+                    if (frame < 0) { for (int s = 0; s < p.field; ++s) if (s < nsteps) put_granule(xbox, (unsigned)s * (RC * 8u), rq, p.epoch, x0); }
+                    else put_granule(xbox, (unsigned)(p.field + frame) * (RC * 8u), rq, p.epoch, x0);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ layer l
+    const int l = block - 1;
+    const int d = p.dil[l];
+    float4 F[32], R[16];
+    load_packed<0, 32>(F, blob, p.fg_w + (unsigned)l * (32 * NT * 16), voff);
+    load_packed<0, 16>(R, blob, p.rs_w + (unsigned)l * (24 * NT * 16), voff);
+    float4 *r2lds = reinterpret_cast<float4 *>(queue + (size_t)d * RC);      // skip rows 128..255: [8][512] float4, same thread map
+    {
+        float4 t[8];
+        load_packed<0, 8>(t, blob, p.rs_w + (unsigned)l * (24 * NT * 16) + 16u * NT * 16u, voff);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r2lds[q * NT + tid] = t[q];
+    }
+    for (int i = tid; i < d * RC; i += NT) queue[i] = 0.f;
+    const float *rsb = p.rs_b + l * 384;
+    const float br = rpart == 0 ? rsb[rq] : 0.f, bs0 = rpart == 0 ? rsb[128 + rq] : 0.f, bs1 = rpart == 0 ? rsb[256 + rq] : 0.f;
+    const unsigned projN = (unsigned)p.layers * 256u * 4u;                                   // bytes per proj row
+    const __amdgpu_buffer_rsrc_t projb = __builtin_amdgcn_make_buffer_rsrc((void *)p.proj, 0, 0x7fffffff, 0x00020000);
+    const unsigned xin = (unsigned)l * xedge, xout = xin + xedge, sout = (unsigned)l * sedge;
+    const bool last = l + 1 == p.layers;
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int frame = s - (p.field - 1);             // >= 0: this step produces a sample, skips are live
+        int arow = s + p.frame_future - (p.field - 1);
+        arow = arow < 0 ? 0 : arow;
+        float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fpart == 0)
+            pb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(projb, fu * 16, (int)((unsigned)arow * projN + (unsigned)l * 1024u), 0));
+        if (!get_granules(xbox, xin + (unsigned)s * (RC * 8u), RC, p.epoch, xbuf, p.status, 0x10000u * (l + 1) + s)) return;
+        float *qslot = queue + (size_t)(s & (d - 1)) * RC;
+        {   // filter/gate (networks.py:303-319)
+            const float4 *v = reinterpret_cast<const float4 *>((fpart < 4 ? qslot + fpart * 32 : xbuf + (fpart - 4) * 32));
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x = v[q];
+                a0 = dot4(F[q], x, a0); a1 = dot4(F[8 + q], x, a1); a2 = dot4(F[16 + q], x, a2); a3 = dot4(F[24 + q], x, a3);
+            }
+            a0 = sum8(a0); a1 = sum8(a1); a2 = sum8(a2); a3 = sum8(a3);
+            if (fpart == 0) {
+                zbuf[fu] = tanhf(a0 + pb.x) * (1.f / (1.f + expf(-(a1 + pb.y))));
+                zbuf[fu + 64] = tanhf(a2 + pb.z) * (1.f / (1.f + expf(-(a3 + pb.w))));
+            }
+        }
+        __syncthreads();
+        {   // residual + skip (networks.py:322-323); the skip rows only once samples are being produced
+            const float4 *v = reinterpret_cast<const float4 *>(zbuf + rpart * 32);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a0 = dot4(R[q], v[q], a0);
+            a0 = sum4(a0);
+            if (rpart == 0) {   // the next layer is waiting for this: forward it before anything else
+                const float x = xbuf[rq];
+                qslot[rq] = x;
+                if (!last) put_granule(xbox, xout + (unsigned)s * (RC * 8u), rq, p.epoch, a0 + br + x);
+            }
+            if (frame >= 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float4 z = v[q]; a1 = dot4(R[8 + q], z, a1); a2 = dot4(r2lds[q * NT + tid], z, a2); }
+                a1 = sum4(a1); a2 = sum4(a2);
+                if (rpart == 0) {
+                    put_granule(sbox, sout + (unsigned)frame * (SC * 8u), rq, p.epoch, a1 + bs0);
+                    put_granule(sbox, sout + (unsigned)frame * (SC * 8u), 128 + rq, p.epoch, a2 + bs1);
+                }
+            }
+        }
+        __syncthreads();   // (dropping this barrier with a double-buffered xbuf measured 1 % slower)
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -333,8 +576,11 @@ struct lspa2h_handle {
     float *ws = nullptr;
     size_t ws_bytes = 0;
     bool packed = false;
-    bool attr_done = false;
+    bool attr_done = false, pipe_attr_done = false, boxes_clean = false;
+    unsigned epoch = 0;
     int last_rows = 0;
+    size_t xbox_bytes() const { return (size_t)(layers + 1) * (size_t)(field - 1 + cfg.max_audio_frames) * RC * 8; }
+    size_t sbox_bytes() const { return (size_t)layers * (size_t)cfg.max_audio_frames * SC * 8; }
 
     void add(const std::string &key, std::vector<size_t> shape)
     {
@@ -368,7 +614,8 @@ int lspa2h_create(const lspa2h_config *cfg, lspa2h_handle **out)
     if (cfg->loss != LSPA2H_LOSS_GMM && cfg->loss != LSPA2H_LOSS_L2) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "loss");
     if (cfg->cond_channels != cfg->hidden_size || cfg->hidden_size % 64 || cfg->hidden_size < 64)
         return fail(LSPA2H_ERR_SHAPE, "cond_channels must equal hidden_size, a multiple of 64");
-    if (cfg->max_audio_frames < 1) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "max_audio_frames");
+    if (cfg->max_audio_frames < 1 || cfg->max_audio_frames > 32768)    // mailbox offsets are 32-bit buffer offsets
+        return fail(LSPA2H_ERR_INVALID_ARGUMENT, "max_audio_frames must be in 1..32768");
     lspa2h_handle *h = new (std::nothrow) lspa2h_handle;
     if (!h) return fail(LSPA2H_ERR_STATE, "out of host memory");
     h->cfg = *cfg;
@@ -564,7 +811,7 @@ size_t lspa2h_workspace_bytes(const lspa2h_handle *h)
 {
     if (!h) return 0;
     const size_t rows = h->cfg.max_audio_frames, H = h->cfg.hidden_size;
-    return (align64(rows * H) * 2 + align64(rows * (size_t)h->layers * 256)) * sizeof(float);
+    return (align64(rows * H) * 2 + align64(rows * (size_t)h->layers * 256)) * sizeof(float) + h->xbox_bytes() + h->sbox_bytes() + 256;
 }
 
 int lspa2h_bind_workspace(lspa2h_handle *h, void *workspace_dev, size_t bytes)
@@ -574,6 +821,7 @@ int lspa2h_bind_workspace(lspa2h_handle *h, void *workspace_dev, size_t bytes)
     if ((uintptr_t)workspace_dev & 15) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
     h->ws = static_cast<float *>(workspace_dev);
     h->ws_bytes = bytes;
+    h->boxes_clean = false;
     return LSPA2H_OK;
 }
 
@@ -623,6 +871,40 @@ static int generate_impl(lspa2h_handle *h, const float *audio_dev, int n_audio, 
     p.layers = L; p.ndim = h->cfg.ndim; p.ncenter = h->cfg.ncenter; p.nout = h->nout; p.loss = h->cfg.loss;
     p.field = h->field; p.nframe = nframe; p.frame_future = frame_future; p.sigma_scale = sigma_scale;
     for (int l = 0; l < L; ++l) { p.dil[l] = h->dil[l]; p.qoff[l] = h->qoff[l]; }
+    static const char *force = std::getenv("LSP_A2H_KERNEL");     // tools only: "stream" | "pipe"
+    const bool single = force ? std::strcmp(force, "stream") == 0 : (h->cfg.flags & LSPA2H_FLAG_SINGLE_WORKGROUP) != 0;
+    char *tail = reinterpret_cast<char *>(proj + align64(rows * (size_t)L * 256));
+    p.xbox = reinterpret_cast<unsigned long long *>(tail);
+    p.sbox = reinterpret_cast<unsigned long long *>(tail + h->xbox_bytes());
+    p.status = reinterpret_cast<unsigned *>(tail + h->xbox_bytes() + h->sbox_bytes());
+    if (hipMemsetAsync(p.status, 0, 64, s) != hipSuccess) return fail(LSPA2H_ERR_HIP, "hipMemsetAsync(status)");
+    if (!single) {
+        // mailbox tags: the call counter, so slots of earlier calls never match; whatever the buffer held when it
+        // was bound is cleared once
+        if (!h->boxes_clean) {
+            const hipError_t e = hipMemsetAsync(tail, 0, h->xbox_bytes() + h->sbox_bytes(), s);
+            if (e != hipSuccess) return hipfail(e, "hipMemsetAsync(mailboxes)");
+            h->boxes_clean = true;
+        }
+        if (++h->epoch == 0) h->epoch = 1;
+        p.epoch = h->epoch;
+        const int maxd = 1 << (h->cfg.residual_layers - 1);
+        const size_t lds_pipe = (size_t)(RC * 3 + SC + 2 * MAX_OUT + 16 + (size_t)maxd * RC) * sizeof(float) + 8 * NT * 16;
+        if (!h->pipe_attr_done) {
+            // not the full 160 KB: __syncthreads_and keeps a word of static LDS
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&a2h_pipe),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
+            if (e != hipSuccess) return hipfail(e, "hipFuncSetAttribute(a2h_pipe)");
+            h->pipe_attr_done = true;
+        }
+        // Blocks are dealt round-robin over the 8 XCDs (observed, not contractual): using every 8th block puts the
+        // whole chain behind one L2.  Measured 45.4 vs 51.0 us per frame; results do not depend on it.
+        static const int spread = std::getenv("LSP_A2H_SPREAD") ? std::atoi(std::getenv("LSP_A2H_SPREAD")) : 0;   // tools: 1 = consecutive blocks
+        p.stride = spread ? 1 : 8;
+        hipLaunchKernelGGL(a2h_pipe, dim3((L + 1) * p.stride), dim3(NT), lds_pipe, s, p);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? LSPA2H_OK : hipfail(e, "a2h_pipe launch");
+    }
     const size_t lds = (size_t)(RC * 3 + SC + 2 * MAX_OUT + 16 + (size_t)h->qrows * RC) * sizeof(float);
     if (!h->attr_done) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&a2h_stream),
@@ -663,6 +945,19 @@ int lspa2h_generate_timed(lspa2h_handle *h, const float *audio_dev, int n_audio,
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return rc;
+}
+
+int lspa2h_status(lspa2h_handle *h, void *stream, uint32_t *code)
+{
+    if (!h || !code) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->ws) return fail(LSPA2H_ERR_STATE, "workspace not bound");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hipfail(e, "hipStreamSynchronize");
+    const size_t rows = h->cfg.max_audio_frames, H = h->cfg.hidden_size;
+    const char *tail = reinterpret_cast<const char *>(h->ws + align64(rows * H) * 2 + align64(rows * (size_t)h->layers * 256));
+    e = hipMemcpy(code, tail + h->xbox_bytes() + h->sbox_bytes(), sizeof(uint32_t), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? LSPA2H_OK : hipfail(e, "hipMemcpy(status)");
 }
 
 int lspa2h_debug_cond(const lspa2h_handle *h, const float **cond_dev, int *rows, int *cols)
