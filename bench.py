@@ -194,6 +194,7 @@ def main():
             torch.cuda.synchronize()
         extra["pcie_inclusive_frames_per_s_batch1_uint8"] = round(nl / (time.perf_counter() - t2), 2)
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
+        extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
 
     line = {
         "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",
@@ -253,6 +254,40 @@ def headpose_extra(dev, cpu_threads):
         out["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "head poses/s", "cores": int(cpu_threads), "kind": "port",
                                "sample": "%d frames of oracle/a2h_oracle.generate_sequences: the reference's per-frame 255-wide "
                                          "re-evaluation (torch %s CPU)" % (n, torch.__version__)}
+    return out
+
+
+def manifold_extra(dev, cpu_threads):
+    """KNN + LLE projection of one clip's APC features (demo.py:196-200): 1374 feature rows
+    (2 per video frame of the 687-frame clip), a 30 000-row synthetic database, d 512, K 10.  Device tensors in/out."""
+    from livespeechportraits_amd import manifold, synth
+    n, m, d, K = 1374, 30000, 512, 10
+    db_np, q_np = synth.make_feature_database(m, n, d, 24)
+    db, q = torch.from_numpy(db_np).to(dev), torch.from_numpy(q_np).to(dev)
+    for _ in range(2):
+        manifold.project(q, db, K, 1.0)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); manifold.project(q, db, K, 1.0); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    out = {"metric": "feature rows/s (KNN_with_torch + compute_LLE_projection_all_frame + blend, n 1374, m 30000, d 512, K 10)",
+           "value": round(n / (ts[2] * 1e-3), 1), "ms_median": round(ts[2], 3), "ms_min_max": [round(ts[0], 3), round(ts[-1], 3)],
+           "note": "per-kernel split in profiles/r01_kernel_stats_side_paths.txt (distance GEMM ~0.51 ms = 83 TFLOP/s, top-K 0.17, LLE 0.14)"}
+    if cpu_threads:
+        from oracle import lle_oracle
+        torch.set_num_threads(int(cpu_threads))
+        t0 = time.perf_counter()
+        ind = lle_oracle.knn(q_np, db_np, K)
+        t1 = time.perf_counter()
+        lle_oracle.lle_all(q_np[:300], db_np, ind[:300])
+        t2 = time.perf_counter()
+        total = (t1 - t0) + (t2 - t1) * n / 300.0
+        out["cpu_baseline"] = {"value": round(n / total, 1), "unit": "feature rows/s", "cores": int(cpu_threads), "kind": "port",
+                               "sample": "oracle/lle_oracle.py: full KNN (%.3f s) + the per-frame LLE loop on 300 of %d rows (%.3f s, scaled)"
+                                         % (t1 - t0, n, t2 - t1)}
     return out
 
 

@@ -1,4 +1,4 @@
-"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h).
+"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h).
 
 There is deliberately no fallback: if the shared library is missing or does not
 load, importing the hot path raises -- a GPU box must never silently run
@@ -114,6 +114,15 @@ A2H_SIGNATURES = {
     "lspa2h_status": (c_int, [c_void_p, c_void_p, POINTER(c_uint32)]),
 }
 
+# every symbol include/lsplle.h declares
+LLE_SIGNATURES = {
+    "lsplle_last_error": (c_char_p, []),
+    "lsplle_knn_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "lsplle_knn": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lsplle_solve": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                             c_float, c_void_p]),
+}
+
 _lib = None
 
 
@@ -131,7 +140,7 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e)) from e
-    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
@@ -164,3 +173,15 @@ def check_a2h(rc: int) -> None:
     if rc != OK:
         msg = load().lspa2h_last_error()
         raise Lspa2hError(rc, msg.decode() if msg else "")
+
+
+class LsplleError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lsplle error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check_lle(rc: int) -> None:
+    if rc != OK:
+        msg = load().lsplle_last_error()
+        raise LsplleError(rc, msg.decode() if msg else "")

@@ -2,7 +2,7 @@
 // Audio2HeadposeModel.generate_sequences (models/audio2headpose_model.py:133-187), gfx950 only.
 //
 // Two kernels:
-//   a2h_gemm     fp32 MFMA GEMM with a per-column affine (+LeakyReLU) epilogue: the audio_downsample MLP
+//   gemm_f32     (gemm_f32.h) fp32 MFMA GEMM with a per-column affine (+LeakyReLU) epilogue: the audio_downsample MLP
 //                (models/audio2headpose.py:16-21, BatchNorm1d folded) and ALL layers' cond_filter/cond_gate
 //                1x1 convs (models/networks.py:277-287) for every audio frame at once -- none of it depends
 //                on the sampled poses, so it leaves the sequential loop.
@@ -16,6 +16,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "gemm_f32.h"
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -26,68 +28,12 @@
 
 namespace lspa2h {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int RC = 128;        // residual == dilation channels
 constexpr int SC = 256;        // skip channels
 constexpr int NT = 512;        // threads of the stream workgroup
 constexpr int MAX_LAYERS = 32;
 constexpr int MAX_OUT = 64;    // (2*ndim+1)*ncenter
 constexpr float LRELU = 0.2f;  // nn.LeakyReLU(0.2), networks.py:147
-
-// ------------------------------------------------------------------------------------------------ GEMM
-struct GemmParams {
-    const float *A;      // [M][K]
-    const float *W;      // [N][K]   (nn.Linear / 1x1 Conv1d weight layout)
-    const float *scale;  // [N] or null (=1)
-    const float *shift;  // [N]
-    float *C;            // [M][N]
-    int M, N, K;
-    int leaky;
-};
-
-// C = act((A W^T) * scale + shift).  64x64 tile, 4 waves (2x2) of one 32x32 MFMA accumulator, K step 32.
-// N % 64 == 0 and K % 32 == 0 (checked by the launcher); M is ragged.
-__global__ __launch_bounds__(256) void a2h_gemm(GemmParams p)
-{
-    constexpr int LD = 36;
-    __shared__ float As[64 * LD];
-    __shared__ float Bs[64 * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int lrow = tid >> 3, lq = (tid & 7) * 4;   // staging: 32 rows x 8 float4 per pass, 2 passes
-    for (int k0 = 0; k0 < p.K; k0 += 32) {
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int r = pass * 32 + lrow;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < p.M) a = *reinterpret_cast<const float4 *>(p.A + (size_t)(m0 + r) * p.K + k0 + lq);
-            const float4 b = *reinterpret_cast<const float4 *>(p.W + (size_t)(n0 + r) * p.K + k0 + lq);
-            *reinterpret_cast<float4 *>(As + r * LD + lq) = a;
-            *reinterpret_cast<float4 *>(Bs + r * LD + lq) = b;
-        }
-        __syncthreads();
-        const float *ap = As + (wm * 32 + (lane & 31)) * LD + (lane >> 5);
-        const float *bp = Bs + (wn * 32 + (lane & 31)) * LD + (lane >> 5);
-#pragma unroll
-        for (int k = 0; k < 32; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
-        __syncthreads();
-    }
-    const int n = n0 + wn * 32 + (lane & 31);
-    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift[n];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
-        float v = acc[r] * sc + sh;
-        if (p.leaky) v = v > 0.f ? v : LRELU * v;
-        p.C[(size_t)m * p.N + n] = v;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- stream
 struct StreamParams {
@@ -828,11 +774,9 @@ int lspa2h_bind_workspace(lspa2h_handle *h, void *workspace_dev, size_t bytes)
 static int launch_gemm(const float *A, const float *W, const float *scale, const float *shift, float *C, int M, int N, int K,
                        int leaky, hipStream_t s)
 {
-    if (N % 64 || K % 32) return fail(LSPA2H_ERR_SHAPE, "gemm needs N % 64 == 0 and K % 32 == 0");
-    GemmParams p{A, W, scale, shift, C, M, N, K, leaky};
-    hipLaunchKernelGGL(a2h_gemm, dim3(N / 64, (M + 63) / 64), dim3(256), 0, s, p);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? LSPA2H_OK : hipfail(e, "a2h_gemm launch");
+    lspgemm::GemmParams p{A, W, scale, shift, nullptr, C, M, N, K, 1.0f, leaky};
+    const hipError_t e = lspgemm::launch_gemm_f32(p, s);
+    return e == hipSuccess ? LSPA2H_OK : hipfail(e, "gemm_f32 launch");
 }
 
 static int generate_impl(lspa2h_handle *h, const float *audio_dev, int n_audio, const float *pre_dev, const float *noise_dev,

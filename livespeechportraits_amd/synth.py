@@ -160,3 +160,24 @@ def make_a2h_inputs(n_audio: int, cfg: Dict, seed: int = 17) -> Tuple[np.ndarray
     audio = symmetric(n_audio * 2 * cfg["hidden_size"], 0.5, _stream(seed, "a2h.audio")).reshape(n_audio, -1)
     pre = symmetric(cfg["ndim"], 0.1, _stream(seed, "a2h.pre"))
     return audio.astype(np.float32), pre.astype(np.float32)
+
+
+# ---- APC feature database for the manifold projection ---------------------
+def make_feature_database(m: int, n: int, d: int = 512, intrinsic: int = 0, seed: int = 3, noise: float = 0.05
+                          ) -> Tuple[np.ndarray, np.ndarray]:
+    """(database [m, d], query features [n, d]).  intrinsic == 0: isotropic points (well-conditioned neighbourhoods);
+    intrinsic > 0: points near an ``intrinsic``-dimensional linear manifold plus ``noise`` isotropic noise, the shape real
+    APC features have (neighbour differences become nearly dependent, the normal equations ill-conditioned).
+    Queries are noisy copies of database rows, so every query has genuine near neighbours."""
+    def gauss(count, key):      # sum of 4 uniforms: bell-shaped, variance 1
+        u = symmetric(count * 4, 1.0, _stream(seed, key)).reshape(count, 4)
+        return (u.sum(1) * np.float32(0.5)).astype(np.float32)
+    if intrinsic:
+        basis = gauss(intrinsic * d, "lle.basis").reshape(intrinsic, d) / np.float32(np.sqrt(intrinsic))
+        db = gauss(m * intrinsic, "lle.coef").reshape(m, intrinsic) @ basis + np.float32(noise) * gauss(m * d, "lle.noise").reshape(m, d)
+    else:
+        db = gauss(m * d, "lle.db").reshape(m, d)
+    pick = (uniform01(n, _stream(seed, "lle.pick")) * m).astype(np.int64) % m
+    scale = np.float32(noise if intrinsic else 0.4)
+    q = db[pick] * np.float32(0.8) + scale * gauss(n * d, "lle.q").reshape(n, d)
+    return np.ascontiguousarray(db, np.float32), np.ascontiguousarray(q, np.float32)

@@ -1,0 +1,129 @@
+"""Manifold projection: oracle vs outputs of the reference's own functions (CPU), HIP path vs
+those outputs (GPU).  Goldens: oracle/make_golden_lle.py."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CASES = ["iso_k10", "manifold_k10", "degenerate_k10", "k1", "k16_ragged"]
+
+
+def load_case(name):
+    from livespeechportraits_amd import synth
+    meta = json.load(open(os.path.join(GOLD, "lle_%s.json" % name)))
+    z = np.load(os.path.join(GOLD, "lle_%s.npz" % name))
+    db, q = synth.make_feature_database(meta["m"], meta["n"], meta["d"], meta["intrinsic"], noise=meta["noise"])
+    return meta, db, q, z
+
+
+def tolerances(meta):
+    """The reference solves near-singular normal equations in fp32; its own distance from exact arithmetic on the
+    same neighbours (recorded when the golden was made) is the floor of any parity claim.  8x that, never below 1e-5."""
+    return max(1e-5, 8 * meta["reference_vs_exact_w"]), max(1e-5, 8 * meta["reference_vs_exact_fuse"])
+
+
+# ---- CPU ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_reference(name):
+    from oracle import lle_oracle
+    meta, db, q, z = load_case(name)
+    ind = lle_oracle.knn(q, db, meta["K"])
+    same = (ind == z["ind"]).all(1)
+    assert same.mean() >= 0.98, "KNN differs on more rows than near-ties can explain"      # other CPU kernels may flip a near-tie
+    w, fuse = lle_oracle.lle_all(q, db, z["ind"])
+    tw, tf = tolerances(meta)
+    assert np.abs(w - z["w"]).max() <= tw and np.abs(fuse - z["fuse"]).max() <= tf
+    assert np.abs(lle_oracle.blend(q, fuse, meta["percent"]) - z["blend"]).max() <= tf
+    assert np.allclose(z["w"].sum(1), 1.0, atol=1e-6)
+
+
+def test_library_exports_every_lsplle_symbol():
+    from livespeechportraits_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "lsplle.h")).read()
+    declared = set(re.findall(r"\b(lsplle_[a-z0-9_]+)\s*\(", hdr))
+    lib = ctypes.CDLL(N.LIB_PATH)
+    assert declared and all(hasattr(lib, n) for n in declared)
+    assert declared == set(N.LLE_SIGNATURES), declared ^ set(N.LLE_SIGNATURES)
+    assert N.load().lsplle_knn_workspace_bytes(10, 100) >= 10 * 100 * 4
+
+
+def test_no_cpu_path():
+    from livespeechportraits_amd import manifold
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        manifold.KNN_with_torch(np.zeros((2, 32), np.float32), np.zeros((4, 32), np.float32), K=2, device="cpu")
+    with pytest.raises(ValueError):
+        manifold.knn(torch.zeros(2, 32), torch.zeros(4, 32), 2)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_knn_matches_reference(name):
+    from livespeechportraits_amd import manifold
+    meta, db, q, z = load_case(name)
+    dev = torch.device("cuda:0")
+    ind = manifold.knn(torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev), meta["K"]).cpu().numpy()
+    ref = z["ind"]
+    bad = np.flatnonzero((ind != ref).any(1))
+    # a row may differ only where two database rows are equidistant to fp32 rounding (different summation order)
+    f64, b64 = q.astype(np.float64), db.astype(np.float64)
+    for i in bad:
+        da = ((f64[i] - b64[ind[i]]) ** 2).sum(1)
+        dr = ((f64[i] - b64[ref[i]]) ** 2).sum(1)
+        assert np.abs(da - dr).max() <= 2e-5 * dr.max(), "row %d: neighbours differ beyond a near-tie" % i
+    print("\n[lle %s] KNN rows differing from the reference (near-ties): %d of %d" % (name, len(bad), len(ref)))
+    assert len(bad) <= max(1, len(ref) // 50)
+    assert (np.diff(((f64[:, None, :] - b64[ind]) ** 2).sum(2), axis=1) >= -1e-4).all(), "neighbours are not sorted nearest first"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_lle_matches_reference(name):
+    from livespeechportraits_amd import manifold
+    meta, db, q, z = load_case(name)
+    dev = torch.device("cuda:0")
+    w, fuse, blend = manifold.lle(torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev), torch.from_numpy(z["ind"]).to(dev), meta["percent"])
+    tw, tf = tolerances(meta)
+    ew, ef, eb = (np.abs(w.cpu().numpy() - z["w"]).max(), np.abs(fuse.cpu().numpy() - z["fuse"]).max(),
+                  np.abs(blend.cpu().numpy() - z["blend"]).max())
+    print("\n[lle %s] max-abs vs reference: w %.2e (tol %.1e), fuse %.2e (tol %.1e), blend %.2e; cond max %.1e"
+          % (name, ew, tw, ef, tf, eb, meta["cond_max"]))
+    assert w.dtype == torch.float64 and fuse.dtype == torch.float32
+    assert ew <= tw and ef <= tf and eb <= tf
+    assert np.allclose(w.cpu().numpy().sum(1), 1.0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_reference_named_wrappers_and_project():
+    from livespeechportraits_amd import manifold
+    meta, db, q, z = load_case("iso_k10")
+    ind = manifold.KNN_with_torch(q, db, K=10)
+    assert ind.dtype == np.int64 and ind.shape == (96, 10)
+    w, fuse = manifold.compute_LLE_projection_all_frame(q, db, z["ind"], q.shape[0])
+    assert w.dtype == np.float64 and fuse.dtype == np.float32
+    assert np.abs(fuse - z["fuse"]).max() <= 1e-5
+    dev = torch.device("cuda:0")
+    out = manifold.project(torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev), K=10, percent=1.0).cpu().numpy()
+    same = (ind == z["ind"]).all(1)
+    assert np.abs(out[same] - z["blend"][same]).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_argument_errors():
+    from livespeechportraits_amd import _native as N, manifold
+    dev = torch.device("cuda:0")
+    f, b = torch.zeros(4, 64, device=dev), torch.zeros(8, 64, device=dev)
+    with pytest.raises(N.LsplleError):
+        manifold.knn(f, b, 9)                        # K > m
+    with pytest.raises(N.LsplleError):
+        manifold.knn(f, b, 17)                       # K > 16
+    with pytest.raises(N.LsplleError):
+        manifold.knn(torch.zeros(4, 40, device=dev), torch.zeros(8, 40, device=dev), 2)    # d % 32
+    with pytest.raises(ValueError):
+        manifold.knn(f, torch.zeros(8, 32, device=dev), 2)
