@@ -195,6 +195,7 @@ def main():
         extra["pcie_inclusive_frames_per_s_batch1_uint8"] = round(nl / (time.perf_counter() - t2), 2)
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
+        extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
 
     line = {
         "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",
@@ -254,6 +255,62 @@ def headpose_extra(dev, cpu_threads):
         out["cpu_baseline"] = {"value": round(n / dt, 2), "unit": "head poses/s", "cores": int(cpu_threads), "kind": "port",
                                "sample": "%d frames of oracle/a2h_oracle.generate_sequences: the reference's per-frame 255-wide "
                                          "re-evaluation (torch %s CPU)" % (n, torch.__version__)}
+    return out
+
+
+def recurrent_extra(dev, cpu_threads):
+    """the two recurrent audio stages at the 687-frame clip's lengths -- APC_encoder
+    (3 x GRU-512 over 1374 mel frames, demo.py:186-191) and Audio2Feature (MLP + 3 x LSTM-256 + MLP over
+    687 + frame_future 18 = 705 steps, demo.py:205).  Device tensors in/out; two lengths give the per-step slope."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.apc import APC_encoder
+    from livespeechportraits_amd.audio2feature import Audio2Feature
+    import argparse as _ap
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    out = {}
+    apc = APC_encoder(80, 512, 3, False)
+    apc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_apc_state_dict().items()})
+    apc = apc.to(dev).eval()
+    ms = {}
+    for T in (274, 1374):
+        mel = torch.from_numpy(synth.make_mel(T)).to(dev).unsqueeze(0)
+        ms[T] = timed(lambda: apc.forward(mel, torch.Tensor([T])))
+    if apc._engine.status() != 0:
+        raise RuntimeError("GRU kernel hand-off timed out")
+    out["apc_gru"] = {"ms_1374_steps": round(ms[1374], 3), "us_per_step_per_layer": round(1e3 * (ms[1374] - ms[274]) / 1100.0 / 3, 3),
+                      "mel_frames_per_s": round(1374 / (ms[1374] * 1e-3), 1)}
+    opt = _ap.Namespace(feature_decoder="LSTM", loss="L2", A2L_GMM_ndim=75, A2L_GMM_ncenter=1, predict_length=1, APC_hidden_size=512)
+    a2f = Audio2Feature(opt)
+    a2f.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_a2f_state_dict().items()}, strict=False)
+    a2f = a2f.to(dev).eval()
+    ms2 = {}
+    for rows in (410, 1410):
+        x = torch.from_numpy(synth.symmetric(rows * 512, 0.5, 77).reshape(1, rows, 512)).to(dev)
+        ms2[rows] = timed(lambda: a2f.forward(x))
+    if a2f.status() != 0:
+        raise RuntimeError("LSTM kernel hand-off timed out")
+    out["audio2feature_lstm"] = {"ms_705_steps": round(ms2[1410], 3), "us_per_step_per_layer": round(1e3 * (ms2[1410] - ms2[410]) / 500.0 / 3, 3),
+                                 "frames_per_s": round(705 / (ms2[1410] * 1e-3), 1)}
+    if cpu_threads:
+        from oracle import rnn_oracle
+        torch.set_num_threads(int(cpu_threads))
+        sd, mel = synth.make_apc_state_dict(), synth.make_mel(1374)
+        rnn_oracle.apc_forward(sd, mel[:64])
+        t0 = time.perf_counter(); rnn_oracle.apc_forward(sd, mel); t_apc = time.perf_counter() - t0
+        sd2, feats = synth.make_a2f_state_dict(), synth.symmetric(1410 * 512, 0.5, 77).reshape(1410, 512)
+        rnn_oracle.a2f_forward(sd2, feats[:64])
+        t0 = time.perf_counter(); rnn_oracle.a2f_forward(sd2, feats); t_a2f = time.perf_counter() - t0
+        out["cpu_baseline"] = {"apc_gru_ms": round(1e3 * t_apc, 1), "audio2feature_ms": round(1e3 * t_a2f, 1), "cores": int(cpu_threads), "kind": "port",
+                               "sample": "oracle/rnn_oracle.py (torch nn.GRU / nn.LSTM on the host, torch %s), the same full sequences, one run each" % torch.__version__}
     return out
 
 

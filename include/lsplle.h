@@ -36,7 +36,7 @@ const char *lsplle_last_error(void);
 size_t lsplle_knn_workspace_bytes(int n, int m);
 
 /* KNN_with_torch (funcs/utils.py:100-118): ind[i][0..K) = database rows nearest to feats[i], nearest first.
- *   feats_dev [n][d], db_dev [m][d], ind_dev int64 [n][K];  d % 32 == 0, 1 <= K <= min(m, LSPLLE_MAX_K). */
+ *   feats_dev [n][d], db_dev [m][d], ind_dev int64 [n][K];  d % 4 == 0, 1 <= K <= min(m, LSPLLE_MAX_K). */
 int lsplle_knn(const float *feats_dev, int n, const float *db_dev, int m, int d, int K, int64_t *ind_dev,
                void *workspace_dev, size_t workspace_bytes, void *stream);
 

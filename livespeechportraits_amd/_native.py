@@ -1,4 +1,4 @@
-"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h).
+"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h, include/lsprnn.h).
 
 There is deliberately no fallback: if the shared library is missing or does not
 load, importing the hot path raises -- a GPU box must never silently run
@@ -123,6 +123,34 @@ LLE_SIGNATURES = {
                              c_float, c_void_p]),
 }
 
+
+
+class RNNConfig(Structure):
+    """lsprnn_config (include/lsprnn.h)"""
+    _fields_ = [(n, c_int32) for n in ("abi_version", "cell", "num_layers", "input_size", "hidden_size", "max_steps")] + [("flags", c_uint32)]
+
+
+RNN_ABI_VERSION = 1
+RNN_CELL_IDS = {"GRU": 0, "LSTM": 1}
+# every symbol include/lsprnn.h declares
+RNN_SIGNATURES = {
+    "lsprnn_create": (c_int, [POINTER(RNNConfig), POINTER(c_void_p)]),
+    "lsprnn_destroy": (c_int, [c_void_p]),
+    "lsprnn_last_error": (c_char_p, []),
+    "lsprnn_abi_version": (c_int, []),
+    "lsprnn_num_tensors": (c_int, [c_void_p]),
+    "lsprnn_tensor_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_size_t)]),
+    "lsprnn_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "lsprnn_packed_bytes": (c_size_t, [c_void_p]),
+    "lsprnn_pack_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lsprnn_bind_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lsprnn_workspace_bytes": (c_size_t, [c_void_p]),
+    "lsprnn_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lsprnn_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "lsprnn_status": (c_int, [c_void_p, c_void_p, POINTER(c_uint32)]),
+    "lsprnn_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
 _lib = None
 
 
@@ -140,7 +168,7 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e)) from e
-    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()) + list(RNN_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
@@ -185,3 +213,15 @@ def check_lle(rc: int) -> None:
     if rc != OK:
         msg = load().lsplle_last_error()
         raise LsplleError(rc, msg.decode() if msg else "")
+
+
+class LsprnnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lsprnn error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check_rnn(rc: int) -> None:
+    if rc != OK:
+        msg = load().lsprnn_last_error()
+        raise LsprnnError(rc, msg.decode() if msg else "")

@@ -1,0 +1,47 @@
+"""Drop-in for the reference's ``APC_encoder`` (models/networks.py:19-66; built and called at demo.py:146-151,
+186-191): same constructor, the same state-dict keys (``rnns.<i>.weight_ih_l0`` ...), ``forward(inputs, lengths)``
+returning the last GRU layer's outputs ``[1, T, hidden]``.  One sequence at a time, as demo.py uses it."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .rnn_engine import RecurrentEngine
+
+
+class APC_encoder(nn.Module):
+    def __init__(self, mel_dim, hidden_size, num_layers, residual):
+        super().__init__()
+        if residual:
+            raise NotImplementedError("residual APC stacks (no shipped config enables them: config/*.yaml residual: false)")
+        sizes = [mel_dim] + [hidden_size] * (num_layers - 1)
+        self.rnns = nn.ModuleList([nn.GRU(input_size=s, hidden_size=hidden_size, batch_first=True) for s in sizes])   # parameter containers
+        self.rnn_residual = residual
+        self.mel_dim, self.hidden_size, self.num_layers = mel_dim, hidden_size, num_layers
+        self._engine = None
+        self._version = None
+
+    def _get_engine(self, device, T) -> RecurrentEngine:
+        version = tuple(p._version for p in self.parameters())
+        e = self._engine
+        if e is None or self._version != version or e.max_steps < T or e.blob.device != device:
+            e = RecurrentEngine("GRU", self.num_layers, self.mel_dim, self.hidden_size, max_steps=max(T, 4096))
+            sd = {}
+            for i, g in enumerate(self.rnns):            # one single-layer GRU per module -> layer i of the stack
+                for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    sd["%s_l%d" % (name, i)] = getattr(g, name + "_l0")
+            e.load_state_dict(sd)
+            e.bind(device)
+            self._engine, self._version = e, version
+        return e
+
+    def forward(self, inputs, lengths):
+        if inputs.dim() != 3 or inputs.shape[0] != 1:
+            raise ValueError("inputs must be [1, seq_len, mel_dim] (the reference calls it with one utterance, demo.py:189)")
+        T = inputs.shape[1]
+        if int(lengths.reshape(-1)[0]) != T:
+            raise ValueError("lengths[0] must equal seq_len for a single sequence")
+        if not inputs.is_cuda:
+            raise RuntimeError("APC_encoder here is the MI355X path: inputs must be a device tensor (no CPU path)")
+        e = self._get_engine(inputs.device, T)
+        return e.forward(inputs[0].float().contiguous()).unsqueeze(0)

@@ -1,6 +1,6 @@
 // fp32 MFMA GEMM shared by the small dense stages around the renderer (csrc/a2h.hip, csrc/lle.hip), gfx950 only.
 //   C[m][n] = act( acc * scale[n] + shift[n] + rowadd[m] ),  acc = sum_k A[m][k] * W[n][k]
-// A [M][K] and W [N][K] row-major (nn.Linear / 1x1-conv weight layout); M and N ragged, K % 32 == 0.
+// A [M][K] and W [N][K] row-major (nn.Linear / 1x1-conv weight layout); M and N ragged, K % 4 == 0 (rows 16-B aligned).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -38,8 +38,9 @@ static __global__ __launch_bounds__(256) void gemm_f32(GemmParams p)   // one co
         for (int pass = 0; pass < 2; ++pass) {
             const int r = pass * 32 + lrow;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (m0 + r < p.M) a = *reinterpret_cast<const float4 *>(p.A + (size_t)(m0 + r) * p.K + k0 + lq);
-            if (n0 + r < p.N) b = *reinterpret_cast<const float4 *>(p.W + (size_t)(n0 + r) * p.K + k0 + lq);
+            const bool kin = k0 + lq < p.K;                  // K tail: zeros
+            if (kin && m0 + r < p.M) a = *reinterpret_cast<const float4 *>(p.A + (size_t)(m0 + r) * p.K + k0 + lq);
+            if (kin && n0 + r < p.N) b = *reinterpret_cast<const float4 *>(p.W + (size_t)(n0 + r) * p.K + k0 + lq);
             *reinterpret_cast<float4 *>(As + r * LD + lq) = a;
             *reinterpret_cast<float4 *>(Bs + r * LD + lq) = b;
         }
@@ -63,10 +64,10 @@ static __global__ __launch_bounds__(256) void gemm_f32(GemmParams p)   // one co
     }
 }
 
-// returns hipSuccess / the launch error; hipErrorInvalidValue if K % 32 != 0
+// returns hipSuccess / the launch error; hipErrorInvalidValue if K % 4 != 0
 static inline hipError_t launch_gemm_f32(const GemmParams &p, hipStream_t s)
 {
-    if (p.K % 32 || p.M < 1 || p.N < 1) return hipErrorInvalidValue;
+    if (p.K % 4 || p.K < 4 || p.M < 1 || p.N < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gemm_f32, dim3((p.N + 63) / 64, (p.M + 63) / 64), dim3(256), 0, s, p);
     return hipGetLastError();
 }

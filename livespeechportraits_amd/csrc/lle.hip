@@ -188,7 +188,7 @@ int lsplle_knn(const float *feats_dev, int n, const float *db_dev, int m, int d,
                void *workspace_dev, size_t workspace_bytes, void *stream)
 {
     if (!feats_dev || !db_dev || !ind_dev || !workspace_dev) return fail(LSPLLE_ERR_INVALID_ARGUMENT, "null argument");
-    if (n < 1 || m < 1 || d < 32 || d % 32) return fail(LSPLLE_ERR_SHAPE, "need n, m >= 1 and d a multiple of 32");
+    if (n < 1 || m < 1 || d < 4 || d % 4) return fail(LSPLLE_ERR_SHAPE, "need n, m >= 1 and d a multiple of 4");
     if (K < 1 || K > MAXK || K > m) return fail(LSPLLE_ERR_UNSUPPORTED, "K must be in 1..min(m, 16)");
     if (workspace_bytes < lsplle_knn_workspace_bytes(n, m)) return fail(LSPLLE_ERR_SHAPE, "workspace smaller than lsplle_knn_workspace_bytes()");
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -1,6 +1,6 @@
 """``from livespeechportraits_amd.models import create_model`` -- the reference's factory
 (models/__init__.py:29-71) for the models this package replaces: feature2face (the renderer) and
-audio2headpose."""
+audio2headpose and audio2feature (rank 4)."""
 from __future__ import annotations
 
 import importlib
@@ -9,8 +9,8 @@ from ..base_model import BaseModel
 
 
 def find_model_using_name(model_name: str):
-    if model_name not in ("feature2face", "audio2headpose"):
-        raise NotImplementedError("livespeechportraits_amd replaces --model feature2face and audio2headpose; "
+    if model_name not in ("feature2face", "audio2headpose", "audio2feature"):
+        raise NotImplementedError("livespeechportraits_amd replaces --model feature2face, audio2headpose and audio2feature; "
                                   "%r stays with the reference implementation" % (model_name,))
     lib = importlib.import_module("livespeechportraits_amd.%s_model" % model_name)
     target = model_name.replace("_", "") + "model"

@@ -181,3 +181,68 @@ def make_feature_database(m: int, n: int, d: int = 512, intrinsic: int = 0, seed
     scale = np.float32(noise if intrinsic else 0.4)
     q = db[pick] * np.float32(0.8) + scale * gauss(n * d, "lle.q").reshape(n, d)
     return np.ascontiguousarray(db, np.float32), np.ascontiguousarray(q, np.float32)
+
+
+# ---- recurrent stacks of the audio front-end ----------------------------------
+def make_rnn_state_dict(cell: str, num_layers: int, input_size: int, hidden_size: int, seed: int = 11, prefix: str = "") -> Dict[str, np.ndarray]:
+    """torch.nn.GRU / nn.LSTM parameter names; PyTorch's own init range U(-1/sqrt(H), 1/sqrt(H)) (scaled 1.6x so the
+    gates leave their linear region and the state carries memory over many steps)."""
+    gates = 3 if cell == "GRU" else 4
+    k = 1.6 / float(np.sqrt(hidden_size))
+    sd = {}
+    for l in range(num_layers):
+        n_in = input_size if l == 0 else hidden_size
+        for name, shape in (("weight_ih", (gates * hidden_size, n_in)), ("weight_hh", (gates * hidden_size, hidden_size)),
+                            ("bias_ih", (gates * hidden_size,)), ("bias_hh", (gates * hidden_size,))):
+            key = "%s%s_l%d" % (prefix, name, l)
+            n = int(np.prod(shape))
+            sd[key] = ((uniform01(n, _stream(seed, key)) * np.float32(2.0) - np.float32(1.0)) * np.float32(k)).reshape(shape).astype(np.float32)
+    return sd
+
+
+def make_apc_state_dict(mel_dim: int = 80, hidden: int = 512, layers: int = 3, seed: int = 11) -> Dict[str, np.ndarray]:
+    """Keys of the reference's APC_encoder: one single-layer nn.GRU per entry of ``rnns`` (models/networks.py:33-34)."""
+    sd = {}
+    for i in range(layers):
+        one = make_rnn_state_dict("GRU", 1, mel_dim if i == 0 else hidden, hidden, seed=seed + i)
+        sd.update({"rnns.%d.%s" % (i, k): v for k, v in one.items()})
+    return sd
+
+
+def a2f_shapes(hidden: int = 512, out: int = 75) -> Dict[str, Tuple[int, ...]]:
+    s = {"downsample.0.weight": (hidden, 2 * hidden), "downsample.0.bias": (hidden,),
+         "downsample.3.weight": (hidden, hidden), "downsample.3.bias": (hidden,),
+         "fc.0.weight": (512, 256), "fc.0.bias": (512,), "fc.3.weight": (512, 512), "fc.3.bias": (512,),
+         "fc.6.weight": (out, 512), "fc.6.bias": (out,)}
+    for bn, n in (("downsample.1", hidden), ("fc.1", 512), ("fc.4", 512)):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s["%s.%s" % (bn, leaf)] = (n,)
+    return s
+
+
+def make_a2f_state_dict(hidden: int = 512, out: int = 75, seed: int = 23) -> Dict[str, np.ndarray]:
+    """Audio2Feature (LSTM decoder) keys: downsample.*, LSTM.weight_ih_l<k> ..., fc.*  (models/audio2feature.py:35-54)."""
+    sd = {}
+    for key, shape in a2f_shapes(hidden, out).items():
+        n = int(np.prod(shape))
+        st = _stream(seed, key)
+        if key.endswith("running_var"):
+            v = uniform01(n, st) * np.float32(0.7) + np.float32(0.9)
+        elif key.endswith("running_mean"):
+            v = symmetric(n, 0.05, st)
+        elif len(shape) == 2:
+            v = symmetric(n, 1.0 / float(np.sqrt(shape[1])), st)
+        elif key.endswith(".1.weight") or key.endswith(".4.weight"):
+            v = np.float32(1.0) + symmetric(n, 0.02, st)
+        else:
+            v = symmetric(n, 0.05, st)
+        sd[key] = v.reshape(shape).astype(np.float32)
+    sd.update(make_rnn_state_dict("LSTM", 3, hidden, 256, seed=seed, prefix="LSTM."))
+    return sd
+
+
+def make_mel(T: int, mel_dim: int = 80, seed: int = 31) -> np.ndarray:
+    """log-mel-like input [T, mel_dim]: smooth in time (a random walk), unit scale."""
+    steps = symmetric(T * mel_dim, 0.35, _stream(seed, "mel")).reshape(T, mel_dim)
+    x = np.cumsum(steps, 0)
+    return (x - x.mean(0)).astype(np.float32) * np.float32(0.5)

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""ORACLE tooling -- freeze outputs of the reference's OWN APC_encoder and Audio2FeatureModel into tests/golden/rnn_*.npz.
+Container only (needs /root/reference).  Asserts oracle/rnn_oracle.py is bit-identical to them."""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from livespeechportraits_amd import synth          # noqa: E402
+from oracle import rnn_oracle                       # noqa: E402
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("make_golden_rnn.py needs /root/reference (build container only)")
+    for name in ("torchvision", "torchvision.models", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, REF)
+    from models.networks import APC_encoder                      # reference classes
+    from models.audio2feature_model import Audio2FeatureModel
+    out = os.path.join(REPO, "tests", "golden")
+
+    # ---- APC encoder, as demo.py:146-151, 186-191 uses it (mel_dim 80, hidden 512, 3 layers, residual False)
+    for name, T in (("apc_t300", 300), ("apc_t1", 1)):
+        sd = synth.make_apc_state_dict()
+        mel = synth.make_mel(T)
+        net = APC_encoder(80, 512, 3, False)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+        ref = net.forward(torch.from_numpy(mel).unsqueeze(0), torch.Tensor([T]))[0].numpy()
+        ora = rnn_oracle.apc_forward(sd, mel)
+        assert np.array_equal(ora, ref), np.abs(ora - ref).max()
+        l0 = rnn_oracle.gru_cell_reference({k[7:]: v for k, v in sd.items() if k.startswith("rnns.0.")}, mel, 512)
+        first = torch.nn.GRU(80, 512, batch_first=True)
+        first.load_state_dict({k[7:]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("rnns.0.")})
+        e0 = np.abs(first(torch.from_numpy(mel).unsqueeze(0))[0][0].detach().numpy() - l0).max()
+        print("%-10s T %4d  |out| max %.3f std %.3f  mean |h_t - h_{t-1}| %.3f  oracle bit-exact; float64 equations vs torch layer 0: %.1e"
+              % (name, T, np.abs(ref).max(), ref.std(), np.abs(np.diff(ref, axis=0)).mean() if T > 1 else 0.0, e0))
+        np.savez_compressed(os.path.join(out, "rnn_%s.npz" % name), out=ref)
+        json.dump({"T": T, "weights_seed": 11, "mel_seed": 31, "keys": {k: list(v.shape) for k, v in net.state_dict().items()}},
+                  open(os.path.join(out, "rnn_%s.json" % name), "w"), indent=0)
+
+    # ---- Audio2Feature (default LSTM decoder, L2 output 75, frame_future 18: options/base_options_audio2feature.py:43-58)
+    for name, n2, ff in (("a2f_n120", 240, 18), ("a2f_n40_ff0", 80, 0)):
+        opt = argparse.Namespace(gpu_ids=[], isTrain=False, checkpoints_dir="/tmp", name="a2f", load_epoch="none", verbose=False,
+                                 feature_decoder="LSTM", loss="L2", A2L_GMM_ndim=75, A2L_GMM_ncenter=1, predict_length=1,
+                                 APC_hidden_size=512, frame_future=ff, model="audio2feature", task="Audio2Feature")
+        model = Audio2FeatureModel(opt)
+        sd = synth.make_a2f_state_dict()
+        net = model.Audio2Feature
+        ref_keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert {k: v for k, v in ref_keys.items() if not k.endswith("num_batches_tracked")} == {k: list(v.shape) for k, v in sd.items()}
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        model.eval()
+        model.device = torch.device("cpu")
+        feats = synth.symmetric(n2 * 512, 0.5, 77).reshape(n2, 512)
+        ref = model.generate_sequences(feats.copy(), 16000, 60, fill_zero=True, opt=opt)
+        ora = rnn_oracle.a2f_generate(sd, feats, ff)
+        assert np.array_equal(ora, ref), np.abs(ora - ref).max()
+        print("%-12s rows %3d frame_future %2d -> %s  |out| max %.3f std %.3f  oracle bit-exact" % (name, n2, ff, ref.shape, np.abs(ref).max(), ref.std()))
+        np.savez_compressed(os.path.join(out, "rnn_%s.npz" % name), out=ref)
+        json.dump({"rows": n2, "frame_future": ff, "weights_seed": 23, "feats_stream": 77, "keys": ref_keys},
+                  open(os.path.join(out, "rnn_%s.json" % name), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()

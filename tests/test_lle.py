@@ -124,6 +124,6 @@ def test_argument_errors():
     with pytest.raises(N.LsplleError):
         manifold.knn(f, b, 17)                       # K > 16
     with pytest.raises(N.LsplleError):
-        manifold.knn(torch.zeros(4, 40, device=dev), torch.zeros(8, 40, device=dev), 2)    # d % 32
+        manifold.knn(torch.zeros(4, 42, device=dev), torch.zeros(8, 42, device=dev), 2)    # d % 4
     with pytest.raises(ValueError):
         manifold.knn(f, torch.zeros(8, 32, device=dev), 2)
