@@ -205,7 +205,9 @@ def test_inference_has_no_cpu_fallback():
     with pytest.raises(NotImplementedError):
         L.create_model(opt_ns(isTrain=True))
     with pytest.raises(NotImplementedError):
-        L.create_model(opt_ns(model="audio2feature"))
+        L.create_model(opt_ns(model="pix2pix"))                     # not one of the three models this package replaces
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        L.create_model(opt_ns(model="audio2feature", feature_decoder="LSTM"))      # supported, but never on the CPU
 
 
 def test_synth_is_deterministic_and_matches_recipe():
