@@ -28,7 +28,9 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, world, local = env_rank()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # LSP_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): used by the tests to run the
+            # multi-rank control flow on a single-GPU box.  Production: nccl (= RCCL over xGMI).
+            backend = os.environ.get("LSP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":

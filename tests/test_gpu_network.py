@@ -271,3 +271,32 @@ def test_batched_render_loop_on_gpu(gpu_device, tmp_path):
         one = model.inference_image(torch.from_numpy(feats[i:i + 1]).to(gpu_device), c)[0].cpu().numpy()
         d = np.abs(one.astype(np.int16) - frames[i].astype(np.int16))
         assert d.max() <= 1            # batch-1 and batch-3 tilings sum in a different order: <= 1 grey level
+
+
+def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path end to end on real hardware: two processes (gloo: RCCL refuses two ranks on one device),
+    both on cuda:0 -- rank 0 packs, one broadcast of the blob, barrier-bracketed timing, MAX over ranks, one JSON line.
+    Says nothing about scaling; it proves the control flow the driver's multi-GPU run goes through executes."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LSP_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                                       "--variant", "normal", "--no-cpu-baseline", "--no-extra"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-600:] for o in outs]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")], "exactly rank 0 prints the JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2
+    assert d["value"] > 0 and abs(d["value"] - 2 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-2 * d["value"]     # whole-job frames / max-rank time
