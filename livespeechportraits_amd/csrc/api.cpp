@@ -195,7 +195,7 @@ static const char *kernel_name(const LayerDesc &l)
 {
     switch (l.kind) {
     case kFirstConv: return "first_conv";
-    case kLastConv: return "last_conv";
+    case kLastConv: return l.wgemm_off >= 0 ? "last_conv (igemm3x3 + pixel_shuffle_tanh)" : "last_conv";
     default: return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3+splitk_reduce" : "igemm3x3");
     }
 }
@@ -249,6 +249,20 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             if (e == hipSuccess) e = launch_first_conv(p, s);
         } else {
             e = launch_first_conv(p, s);
+        }
+    } else if (l.kind == kLastConv && P.last_as_gemm(l) && !std::getenv("LSP_HIP_LASTCONV_DIRECT")) {
+        // bf16: 3x3 conv on the low-res source with N = 4 parities x cout through the MFMA kernel, then shuffle + tanh
+        IgemmParams g{};
+        g.src0 = tptr(l.src0); g.src1 = tptr(l.src1); g.w = h->blob + l.wgemm_off;
+        g.out = h->ws + P.partial_offset; g.out_f32 = 1;
+        g.B = batch; g.Hs = l.hs; g.Ws = l.hs; g.Ho = l.hs; g.Wo = l.hs;
+        g.C0 = l.c0; g.C1 = l.c1; g.Cin = l.cin; g.Cout = 4 * l.cout;
+        g.stride = 1; g.Mout = batch * l.hs * l.hs; g.M = g.Mout; g.dtype = P.dtype;
+        g.ktiles_total = 9 * l.cin / P.ktile_channels(); g.splits = 1; g.ktiles_per_split = g.ktiles_total;
+        e = launch_igemm(g, 128, 32, 1, s);
+        if (e == hipSuccess) {
+            ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0};
+            e = launch_pixel_shuffle(sp, s);
         }
     } else if (l.kind == kLastConv) {
         LastConvParams p{};

@@ -537,4 +537,38 @@ hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
     }
 }
 
+// Pixel shuffle + tanh after the GEMM form of the last conv.  One thread per low-res pixel: 4*Cout values in, the 2x2
+// output pixels of every channel out; lanes run along x so every store instruction writes one contiguous row segment.
+__global__ __launch_bounds__(256) void pixel_shuffle_tanh(ShuffleParams p)
+{
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.B * p.Hs * p.Ws;
+    if (gid >= total) return;
+    const int x = (int)(gid % p.Ws), y = (int)((gid / p.Ws) % p.Hs), b = (int)(gid / ((long)p.Ws * p.Hs));
+    const int n = 4 * p.Cout, Ho = 2 * p.Hs, Wo = 2 * p.Ws;
+    const float4 *g4 = reinterpret_cast<const float4 *>(p.g + gid * n);
+    float v[16];
+    for (int i = 0; i < n / 4; ++i) { const float4 t = g4[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+    if (p.apply_tanh) for (int i = 0; i < n; ++i) v[i] = tanhf(v[i]);
+    for (int py = 0; py < 2; ++py) {
+        if (p.out)
+            for (int co = 0; co < p.Cout; ++co)
+                *reinterpret_cast<float2 *>(p.out + (((long)b * p.Cout + co) * Ho + 2 * y + py) * Wo + 2 * x) =
+                    make_float2(v[(py * 2) * p.Cout + co], v[(py * 2 + 1) * p.Cout + co]);
+        if (p.out_u8) {
+            unsigned char *o = p.out_u8 + (((long)b * Ho + 2 * y + py) * Wo + 2 * x) * p.Cout;
+            for (int px = 0; px < 2; ++px)
+                for (int co = 0; co < p.Cout; ++co) o[px * p.Cout + co] = to_u8(v[(py * 2 + px) * p.Cout + co]);
+        }
+    }
+}
+
+hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s)
+{
+    if (p.Cout < 1 || p.Cout > 4) return hipErrorInvalidValue;
+    const long total = (long)p.B * p.Hs * p.Ws;
+    hipLaunchKernelGGL(pixel_shuffle_tanh, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace lspf2f

@@ -358,7 +358,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
+                    if (p.out_f32) store4(static_cast<float *>(p.out) + orow * p.Cout + n, v);
+                    else store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
                 }
             }
         }
@@ -499,6 +500,7 @@ static hipError_t launch_igemm_typed(const IgemmParams &p, int bm, int bn, int g
         if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 2, false>(p, s);
         return hipErrorInvalidValue;
     }
+    if (bm == 128 && bn == 32) return launch_igemm_t<T, 128, 32, 4, 1, 1, false>(p, s);     // narrow N: the last conv as a GEMM
     if (bm == 128 && bn == 128) return launch_igemm_t<T, 128, 128, 2, 2, 1, false>(p, s);
     if (bm == 128 && bn == 64) return launch_igemm_t<T, 128, 64, 2, 2, 1, false>(p, s);
     if (bm == 64 && bn == 128) return launch_igemm_t<T, 64, 128, 2, 2, 1, false>(p, s);

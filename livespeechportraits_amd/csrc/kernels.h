@@ -52,13 +52,14 @@ struct IgemmParams {
     int ktiles_per_split;
     int splits;
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
+    int out_f32;                // write fp32 output whatever the storage type (GEMM form of the last conv)
     int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
     int dbg;                    // ablation bits for tools/ (0 in production): 1 no refetch, 2 no LDS restage, 4 no barrier, 8 no buffer flip
 };
 
 struct TileConfig { int bm, bn; };
 // tile shapes the igemm kernel is instantiated for
-static const TileConfig kTileConfigs[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {32, 64}};
+static const TileConfig kTileConfigs[] = {{128, 32}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {32, 64}};
 static const int kNumTileConfigs = sizeof(kTileConfigs) / sizeof(kTileConfigs[0]);
 
 bool igemm_tile_supported(int bm, int bn);
@@ -107,5 +108,15 @@ struct LastConvParams {
     unsigned char *out_u8;     // optional HWC uint8 frame [B][2Hs][2Ws][Cout] = tensor2im(out); out may then be nullptr
 };
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);
+
+// second pass of the GEMM form of the last conv: [B][Hs][Ws][4*Cout] fp32 (channel = parity*Cout + co) ->
+// tanh -> NCHW fp32 [B][Cout][2Hs][2Ws] and/or HWC uint8 (tensor2im)
+struct ShuffleParams {
+    const float *g;
+    float *out;
+    unsigned char *out_u8;
+    int B, Hs, Ws, Cout, apply_tanh;
+};
+hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s);
 
 }  // namespace lspf2f

@@ -204,6 +204,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
         l.up4 = l.kind == kIgemm && l.up && l.ho >= kUp4MinExtent;
         if (l.up4) l.up = false;
         off += (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9) * (layer_weights_typed(l) ? elt() : sizeof(float));
+        if (last_as_gemm(l)) {
+            off = align_up(off, 256);
+            l.wgemm_off = (int64_t)off;
+            off += (size_t)4 * l.cout * 9 * l.cin * elt();
+        }
         if (!l.bnkey.empty()) {
             off = align_up(off, 256);
             l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
@@ -301,6 +306,8 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }
+        // the GEMM form of the last conv parks its [B][hs][hs][4*cout] fp32 result in the split-K scratch (idle by then)
+        if (p.last_as_gemm(l)) partial = std::max(partial, (size_t)batch * l.hs * l.hs * 4 * l.cout * sizeof(float));
     }
     if (offsets) *offsets = off;
     return {align_up(a.end, 256), align_up(partial, 256)};
@@ -362,6 +369,23 @@ std::string Plan::pack(void *blob, size_t bytes) const
                                     dst[(((size_t)(py * 2 + px) * cout + co) * 4 + a * 2 + b) * cin + ci] = (float)acc;
                                 }
                         }
+            if (last_as_gemm(l)) {
+                // the same pre-summed taps as one 3x3 conv on the LOW-res source: output channel par*cout + co, tap
+                // (a, b) of parity (py, px) sits at low-res offset (py - 1 + a, px - 1 + b); the other taps are zero
+                uint16_t *g = reinterpret_cast<uint16_t *>(base + l.wgemm_off);
+                for (int par = 0; par < 4; ++par)
+                    for (int co = 0; co < cout; ++co)
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b) {
+                                const int tap = ((par >> 1) + a) * 3 + (par & 1) + b;
+                                for (int ci = 0; ci < cin; ++ci) {
+                                    uint32_t u;
+                                    std::memcpy(&u, &dst[(((size_t)par * cout + co) * 4 + a * 2 + b) * cin + ci], 4);
+                                    u += 0x7fffu + ((u >> 16) & 1u);
+                                    g[(((size_t)par * cout + co) * 9 + tap) * cin + ci] = (uint16_t)(u >> 16);
+                                }
+                            }
+            }
         } else if (l.kind == kIgemm) {
             // [co][tap][ci]  -- the implicit-GEMM B operand, K contiguous per output channel
             for (int co = 0; co < cout; ++co)

@@ -36,6 +36,7 @@ struct LayerDesc {
     std::string wkey;      // state-dict key of the OIHW weight
     std::string bnkey;     // state-dict prefix of the following BatchNorm2d ("" = none)
     int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
+    int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
     int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
     bool smallm = false;   // executed by the single-launch tiny-M kernel (M <= 16) instead of the igemm
@@ -56,6 +57,8 @@ struct Plan {
     size_t elt() const { return dtype == 1 ? 2 : 4; }
     int ktile_channels() const { return dtype == 1 ? 64 : 32; }   // a K-tile is 128 B of channels
     bool layer_weights_typed(const LayerDesc &l) const { return l.kind == kIgemm; }   // else fp32
+    // bf16: the last conv runs as an implicit GEMM on the low-res source (N = 4 parities x cout) + a pixel-shuffle/tanh pass
+    bool last_as_gemm(const LayerDesc &l) const { return dtype == 1 && l.kind == kLastConv && l.cin % 64 == 0; }
     std::vector<LayerDesc> layers;
     std::vector<TensorDesc> tensors;
     std::vector<ParamDesc> params;
