@@ -1,0 +1,77 @@
+"""Hand-off robustness of the multi-workgroup kernels (csrc/a2h.hip a2h_pipe, csrc/rnn.hip rnn_layer): the protocols must
+not depend on timing, placement or an idle GPU.  Every repetition must be bit-identical to a quiet run and report no
+timeout while the renderer saturates the device on another stream (cdna_hip_programming.md Guideline 16, pitfall 3:
+a test on an idle, L1-cold GPU cannot see a missing acquire)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _renderer(dev):
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.topology import build_topology
+    topo = build_topology("normal", size=512)
+    e = Engine("normal", size=512, max_batch=8)
+    e.load_state_dict(synth.make_state_dict(topo, 1234))
+    e.bind(e.pack(), dev)
+    feat, cand = synth.make_inputs(8, 512, seed=99, cand_batch=1)
+    return e, torch.from_numpy(feat).to(dev), torch.from_numpy(cand).to(dev)
+
+
+def test_headpose_pipeline_under_load_is_bit_stable():
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.a2h_engine import HeadposeEngine
+    dev = torch.device("cuda:0")
+    cfg, ff, nframe = dict(synth.A2H_DEFAULTS), 15, 400
+    e = HeadposeEngine(max_audio_frames=nframe + ff)
+    e.load_state_dict(synth.make_a2h_state_dict(cfg))
+    e.bind(dev)
+    audio, pre = synth.make_a2h_inputs(nframe + ff, cfg)
+    au, pr = torch.from_numpy(audio).to(dev), torch.from_numpy(pre).to(dev)
+    noise = torch.from_numpy(synth.symmetric(nframe * 12, 1.0, 5).reshape(nframe, 12)).to(dev)
+    quiet = e.generate(au, pr, noise, None, 0.3, ff)
+    assert e.status() == 0
+    quiet = quiet.cpu().numpy()
+    ref_single = HeadposeEngine(max_audio_frames=nframe + ff, single_workgroup=True)
+    ref_single.load_state_dict(synth.make_a2h_state_dict(cfg)); ref_single.bind(dev)
+    assert np.array_equal(ref_single.generate(au, pr, noise, None, 0.3, ff).cpu().numpy(), quiet)
+
+    rend, f8, c = _renderer(dev)
+    side = torch.cuda.Stream(dev)
+    o8 = torch.empty((8, 3, 512, 512), device=dev)
+    for rep in range(12):
+        with torch.cuda.stream(side):                      # ~15 ms of renderer work queued per repetition: the GPU stays busy
+            for _ in range(4):
+                rend.forward(f8, c, o8)
+        out = e.generate(au, pr, noise, None, 0.3, ff)
+        assert e.status() == 0, "hand-off timed out under load (rep %d)" % rep
+        assert np.array_equal(out.cpu().numpy(), quiet), "repetition %d differs from the quiet run" % rep
+    torch.cuda.synchronize()
+
+
+def test_recurrent_stacks_under_load_are_bit_stable():
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.rnn_engine import RecurrentEngine
+    dev = torch.device("cuda:0")
+    rend, f8, c = _renderer(dev)
+    side = torch.cuda.Stream(dev)
+    o8 = torch.empty((8, 3, 512, 512), device=dev)
+    for cell, n_in, H, T in (("GRU", 80, 512, 700), ("LSTM", 512, 256, 500)):
+        e = RecurrentEngine(cell, 3, n_in, H, max_steps=T)
+        e.load_state_dict(synth.make_rnn_state_dict(cell, 3, n_in, H))
+        e.bind(dev)
+        x = torch.from_numpy(synth.symmetric(T * n_in, 0.7, 3).reshape(T, n_in)).to(dev)
+        quiet = e.forward(x)
+        assert e.status() == 0
+        quiet = quiet.cpu().numpy()
+        for rep in range(12):
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    rend.forward(f8, c, o8)
+            out = e.forward(x)
+            assert e.status() == 0, "%s hand-off timed out under load (rep %d)" % (cell, rep)
+            assert np.array_equal(out.cpu().numpy(), quiet), "%s repetition %d differs from the quiet run" % (cell, rep)
+    torch.cuda.synchronize()
