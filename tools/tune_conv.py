@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--shape", action="append", default=[], help="extra shape 'cin,cout,h[,stride]' (plain 3x3, one source); repeatable; replaces the built-in list")
     a = ap.parse_args()
     global DT
     DT = 1 if a.dtype == "bf16" else 0
@@ -51,7 +52,13 @@ def main():
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     lines = []
-    for name, c0, c1, cout, hs, stride, up in SHAPES:
+    shapes = SHAPES
+    if a.shape:
+        shapes = []
+        for spec in a.shape:
+            f = [int(v) for v in spec.split(",")]
+            shapes.append(("%d>%d@%d%s" % (f[0], f[1], f[2], "s2" if len(f) > 3 and f[3] == 2 else ""), f[0], 0, f[1], f[2], f[3] if len(f) > 3 else 1, 0))
+    for name, c0, c1, cout, hs, stride, up in shapes:
         if a.only and a.only not in name:
             continue
         b = a.batch
