@@ -524,7 +524,12 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
         static const int forced = std::getenv("LSP_HIP_XCD") ? std::atoi(std::getenv("LSP_HIP_XCD")) : -1;
         const size_t act = (size_t)p.B * p.Hs * p.Ws * p.Cin * eb;
         const size_t wgt = (size_t)(p.up4 ? 16 : 9) * p.Cin * p.Cout * eb;
-        p.xcd = forced >= 0 ? forced : (wgt > act ? 2 : 1);
+        int rule = wgt > act ? 2 : 1;
+        // Measured exception, keyed on dtype like choose_tiling(): activation-heavy split-K layers keep dispatch order in
+        // fp32 plans (m-major chunks cost them 4 %: fp32 batch 1 +0.8 % with the exception) but not in bf16 plans
+        // (batch 8 -1.1 / -1.4 % with it); DESIGN.md 4.1.
+        if (rule == 1 && p.splits > 1 && p.dtype == 0) rule = 0;
+        p.xcd = forced >= 0 ? forced : rule;
     }
     return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
 }
