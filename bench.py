@@ -196,6 +196,7 @@ def main():
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
+        extra["pipeline_gpu_stages_plumbing_only"] = pipeline_extra(dev, eng, cand)
 
     line = {
         "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",
@@ -256,6 +257,60 @@ def headpose_extra(dev, cpu_threads):
                                "sample": "%d frames of oracle/a2h_oracle.generate_sequences: the reference's per-frame 255-wide "
                                          "re-evaluation (torch %s CPU)" % (n, torch.__version__)}
     return out
+
+
+def pipeline_extra(dev, eng, cand):
+    """BASELINE.json configs[4] shape, PLUMBING ONLY: the device stages of demo.py chained on one stream for a 687-frame clip
+    (data/Input/00083.wav is 687 frames at 60 fps = 11.45 s) with synthetic weights and stand-in data -- APC encoder ->
+    manifold projection -> Audio2Feature and Audio2Headpose -> renderer (batch 8, fused tensor2im, uint8 frames left on the
+    device).  NOT in it, because the reference does them on the CPU with libraries absent here (librosa, cv2) or with
+    per-person assets that cannot be obtained: mel spectrogram, smoothing / head-pose post-processing, 3-D projection,
+    landmark rasterisation (the feature maps are synthetic), JPEG / video writing.  One number: clip frames per second of
+    wall-clock over those device stages."""
+    from livespeechportraits_amd import manifold, synth
+    from livespeechportraits_amd.a2h_engine import HeadposeEngine
+    from livespeechportraits_amd.apc import APC_encoder
+    from livespeechportraits_amd.audio2feature import Audio2Feature
+    import argparse as _ap
+    nframe, ff_head, ff_feat = 687, 15, 18
+    apc = APC_encoder(80, 512, 3, False)
+    apc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_apc_state_dict().items()})
+    apc = apc.to(dev).eval()
+    a2f = Audio2Feature(_ap.Namespace(feature_decoder="LSTM", loss="L2", A2L_GMM_ndim=75, A2L_GMM_ncenter=1, predict_length=1, APC_hidden_size=512))
+    a2f.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_a2f_state_dict().items()}, strict=False)
+    a2f = a2f.to(dev).eval()
+    cfg = dict(synth.A2H_DEFAULTS)
+    a2h = HeadposeEngine(max_audio_frames=nframe + ff_head)
+    a2h.load_state_dict(synth.make_a2h_state_dict(cfg)); a2h.bind(dev)
+    db = torch.from_numpy(synth.make_feature_database(30000, 8, 512, 24)[0]).to(dev)
+    mel = torch.from_numpy(synth.make_mel(2 * nframe)).to(dev).unsqueeze(0)
+    pre = torch.zeros(12, device=dev)
+    noise = torch.from_numpy(synth.symmetric(nframe * 12, 1.0, 5).reshape(nframe, 12)).to(dev)
+    maps = torch.from_numpy(synth.make_inputs(8, eng.size, seed=7, cand_batch=1)[0]).to(dev)     # stand-in edge maps, reused per batch
+    frames = torch.empty((8, eng.size, eng.size, 3), dtype=torch.uint8, device=dev)
+
+    def clip():
+        feats = apc.forward(mel, torch.Tensor([2 * nframe]))[0]                                 # [1374, 512]
+        feats = manifold.project(feats.contiguous(), db, 10, 1.0)
+        tail = feats[-1:].expand(2 * ff_feat, -1)
+        mouth = a2f.forward(torch.cat([feats, tail]).unsqueeze(0))[0, ff_feat:]                 # [687, 75]
+        a2h_in = torch.cat([feats.reshape(nframe, 1024), feats.reshape(nframe, 1024)[-1:].expand(ff_head, -1)]).contiguous()
+        poses = a2h.generate(a2h_in, pre, noise, None, 0.3, ff_head)                            # [687, 12]
+        for i in range(0, nframe, 8):
+            b = min(8, nframe - i)
+            eng.forward_image(maps[:b], cand, frames[:b])
+        return mouth, poses
+
+    clip(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); clip(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    if a2h.status() != 0 or a2f.status() != 0 or apc._engine.status() != 0:
+        raise RuntimeError("a hand-off kernel timed out")
+    ts.sort()
+    return {"label": "plumbing only: synthetic weights, stand-in feature maps, device stages only (see bench.py pipeline_extra)",
+            "clip_frames": nframe, "seconds_median": round(ts[1], 4), "clip_frames_per_s": round(nframe / ts[1], 1),
+            "x_realtime_at_60fps": round((nframe / 60.0) / ts[1], 2)}
 
 
 def recurrent_extra(dev, cpu_threads):
