@@ -44,12 +44,13 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
 {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
-// sum over aligned groups of P lanes (8 or 16), every lane gets the total
+// sum over aligned groups of P lanes (8, 16 or 32), every lane gets the total
 template <int P> __device__ __forceinline__ float sum_p(float v)
 {
     v = dpp_add<0x4E>(dpp_add<0xB1>(v));        // quad_perm xor 1, xor 2
     v = dpp_add<0x141>(v);                      // row_half_mirror: + the other quad of the 8
-    if (P == 16) v = dpp_add<0x140>(v);         // row_mirror: + the other half of the 16
+    if (P >= 16) v = dpp_add<0x140>(v);         // row_mirror: + the other half of the 16
+    if (P == 32) v += __shfl_xor(v, 16);        // the neighbouring DPP row
     return v;
 }
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
@@ -138,6 +139,132 @@ template <int GATES, int P> __global__ __launch_bounds__(NT) void rnn_layer(Laye
     }
 }
 
+// Wavefront form: every layer of the stack runs in the same launch, layer l working on step t while layer l-1 is already
+// on a later step.  A workgroup of layer l >= 1 also keeps the W_ih rows of its units resident (its input is the layer
+// below's h_t, known only step by step) and polls two vectors per step: its own layer's h_{t-1} and the layer below's
+// h_t.  Layer 0 still takes its input projection from the gemm (x is known for all steps).  Two matrices per thread,
+// so the columns are cut into parts of 16: P = H / 16 lanes share a unit (48 + 48 VGPRs of weights for a GRU,
+// 64 + 64 for an LSTM); 32 parts of 32 columns spilled for the GRU-512.
+struct WaveParams {
+    const float *blob; unsigned blob_bytes;
+    unsigned whh[8], wih[8];       // byte offsets per layer: packed W_hh; packed W_ih (layers >= 1, same thread map)
+    const float *bias[8];          // layers >= 1: b_ih (+ b_hh except the GRU's n gate), [GATES*H]
+    const float *bhn[8];           // GRU: b_hn [H]
+    const float *xproj;            // layer 0: [T][GATES*H]
+    float *out;                    // [T][H] top layer
+    unsigned long long *hbox;      // [layers][T][H] granules
+    unsigned *status;
+    unsigned epoch;
+    int T, H, layers, wgs_per_layer, stride;
+};
+
+template <int GATES, int P, int CPP> __global__ __launch_bounds__(NT) void rnn_wave(WaveParams p)
+{
+    __shared__ __attribute__((aligned(16))) float hown[512];
+    __shared__ __attribute__((aligned(16))) float hlow[512];
+    if (blockIdx.x % p.stride) return;
+    const int b = blockIdx.x / p.stride;
+    const int l = b / p.wgs_per_layer, wg = b % p.wgs_per_layer;
+    constexpr int U = NT / P, Q = CPP / 4;                  // units per workgroup; float4 per gate per thread
+    const int tid = threadIdx.x, part = tid % P, ul = tid / P;
+    const int unit = wg * U + ul;
+    const int H = p.H;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void *)p.blob, 0, (int)p.blob_bytes, 0x00020000);
+    const unsigned plane = (unsigned)p.T * (unsigned)H * 8u;
+    const __amdgpu_buffer_rsrc_t box = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbox, 0, (int)(plane * (unsigned)p.layers), 0x00020000);
+    float4 W[GATES * Q], V[GATES * Q];
+#pragma unroll
+    for (int i = 0; i < GATES * Q; ++i) {
+        W[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+            blob, tid * 16, (int)(p.whh[l] + ((unsigned)wg * GATES * Q + (unsigned)i) * NT * 16u), 0));
+        V[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l > 0)
+            V[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                blob, tid * 16, (int)(p.wih[l] + ((unsigned)wg * GATES * Q + (unsigned)i) * NT * 16u), 0));
+    }
+    float bg[GATES];
+#pragma unroll
+    for (int g = 0; g < GATES; ++g) bg[g] = (l > 0 && part == 0) ? p.bias[l][g * H + unit] : 0.f;
+    const float bhn = (GATES == 3 && part == 0) ? p.bhn[l][unit] : 0.f;
+    const bool top = l + 1 == p.layers;
+    float hprev = 0.f, cprev = 0.f;
+    for (int t = 0; t < p.T; ++t) {
+        float xg[GATES];
+#pragma unroll
+        for (int g = 0; g < GATES; ++g) xg[g] = bg[g];
+        if (l == 0 && part == 0) {
+#pragma unroll
+            for (int g = 0; g < GATES; ++g) xg[g] = p.xproj[((size_t)t * GATES + g) * H + unit];
+        }
+        bool ok = true;
+        // two polls per thread at most: own layer's h_{t-1} (slot t-1), the layer below's h_t (slot t)
+        for (int which = 0; which < 2 && ok; ++which) {
+            float *dst = which ? hlow : hown;
+            if (which == 0 && t == 0) { if (tid < H) dst[tid] = 0.f; continue; }
+            if (which == 1 && l == 0) continue;
+            if (tid < H) {
+                const int slot = (int)((unsigned)(which ? l - 1 : l) * plane + (unsigned)(which ? t : t - 1) * (unsigned)H * 8u);
+                for (unsigned spins = 0;;) {
+                    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(box, tid * 8, slot, AUX_SC1);
+                    asm volatile("" ::: "memory");
+                    if (g.y == p.epoch) { dst[tid] = __uint_as_float(g.x); break; }
+                    if (++spins > SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(p.status, RLX_AGENT) != 0)) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) atomicCAS(p.status, 0u, 0x2000000u + ((unsigned)l << 20) + (unsigned)t);
+            }
+        }
+        if (!__syncthreads_and(ok)) return;
+        float a[GATES], c[GATES];
+        {
+            const float4 *v = reinterpret_cast<const float4 *>(hown + part * CPP);
+            const float4 *u = reinterpret_cast<const float4 *>(hlow + part * CPP);
+#pragma unroll
+            for (int g = 0; g < GATES; ++g) { a[g] = 0.f; c[g] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float4 x = v[q];
+#pragma unroll
+                for (int g = 0; g < GATES; ++g) a[g] = dot4(W[g * Q + q], x, a[g]);
+            }
+            if (l > 0) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float4 x = u[q];
+#pragma unroll
+                    for (int g = 0; g < GATES; ++g) c[g] = dot4(V[g * Q + q], x, c[g]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < GATES; ++g) { a[g] = sum_p<P>(a[g]); c[g] = sum_p<P>(c[g]); }
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int g = 0; g < GATES; ++g) xg[g] += c[g];       // input side: W_ih h_below + biases (layer 0: from the gemm)
+            float hn;
+            if (GATES == 3) {
+                const float r = sigmoidf(xg[0] + a[0]);
+                const float z = sigmoidf(xg[1] + a[1]);
+                const float n = tanhf(xg[2] + r * (a[2] + bhn));
+                hn = (1.f - z) * n + z * hprev;
+            } else {
+                const float i = sigmoidf(xg[0] + a[0]);
+                const float f = sigmoidf(xg[1] + a[1]);
+                const float g = tanhf(xg[2] + a[2]);
+                const float o = sigmoidf(xg[GATES - 1] + a[GATES - 1]);
+                cprev = f * cprev + i * g;
+                hn = o * tanhf(cprev);
+            }
+            hprev = hn;
+            u32x2 gr; gr.x = __float_as_uint(hn); gr.y = p.epoch;
+            if (t + 1 < p.T || !top)          // consumers: this layer's next step, and the layer above at this step
+                __builtin_amdgcn_raw_buffer_store_b64(gr, box, unit * 8, (int)((unsigned)l * plane + (unsigned)t * (unsigned)H * 8u), AUX_SC1);
+            if (top) p.out[(size_t)t * H + unit] = hn;
+        }
+        __syncthreads();
+    }
+}
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 static int hipfail(hipError_t e, const char *what) { return fail(LSPRNN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
@@ -160,6 +287,8 @@ struct lsprnn_handle {
     std::vector<Slot> tensors;
     std::map<std::string, int> index;
     std::vector<size_t> o_wih, o_bias, o_whh, o_bhn;     // per layer, float offsets
+    std::vector<size_t> o_whh_w, o_wih_w;                // wavefront kernel: packed W_hh / W_ih (its own thread map)
+    int Pw = 0, CPPw = 0, Uw = 0, Gw = 0;               // wavefront geometry
     size_t blob_floats = 0;
     const float *blob = nullptr;
     float *ws = nullptr;
@@ -170,7 +299,7 @@ struct lsprnn_handle {
     int in_size(int l) const { return l == 0 ? cfg.input_size : cfg.hidden_size; }
     size_t xproj_floats() const { return align64((size_t)cfg.max_steps * gates * cfg.hidden_size); }
     size_t hseq_floats() const { return align64((size_t)cfg.max_steps * cfg.hidden_size); }
-    size_t box_bytes() const { return (size_t)cfg.max_steps * cfg.hidden_size * 8; }
+    size_t box_bytes() const { return (size_t)cfg.num_layers * cfg.max_steps * cfg.hidden_size * 8; }
 };
 
 extern "C" {
@@ -208,7 +337,11 @@ int lsprnn_create(const lsprnn_config *cfg, lsprnn_handle **out)
         h->o_bias.push_back(take(gh));
         h->o_whh.push_back(take(gh * H));
         h->o_bhn.push_back(take(H));
+        h->o_whh_w.push_back(take(gh * H));
+        h->o_wih_w.push_back(l ? take(gh * H) : 0);
     }
+    // wavefront geometry: two weight matrices per thread -> parts of 16 columns
+    h->CPPw = 16; h->Pw = cfg->hidden_size / 16; h->Uw = NT / h->Pw; h->Gw = cfg->hidden_size / h->Uw;
     h->blob_floats = o;
     *out = h;
     return LSPRNN_OK;
@@ -257,6 +390,22 @@ int lsprnn_pack_weights(lsprnn_handle *h, void *host_dst, size_t bytes)
             d[h->o_bias[l] + r] = gru_n ? bih[r] : bih[r] + bhh[r];
         }
         if (GT == 3) std::memcpy(d + h->o_bhn[l], bhh.data() + 2 * H, sizeof(float) * H);
+        // the wavefront kernel's layout of W_hh and (layers >= 1) W_ih: Pw parts of CPPw columns, Uw units per workgroup
+        {
+            const int Pw = h->Pw, Q = h->CPPw / 4, Uw = h->Uw;
+            for (int m = 0; m < (l ? 2 : 1); ++m) {
+                const std::vector<float> &src = m ? wih : whh;
+                float *o2 = d + (m ? h->o_wih_w[l] : h->o_whh_w[l]);
+                for (int w = 0; w < h->Gw; ++w)
+                    for (int g = 0; g < GT; ++g)
+                        for (int q = 0; q < Q; ++q)
+                            for (int t = 0; t < NT; ++t)
+                                for (int e = 0; e < 4; ++e) {
+                                    const int row = g * H + w * Uw + t / Pw, col = (t % Pw) * h->CPPw + q * 4 + e;
+                                    o2[((((size_t)w * GT + g) * Q + q) * NT + t) * 4 + e] = src[(size_t)row * H + col];
+                                }
+            }
+        }
         // W_hh: workgroup w, thread t = (unit w*U + t/P, column part t%P), gate g, float4 q of its 32 columns
         float *o = d + h->o_whh[l];
         for (int w = 0; w < h->G; ++w)
@@ -313,6 +462,32 @@ int lsprnn_forward(lsprnn_handle *h, const float *x_dev, int T, float *out_dev, 
         const hipError_t e = hipMemsetAsync(box, 0, h->box_bytes(), s);
         if (e != hipSuccess) return hipfail(e, "hipMemsetAsync(mailboxes)");
         h->boxes_clean = true;
+    }
+    const char *force = std::getenv("LSP_RNN_KERNEL");               // tools / tests: "layers" | "wave" (read per call)
+    const bool wave = force ? std::strcmp(force, "wave") == 0 : L > 1;
+    if (wave) {
+        lspgemm::GemmParams g{x_dev, h->blob + h->o_wih[0], nullptr, h->blob + h->o_bias[0], nullptr, xproj, T, GT * H, h->in_size(0), 1.0f, 0};
+        hipError_t e = lspgemm::launch_gemm_f32(g, s);
+        if (e != hipSuccess) return hipfail(e, "input projection gemm launch");
+        if (++h->epoch == 0) h->epoch = 1;
+        WaveParams p{};
+        p.blob = h->blob; p.blob_bytes = (unsigned)(h->blob_floats * sizeof(float));
+        for (int l = 0; l < L; ++l) {
+            p.whh[l] = (unsigned)(h->o_whh_w[l] * sizeof(float)); p.wih[l] = (unsigned)(h->o_wih_w[l] * sizeof(float));
+            p.bias[l] = h->blob + h->o_bias[l]; p.bhn[l] = h->blob + h->o_bhn[l];
+        }
+        p.xproj = xproj; p.out = out_dev; p.hbox = box; p.status = status; p.epoch = h->epoch;
+        p.T = T; p.H = H; p.layers = L; p.wgs_per_layer = h->Gw;
+        // workgroup b runs on XCD b % 8 (observed, speed only): keep the stack on as few XCDs as its size allows
+        const int nwg = L * h->Gw;
+        p.stride = nwg <= 32 ? 8 : (nwg <= 64 ? 4 : (nwg <= 128 ? 2 : 1));
+        const dim3 grid(L * h->Gw * p.stride), block(NT);
+        if (GT == 3 && h->Pw == 32) hipLaunchKernelGGL((rnn_wave<3, 32, 16>), grid, block, 0, s, p);
+        else if (GT == 3) hipLaunchKernelGGL((rnn_wave<3, 16, 16>), grid, block, 0, s, p);
+        else if (h->Pw == 32) hipLaunchKernelGGL((rnn_wave<4, 32, 16>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((rnn_wave<4, 16, 16>), grid, block, 0, s, p);
+        e = hipGetLastError();
+        return e == hipSuccess ? LSPRNN_OK : hipfail(e, "rnn_wave launch");
     }
     const float *in = x_dev;
     for (int l = 0; l < L; ++l) {

@@ -147,6 +147,38 @@ def test_audio2feature_model_matches_reference(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["wave", "layers"])
+def test_both_recurrent_routes_match_reference(route, monkeypatch):
+    """The default for stacks is the wavefront kernel (all layers in one launch); LSP_RNN_KERNEL=layers runs one launch
+    per layer.  Different summation orders, same goldens."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.apc import APC_encoder
+    from livespeechportraits_amd.rnn_engine import RecurrentEngine
+    monkeypatch.setenv("LSP_RNN_KERNEL", route)
+    dev = torch.device("cuda:0")
+    meta, ref = gold("apc_t300")
+    net = APC_encoder(80, 512, 3, False)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_apc_state_dict().items()})
+    net = net.to(dev).eval()
+    out = net.forward(torch.from_numpy(synth.make_mel(300)).to(dev).unsqueeze(0), torch.Tensor([300]))[0]
+    assert net._engine.status() == 0
+    e1 = np.abs(out.cpu().numpy() - ref).max()
+    sd = synth.make_rnn_state_dict("LSTM", 3, 512, 256, seed=23, prefix="")
+    lstm = torch.nn.LSTM(512, 256, num_layers=3, batch_first=True)
+    lstm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = synth.symmetric(200 * 512, 0.5, 77).reshape(200, 512)
+    with torch.no_grad():
+        want = lstm(torch.from_numpy(x).unsqueeze(0))[0][0].numpy()
+    e = RecurrentEngine("LSTM", 3, 512, 256, max_steps=256)
+    e.load_state_dict(sd); e.bind(dev)
+    got = e.forward(torch.from_numpy(x).to(dev))
+    assert e.status() == 0
+    e2 = np.abs(got.cpu().numpy() - want).max()
+    print("\n[rnn route %s] GRU x3 vs reference %.2e, LSTM x3 vs torch %.2e" % (route, e1, e2))
+    assert e1 <= TOL and e2 <= TOL
+
+
+@pytest.mark.gpu
 def test_lstm_and_gru_engines_against_torch_other_shapes():
     """hidden 256 GRU and hidden 512 LSTM (the two template instances no reference module uses), ragged lengths."""
     from livespeechportraits_amd import synth
