@@ -316,7 +316,8 @@ def pipeline_extra(dev, eng, cand):
 def recurrent_extra(dev, cpu_threads):
     """the two recurrent audio stages at the 687-frame clip's lengths -- APC_encoder
     (3 x GRU-512 over 1374 mel frames, demo.py:186-191) and Audio2Feature (MLP + 3 x LSTM-256 + MLP over
-    687 + frame_future 18 = 705 steps, demo.py:205).  Device tensors in/out; two lengths give the per-step slope."""
+    687 + frame_future 18 = 705 steps, demo.py:205).  Device tensors in/out; two lengths give the per-step slope
+    (all three layers advance together in the wavefront kernel, so a step is one time step of the whole stack)."""
     from livespeechportraits_amd import synth
     from livespeechportraits_amd.apc import APC_encoder
     from livespeechportraits_amd.audio2feature import Audio2Feature
@@ -341,7 +342,7 @@ def recurrent_extra(dev, cpu_threads):
         ms[T] = timed(lambda: apc.forward(mel, torch.Tensor([T])))
     if apc._engine.status() != 0:
         raise RuntimeError("GRU kernel hand-off timed out")
-    out["apc_gru"] = {"ms_1374_steps": round(ms[1374], 3), "us_per_step_per_layer": round(1e3 * (ms[1374] - ms[274]) / 1100.0 / 3, 3),
+    out["apc_gru"] = {"ms_1374_steps": round(ms[1374], 3), "us_per_step": round(1e3 * (ms[1374] - ms[274]) / 1100.0, 3),
                       "mel_frames_per_s": round(1374 / (ms[1374] * 1e-3), 1)}
     opt = _ap.Namespace(feature_decoder="LSTM", loss="L2", A2L_GMM_ndim=75, A2L_GMM_ncenter=1, predict_length=1, APC_hidden_size=512)
     a2f = Audio2Feature(opt)
@@ -353,7 +354,7 @@ def recurrent_extra(dev, cpu_threads):
         ms2[rows] = timed(lambda: a2f.forward(x))
     if a2f.status() != 0:
         raise RuntimeError("LSTM kernel hand-off timed out")
-    out["audio2feature_lstm"] = {"ms_705_steps": round(ms2[1410], 3), "us_per_step_per_layer": round(1e3 * (ms2[1410] - ms2[410]) / 500.0 / 3, 3),
+    out["audio2feature_lstm"] = {"ms_705_steps": round(ms2[1410], 3), "us_per_step": round(1e3 * (ms2[1410] - ms2[410]) / 500.0, 3),
                                  "frames_per_s": round(705 / (ms2[1410] * 1e-3), 1)}
     if cpu_threads:
         from oracle import rnn_oracle
