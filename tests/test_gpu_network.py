@@ -270,6 +270,59 @@ def test_bf16_last_conv_gemm_and_direct_routes_agree(gpu_device, monkeypatch):
     assert np.abs(imgs[0][0] - want).max() <= 1
 
 
+def test_bf16_layers_match_the_storage_model_given_the_gpus_own_inputs(gpu_device):
+    """Teacher-forced per-layer check of the bf16 path INSIDE the network: feed the GPU's own stored (bf16) inputs of a
+    layer to oracle/bf16_model.py's arithmetic for that layer (weights folded and rounded from the state dict exactly as
+    the packer does) and compare with what the GPU stored.  Only the accumulation order differs, so a value may move by
+    one bf16 unit in the last place and nothing else.  (Whole-network agreement cannot be tighter than the distance to
+    the fp32 reference: rounding decisions decorrelate within a few layers -- tools/bf16_model_check.py)"""
+    import torch.nn.functional as F
+    from livespeechportraits_amd.engine import Engine
+    from oracle import bf16_model, torch_oracle
+    meta, arrays, topo, sd, feat, cand = golden_problem("normal_512")
+    sdt = torch_oracle.to_torch(sd)
+    e = Engine(topo.variant, size=topo.size, max_batch=1, dtype="bf16", keep_intermediates=True)
+    e.load_state_dict(sd)
+    e.bind(e.pack(), gpu_device)
+    out = e.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu()
+    t = lambda name: e.intermediate(name, 1).float().cpu().permute(0, 3, 1, 2).contiguous()      # NHWC bf16 -> NCHW fp32
+    names = [l["name"] for l in e.layers(1)]
+
+    def ulp(v):                                     # one bf16 unit in the last place at magnitude |v|
+        return torch.clamp(v.abs(), min=2.0 ** -126).log2().floor().exp2() * 2.0 ** -7
+
+    def within_one_ulp(got, want):
+        # one bf16 ulp of the larger of the two, plus the fp32 accumulation noise that is all that separates them where a
+        # near-cancelling sum lands next to zero (measured: differences of 1e-9..5e-9 on values of 1e-7)
+        return ((got - want).abs() <= torch.maximum(ulp(got), ulp(want)) * 1.001 + 1e-6).all()
+
+    # normal variant, one res block per side: level L1 = indices 0 conv,1 BN,2 ReLU,3 Res,4 SUB,5 Up,6 Conv,7 BN,8 ReLU,9 Res
+    k1 = "netG.model.model.3"                       # L0: 0 conv, 1 ReLU, 2 Res, 3 SUB -> L1 lives under .model.3
+    # (a) a plain 3x3 s1 residual-block conv at 256^2: L0.d.res0.a
+    x0 = t("L0.down")
+    s, sh = bf16_model._affine(sdt, "netG.model.model.2.block.1")
+    want = bf16_model.rb(F.relu(F.conv2d(x0, bf16_model.rb(sdt["netG.model.model.2.block.0.weight"]), None, 1, 1) * s + sh))
+    got = t("L0.d.res0.a")
+    assert within_one_ulp(got, want), "res conv: more than one bf16 ulp"
+    frac_a = ((got - want).abs() > 0).float().mean().item()
+    # (b) an up-conv in sub-pixel form with concat input: L1.up reads [L1.d.res0.b, L2 output] at 128^2, writes 256^2
+    src = torch.cat([t("L1.d.res0.b"), t("L2.u.res0.b")], 1)
+    s, sh = bf16_model._affine(sdt, k1 + ".model.7")
+    want = bf16_model.rb(F.relu(bf16_model._up_subpixel(src, bf16_model.rb(bf16_model._fold(sdt[k1 + ".model.6.weight"]))) * s + sh))
+    got = t("L1.up")
+    assert within_one_ulp(got, want), "sub-pixel up-conv: more than one bf16 ulp"
+    frac_b = ((got - want).abs() > 0).float().mean().item()
+    # (c) the last conv (GEMM form + pixel shuffle + tanh): fp32 result, never rounded
+    src = torch.cat([t("L0.d.res0.b"), t("L1.u.res0.b")], 1)
+    want = torch.tanh(bf16_model._up_subpixel(src, bf16_model.rb(bf16_model._fold(sdt["netG.model.model.5.weight"]))))
+    e_last = (out - want).abs().max().item()
+    print("bf16 teacher-forced: res conv differs on %.4f of elements, up-conv on %.4f (all within 1 ulp); last conv max-abs %.2e"
+          % (frac_a, frac_b, e_last))
+    assert frac_a < 0.02 and frac_b < 0.02
+    assert e_last <= 2e-5
+    assert "L1.up" in names and "L0.up" in names
+
+
 def test_bf16_rejects_unsupported_width():
     from livespeechportraits_amd import _native as N
     from livespeechportraits_amd.engine import Engine
