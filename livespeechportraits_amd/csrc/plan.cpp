@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace lspf2f {
@@ -18,7 +19,7 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
     // Rules distilled from tools/tune_conv.py sweeps on MI355X (profiles/r01_tune_*.txt).  The kernel is
     // MFMA-bound and its throughput is flat (+-5 %) across tile shapes, so what matters is having
     // >= ~2 workgroups per CU (256 CUs): 64x128 when that still leaves >= 384 workgroups, else 64x64,
-    // else 64x64 + split-K up to ~512 workgroups with >= 4 K-tiles per split.  128-row tiles never won.
+    // else 64x64 + split-K up to ~768 (fp32) / ~512 (bf16) workgroups with >= 4 K-tiles per split.  128-row tiles never won.
     const int want = 384;
     int bm = 64, bn = 64, splits = 1, group = 1;
     if (M <= 32) {
@@ -43,7 +44,11 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
             if (tbig >= 256) { bm = 128; bn = wn; tiles = tbig; }
         }
         if (tiles < (bm == 128 ? 512 : want)) {
-            splits = (int)((512 + tiles - 1) / tiles);
+            // workgroups to aim for when splitting K.  fp32: 768 beats 512 (batch 1 `large` 388.8-389.5 -> 392.3-393.2 frames/s,
+            // `normal` 633.5-635.0 -> 638.5-640.9, batch 8 +0.4 %; 1024 is slightly below 768).  bf16 keeps 512 (768: batch 8
+            // `large` -0.7 %, `normal` no change).  Same session, 3 runs per arm.
+            const int target = dtype == 0 ? 768 : 512;
+            splits = (int)((target + tiles - 1) / tiles);
             splits = std::min(splits, std::max(1, ktiles / 4));   // keep >= 4 K-tiles per split
             const int per = (ktiles + splits - 1) / splits;      // make every split non-empty
             splits = (ktiles + per - 1) / per;
