@@ -201,6 +201,27 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                    int tile_n, int split_k, int k_group, int dtype, void *scratch, size_t scratch_bytes,
                    void *hip_stream);
 
+/* ---- building blocks of the `size == 'small'` generator (Feature2FaceGenerator_Unet, models/networks.py:680-769) ----
+ * That U-Net is made of 4x4 stride-2 convs and 4x4 stride-2 transposed convs.  Both map onto lspf2f_conv3x3:
+ *   Conv2d(k4, s2, p1) on X  ==  a 3x3 stride-1 conv on the space-to-depth image Y[i][j][(dy*2+dx)*C + c] = X[2i+dy][2j+dx][c]
+ *                                with W3[co][ty][tx][(dy,dx,c)] = W[co][c][ky][kx], (ty,dy) = {0:(0,1), 1:(1,0), 2:(1,1), 3:(2,0)}[ky]
+ *                                (likewise x; the other 20 of 36 (tap, dy, dx) blocks are zero);
+ *   ConvTranspose2d(k4, s2, p1)  ==  the sub-pixel form (upsample = 2) with W[par][co][a*2+b][ci] = Wt[ci][co][{{3,1},{2,0}}[py][a]][..[px][b]].
+ * lspf2f_unet_prepare is the elementwise pass between them; the reference's in-place LeakyReLU/ReLU mean a stored skip
+ * tensor d is read as leaky_relu(d) by the next down-conv and as relu(d) by the up-conv (networks.py:737-741, 751-767). */
+
+/* src: fp32, NHWC [batch][h][w][c] (src_nchw == 0) or NCHW [batch][c][h][w] (src_nchw != 0); h, w even.
+ *   s2d_out   NHWC [batch][h/2][w/2][s2d_channels] or NULL: channel (dy*2+dx)*c + k = act(src[2i+dy][2j+dx][k]) with
+ *             act(v) = v > 0 ? v : slope * v (slope 1 = identity); channels >= 4c are written as 0 (s2d_channels >= 4c, % 4 == 0)
+ *   relu_out  NHWC [batch][h][w][c] or NULL: max(src, 0) */
+int lspf2f_unet_prepare(const float *src_dev, int src_nchw, int batch, int h, int w, int c, float slope,
+                        float *s2d_out_dev, int s2d_channels, float *relu_out_dev, void *hip_stream);
+
+/* g NHWC [batch][hs][ws][4*cout] fp32 (channel = parity*cout + co, parity = py*2+px) -> optional tanh ->
+ *   out_f32 NCHW [batch][cout][2hs][2ws] and/or out_u8 HWC uint8 [batch][2hs][2ws][cout] (util.tensor2im); cout <= 4 */
+int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout, int apply_tanh,
+                         float *out_f32_dev, unsigned char *out_u8_dev, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,6 +219,26 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     return LSPF2F_OK;
 }
 
+int lspf2f_unet_prepare(const float *src_dev, int src_nchw, int batch, int h, int w, int c, float slope,
+                        float *s2d_out_dev, int s2d_channels, float *relu_out_dev, void *hip_stream)
+{
+    if (!src_dev || (!s2d_out_dev && !relu_out_dev)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    PrepareParams p{src_dev, src_nchw ? 1 : 0, batch, h, w, c, slope, s2d_out_dev, s2d_channels, relu_out_dev};
+    const hipError_t e = launch_unet_prepare(p, static_cast<hipStream_t>(hip_stream));
+    if (e == hipErrorInvalidValue) return fail(LSPF2F_ERR_SHAPE, "unet_prepare: h, w must be even and s2d_channels >= 4c, a multiple of 4");
+    return e == hipSuccess ? LSPF2F_OK : hipfail(e, "unet_prepare launch");
+}
+
+int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout, int apply_tanh,
+                         float *out_f32_dev, unsigned char *out_u8_dev, void *hip_stream)
+{
+    if (!g_dev || (!out_f32_dev && !out_u8_dev)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    if (batch < 1 || hs < 1 || ws < 1 || cout < 1 || cout > 4) return fail(LSPF2F_ERR_SHAPE, "pixel_shuffle: cout must be in 1..4");
+    ShuffleParams sp{g_dev, out_f32_dev, out_u8_dev, batch, hs, ws, cout, apply_tanh ? 1 : 0};
+    const hipError_t e = launch_pixel_shuffle(sp, static_cast<hipStream_t>(hip_stream));
+    return e == hipSuccess ? LSPF2F_OK : hipfail(e, "pixel_shuffle launch");
+}
+
 }  // extern "C"
 
 static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, const float *cand, int cand_batch,

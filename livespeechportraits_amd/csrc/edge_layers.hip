@@ -571,4 +571,43 @@ hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// One thread per (pixel, 4-channel group) of the SOURCE; writes its values into the s2d tensor and / or the relu copy.
+__global__ __launch_bounds__(256) void unet_prepare(PrepareParams p)
+{
+    const int cg = (p.C + 3) / 4;
+    const long total = (long)p.B * p.H * p.W * cg;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int g = (int)(gid % cg);
+    const long pix = gid / cg;
+    const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / ((long)p.W * p.H));
+    float v[4];
+    for (int e = 0; e < 4; ++e) {
+        const int c = g * 4 + e;
+        v[e] = 0.f;
+        if (c < p.C) v[e] = p.nchw ? p.src[(((long)b * p.C + c) * p.H + y) * p.W + x] : p.src[pix * p.C + c];
+    }
+    if (p.relu)
+        for (int e = 0; e < 4; ++e)
+            if (g * 4 + e < p.C) p.relu[pix * p.C + g * 4 + e] = fmaxf(v[e], 0.f);
+    if (p.s2d) {
+        const long opix = ((long)b * (p.H / 2) + (y >> 1)) * (p.W / 2) + (x >> 1);
+        float *o = p.s2d + opix * p.s2d_c + ((y & 1) * 2 + (x & 1)) * p.C;
+        for (int e = 0; e < 4; ++e)
+            if (g * 4 + e < p.C) o[g * 4 + e] = v[e] > 0.f ? v[e] : p.slope * v[e];
+        // zero the padding channels once per output pixel
+        if (g == 0 && (y & 1) == 0 && (x & 1) == 0)
+            for (int c = 4 * p.C; c < p.s2d_c; ++c) p.s2d[opix * p.s2d_c + c] = 0.f;
+    }
+}
+
+hipError_t launch_unet_prepare(const PrepareParams &p, hipStream_t s)
+{
+    if (p.B < 1 || p.H < 2 || p.W < 2 || (p.H & 1) || (p.W & 1) || p.C < 1) return hipErrorInvalidValue;
+    if (p.s2d && (p.s2d_c < 4 * p.C || (p.s2d_c & 3))) return hipErrorInvalidValue;
+    const long total = (long)p.B * p.H * p.W * ((p.C + 3) / 4);
+    hipLaunchKernelGGL(unet_prepare, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace lspf2f

@@ -119,4 +119,14 @@ struct ShuffleParams {
 };
 hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s);
 
+// elementwise pass of the 'small' U-Net: space-to-depth (+ LeakyReLU) for the next 4x4 s2 conv, ReLU copy for the skip
+struct PrepareParams {
+    const float *src;
+    int nchw, B, H, W, C;
+    float slope;
+    float *s2d; int s2d_c;
+    float *relu;
+};
+hipError_t launch_unet_prepare(const PrepareParams &p, hipStream_t s);
+
 }  // namespace lspf2f

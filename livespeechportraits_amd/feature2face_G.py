@@ -11,6 +11,7 @@ import warnings
 import torch.nn as nn
 
 from .networks import Feature2FaceGenerator
+from .unet_small import Feature2FaceGenerator_Unet
 
 
 class Feature2Face_G(nn.Module):
@@ -19,15 +20,15 @@ class Feature2Face_G(nn.Module):
         self.opt = opt
         self.isTrain = getattr(opt, "isTrain", False)
         size = getattr(opt, "size", None)
+        if size not in ("small", "normal", "large"):
+            raise ValueError("opt.size must be 'small', 'normal' or 'large' (feature2face_G.py:16-21), got %r" % (size,))
         if size == "small":
-            raise NotImplementedError(
-                "opt.size == 'small' (pix2pix U-Net, networks.py:680-769, 23-channel input) is not "
-                "selected by any shipped config and is not implemented by the HIP renderer")
-        if size not in ("normal", "large"):
-            raise ValueError("opt.size must be 'normal' or 'large' (config/*.yaml:23), got %r" % (size,))
-        # feature2face_G.py:19-21 hard-codes input_nc=13, output_nc=3
-        self.netG = Feature2FaceGenerator(size, input_nc=13, output_nc=3,
-                                          num_downs=opt.n_downsample_G, ngf=opt.ngf, feat_nc=1)
+            # feature2face_G.py:17: the pix2pix U-Net on a 23-channel input; no shipped config selects it
+            self.netG = Feature2FaceGenerator_Unet(input_nc=23, output_nc=3, num_downs=opt.n_downsample_G, ngf=opt.ngf)
+        else:
+            # feature2face_G.py:19-21 hard-codes input_nc=13, output_nc=3
+            self.netG = Feature2FaceGenerator(size, input_nc=13, output_nc=3,
+                                              num_downs=opt.n_downsample_G, ngf=opt.ngf, feat_nc=1)
         if getattr(opt, "fp16", 0):
             warnings.warn("opt.fp16 is ignored: the HIP renderer computes in fp32 "
                           "(>= the precision of the reference's autocast branch)")

@@ -246,3 +246,56 @@ def make_mel(T: int, mel_dim: int = 80, seed: int = 31) -> np.ndarray:
     steps = symmetric(T * mel_dim, 0.35, _stream(seed, "mel")).reshape(T, mel_dim)
     x = np.cumsum(steps, 0)
     return (x - x.mean(0)).astype(np.float32) * np.float32(0.5)
+
+
+# ---- the 'small' U-Net generator ----------------------------------------------
+def unet_small_shapes(input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, prefix: str = "model"):
+    """state-dict key -> shape of Feature2FaceGenerator_Unet (models/networks.py:680-692); same walk as the oracle's block_keys."""
+    chans = [ngf * min(2 ** i, 8) for i in range(num_downs)]              # inner channels: ngf, 2ngf, 4ngf, 8ngf, 8ngf, ...
+    shapes = {}
+    pfx = prefix + ".model"
+    for depth in range(num_downs):
+        outer, inner = depth == 0, depth == num_downs - 1
+        cin = input_nc if outer else chans[depth - 1]
+        cout_up = output_nc if outer else chans[depth - 1]
+        c = chans[depth]
+        bn = lambda key, n: shapes.update({key + ".weight": (n,), key + ".bias": (n,), key + ".running_mean": (n,), key + ".running_var": (n,)})
+        if outer:
+            shapes[pfx + ".0.weight"] = (c, cin, 4, 4)
+            shapes[pfx + ".3.weight"] = (2 * c, cout_up, 4, 4)            # ConvTranspose2d weight: [in][out][kh][kw]
+            shapes[pfx + ".3.bias"] = (cout_up,)
+            pfx += ".1.model"
+        elif inner:
+            shapes[pfx + ".1.weight"] = (c, cin, 4, 4)
+            shapes[pfx + ".3.weight"] = (c, cout_up, 4, 4)
+            bn(pfx + ".4", cout_up)
+        else:
+            shapes[pfx + ".1.weight"] = (c, cin, 4, 4)
+            bn(pfx + ".2", c)
+            shapes[pfx + ".5.weight"] = (2 * c, cout_up, 4, 4)
+            bn(pfx + ".6", cout_up)
+            pfx += ".3.model"
+    return shapes
+
+
+def make_unet_small_state_dict(input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, seed: int = 97,
+                               prefix: str = "model") -> Dict[str, np.ndarray]:
+    """Conv weights with std sqrt(2 / fan_in) (the activations keep unit scale through 16 layers, tanh not saturated),
+    BN statistics perturbed as for the residual generators."""
+    sd = {}
+    for key, shape in unet_small_shapes(input_nc, output_nc, num_downs, ngf, prefix).items():
+        n = int(np.prod(shape))
+        st = _stream(seed, key)
+        if key.endswith("running_var"):
+            v = uniform01(n, st) * np.float32(0.7) + np.float32(0.9)
+        elif key.endswith("running_mean") or key.endswith(".bias"):
+            v = symmetric(n, 0.05, st)
+        elif len(shape) == 4:
+            is_t = key.endswith(".3.weight") or key.endswith(".5.weight")          # transposed conv: fan_in = in * 4 taps per output
+            fan_in = shape[0] * 4 if is_t else shape[1] * 16
+            gain = 0.5 if key == prefix + ".model.3.weight" else 1.0                # keep the frame away from tanh saturation
+            v = symmetric(n, gain * float(np.sqrt(2.0 / fan_in)), st)
+        else:
+            v = np.float32(1.0) + symmetric(n, 0.02, st)
+        sd[key] = v.reshape(shape).astype(np.float32)
+    return sd

@@ -1,0 +1,246 @@
+"""The reference's `size == 'small'` generator (Feature2FaceGenerator_Unet, models/networks.py:680-769; selected at
+models/feature2face_G.py:16-17 with a 23-channel input) on the MI355X, built from the library's existing kernels:
+
+  Conv2d(k4, s2, p1)           -> lspf2f_unet_prepare (space-to-depth + the in-place LeakyReLU) + lspf2f_conv3x3 on 4x the
+                                  channels with the 16 real taps scattered into a 3x3 pattern (20 of 36 blocks are zero)
+  ConvTranspose2d(k4, s2, p1)  -> lspf2f_conv3x3 in sub-pixel form (upsample = 2): 4 output parities x 2x2 taps
+  last ConvTranspose + Tanh    -> 3x3 GEMM with N = 4 parities x 3 on the low-res source + lspf2f_pixel_shuffle (tanh)
+
+No shipped configuration selects this variant, so it is sequenced from the host, one C call per launch, rather than
+planned, fused and graph-captured like 'normal' / 'large'; all arithmetic is in the HIP kernels (no CPU path).
+The mappings are documented in include/lspf2f.h next to lspf2f_unet_prepare."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+_KY = {0: (0, 1), 1: (1, 0), 2: (1, 1), 3: (2, 0)}      # 4x4 s2 tap ky -> (3x3 tap row ty, space-to-depth row dy)
+_KT = ((3, 1), (2, 0))                                   # transposed conv: ky of output parity py, sub-pixel tap a
+
+
+def _fold_bn(sd, key):
+    g, b = sd[key + ".weight"].astype(np.float64), sd[key + ".bias"].astype(np.float64)
+    m, v = sd[key + ".running_mean"].astype(np.float64), sd[key + ".running_var"].astype(np.float64)
+    s = g / np.sqrt(v + 1e-5)
+    return s.astype(np.float32), (b - m * s).astype(np.float32)
+
+
+def pack_down(w: np.ndarray, s2d_channels: int) -> np.ndarray:
+    """[co][ci][4][4] -> [co][3][3][s2d_channels] for the 3x3 conv on the space-to-depth image."""
+    co, ci = w.shape[:2]
+    out = np.zeros((co, 3, 3, s2d_channels), np.float32)
+    for ky in range(4):
+        ty, dy = _KY[ky]
+        for kx in range(4):
+            tx, dx = _KY[kx]
+            out[:, ty, tx, (dy * 2 + dx) * ci:(dy * 2 + dx + 1) * ci] = w[:, :, ky, kx]
+    return out
+
+
+def pack_up(wt: np.ndarray) -> np.ndarray:
+    """ConvTranspose2d weight [ci][co][4][4] -> sub-pixel form [4 parities][co][2][2][ci]."""
+    ci, co = wt.shape[:2]
+    out = np.zeros((4, co, 2, 2, ci), np.float32)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):
+                    out[py * 2 + px, :, a, b, :] = wt[:, :, _KT[py][a], _KT[px][b]].T
+    return out
+
+
+def pack_last(wt: np.ndarray) -> np.ndarray:
+    """[ci][co][4][4] -> [4*co][3][3][ci]: the sub-pixel taps as one 3x3 conv on the low-res source (channel par*co + c)."""
+    sub = pack_up(wt)
+    ci, co = wt.shape[:2]
+    out = np.zeros((4 * co, 3, 3, ci), np.float32)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):
+                    out[(py * 2 + px) * co:(py * 2 + px + 1) * co, py + a, px + b, :] = sub[py * 2 + px, :, a, b, :]
+    return out
+
+
+def block_keys(num_downs: int, prefix: str = "model"):
+    out, pfx = [], prefix + ".model"
+    for depth in range(num_downs):
+        if depth == 0:
+            out.append((pfx + ".0", None, pfx + ".3", None)); pfx += ".1.model"
+        elif depth == num_downs - 1:
+            out.append((pfx + ".1", None, pfx + ".3", pfx + ".4"))
+        else:
+            out.append((pfx + ".1", pfx + ".2", pfx + ".5", pfx + ".6")); pfx += ".3.model"
+    return out
+
+
+class SmallUnetEngine:
+    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64):
+        if ngf % 32 or num_downs < 5 or not (1 <= output_nc <= 4):
+            raise ValueError("ngf must be a multiple of 32, num_downs >= 5, output_nc <= 4")
+        self.lib = N.load()
+        self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
+        self.chans = [ngf * min(2 ** i, 8) for i in range(num_downs)]
+        self.s2d0 = (4 * input_nc + 31) // 32 * 32
+        self.layers: Optional[List[dict]] = None
+        self.device = None
+        self._scratch = None
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray], prefix: str = "model", device="cuda:0") -> None:
+        sd = {k: (v.detach().float().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)) for k, v in sd.items()}
+        keys = block_keys(self.num_downs, prefix)
+        need = [k + ".weight" for blk in keys for k in (blk[0], blk[2])]
+        missing = [k for k in need if k not in sd]
+        if missing:
+            raise KeyError("state dict lacks %s" % missing[:3])
+        dev = torch.device(device)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        L = []
+        for k, (dc, dbn, uc, ubn) in enumerate(keys):
+            cin = self.input_nc if k == 0 else self.chans[k - 1]
+            s2d = self.s2d0 if k == 0 else 4 * cin
+            e = {"down_w": up(pack_down(sd[dc + ".weight"], s2d)), "s2d": s2d, "cin": cin, "cout": self.chans[k]}
+            e["down_scale"], e["down_shift"] = (up(t) for t in _fold_bn(sd, dbn)) if dbn else (None, None)
+            wt = sd[uc + ".weight"]
+            if k == 0:
+                e["up_w"] = up(pack_last(wt))
+                bias = sd.get(uc + ".bias")
+                e["up_shift"] = up(np.tile(bias if bias is not None else np.zeros(self.output_nc, np.float32), 4).astype(np.float32))
+                e["up_scale"] = up(np.ones(4 * self.output_nc, np.float32))        # the entry point takes scale and shift together
+            else:
+                e["up_w"] = up(pack_up(wt))
+                e["up_scale"], e["up_shift"] = (up(t) for t in _fold_bn(sd, ubn))
+            e["up_cout"] = wt.shape[1]
+            L.append(e)
+        self.layers, self.device = L, dev
+
+    # ---- launches ---------------------------------------------------------------------------------
+    def _conv(self, src0, src1, w, scale, shift, out, stride, upsample, relu):
+        b, hs, ws, c0 = src0.shape
+        c1 = src1.shape[3] if src1 is not None else 0
+        cout = out.shape[3]
+        sb = self.lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, upsample, 0, 0, 0, 0, 0)
+        if self._scratch is None or self._scratch.numel() < sb:
+            self._scratch = torch.empty(max(sb, 256), dtype=torch.uint8, device=self.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        N.check(self.lib.lspf2f_conv3x3(p(src0), p(src1), p(w), p(scale), p(shift), None, p(out), b, hs, ws, c0, c1, cout,
+                                        stride, upsample, int(relu), 0, 0, 0, 0, 0, p(self._scratch), self._scratch.numel(),
+                                        ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def _prepare(self, src, nchw, b, h, w, c, slope, s2d, s2d_c, relu):
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        N.check(self.lib.lspf2f_unet_prepare(p(src), int(nchw), b, h, w, c, ctypes.c_float(slope), p(s2d), s2d_c, p(relu),
+                                             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def forward(self, x: torch.Tensor, out_u8: bool = False) -> torch.Tensor:
+        """x [B, input_nc, S, S] fp32 on the device -> [B, output_nc, S, S] fp32 (or uint8 HWC frames)."""
+        if self.layers is None:
+            raise RuntimeError("SmallUnetEngine.load_state_dict first")
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != self.input_nc:
+            raise ValueError("x must be a float32 device tensor [B, %d, S, S] (there is no CPU path)" % self.input_nc)
+        x = x.contiguous()
+        B, _, S, _ = x.shape
+        if S % (1 << self.num_downs):
+            raise ValueError("frame size must be a multiple of 2**num_downs")
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
+        nd, L = self.num_downs, self.layers
+        with torch.cuda.device(self.device):
+            # ---- down path
+            h = S
+            y = new(B, h // 2, h // 2, L[0]["s2d"])
+            self._prepare(x, True, B, h, h, self.input_nc, 1.0, y, L[0]["s2d"], None)          # no activation in front of block 0
+            skips = []
+            d = None
+            for k in range(nd):
+                h //= 2
+                inner = k == nd - 1
+                d = new(B, h, h, L[k]["cout"])
+                self._conv(y, None, L[k]["down_w"], L[k]["down_scale"], L[k]["down_shift"], d, 1, 0, relu=inner)
+                if inner:
+                    break                                                                     # stored as relu(d): only the up-conv reads it
+                y = new(B, h // 2, h // 2, 4 * L[k]["cout"])
+                r = new(B, h, h, L[k]["cout"])
+                self._prepare(d, False, B, h, h, L[k]["cout"], 0.2, y, 4 * L[k]["cout"], r)      # lrelu for the next conv, relu for the skip
+                skips.append(r)
+            # ---- up path
+            u = None
+            for k in range(nd - 1, 0, -1):
+                src0 = d if u is None else skips[k]
+                o = new(B, 2 * h, 2 * h, L[k]["up_cout"])
+                self._conv(src0, u, L[k]["up_w"], L[k]["up_scale"], L[k]["up_shift"], o, 1, 2, relu=True)   # relu: read only through the parent's uprelu
+                u, h = o, 2 * h
+            g = new(B, h, h, 4 * self.output_nc)
+            self._conv(skips[0], u, L[0]["up_w"], L[0]["up_scale"], L[0]["up_shift"], g, 1, 0, relu=False)
+            p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+            if out_u8:
+                out = torch.empty((B, 2 * h, 2 * h, self.output_nc), dtype=torch.uint8, device=self.device)
+                N.check(self.lib.lspf2f_pixel_shuffle(p(g), B, h, h, self.output_nc, 1, None, p(out),
+                                                      ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            else:
+                out = new(B, self.output_nc, 2 * h, 2 * h)
+                N.check(self.lib.lspf2f_pixel_shuffle(p(g), B, h, h, self.output_nc, 1, p(out), None,
+                                                      ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
+
+
+# ---- parameter container with the reference's keys ---------------------------------------------------
+class _Slot(nn.Identity):
+    """occupies an index of the reference's nn.Sequential that holds no parameters (activations, Tanh)"""
+
+
+class UnetSkipConnectionBlock(nn.Module):
+    def __init__(self, outer_nc, inner_nc, input_nc=None, submodule=None, outermost=False, innermost=False):
+        super().__init__()
+        input_nc = outer_nc if input_nc is None else input_nc
+        down = nn.Conv2d(input_nc, inner_nc, 4, 2, 1, bias=False)
+        if outermost:
+            mods = [down, submodule, _Slot(), nn.ConvTranspose2d(inner_nc * 2, outer_nc, 4, 2, 1), _Slot()]
+        elif innermost:
+            mods = [_Slot(), down, _Slot(), nn.ConvTranspose2d(inner_nc, outer_nc, 4, 2, 1, bias=False), nn.BatchNorm2d(outer_nc)]
+        else:
+            mods = [_Slot(), down, nn.BatchNorm2d(inner_nc), submodule, _Slot(),
+                    nn.ConvTranspose2d(inner_nc * 2, outer_nc, 4, 2, 1, bias=False), nn.BatchNorm2d(outer_nc)]
+        self.model = nn.Sequential(*mods)
+
+
+class Feature2FaceGenerator_Unet(nn.Module):
+    """Weights container + device evaluation; same constructor and state-dict keys as the reference class."""
+
+    def __init__(self, input_nc=4, output_nc=3, num_downs=8, ngf=64):
+        super().__init__()
+        blk = UnetSkipConnectionBlock(ngf * 8, ngf * 8, innermost=True)
+        for _ in range(num_downs - 5):
+            blk = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=blk)
+        blk = UnetSkipConnectionBlock(ngf * 4, ngf * 8, submodule=blk)
+        blk = UnetSkipConnectionBlock(ngf * 2, ngf * 4, submodule=blk)
+        blk = UnetSkipConnectionBlock(ngf, ngf * 2, submodule=blk)
+        self.model = UnetSkipConnectionBlock(output_nc, ngf, input_nc=input_nc, submodule=blk, outermost=True)
+        self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
+        self._engine = None
+        self._version = None
+
+    def mark_dirty(self):
+        self._engine = None
+
+    def _get_engine(self, device) -> SmallUnetEngine:
+        version = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        if self._engine is None or self._version != version or self._engine.device != device:
+            e = SmallUnetEngine(self.input_nc, self.output_nc, self.num_downs, self.ngf)
+            e.load_state_dict({k: v for k, v in self.state_dict().items() if not k.endswith("num_batches_tracked")}, "model", device)
+            self._engine, self._version = e, version
+        return self._engine
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.device.type != "cuda":
+            raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
+        return self._get_engine(x.device).forward(x.float())
+
+    def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor]) -> torch.Tensor:
+        """feature2face_model.py:229-231: cat([feature_map, cand_image], 1) unless cand_image is None"""
+        return self.forward(feat if cand is None else torch.cat([feat, cand], 1))

@@ -1,0 +1,139 @@
+"""The reference's `size == 'small'` generator.  Goldens: the reference's own
+Feature2FaceGenerator_Unet (oracle/make_golden_unet.py)."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 1e-4           # fp32, 16 layers; measured values are printed
+
+
+def load_case(name):
+    from livespeechportraits_amd import synth
+    meta = json.load(open(os.path.join(GOLD, "unet_%s.json" % name)))
+    ref = np.load(os.path.join(GOLD, "unet_%s.npz" % name))["out"]
+    sd = synth.make_unet_small_state_dict(23, 3, meta["num_downs"], meta["ngf"], seed=meta["weights_seed"])
+    n = meta["batch"] * 23 * meta["size"] ** 2
+    x = synth.symmetric(n, 0.6, synth._stream(5, name)).reshape(meta["batch"], 23, meta["size"], meta["size"])
+    return meta, sd, x, ref
+
+
+# ---- CPU ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["small_s64_b2", "small_512"])
+def test_oracle_reproduces_reference(name):
+    from oracle import unet_small_oracle
+    meta, sd, x, ref = load_case(name)
+    out = unet_small_oracle.generator_forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(x), meta["num_downs"]).numpy()
+    assert out.shape == ref.shape and np.abs(out - ref).max() <= 2e-6
+    assert (np.abs(ref) > 0.99).mean() < 0.01 and ref.std() > 0.1            # not saturated, not degenerate
+
+
+def test_container_keys_and_weight_mappings():
+    from livespeechportraits_amd.unet_small import Feature2FaceGenerator_Unet, pack_down, pack_last, pack_up
+    meta = json.load(open(os.path.join(GOLD, "unet_small_512.json")))
+    assert {k: list(v.shape) for k, v in Feature2FaceGenerator_Unet(23, 3, 8, 64).state_dict().items()} == meta["keys"]
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(2, 5, 8, 8, generator=g), torch.randn(7, 5, 4, 4, generator=g)
+    y = torch.zeros(2, 24, 4, 4)                                              # space-to-depth, 4 padding channels
+    for dy in range(2):
+        for dx in range(2):
+            y[:, (dy * 2 + dx) * 5:(dy * 2 + dx + 1) * 5] = x[:, :, dy::2, dx::2]
+    w3 = torch.from_numpy(pack_down(w.numpy(), 24)).permute(0, 3, 1, 2)
+    assert (F.conv2d(y, w3, None, 1, 1) - F.conv2d(x, w, None, 2, 1)).abs().max() < 1e-5      # Conv2d(k4,s2,p1)
+    xt, wt = torch.randn(2, 6, 4, 4, generator=g), torch.randn(6, 3, 4, 4, generator=g)
+    ref = F.conv_transpose2d(xt, wt, None, 2, 1)
+    sub = torch.from_numpy(pack_up(wt.numpy()))
+    xp, out = F.pad(xt, (1, 1, 1, 1)), torch.zeros_like(ref)
+    for py in range(2):
+        for px in range(2):
+            out[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + 5, px:px + 5], sub[py * 2 + px].permute(0, 3, 1, 2))
+    assert (out - ref).abs().max() < 1e-5                                      # ConvTranspose2d(k4,s2,p1) == sub-pixel form
+    gq = F.conv2d(xt, torch.from_numpy(pack_last(wt.numpy())).permute(0, 3, 1, 2), None, 1, 1)
+    out2 = torch.zeros_like(ref)
+    for par in range(4):
+        out2[:, :, par // 2::2, par % 2::2] = gq[:, par * 3:(par + 1) * 3]
+    assert (out2 - ref).abs().max() < 1e-5                                     # GEMM form + pixel shuffle
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_s64_b2", "small_512"])
+def test_engine_matches_reference(name):
+    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    meta, sd, x, ref = load_case(name)
+    dev = torch.device("cuda:0")
+    e = SmallUnetEngine(23, 3, meta["num_downs"], meta["ngf"])
+    e.load_state_dict(sd, "model", dev)
+    xd = torch.from_numpy(x).to(dev)
+    out = e.forward(xd)
+    torch.cuda.synchronize()
+    err = np.abs(out.cpu().numpy() - ref).max()
+    print("\n[unet %s] max-abs vs reference %.3e (|ref| max %.2f)" % (name, err, np.abs(ref).max()))
+    assert out.shape == ref.shape and err <= TOL
+    assert torch.equal(e.forward(xd), out)                                     # deterministic
+    u8 = e.forward(xd, out_u8=True).cpu().numpy().astype(np.int32)
+    want = np.clip((ref.transpose(0, 2, 3, 1) + 1.0) / 2.0 * 255.0, 0, 255).astype(np.uint8).astype(np.int32)
+    assert u8.shape == want.shape and np.abs(u8 - want).max() <= 1            # util.tensor2im
+
+
+@pytest.mark.gpu
+def test_drop_in_model_with_size_small(tmp_path):
+    """create_model(opt) with opt.size == 'small' -> setup() from a 'module.'-prefixed checkpoint -> inference()."""
+    from livespeechportraits_amd.models import create_model
+    meta, sd, x, ref = load_case("small_s64_b2")
+    ckpt = os.path.join(tmp_path, "Feature2Face.pkl")
+    torch.save({"module.netG." + k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
+    opt = argparse.Namespace(model="feature2face", gpu_ids=[0], isTrain=False, size="small", ngf=meta["ngf"], n_downsample_G=meta["num_downs"],
+                             fp16=0, checkpoints_dir=str(tmp_path), name="x", load_epoch=ckpt, verbose=False)
+    m = create_model(opt)
+    m.setup(opt)
+    m.eval()
+    xd = torch.from_numpy(x).cuda()
+    out = m.inference(xd[:, :1], xd[:, 1:])                                   # feature map + 22 candidate channels (cat -> 23)
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL
+    out2 = m.inference(xd, None)                                               # cand_image None: feature_map already has 23 channels
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.gpu
+def test_prepare_and_shuffle_entry_points():
+    import ctypes
+    from livespeechportraits_amd import _native as N
+    lib, dev = N.load(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    stream = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    for nchw in (0, 1):
+        src = torch.randn(2, 6, 8, 5, generator=g) if nchw else torch.randn(2, 8, 6, 5, generator=g)   # NCHW [b,c,h,w] / NHWC [b,h,w,c]
+        b, c, h, w = (2, 6, 8, 5) if nchw else (2, 5, 8, 6)
+        if nchw:
+            src = torch.randn(2, 5, 8, 6, generator=g)                        # [b, c=5, h=8, w=6]
+        x = (src if nchw else src.permute(0, 3, 1, 2)).contiguous()           # NCHW view of the same data
+        d = src.to(dev)
+        s2d = torch.full((2, 4, 3, 24), float("nan"), device=dev)
+        relu = torch.full((2, 8, 6, 5), float("nan"), device=dev)
+        N.check(lib.lspf2f_unet_prepare(p(d), nchw, 2, 8, 6, 5, ctypes.c_float(0.2), p(s2d), 24, p(relu), stream()))
+        torch.cuda.synchronize()
+        want = torch.zeros(2, 24, 4, 3)
+        for dy in range(2):
+            for dx in range(2):
+                want[:, (dy * 2 + dx) * 5:(dy * 2 + dx + 1) * 5] = F.leaky_relu(x[:, :, dy::2, dx::2], 0.2)
+        assert torch.equal(s2d.cpu(), want.permute(0, 2, 3, 1))
+        assert torch.equal(relu.cpu(), F.relu(x).permute(0, 2, 3, 1))
+    with pytest.raises(N.Lspf2fError):
+        N.check(lib.lspf2f_unet_prepare(p(d), 0, 2, 7, 6, 5, ctypes.c_float(0.2), p(s2d), 24, None, stream()))       # odd height
+    with pytest.raises(N.Lspf2fError):
+        N.check(lib.lspf2f_unet_prepare(p(d), 0, 2, 8, 6, 5, ctypes.c_float(0.2), p(s2d), 16, None, stream()))       # s2d_channels < 4c
+    gq = torch.randn(2, 4, 3, 12, generator=g)
+    out = torch.empty(2, 3, 8, 6, device=dev)
+    N.check(lib.lspf2f_pixel_shuffle(p(gq.to(dev)), 2, 4, 3, 3, 1, p(out), None, stream()))
+    want = torch.zeros(2, 3, 8, 6)
+    for par in range(4):
+        want[:, :, par // 2::2, par % 2::2] = torch.tanh(gq[..., par * 3:(par + 1) * 3]).permute(0, 3, 1, 2)
+    assert (out.cpu() - want).abs().max() < 1e-6
