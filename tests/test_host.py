@@ -200,8 +200,11 @@ def test_inference_has_no_cpu_fallback():
     m = L.create_model(opt_ns(size="normal", ngf=32, n_downsample_G=5))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.inference(torch.zeros(1, 1, 64, 64), torch.zeros(1, 12, 64, 64))
-    with pytest.raises(NotImplementedError):
-        L.create_model(opt_ns(size="small"))
+    small = L.create_model(opt_ns(size="small"))                    # the pix2pix U-Net variant is supported, but never on the CPU
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        small.inference(torch.zeros(1, 1, 64, 64), torch.zeros(1, 22, 64, 64))
+    with pytest.raises(ValueError):
+        L.create_model(opt_ns(size="medium"))
     with pytest.raises(NotImplementedError):
         L.create_model(opt_ns(isTrain=True))
     with pytest.raises(NotImplementedError):
