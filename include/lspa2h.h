@@ -100,6 +100,15 @@ int lspa2h_generate(lspa2h_handle *h, const float *audio_dev, int n_audio, const
  * first inter-workgroup hand-off that timed out (the kernel never spins unbounded; output rows are then undefined). */
 int lspa2h_status(lspa2h_handle *h, void *stream, uint32_t *code);
 
+/* Sample_GMM (models/losses.py:68-112) for `rows` independent rows at once -- what the LSTM decoder branch of
+ * generate_sequences does in one call (audio2headpose_model.py:196-199).  Stateless.
+ *   params_dev [rows][(2*ndim+1)*ncenter]  network output: ncenter logits, ncenter*ndim means, ncenter*ndim -log(sigma)
+ *   noise_dev  [rows][ndim]     torch.randn(rows, ndim), or NULL (= 0)
+ *   expq_dev   [rows][ncenter]  the Exp(1) draws of torch.multinomial(prob, 1); required iff ncenter > 1
+ *   out_dev    [rows][ndim]     noise * exp(-nls) * sigma_scale + mu of the selected centre */
+int lspa2h_sample_gmm(const float *params_dev, int rows, int ncenter, int ndim, const float *noise_dev,
+                      const float *expq_dev, float sigma_scale, float *out_dev, void *stream);
+
 /* Test / profiling hooks (no reference counterpart). */
 /* down_audio_feats of Audio2Headpose.forward (audio2headpose.py:47): [n_audio][hidden_size], valid after generate */
 int lspa2h_debug_cond(const lspa2h_handle *h, const float **cond_dev, int *rows, int *cols);

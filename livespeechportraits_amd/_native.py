@@ -114,6 +114,7 @@ A2H_SIGNATURES = {
     "lspa2h_generate_timed": (c_int, _GEN_ARGS + [POINTER(c_float), POINTER(c_float)]),
     "lspa2h_debug_cond": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int)]),
     "lspa2h_status": (c_int, [c_void_p, c_void_p, POINTER(c_uint32)]),
+    "lspa2h_sample_gmm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
 }
 
 # every symbol include/lsplle.h declares

@@ -87,3 +87,54 @@ class Audio2Headpose(nn.Module):
     def forward(self, *a, **kw):
         raise RuntimeError("Audio2Headpose has no per-window forward here: use Audio2HeadposeModel.generate_sequences "
                            "(the HIP path evaluates the WaveNet incrementally; there is no CPU path)")
+
+
+class Audio2Headpose_LSTM(nn.Module):
+    """``feature_decoder == 'LSTM'`` (reference models/audio2headpose.py:56-100): Linear-BN-LeakyReLU-Linear on the 1024-d
+    audio rows, LSTM(512 -> 256, 3 layers), Linear-BN-LReLU-Linear-BN-LReLU-Linear to the GMM parameters.  Same keys."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nd, nc, H = opt.A2H_GMM_ndim, opt.A2H_GMM_ncenter, opt.APC_hidden_size
+        out = (2 * nd + 1) * nc if opt.loss == "GMM" else nd
+        self.audio_downsample = nn.Sequential(nn.Linear(2 * H, H), nn.BatchNorm1d(H), nn.LeakyReLU(0.2), nn.Linear(H, H))
+        self.LSTM = nn.LSTM(input_size=H, hidden_size=256, num_layers=3, dropout=0, bidirectional=False, batch_first=True)
+        self.fc = nn.Sequential(nn.Linear(256, 512), nn.BatchNorm1d(512), nn.LeakyReLU(0.2),
+                                nn.Linear(512, 512), nn.BatchNorm1d(512), nn.LeakyReLU(0.2), nn.Linear(512, out))
+        self._packed = None
+        self._version = None
+
+    def mark_dirty(self):
+        self._packed = None
+
+    def _pack(self, device, T):
+        from .rnn_engine import Linear, RecurrentEngine
+        version = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        pk = self._packed
+        if pk is None or self._version != version or pk["lstm"].max_steps < T or pk["lstm"].blob.device != device:
+            bn = lambda m: (m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), m.running_mean.cpu().numpy(), m.running_var.cpu().numpy())
+            lin = lambda m, b=None, leaky=False: Linear(m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(),
+                                                        bn(b) if b is not None else None, leaky, device)
+            d, f = self.audio_downsample, self.fc
+            lstm = RecurrentEngine("LSTM", 3, self.opt.APC_hidden_size, 256, max_steps=max(T, 4096))
+            lstm.load_state_dict(dict(self.LSTM.state_dict()))
+            lstm.bind(device)
+            pk = {"d0": lin(d[0], d[1], True), "d3": lin(d[3]), "lstm": lstm,
+                  "f0": lin(f[0], f[1], True), "f3": lin(f[3], f[4], True), "f6": lin(f[6])}
+            self._packed, self._version = pk, version
+        return pk
+
+    def forward(self, audio_features):
+        """[1, T, 2*APC_hidden] -> [1, T, output]   (audio2headpose.py:88-99)"""
+        if audio_features.dim() != 3 or audio_features.shape[0] != 1:
+            raise ValueError("audio_features must be [1, T, ndim]")
+        if not audio_features.is_cuda:
+            raise RuntimeError("Audio2Headpose_LSTM here is the MI355X path: device tensors only (no CPU path)")
+        x = audio_features[0].float().contiguous()
+        pk = self._pack(audio_features.device, x.shape[0])
+        x = pk["lstm"].forward(pk["d3"](pk["d0"](x)))
+        return pk["f6"](pk["f3"](pk["f0"](x))).unsqueeze(0)
+
+    def status(self) -> int:
+        return self._packed["lstm"].status() if self._packed else 0

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import networks
-from .audio2headpose import Audio2Headpose
+from .audio2headpose import Audio2Headpose, Audio2Headpose_LSTM
 from .base_model import BaseModel
 
 
@@ -35,11 +35,12 @@ class Audio2HeadposeModel(BaseModel):
     def __init__(self, opt):
         BaseModel.__init__(self, opt)
         self.model_names = ["Audio2Headpose"]
-        if opt.feature_decoder != "WaveNet":
-            raise NotImplementedError("feature_decoder=%r: only the (default) WaveNet decoder has a HIP path" % (opt.feature_decoder,))
+        if opt.feature_decoder not in ("WaveNet", "LSTM"):
+            raise NotImplementedError("feature_decoder=%r: the reference knows 'WaveNet' and 'LSTM'" % (opt.feature_decoder,))
         if not self.gpu_ids:
             raise RuntimeError("Audio2HeadposeModel here is the MI355X path: gpu_ids must name a device (no CPU path)")
-        self.Audio2Headpose = networks.init_net(Audio2Headpose(opt), init_type="normal", init_gain=0.02, gpu_ids=opt.gpu_ids)
+        net = Audio2Headpose(opt) if opt.feature_decoder == "WaveNet" else Audio2Headpose_LSTM(opt)
+        self.Audio2Headpose = networks.init_net(net, init_type="normal", init_gain=0.02, gpu_ids=opt.gpu_ids)
 
     def _net(self) -> Audio2Headpose:
         n = self.Audio2Headpose
@@ -52,6 +53,8 @@ class Audio2HeadposeModel(BaseModel):
         audio = np.asarray(audio_feats, dtype=np.float32).reshape(-1, 2 * H)
         frame_future = opt.frame_future
         nframe = audio.shape[0] - frame_future
+        if self.opt.feature_decoder == "LSTM":
+            return self._generate_lstm(net, audio, sigma_scale)
         if not fill_zero:
             return None                                   # reference :166-167
         if nframe < 1:
@@ -71,3 +74,26 @@ class Audio2HeadposeModel(BaseModel):
         if code:
             raise RuntimeError("head-pose kernel: inter-workgroup hand-off 0x%x timed out" % code)
         return out.cpu().numpy().astype(np.float64)       # the reference fills an np.zeros (float64) array, :149
+
+    def _generate_lstm(self, net, audio, sigma_scale):
+        """reference :189-202: one forward over ALL audio rows, one Sample_GMM over all of them; returns [rows, ndim] float32.
+        RNG order of that single call: torch.multinomial draws rows x ncenter exponentials, then torch.randn(rows, ndim)."""
+        import ctypes
+        from . import _native as N
+        nd, nc = self.opt.A2H_GMM_ndim, self.opt.A2H_GMM_ncenter
+        rows = audio.shape[0]
+        dev = self.device
+        preds = net.forward(torch.from_numpy(np.ascontiguousarray(audio)).unsqueeze(0).to(dev))[0].contiguous()
+        if net.status():
+            raise RuntimeError("LSTM kernel: inter-workgroup hand-off timed out")
+        if self.opt.loss != "GMM":
+            return preds.cpu().numpy()
+        expq = torch.empty(rows, nc).exponential_(1)
+        noise = torch.randn(rows, nd).float()
+        out = torch.empty((rows, nd), dtype=torch.float32, device=dev)
+        nz, eq = noise.to(dev), (expq.to(dev) if nc > 1 else None)
+        with torch.cuda.device(dev):
+            N.check_a2h(N.load().lspa2h_sample_gmm(ctypes.c_void_p(preds.data_ptr()), rows, nc, nd, ctypes.c_void_p(nz.data_ptr()),
+                                                   ctypes.c_void_p(eq.data_ptr()) if eq is not None else None, ctypes.c_float(float(sigma_scale)),
+                                                   ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out.cpu().numpy()

@@ -489,6 +489,31 @@ __global__ __launch_bounds__(NT) void a2h_pipe(StreamParams p)
     }
 }
 
+// Sample_GMM for independent rows (the LSTM decoder samples the whole sequence in one call)
+__global__ __launch_bounds__(256) void gmm_sample_rows(const float *params, int rows, int nc, int nd, const float *noise,
+                                                       const float *expq, float sigma_scale, float *out)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * nd) return;
+    const int r = gid / nd, d = gid - r * nd;
+    const float *g = params + (size_t)r * (2 * nd + 1) * nc;
+    int idx = 0;
+    if (nc > 1) {
+        float mx = g[0];
+        for (int k = 1; k < nc; ++k) mx = fmaxf(mx, g[k]);
+        float den = 0.f;
+        for (int k = 0; k < nc; ++k) den += expf(g[k] - mx);
+        float best = -1.f;
+        for (int k = 0; k < nc; ++k) {
+            const float val = (expf(g[k] - mx) / den) / expq[(size_t)r * nc + k];
+            if (val > best) { best = val; idx = k; }
+        }
+    }
+    const float mu = g[nc + idx * nd + d];
+    const float sigma = expf(-g[nc + nc * nd + idx * nd + d]) * sigma_scale;
+    out[gid] = (noise ? noise[gid] : 0.f) * sigma + mu;
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -889,6 +914,18 @@ int lspa2h_generate_timed(lspa2h_handle *h, const float *audio_dev, int n_audio,
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return rc;
+}
+
+int lspa2h_sample_gmm(const float *params_dev, int rows, int ncenter, int ndim, const float *noise_dev,
+                      const float *expq_dev, float sigma_scale, float *out_dev, void *stream)
+{
+    if (!params_dev || !out_dev) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "null argument");
+    if (rows < 1 || ncenter < 1 || ncenter > 8 || ndim < 1) return fail(LSPA2H_ERR_SHAPE, "rows >= 1, 1 <= ncenter <= 8, ndim >= 1");
+    if (ncenter > 1 && !expq_dev) return fail(LSPA2H_ERR_INVALID_ARGUMENT, "expq_dev is required when ncenter > 1");
+    hipLaunchKernelGGL(gmm_sample_rows, dim3((rows * ndim + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       params_dev, rows, ncenter, ndim, noise_dev, expq_dev, sigma_scale, out_dev);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LSPA2H_OK : hipfail(e, "gmm_sample_rows launch");
 }
 
 int lspa2h_status(lspa2h_handle *h, void *stream, uint32_t *code)

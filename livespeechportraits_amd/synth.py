@@ -299,3 +299,13 @@ def make_unet_small_state_dict(input_nc: int = 23, output_nc: int = 3, num_downs
             v = np.float32(1.0) + symmetric(n, 0.02, st)
         sd[key] = v.reshape(shape).astype(np.float32)
     return sd
+
+
+def make_a2h_lstm_state_dict(hidden: int = 512, ncenter: int = 1, ndim: int = 12, loss: str = "GMM", seed: int = 41) -> Dict[str, np.ndarray]:
+    """Audio2Headpose_LSTM keys (models/audio2headpose.py:56-86): the Audio2Feature layout with ``audio_downsample`` in place
+    of ``downsample`` and a GMM-parameter output."""
+    out = (2 * ndim + 1) * ncenter if loss == "GMM" else ndim
+    sd = {}
+    for k, v in make_a2f_state_dict(hidden, out, seed=seed).items():
+        sd[("audio_" + k) if k.startswith("downsample.") else k] = v
+    return sd

@@ -156,3 +156,31 @@ def stream(sd, cfg, audio_feats, pre_headpose, noise, expq, sigma_scale, frame_f
         out[i] = smp
         x_in = smp
     return out
+
+
+def lstm_generate(sd, cfg, audio_feats, noise, expq, sigma_scale):
+    """The LSTM decoder branch: Audio2Headpose_LSTM.forward (models/audio2headpose.py:88-99) over ALL audio rows, then one
+    Sample_GMM over all rows (models/audio2headpose_model.py:189-202).  noise [rows, ndim], expq [rows, ncenter]."""
+    import torch.nn as nn
+    W = _t(sd)
+    H, nd, nc = cfg["hidden_size"], cfg["ndim"], cfg["ncenter"]
+    x = torch.from_numpy(np.asarray(audio_feats, np.float32).reshape(-1, 2 * H))
+    bn = lambda h, p: F.batch_norm(h, W[p + ".running_mean"], W[p + ".running_var"], W[p + ".weight"], W[p + ".bias"], False, 0.1, 1e-5)
+    with torch.no_grad():
+        h = F.leaky_relu(bn(F.linear(x, W["audio_downsample.0.weight"], W["audio_downsample.0.bias"]), "audio_downsample.1"), 0.2)
+        h = F.linear(h, W["audio_downsample.3.weight"], W["audio_downsample.3.bias"])
+        lstm = nn.LSTM(input_size=H, hidden_size=256, num_layers=3, batch_first=True)
+        lstm.load_state_dict({k[5:]: v for k, v in W.items() if k.startswith("LSTM.")})
+        h, _ = lstm(h.unsqueeze(0))
+        h = h.reshape(-1, 256)
+        h = F.leaky_relu(bn(F.linear(h, W["fc.0.weight"], W["fc.0.bias"]), "fc.1"), 0.2)
+        h = F.leaky_relu(bn(F.linear(h, W["fc.3.weight"], W["fc.3.bias"]), "fc.4"), 0.2)
+        g = F.linear(h, W["fc.6.weight"], W["fc.6.bias"])                 # [rows, nout]
+        if cfg["loss"] != "GMM":
+            return g.numpy()
+        prob = F.softmax(g[:, :nc], dim=1)
+        idx = torch.argmax(prob / torch.as_tensor(expq).float(), dim=1)      # == torch.multinomial(prob, 1, True)
+        mu = g[:, nc: nc + nc * nd].reshape(-1, nc, nd)
+        sigma = (torch.exp(-g[:, nc + nc * nd:]) * sigma_scale).reshape(-1, nc, nd)
+        r = torch.arange(g.shape[0])
+        return (torch.as_tensor(noise).float() * sigma[r, idx] + mu[r, idx]).numpy()

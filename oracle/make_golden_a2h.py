@@ -102,5 +102,35 @@ def main():
                 json.dump(ref_keys, f, indent=0)
 
 
+def main_lstm(out_dir):
+    """feature_decoder == 'LSTM': the reference's Audio2HeadposeModel with its LSTM network, one vectorised Sample_GMM."""
+    from models.audio2headpose_model import Audio2HeadposeModel
+    for name, nc, loss, rows, sigma, seed in (("lstm_nc1", 1, "GMM", 96, 0.3, 91), ("lstm_nc3", 3, "GMM", 64, 0.5, 92), ("lstm_l2", 1, "L2", 40, 0.0, 93)):
+        cfg = dict(synth.A2H_DEFAULTS, ncenter=nc, loss=loss)
+        opt = ref_opt(cfg, 15)
+        opt.feature_decoder = "LSTM"
+        model = Audio2HeadposeModel(opt)
+        net = model.Audio2Headpose
+        sd = synth.make_a2h_lstm_state_dict(512, nc, 12, loss)
+        ref_keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert {k: v for k, v in ref_keys.items() if not k.endswith("num_batches_tracked")} == {k: list(v.shape) for k, v in sd.items()}, "key map differs"
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        model.eval()
+        model.device = torch.device("cpu")
+        audio, pre = synth.make_a2h_inputs(rows, cfg, seed=19)
+        torch.manual_seed(seed)
+        ref = model.generate_sequences(audio.copy(), pre.copy(), fill_zero=True, sigma_scale=sigma, opt=opt)
+        torch.manual_seed(seed)
+        expq = torch.empty(rows, nc).exponential_(1).numpy() if loss == "GMM" else np.ones((rows, nc), np.float32)
+        noise = torch.randn(rows, 12).float().numpy() if loss == "GMM" else np.zeros((rows, 12), np.float32)
+        ora = a2h_oracle.lstm_generate(sd, cfg, audio, noise, expq, sigma)
+        assert ref.shape == (rows, 12) and np.array_equal(ora, ref), np.abs(ora - ref).max()
+        print("%-10s rows %3d ncenter %d loss %s: |out| max %.2f std %.2f  oracle bit-exact" % (name, rows, nc, loss, np.abs(ref).max(), ref.std()))
+        np.savez_compressed(os.path.join(out_dir, "a2h_%s.npz" % name), out=ref.astype(np.float32), noise=noise, expq=expq)
+        with open(os.path.join(out_dir, "a2h_%s.json" % name), "w") as f:
+            json.dump({"cfg": cfg, "rows": rows, "sigma_scale": sigma, "torch_seed": seed, "weights_seed": 41, "inputs_seed": 19, "keys": ref_keys}, f, indent=0)
+
+
 if __name__ == "__main__":
     main()
+    main_lstm(os.path.join(REPO, "tests", "golden"))

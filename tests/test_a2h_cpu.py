@@ -154,4 +154,4 @@ def test_model_requires_a_device_and_wavenet_decoder():
     with pytest.raises(RuntimeError, match="no CPU path"):
         create_model(argparse.Namespace(**base))
     with pytest.raises(NotImplementedError):
-        create_model(argparse.Namespace(**dict(base, feature_decoder="LSTM", gpu_ids=[0])))
+        create_model(argparse.Namespace(**dict(base, feature_decoder="GRU", gpu_ids=[0])))      # the reference knows WaveNet and LSTM

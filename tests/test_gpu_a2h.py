@@ -137,3 +137,54 @@ def test_drop_in_model_reproduces_seeded_reference_run(tmp_path):
     assert out.shape == ref.shape and out.dtype == np.float64
     assert np.abs(out - ref).max() <= TOL
     assert m.generate_sequences(audio, pre, fill_zero=False, opt=opt) is None      # reference :166-167
+
+
+@pytest.mark.parametrize("name", ["lstm_nc1", "lstm_nc3", "lstm_l2"])
+def test_lstm_decoder_reproduces_seeded_reference_run(name, tmp_path):
+    """feature_decoder == 'LSTM' (reference audio2headpose.py:56-100, audio2headpose_model.py:189-202): one forward over
+    all audio rows, one vectorised Sample_GMM; under the golden's torch seed the numbers are the reference's."""
+    import json
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.models import create_model
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gold, "a2h_%s.json" % name)))
+    ref = np.load(os.path.join(gold, "a2h_%s.npz" % name))["out"]
+    cfg = meta["cfg"]
+    sd = synth.make_a2h_lstm_state_dict(512, cfg["ncenter"], 12, cfg["loss"], seed=meta["weights_seed"])
+    ckpt = os.path.join(tmp_path, "Audio2Headpose.pkl")
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
+    opt = argparse.Namespace(model="audio2headpose", gpu_ids=[0], isTrain=False, checkpoints_dir=str(tmp_path), name="x", load_epoch=ckpt,
+                             verbose=False, feature_decoder="LSTM", loss=cfg["loss"], A2H_GMM_ndim=12, A2H_GMM_ncenter=cfg["ncenter"],
+                             APC_hidden_size=512, frame_future=15)
+    m = create_model(opt)
+    m.setup(opt)
+    m.eval()
+    audio, pre = synth.make_a2h_inputs(meta["rows"], cfg, seed=meta["inputs_seed"])
+    torch.manual_seed(meta["torch_seed"])
+    out = m.generate_sequences(audio, pre, fill_zero=True, sigma_scale=meta["sigma_scale"], opt=opt)
+    err = np.abs(out - ref).max()
+    print("\n[a2h %s] LSTM decoder max-abs vs reference %.3e" % (name, err))
+    assert out.shape == ref.shape == (meta["rows"], 12) and out.dtype == np.float32 and err <= 5e-5
+
+
+def test_sample_gmm_entry_point():
+    import ctypes
+    from livespeechportraits_amd import _native as N
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    rows, nc, nd = 37, 4, 12
+    params = torch.randn(rows, (2 * nd + 1) * nc, generator=g)
+    noise, expq = torch.randn(rows, nd, generator=g), torch.empty(rows, nc).exponential_(1, generator=g)
+    prob = torch.softmax(params[:, :nc], 1)
+    idx = torch.argmax(prob / expq, 1)
+    r = torch.arange(rows)
+    mu = params[:, nc:nc + nc * nd].reshape(rows, nc, nd)[r, idx]
+    sg = (torch.exp(-params[:, nc + nc * nd:]) * 0.7).reshape(rows, nc, nd)[r, idx]
+    want = noise * sg + mu
+    out = torch.empty(rows, nd, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    pd, nz, eq = params.to(dev), noise.to(dev), expq.to(dev)
+    N.check_a2h(N.load().lspa2h_sample_gmm(p(pd), rows, nc, nd, p(nz), p(eq), ctypes.c_float(0.7), p(out), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert (out.cpu() - want).abs().max() <= 1e-5
+    with pytest.raises(N.Lspa2hError, match="expq"):
+        N.check_a2h(N.load().lspa2h_sample_gmm(p(pd), rows, nc, nd, p(nz), None, ctypes.c_float(0.7), p(out), None))
