@@ -270,6 +270,25 @@ def test_bf16_last_conv_gemm_and_direct_routes_agree(gpu_device, monkeypatch):
     assert np.abs(imgs[0][0] - want).max() <= 1
 
 
+@pytest.mark.parametrize("variant,size,batch", [("normal", 1024, 2), ("large", 768, 1)])
+def test_frame_sizes_beyond_the_goldens(variant, size, batch, gpu_device):
+    """Sizes larger than any golden (the index arithmetic is 32-bit with a reserved top bit): live oracle comparison."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.topology import build_topology
+    from oracle import torch_oracle
+    topo = build_topology(variant, size=size)
+    sd = synth.make_state_dict(topo, 1234)
+    feat, cand = synth.make_inputs(batch, size, seed=5, cand_batch=1)
+    e = Engine(variant, size=size, max_batch=batch)
+    e.load_state_dict(sd)
+    e.bind(e.pack(), gpu_device)
+    out = e.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
+    x = torch.cat([torch.from_numpy(feat), torch.from_numpy(cand).expand(batch, -1, -1, -1)], 1)
+    ref = torch_oracle.generator_forward(torch_oracle.to_torch(sd), x, 2 if variant == "large" else 1, topo.num_downs).numpy()
+    assert np.abs(out - ref).max() <= 5e-5
+
+
 def test_bf16_layers_match_the_storage_model_given_the_gpus_own_inputs(gpu_device):
     """Teacher-forced per-layer check of the bf16 path INSIDE the network: feed the GPU's own stored (bf16) inputs of a
     layer to oracle/bf16_model.py's arithmetic for that layer (weights folded and rounded from the state dict exactly as
