@@ -56,7 +56,7 @@ def main():
 
     topo = build_topology(a.variant, size=a.size)
     B = a.batch
-    eng = Engine(a.variant, size=a.size, max_batch=max(B, 8 if not a.no_extra and world == 1 else B), dtype=a.dtype)
+    eng = Engine(a.variant, size=a.size, max_batch=max(B, B if a.no_extra else 8), dtype=a.dtype)
     peak = PEAK_F32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     sd = synth.make_state_dict(topo, 1234) if rank == 0 else None
     D.setup_engine(eng, sd, dev)          # pack on rank 0, ONE RCCL broadcast, bind everywhere
@@ -89,6 +89,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ev_ms = ev0.elapsed_time(ev1) / a.steps     # device-side, this rank's stream
+
+    # BASELINE.json configs[3] shape beside the headline when N > 1: 8 frames per GPU per step, ONE candidate stack shared by
+    # the batch, distinct feature maps per rank and frame (seed 99 + 1000*rank + i), same barrier / MAX-over-ranks protocol.
+    # Efficiency = this aggregate / (N x the 1-GPU `extra.batch8_frames_per_s` of the N = 1 run) -- computed by the reader.
+    config3 = None
+    if world > 1 and not a.no_extra:
+        f8 = torch.from_numpy(synth.make_inputs(8, a.size, seed=99 + 1000 * rank, cand_batch=1)[0]).to(dev)
+        o8 = torch.empty((8, 3, a.size, a.size), device=dev)
+        for _ in range(3):
+            eng.forward(f8, cand, o8)
+        torch.cuda.synchronize()
+        barrier()
+        n8 = max(5, a.steps // 5)
+        t1 = time.perf_counter()
+        for _ in range(n8):
+            eng.forward(f8, cand, o8)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t1
+        barrier()
+        t = torch.tensor([time.perf_counter() - t1, mine, -mine], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        config3 = {"frames_per_s": round(world * 8 * n8 / float(t[0].item()), 2), "global_batch": 8 * world, "frames_per_gpu": 8,
+                   "steps": n8, "per_gpu_frames_per_s_slowest_fastest": [round(8 * n8 / float(t[1].item()), 2), round(8 * n8 / float(-t[2].item()), 2)],
+                   "backend": dist.get_backend(), "ranks_in_group": dist.get_world_size(),
+                   "note": "BASELINE.json configs[3]: batch 64 = 8 frames x 8 GPUs at N = 8; candidates shared; one RCCL weight broadcast at start-up, no per-frame collective"}
 
     if rank != 0:
         if world > 1:
@@ -209,6 +234,11 @@ def main():
                    "gflop_per_frame": round(topo.flops_per_frame() / 1e9, 2)},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
+    if config3:
+        extra = dict(extra or {}, config3_batch8_per_gpu=config3)
+    if world > 1:
+        line["config"]["collective_backend"] = dist.get_backend()
+        line["config"]["ranks_in_group"] = dist.get_world_size()
     if extra:
         line["extra"] = extra
     print(json.dumps(line))

@@ -42,7 +42,9 @@ int lsplle_knn(const float *feats_dev, int n, const float *db_dev, int m, int d,
 
 /* compute_LLE_projection_all_frame (funcs/utils.py:171-179) for all frames at once, optionally followed by the
  * blend of demo.py:200.
- *   ind_dev      int64 [n][K]   neighbour rows (ind[i][0] is the pivot f1 of the derivation in utils.py:126-141)
+ *   ind_dev      int64 [n][K]   neighbour rows (ind[i][0] is the pivot f1 of the derivation in utils.py:126-141).
+ *                               A row holding an index outside [0, m) -- lsplle_knn writes -1 when a feature row had fewer
+ *                               than K finite distances (NaN input) -- reads nothing and produces NaN outputs for that row.
  *   weights_dev  double [n][K]  or NULL   (the reference's w is float64: utils.py:148)
  *   fuse_dev     float [n][d]   or NULL   feat_fuse
  *   blend_dev    float [n][d]   or NULL   feats * (1 - percent) + feat_fuse * percent

@@ -6,7 +6,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -48,6 +47,8 @@ struct lspf2f_handle {
     size_t ws_size = 0;
     bool packed = false;
     bool use_graph = true;
+    bool last_direct = false;     // bf16 plans: direct last-conv kernel instead of the GEMM form (LSP_HIP_LASTCONV_DIRECT, read at create)
+    int last_route = 0;           // forced direct last-conv kernel (LSP_HIP_LASTCONV_{STRIP,ROWS,GENERIC}, read at create; tests only)
     const void *cand_cached = nullptr;   // candidate stack whose first-conv contribution sits in the workspace cache
     hipStream_t cap_stream = nullptr;
     std::vector<CachedGraph> graphs;
@@ -71,14 +72,6 @@ static int hipfail(hipError_t e, const char *what)
     return fail(LSPF2F_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-static std::once_flag g_init_once;
-static hipError_t g_init_err = hipSuccess;
-static hipError_t ensure_init()
-{
-    std::call_once(g_init_once, [] { g_init_err = igemm_init(); });
-    return g_init_err;
-}
-
 extern "C" {
 
 const char *lspf2f_last_error(void) { return g_err.c_str(); }
@@ -100,7 +93,11 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
+    // environment switches are read HERE, once per handle, never on the launch path
     if (const char *env = std::getenv("LSP_HIP_GRAPH")) h->use_graph = h->use_graph && std::strcmp(env, "0") != 0;
+    h->last_direct = std::getenv("LSP_HIP_LASTCONV_DIRECT") != nullptr;
+    h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
+                  : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : 0;
     *out = h;
     return LSPF2F_OK;
 }
@@ -254,7 +251,9 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.B = batch; p.H = l.hs; p.W = l.hs; p.feat_nc = P.feat_nc; p.cand_nc = P.input_nc - P.feat_nc;
         p.cand_batch = cand_batch; p.Cout = l.cout; p.dtype = P.dtype;
         p.ci_begin = 0; p.ci_end = P.input_nc; p.base = nullptr; p.relu = 1;
-        float *cache = reinterpret_cast<float *>(h->ws);
+        // two slots at the head of the workspace: [0] lspf2f_set_candidates' per-person cache, [1] the per-forward share of a
+        // broadcast stack -- separate, so a broadcast forward never overwrites what the cache holds
+        float *cache = reinterpret_cast<float *>(cand != nullptr ? h->ws + P.cand_cache_bytes() : h->ws);
         const bool shared = p.cand_nc > 0 && P.feat_nc > 0 && (cand == nullptr || (cand_batch == 1 && batch > 1));
         if (shared) {
             // candidate stack shared by the whole batch: its contribution is computed once (or taken
@@ -270,7 +269,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         } else {
             e = launch_first_conv(p, s);
         }
-    } else if (l.kind == kLastConv && P.last_as_gemm(l) && !std::getenv("LSP_HIP_LASTCONV_DIRECT")) {
+    } else if (l.kind == kLastConv && P.last_as_gemm(l) && !h->last_direct) {
         // bf16: 3x3 conv on the low-res source with N = 4 parities x cout through the MFMA kernel, then shuffle + tanh
         IgemmParams g{};
         g.src0 = tptr(l.src0); g.src1 = tptr(l.src1); g.w = h->blob + l.wgemm_off;
@@ -288,6 +287,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         LastConvParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.out = out;
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out; p.out_u8 = out_u8; p.dtype = P.dtype;
+        p.route = h->last_route;
         e = launch_last_conv(p, s);
     } else if (l.smallm) {
         SmallMParams p{};
@@ -334,8 +334,6 @@ static int check_forward_args(lspf2f_handle *h, const float *feat, const float *
     h->plan.plan_batch(batch);
     if (h->ws_size < h->plan.act_bytes + h->plan.partial_bytes)
         return fail(LSPF2F_ERR_STATE, "workspace too small for this batch (lspf2f_workspace_bytes)");
-    const hipError_t e = ensure_init();
-    if (e != hipSuccess) return hipfail(e, "kernel attribute setup");
     return LSPF2F_OK;
 }
 
@@ -481,8 +479,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     if (stride != 1 && stride != 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "stride must be 1 or 2");
     if (upsample && stride != 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "upsample requires stride 1");
     if ((scale == nullptr) != (shift == nullptr)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "scale and shift come together");
-    hipError_t e = ensure_init();
-    if (e != hipSuccess) return hipfail(e, "kernel attribute setup");
+    hipError_t e = hipSuccess;
     {
         // tile 1x1 forces the tiny-M single-launch kernel; tile 0x0 lets the planner's rule pick it
         SmallMParams q{};
@@ -529,7 +526,9 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             return fail(LSPF2F_ERR_STATE, "split-K scratch missing or too small");
         p.partial = static_cast<float *>(scratch);
     }
-    if (const char *env = std::getenv("LSP_HIP_DBG")) p.dbg = std::atoi(env);   // ablation knob, tools only
+#ifdef LSPF2F_ABLATE
+    if (const char *env = std::getenv("LSP_HIP_DBG")) p.dbg = std::atoi(env);   // tools/ablate.sh builds only
+#endif
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     e = launch_igemm(p, bm, bn, grp, s);
     if (e == hipSuccess && sp > 1) e = launch_splitk_reduce(p, s);

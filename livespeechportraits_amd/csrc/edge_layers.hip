@@ -491,8 +491,8 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
     const long quads = (long)p.B * p.Hs * ((p.Ws + 3) / 4);
     // measured on MI355X (512x512 output): batch 1 rows 43 us / strip 55 us; batch 8 rows 270 us / strip 221 us
     const bool big = (long)p.B * p.Hs * p.Ws >= 4 * 65536;
-    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 64 && (big || std::getenv("LSP_HIP_LASTCONV_STRIP")) &&
-        !std::getenv("LSP_HIP_LASTCONV_ROWS") && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
+    // p.route: 0 = by size (the rule above), 1 strip, 2 rows, 3 generic (fixed per handle at create time, tests only)
+    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 64 && ((big && p.route == 0) || p.route == 1)) {
         // sliding-window kernel; segment length trades window priming (2 extra columns) for parallelism
         const int seg = 32;
         const long groups = (long)p.B * p.Hs * ((p.Ws + seg - 1) / seg);
@@ -500,7 +500,7 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
         hipLaunchKernelGGL((last_conv_strip<T, CO>), dim3((unsigned)((groups + 15) / 16)), dim3(256), smem, s, p, seg);
         return hipGetLastError();
     }
-    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 128 && !std::getenv("LSP_HIP_LASTCONV_GENERIC")) {
+    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 128 && p.route != 3) {
         // 4 parities x quads wave-iterations; 4 waves per block, parity = wave & 3
         long blocks = (quads + 3) / 4;                      // >= ~4 quads per wave
         if (blocks > 2048) blocks = 2048;                   // 8 blocks (32 waves) per CU, all resident

@@ -14,8 +14,11 @@
 #include <cstdlib>
 
 
-#ifndef LSPF2F_SWP
-#define LSPF2F_SWP 1   // 1: LDS fragment reads issued one step ahead of the MFMAs
+// Ablation switches (tools/ablate.sh builds with -DLSPF2F_ABLATE); the shipped kernel has none of them.
+#ifdef LSPF2F_ABLATE
+#define ABL(p, bit) ((p).dbg & (bit))
+#else
+#define ABL(p, bit) 0
 #endif
 
 
@@ -277,11 +280,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             }
     };
 
-    // ---- main loop.  Per pipeline step (G K-tiles in LDS buffer `cur`):
-    //   global loads of step t+1 -> registers | fragment steps 0..S-2 (LDS reads one step ahead)
-    //   | registers -> LDS buffer cur^1 (its latency hides behind the last MFMA block)
-    //   | last MFMA block | barrier | first fragment read of step t+1 (hidden behind the next fetch).
-    if (kt_begin < kt_end && !(p.dbg & 32)) {
+    // ---- main loop.  Per pipeline step t (G K-tiles in LDS ring slot `cur`):
+    //   issue the LDS-DMA of step t+NS-1 into the slot that step t-1 just released (no registers, no ds_write)
+    //   | fragment steps 0..S-1: ds_read of fragment s+1 issued before the MFMAs of fragment s
+    //   | counted vmcnt wait: step t+1 has landed | barrier (publishes it, releases slot `cur`)
+    //   | first fragment read of step t+1 (its latency hides behind the next DMA issue).
+    if (kt_begin < kt_end && !ABL(p, 32)) {
         constexpr int PIECES = G * (PA + PB);      // DMA instructions this wave issues per step
         const int nsteps = (kt_end - kt_begin + G - 1) / G;
         fetch(kt_begin, 0);
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
         for (int t = 0; t < nsteps; ++t) {
             // ring slot (cur + NS-1) % NS was last read in step t-1; every wave has passed that barrier
             const int ahead = t + NS - 1;
-            const bool issue = ahead < nsteps && !(p.dbg & 1);
+            const bool issue = ahead < nsteps && !ABL(p, 1);
             int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
             if (issue) fetch(kt_begin + ahead * G, slot);
 #pragma unroll
@@ -304,8 +308,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             mfma_frag((S - 1) & 1);
             // step t+1 must have landed: everything but the pieces issued in THIS iteration
             if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
-            if (!(p.dbg & 4)) __syncthreads();
-            if (!(p.dbg & 8)) { if (++cur == NS) cur = 0; }
+            if (!ABL(p, 4)) __syncthreads();
+            if (!ABL(p, 8)) { if (++cur == NS) cur = 0; }
             if (t + 1 < nsteps) read_frag(cur, 0, 0);
         }
     }
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     // are free after the last barrier) so every lane ends up with 4 consecutive channels of a row:
     // float4 residual loads / stores, 8 lanes per 128-B row segment, 4 instead of 16 memory
     // instructions per tile.  Same-wave LDS traffic needs no barrier (a wave's DS ops execute in order).
-    if (p.dbg & 16) return;
+    if (ABL(p, 16)) return;
     constexpr int EP = 36;                                   // patch row pitch (floats), keeps rows 16-B aligned
     float *patch = smem + wave * (32 * EP);
     const int ccol = lane & 31, crow = 4 * (lane >> 5);
@@ -451,12 +455,11 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
     constexpr size_t smem_patch = (size_t)WGM * WGN * 32 * 36 * sizeof(float);   // epilogue transpose patches
     size_t smem = p.ktiles_per_split > G ? smem_max : smem_one;
     if (smem < smem_patch) smem = smem_patch;
-    static bool attr_done = false;   // raise the dynamic-LDS cap once per instantiation
-    if (smem_max > 64 * 1024 && !attr_done) {
+    static unsigned long long attr_mask = 0;   // raise the dynamic-LDS cap once per instantiation and device
+    if (smem_max > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3<T, BM, BN, WGM, WGN, G, UP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((igemm3x3<T, BM, BN, WGM, WGN, G, UP>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
                        smem, s, p);
@@ -478,8 +481,6 @@ bool igemm_group_supported(int bm, int bn, int g, bool up)
     if (g == 4) return (bm == 64 && bn == 64) || (bm == 32 && bn == 64);
     return false;
 }
-
-hipError_t igemm_init() { return hipSuccess; }
 
 template <typename T>
 static hipError_t launch_igemm_typed(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)

@@ -54,8 +54,20 @@ struct IgemmParams {
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
     int out_f32;                // write fp32 output whatever the storage type (GEMM form of the last conv)
     int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
-    int dbg;                    // ablation bits for tools/ (0 in production): 1 no refetch, 2 no LDS restage, 4 no barrier, 8 no buffer flip
+    int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,
+                                // 4 no barrier, 8 no buffer flip, 16 no epilogue, 32 no K loop
 };
+
+// Kernel attributes (dynamic-LDS cap) are per device: `mask` has one bit per HIP device that already has the attribute of
+// one kernel instantiation.  Returns true when the current device still needs it (and marks it).
+inline bool attr_needed_on_this_device(unsigned long long &mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (mask >> dev & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
 
 struct TileConfig { int bm, bn; };
 // tile shapes the igemm kernel is instantiated for
@@ -63,7 +75,6 @@ static const TileConfig kTileConfigs[] = {{128, 32}, {128, 128}, {128, 64}, {64,
 static const int kNumTileConfigs = sizeof(kTileConfigs) / sizeof(kTileConfigs[0]);
 
 bool igemm_tile_supported(int bm, int bn);
-hipError_t igemm_init();  // raises the dynamic-LDS limit of the big-tile instantiations
 // g = K-tiles per pipeline step: 1 (all shapes), 2 (128x64, 64x64), 4 (64x64, 32x64)
 bool igemm_group_supported(int bm, int bn, int g, bool up);
 hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t s);
@@ -106,6 +117,7 @@ struct LastConvParams {
     int B, Hs, Ws, C0, C1, Cout;
     int apply_tanh;
     unsigned char *out_u8;     // optional HWC uint8 frame [B][2Hs][2Ws][Cout] = tensor2im(out); out may then be nullptr
+    int route;                 // 0 = kernel chosen by size; 1 strip, 2 rows, 3 generic (forced per handle, tests only)
 };
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);
 

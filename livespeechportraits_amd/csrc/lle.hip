@@ -67,7 +67,8 @@ template <int K> __global__ __launch_bounds__(256) void topk_rows(const float *d
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (sv[w] < v || (sv[w] == v && sj[w] < j)) { v = sv[w]; j = sj[w]; t = st[w]; }
-        if (tid == 0) ind[(size_t)row * k + round] = j;
+        // a row with fewer than k finite distances (NaN input) has no k-th neighbour: -1, which lle_rows refuses
+        if (tid == 0) ind[(size_t)row * k + round] = j < m ? j : -1;
         if (tid == t) {
 #pragma unroll
             for (int i = 0; i + 1 < K; ++i) { bv[i] = bv[i + 1]; bj[i] = bj[i + 1]; }
@@ -104,6 +105,19 @@ __global__ __launch_bounds__(256) void lle_rows(LleParams p)
     const int K = p.K, n1 = K - 1;
     const float *f = p.feats + (size_t)row * p.d;
     const long long *id = p.ind + (size_t)row * K;
+    // neighbour indices are caller data: a row holding one outside [0, m) (or topk_rows' -1) reads nothing and yields NaN
+    {
+        const bool bad = lane < K && (id[lane] < 0 || id[lane] >= (long long)p.m);
+        if (__ballot(bad)) {
+            const float qn = __builtin_nanf("");
+            if (p.weights && lane < K) p.weights[(size_t)row * K + lane] = (double)qn;
+            for (int c = lane; c < p.d; c += 64) {
+                if (p.fuse) p.fuse[(size_t)row * p.d + c] = qn;
+                if (p.blend) p.blend[(size_t)row * p.d + c] = qn;
+            }
+            return;
+        }
+    }
     const float *b0 = p.db + (size_t)id[0] * p.d;
     float *G = Gs[wave], *R = Bs[wave];
     double *W = Ws[wave];

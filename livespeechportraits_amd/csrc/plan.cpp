@@ -324,8 +324,8 @@ void Plan::plan_batch(int batch)
     if (batch == planned_batch) return;
     std::vector<size_t> off;
     const BatchLayout bl = layout_for(*this, batch, &off, &layers);
-    for (size_t i = 0; i < tensors.size(); ++i) tensors[i].offset = cand_cache_bytes() + off[i];
-    act_bytes = cand_cache_bytes() + bl.act_bytes;
+    for (size_t i = 0; i < tensors.size(); ++i) tensors[i].offset = persistent_bytes() + off[i];
+    act_bytes = persistent_bytes() + bl.act_bytes;
     partial_bytes = bl.partial_bytes;
     partial_offset = act_bytes;
     planned_batch = batch;
@@ -334,7 +334,7 @@ void Plan::plan_batch(int batch)
 size_t Plan::workspace_bytes(int batch) const
 {
     const BatchLayout bl = layout_for(*this, batch, nullptr, nullptr);
-    return cand_cache_bytes() + bl.act_bytes + bl.partial_bytes;
+    return persistent_bytes() + bl.act_bytes + bl.partial_bytes;
 }
 
 std::string Plan::pack(void *blob, size_t bytes) const

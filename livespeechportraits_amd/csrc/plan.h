@@ -73,6 +73,9 @@ struct Plan {
     // persistent region at workspace offset 0: pre-activation contribution of the candidate channels to the
     // first conv, [H/2][W/2][ngf] fp32 (constant per person: demo.py:89-95 builds img_candidates once)
     size_t cand_cache_bytes() const { return ((size_t)(size / 2) * (size / 2) * ngf * sizeof(float) + 255) / 256 * 256; }
+    // head of the workspace: slot 0 = that per-person cache (lspf2f_set_candidates), slot 1 = the same quantity for a
+    // candidate stack broadcast over ONE forward's batch (never aliases slot 0)
+    size_t persistent_bytes() const { return 2 * cand_cache_bytes(); }
 
     std::string build(int variant, int input_nc, int feat_nc, int output_nc, int ngf, int num_downs,
                       int size, bool keep, int dtype = 0);   // returns "" or an error message

@@ -23,10 +23,11 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun)."""
+def init_process_group(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun).  A single process needs no group;
+    ``force`` creates one anyway (world size 1), which is how the RCCL path is exercised on a 1-GPU box."""
     rank, world, local = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # LSP_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): used by the tests to run the
             # multi-rank control flow on a single-GPU box.  Production: nccl (= RCCL over xGMI).
@@ -52,14 +53,13 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 def broadcast_blob(blob: Optional[torch.Tensor], nbytes: int, device: torch.device, src: int = 0) -> torch.Tensor:
     """Every rank returns a uint8 tensor of ``nbytes`` on ``device`` holding rank ``src``'s blob.
     One collective, start-up only."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     if rank == src:
         if blob is None or blob.numel() != nbytes:
             raise ValueError("source rank must supply the packed blob")
         buf.copy_(blob)
-    if world > 1:
+    if dist.is_initialized():          # also at world size 1: the collective then runs through the backend (RCCL) for real
         dist.broadcast(buf, src=src)
     return buf
 

@@ -112,8 +112,9 @@ class Engine:
             if not torch.cuda.is_available():
                 raise N.NativeLibraryError("no ROCm device visible: the feature2face HIP renderer has no CPU path")
             blob = blob.to(device)
-        if blob.dtype != torch.uint8 or blob.numel() < self.packed_bytes():
-            raise ValueError("bad packed blob")
+        if blob.dtype != torch.uint8 or blob.numel() != self.packed_bytes():
+            # exact size: a blob packed for another frame size has a different layout (and a different size)
+            raise ValueError("bad packed blob: %d bytes, this plan packs to %d" % (blob.numel(), self.packed_bytes()))
         self.device = blob.device
         self._blob_dev = blob
         N.check(self.lib.lspf2f_bind_weights(self._h, blob.data_ptr(), blob.numel()))
@@ -163,7 +164,8 @@ class Engine:
         if tuple(cand.shape) != (1, cand_nc, s, s) or cand.dtype != torch.float32 or not cand.is_contiguous():
             raise ValueError("set_candidates wants a contiguous float32 [1,%d,%d,%d] tensor" % (cand_nc, s, s))
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        N.check(self.lib.lspf2f_set_candidates(self._h, cand.data_ptr(), ctypes.c_void_p(stream)))
+        with torch.cuda.device(self.device):       # launches (and graph capture) must happen with the engine's device current
+            N.check(self.lib.lspf2f_set_candidates(self._h, cand.data_ptr(), ctypes.c_void_p(stream)))
         self._cand_key = (id(cand), cand.data_ptr(), cand._version)
         self._cand_ref = cand       # keep it alive: the key contains its id()
 
@@ -187,8 +189,9 @@ class Engine:
         if out is None:
             out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        cptr, cb = self._cand_arg(cand)
-        N.check(self.lib.lspf2f_forward(self._h, feat.data_ptr(), cptr, cb, out.data_ptr(), b, ctypes.c_void_p(stream)))
+        with torch.cuda.device(self.device):
+            cptr, cb = self._cand_arg(cand)
+            N.check(self.lib.lspf2f_forward(self._h, feat.data_ptr(), cptr, cb, out.data_ptr(), b, ctypes.c_void_p(stream)))
         return out
 
     def forward_image(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: Optional[torch.Tensor] = None,
@@ -203,10 +206,11 @@ class Engine:
             out_u8 = torch.empty((b, self.size, self.size, self.output_nc), dtype=torch.uint8, device=self.device)
         out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device) if also_float else None
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        cptr, cb = self._cand_arg(cand)
-        N.check(self.lib.lspf2f_forward_ex(self._h, feat.data_ptr(), cptr, cb,
-                                           out.data_ptr() if out is not None else None, out_u8.data_ptr(), b,
-                                           ctypes.c_void_p(stream)))
+        with torch.cuda.device(self.device):
+            cptr, cb = self._cand_arg(cand)
+            N.check(self.lib.lspf2f_forward_ex(self._h, feat.data_ptr(), cptr, cb,
+                                               out.data_ptr() if out is not None else None, out_u8.data_ptr(), b,
+                                               ctypes.c_void_p(stream)))
         return (out_u8, out) if also_float else out_u8
 
     def forward_timed(self, feat, cand, out=None):
@@ -216,9 +220,10 @@ class Engine:
         n = self.lib.lspf2f_num_layers(self._h)
         ms = (ctypes.c_float * n)()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        N.check(self.lib.lspf2f_forward_timed(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
-                                              cand.shape[0] if cand is not None else 0, out.data_ptr(), b,
-                                              ctypes.c_void_p(stream), ms))
+        with torch.cuda.device(self.device):
+            N.check(self.lib.lspf2f_forward_timed(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
+                                                  cand.shape[0] if cand is not None else 0, out.data_ptr(), b,
+                                                  ctypes.c_void_p(stream), ms))
         return out, [float(x) for x in ms]
 
     # ---- introspection -------------------------------------------------------------------

@@ -17,6 +17,7 @@ import torch
 from . import networks
 from .base_model import BaseModel
 from .feature2face_G import Feature2Face_G
+from .unet_small import Feature2FaceGenerator_Unet
 
 
 class Feature2FaceModel(BaseModel):
@@ -44,6 +45,10 @@ class Feature2FaceModel(BaseModel):
             g = self._g().netG
             if feature_map.device.type != "cuda":
                 raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
+            if isinstance(g, Feature2FaceGenerator_Unet):        # size == 'small': its own engine, same fused uint8 output
+                x = feature_map if cand_image is None else torch.cat(
+                    [feature_map, cand_image.expand(feature_map.shape[0], -1, -1, -1)], 1)
+                return g._get_engine(x.device).forward(x.float(), out_u8=True)
             e = g._engine_for(feature_map.shape[-1], feature_map.shape[0], feature_map.device)
             return e.forward_image(feature_map.float(), cand_image.float() if cand_image is not None else None)
 

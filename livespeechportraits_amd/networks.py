@@ -87,12 +87,15 @@ class Feature2FaceGenerator(nn.Module):
     def _engine_for(self, size: int, batch: int, device: torch.device) -> Engine:
         e = self._engine
         if e is None or e.size != size or e.max_batch < batch:
-            mb = batch if e is None else max(batch, e.max_batch)
+            same_size = e is not None and e.size == size
+            mb = max(batch, e.max_batch) if same_size else batch
             e = Engine(self.variant, self.input_nc, self.feat_nc, self.output_nc, self.ngf,
                        self.num_downs, size, mb)
-            if self._engine is not None and not self._dirty and self._blob is not None \
-                    and self._blob.device == device:
-                e.bind(self._blob)        # blob layout does not depend on size / batch
+            # The packed layout depends on the frame size (an up-conv switches to the 16-tap sub-pixel form once it writes
+            # >= 32x32, plan.cpp), not on the batch: the blob is reused only when just max_batch grew.
+            if same_size and not self._dirty and self._blob is not None and self._blob.device == device \
+                    and self._blob.numel() == e.packed_bytes():
+                e.bind(self._blob)
             else:
                 self._dirty = True
             e.auto_cand_cache = os.environ.get("LSP_HIP_CAND_CACHE", "1") != "0"

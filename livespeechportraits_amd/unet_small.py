@@ -243,4 +243,6 @@ class Feature2FaceGenerator_Unet(nn.Module):
 
     def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor]) -> torch.Tensor:
         """feature2face_model.py:229-231: cat([feature_map, cand_image], 1) unless cand_image is None"""
+        if cand is not None and cand.shape[0] != feat.shape[0]:
+            cand = cand.expand(feat.shape[0], -1, -1, -1)          # shared candidate stack (batch 1) with a batch of feature maps
         return self.forward(feat if cand is None else torch.cat([feat, cand], 1))

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
     if not os.path.isdir(REF):
         raise SystemExit("make_golden_a2h.py needs /root/reference (build container only)")
     for name in ("torchvision", "torchvision.models", "cv2"):
@@ -100,6 +101,7 @@ def main():
         if name == "default_n48":
             with open(os.path.join(a.out, "keys_a2h.json"), "w") as f:
                 json.dump(ref_keys, f, indent=0)
+    return a.out
 
 
 def main_lstm(out_dir):
@@ -132,5 +134,4 @@ def main_lstm(out_dir):
 
 
 if __name__ == "__main__":
-    main()
-    main_lstm(os.path.join(REPO, "tests", "golden"))
+    main_lstm(main())          # both parts write where --out says

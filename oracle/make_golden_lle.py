@@ -3,6 +3,7 @@
 Container only (needs /root/reference).  funcs/utils.py is imported unmodified; the two modules it pulls in that do
 not exist here (librosa via funcs/audio_funcs.py:9,18) are stubbed -- none of the functions used touch them.
 Asserts oracle/lle_oracle.py is bit-identical to the reference functions."""
+import argparse
 import json
 import os
 import sys
@@ -35,7 +36,10 @@ def main():
     sys.modules["librosa.filters"].mel = None
     sys.path.insert(0, REF)
     from funcs import utils                         # the reference module
-    out = os.path.join(REPO, "tests", "golden")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"), help="directory the fixtures are written to")
+    out = ap.parse_args().out
+    os.makedirs(out, exist_ok=True)
     for name, (m, n, d, intr, K, pct, noise) in CASES.items():
         db, q = synth.make_feature_database(m, n, d, intr, noise=noise)
         ind = utils.KNN_with_torch(q, db, K=K)

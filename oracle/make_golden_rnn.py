@@ -26,7 +26,10 @@ def main():
     sys.path.insert(0, REF)
     from models.networks import APC_encoder                      # reference classes
     from models.audio2feature_model import Audio2FeatureModel
-    out = os.path.join(REPO, "tests", "golden")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"), help="directory the fixtures are written to")
+    out = ap.parse_args().out
+    os.makedirs(out, exist_ok=True)
 
     # ---- APC encoder, as demo.py:146-151, 186-191 uses it (mel_dim 80, hidden 512, 3 layers, residual False)
     for name, T in (("apc_t300", 300), ("apc_t1", 1)):

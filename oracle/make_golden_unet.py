@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """ORACLE tooling -- freeze outputs of the reference's OWN Feature2FaceGenerator_Unet (size == 'small') into
 tests/golden/unet_*.npz.  Container only.  Asserts oracle/unet_small_oracle.py is bit-identical to the module."""
+import argparse
 import json
 import os
 import sys
@@ -28,7 +29,10 @@ def main():
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.path.insert(0, REF)
     from models.networks import Feature2FaceGenerator_Unet
-    out = os.path.join(REPO, "tests", "golden")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"), help="directory the fixtures are written to")
+    out = ap.parse_args().out
+    os.makedirs(out, exist_ok=True)
     for name, (ngf, nd, size, batch) in CASES.items():
         net = Feature2FaceGenerator_Unet(input_nc=23, output_nc=3, num_downs=nd, ngf=ngf).eval()
         ref_keys = {k: list(v.shape) for k, v in net.state_dict().items()}
