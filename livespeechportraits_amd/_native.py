@@ -1,4 +1,4 @@
-"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h, include/lsprnn.h).
+"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h, include/lsprnn.h, include/lspraster.h).
 
 There is deliberately no fallback: if the shared library is missing or does not
 load, importing the hot path raises -- a GPU box must never silently run
@@ -154,6 +154,13 @@ RNN_SIGNATURES = {
     "lsprnn_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
+# every symbol include/lspraster.h declares
+RASTER_SIGNATURES = {
+    "lspraster_last_error": (c_char_p, []),
+    "lspraster_edge_maps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+}
+RASTER_POINT_DTYPES = {"int32": 0, "float32": 1, "float64": 2}
+
 _lib = None
 
 
@@ -171,7 +178,7 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e)) from e
-    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()) + list(RNN_SIGNATURES.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()) + list(RNN_SIGNATURES.items()) + list(RASTER_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
@@ -228,3 +235,15 @@ def check_rnn(rc: int) -> None:
     if rc != OK:
         msg = load().lsprnn_last_error()
         raise LsprnnError(rc, msg.decode() if msg else "")
+
+
+class LsprasterError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lspraster error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check_raster(rc: int) -> None:
+    if rc != OK:
+        msg = load().lspraster_last_error()
+        raise LsprasterError(rc, msg.decode() if msg else "")

@@ -69,3 +69,47 @@ def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch
         idx += len(chunk)
     flush()
     return frames
+
+
+def render_frames_from_landmarks(model, landmarks: Iterable, shoulders: Iterable, cand_image: torch.Tensor,
+                                 pad=None, load_size: int = 512, batch: int = 8,
+                                 on_frame: Optional[Callable[[int, np.ndarray], None]] = None) -> List[np.ndarray]:
+    """demo.py:260-272 with the edge map drawn on the device: per frame the loop moves the 73 landmarks and the shoulder
+    points (~1.5 KB) instead of a host-rasterised 1 MiB feature map.  ``landmarks`` yields [73, 2] arrays (``pred_landmarks[i]``
+    of demo.py:262), ``shoulders`` yields [n, 2] arrays (``pred_shoulders[i]``); ``pad`` as ``facedataset.dataset.image_pad``."""
+    from .feature_map import FeatureMapRasteriser
+    device = cand_image.device
+    rast = None
+    maps_buf = None
+
+    def chunks():
+        nonlocal rast, maps_buf
+        for lm, sh in zip(batched(landmarks, batch), batched(shoulders, batch)):
+            lm_a, sh_a = np.stack([np.asarray(x) for x in lm]), np.stack([np.asarray(x) for x in sh])
+            if rast is None:
+                rast = FeatureMapRasteriser(load_size, sh_a.shape[1], device)
+                maps_buf = torch.empty((batch, 1, load_size, load_size), dtype=torch.float32, device=device)
+            yield rast.rasterise(lm_a, sh_a, pad, out=maps_buf[:lm_a.shape[0]])
+
+    frames: List[np.ndarray] = []
+    pending = None
+    idx = 0
+    for maps in chunks():
+        u8 = model.inference_image(maps, cand_image)
+        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(u8, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if pending is not None:
+            i0, h0, e0 = pending
+            e0.synchronize()
+            for k in range(h0.shape[0]):
+                (on_frame(i0 + k, h0[k].numpy().copy()) if on_frame else frames.append(h0[k].numpy().copy()))
+        pending = (idx, host, ev)
+        idx += u8.shape[0]
+    if pending is not None:
+        i0, h0, e0 = pending
+        e0.synchronize()
+        for k in range(h0.shape[0]):
+            (on_frame(i0 + k, h0[k].numpy().copy()) if on_frame else frames.append(h0[k].numpy().copy()))
+    return frames

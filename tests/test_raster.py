@@ -1,0 +1,179 @@
+"""Landmark edge map (second half; datasets/face_dataset.py:276-323).
+
+PARITY UNPINNED against cv2 (OpenCV is absent from the build image): what is checked is
+  CPU: known-answer anchors of oracle/raster_oracle.c (a restatement of OpenCV 4.4.0's cv::line), its invariants, the host logic;
+  GPU: the HIP kernel bit-exact (uint8 and float32) to that oracle on > 100 random landmark sets including out-of-frame,
+       degenerate and clipped edges, every point dtype, other thicknesses and frame sizes."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def random_frame(rng, size=512, wild=0.0, n_shoulder=18):
+    """73 landmarks around a face-like blob + shoulder chains; `wild` = fraction of points thrown far outside the frame"""
+    c = rng.uniform(0.3, 0.7, 2) * size
+    lm = c + rng.normal(0, size * 0.12, (73, 2))
+    sh = np.stack([np.linspace(0, size, n_shoulder) + rng.normal(0, 6, n_shoulder), size * 0.9 + rng.normal(0, 12, n_shoulder)], 1)
+    for a in (lm, sh):
+        k = rng.random(a.shape[0]) < wild
+        a[k] = rng.uniform(-1.5 * size, 2.5 * size, (int(k.sum()), 2))
+    return lm, sh
+
+
+# ---- CPU -----------------------------------------------------------------------------------------------------------------
+def test_oracle_known_answers():
+    from oracle import raster_oracle as R
+    seg = np.array([[0, 1]], np.int32)
+    img = R.draw(np.array([[10, 10], [20, 10]], np.int32), seg, (32, 32))
+    ys, xs = np.nonzero(img)
+    # cv2.line with thickness 2 is three pixels wide on an axis-aligned line (the quad spans y0-1 .. y0+1), caps one pixel longer
+    assert (ys.min(), ys.max()) == (9, 11) and (xs.min(), xs.max()) == (9, 21)
+    assert img[10, 9:22].all() and img[9, 10:21].all() and img[11, 10:21].all() and not img[9, 9] and not img[9, 21]
+    assert set(np.unique(img)) == {0, 255}
+    # zero-length edge (part_list holds 18 -> 18 and 24 -> 24): no quad, the radius-1 cap = a 5-pixel plus
+    dot = R.draw(np.array([[10, 10]], np.int32), np.array([[0, 0]], np.int32), (32, 32))
+    assert dot.sum() == 5 * 255 and dot[10, 9:12].all() and dot[9:12, 10].all()
+    # vertical line: the transpose of the horizontal one
+    v = R.draw(np.array([[10, 10], [10, 20]], np.int32), seg, (32, 32))
+    assert np.array_equal(v, img.T)
+    # fully outside the frame: nothing; crossing the frame: clipped, not wrapped
+    assert R.draw(np.array([[-50, -50], [-10, -20]], np.int32), seg, (32, 32)).sum() == 0
+    cross = R.draw(np.array([[-40, 16], [80, 16]], np.int32), seg, (32, 32))
+    assert cross[15:18].all() and cross[:15].sum() == 0 and cross[18:].sum() == 0
+
+
+def test_oracle_is_translation_invariant_inside_the_frame():
+    from oracle import raster_oracle as R
+    rng = np.random.default_rng(0)
+    pts = rng.integers(40, 120, (12, 2)).astype(np.int32)
+    seg = np.stack([np.arange(11), np.arange(1, 12)], 1).astype(np.int32)
+    a = R.draw(pts, seg, (256, 256))
+    b = R.draw(pts + np.array([37, 91], np.int32), seg, (256, 256))
+    assert np.array_equal(a[:160, :160], b[91:251, 37:197])
+
+
+def test_edge_list_and_oracle_agree_on_the_topology():
+    from livespeechportraits_amd import feature_map as F
+    from oracle import raster_oracle as R
+    assert F.PART_LIST == R.PART_LIST
+    e = F.edge_list(18)
+    assert e.shape == (88, 2) and e.dtype == np.int32           # 72 face edges + 2 x 8 shoulder edges
+    assert e[:72].max() == 72 and e[72:].min() == 73 and e[72:].max() == 90
+    assert (e[72:80, 1] - e[72:80, 0] == 1).all() and e[79, 1] == 81 and e[80, 0] == 82     # two separate chains
+    # drawing face and shoulders in one pass == the reference's two passes
+    rng = np.random.default_rng(1)
+    lm, sh = random_frame(rng)
+    pad = (3, 11, 5, 0)
+    one = R.draw(np.trunc(np.concatenate([lm, sh + np.array([pad[3] - pad[2], pad[0] - pad[1]])])).astype(np.int32), e, (512, 512))
+    assert np.array_equal(one, R.get_feature_image(lm, (512, 512), sh, pad))
+    f = R.get_data_test_mode(lm, sh, pad)
+    assert f.shape == (1, 512, 512) and f.dtype == np.float32 and set(np.unique(f)) == {0.0, 1.0}
+    assert 0.002 < f.mean() < 0.2
+
+
+def test_library_exports_every_lspraster_symbol_and_has_no_cpu_path():
+    from livespeechportraits_amd import _native as N
+    from livespeechportraits_amd import feature_map as F
+    hdr = open(os.path.join(ROOT, "include", "lspraster.h")).read()
+    declared = set(re.findall(r"\b(lspraster_[a-z0-9_]+)\s*\(", hdr))
+    lib = ctypes.CDLL(N.LIB_PATH)
+    assert declared and all(hasattr(lib, n) for n in declared)
+    assert declared == set(N.RASTER_SIGNATURES)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        F.FeatureMapRasteriser(device="cpu")
+    assert N.load().lspraster_edge_maps(None, 0, 1, 1, None, 0, 2, 512, 512, None, None, None) == -1   # argument check, no launch
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_kernel_is_bit_exact_to_the_oracle_on_random_landmark_sets(gpu_device):
+    from livespeechportraits_amd.feature_map import FeatureMapRasteriser
+    from oracle import raster_oracle as R
+    rng = np.random.default_rng(2024)
+    r = FeatureMapRasteriser(512, 18, gpu_device)
+    frames = [random_frame(rng, wild=w) for w in [0.0] * 60 + [0.15] * 40 + [0.6] * 20]
+    lm = np.stack([f[0] for f in frames])
+    sh = np.stack([f[1] for f in frames])
+    pad = (7, 2, 0, 9)
+    got8 = r.rasterise(lm, sh, pad, as_uint8=True).cpu().numpy()
+    gotf = r.rasterise(lm, sh, pad).cpu().numpy()
+    assert gotf.shape == (120, 1, 512, 512) and gotf.dtype == np.float32
+    bad = 0
+    for i in range(120):
+        want = R.get_feature_image(lm[i], (512, 512), sh[i], pad)
+        if not np.array_equal(got8[i], want):
+            bad += 1
+            d = np.argwhere(got8[i] != want)
+            print("frame %d: %d pixels differ, first %s" % (i, len(d), d[:3].tolist()))
+        assert np.array_equal(gotf[i, 0], want.astype(np.float32) / 255.)
+    assert bad == 0
+    assert 0 < got8[:60].mean() / 255 < 0.2
+
+
+@pytest.mark.gpu
+def test_point_dtypes_batching_and_reference_named_methods(gpu_device):
+    from livespeechportraits_amd.feature_map import FeatureMapRasteriser
+    from oracle import raster_oracle as R
+    rng = np.random.default_rng(5)
+    r = FeatureMapRasteriser(512, 18, gpu_device)
+    lm, sh = random_frame(rng, wild=0.1)
+    lm -= 0.5                                    # negative fractions: int() truncates toward zero, floor would differ
+    lm[3] = [-0.7, 12.9]
+    want = R.get_feature_image(lm, (512, 512), sh, None)
+    for cast in (np.float64, np.float32):
+        assert np.array_equal(r.get_feature_image(lm.astype(cast), (512, 512), sh.astype(cast)).cpu().numpy(),
+                              R.get_feature_image(lm.astype(cast), (512, 512), sh.astype(cast), None))
+    ti = np.trunc(lm).astype(np.int32), np.trunc(sh).astype(np.int32)
+    assert np.array_equal(r.get_feature_image(*[ti[0], None, ti[1]]).cpu().numpy(), want)
+    one = r.get_data_test_mode(torch.from_numpy(lm).to(gpu_device), torch.from_numpy(sh).to(gpu_device))      # device-resident points
+    assert one.shape == (1, 512, 512) and one.dtype == torch.float32 and np.array_equal(one[0].cpu().numpy(), want / 255.0)
+    # writing into a caller's buffer (the render loop's input tensor)
+    buf = torch.full((2, 1, 512, 512), 7.0, device=gpu_device)
+    r.rasterise(np.stack([lm, lm]), np.stack([sh, sh]), out=buf)
+    assert torch.equal(buf[0], buf[1]) and np.array_equal(buf[0, 0].cpu().numpy(), want / 255.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,thickness,n_shoulder", [(256, 2, 18), (1024, 2, 18), (512, 3, 18), (512, 5, 0), (512, 8, 6)])
+def test_other_sizes_and_thicknesses(size, thickness, n_shoulder, gpu_device):
+    from livespeechportraits_amd import feature_map as F
+    from oracle import raster_oracle as R
+    rng = np.random.default_rng(size + thickness)
+    r = F.FeatureMapRasteriser(size, n_shoulder, gpu_device, thickness=thickness)
+    frames = [random_frame(rng, size, wild=0.2, n_shoulder=max(n_shoulder, 2)) for _ in range(6)]
+    lm = np.stack([f[0] for f in frames])
+    sh = np.stack([f[1] for f in frames]) if n_shoulder else None
+    got = r.rasterise(lm, sh, as_uint8=True).cpu().numpy()
+    for i in range(6):
+        pts = np.trunc(lm[i] if sh is None else np.concatenate([lm[i], sh[i]])).astype(np.int32)
+        assert np.array_equal(got[i], R.draw(pts, F.edge_list(n_shoulder), (size, size), thickness)), (size, thickness, i)
+
+
+@pytest.mark.gpu
+def test_render_loop_from_landmarks(gpu_device, tmp_path):
+    """demo.py:260-272 with the rasterisation on the device: landmarks in, uint8 frames out, == the host-rasterised route."""
+    import argparse
+    import livespeechportraits_amd as L
+    from conftest import golden_problem
+    from livespeechportraits_amd.render_loop import render_frames, render_frames_from_landmarks
+    from oracle import raster_oracle as R
+    meta, _, topo, sd, _, cand = golden_problem("large_s128_b2")
+    opt = argparse.Namespace(model="feature2face", gpu_ids=[0], isTrain=False, size=meta["variant"], ngf=meta["ngf"],
+                             n_downsample_G=meta["num_downs"], fp16=0, checkpoints_dir=str(tmp_path), name="t", load_epoch="none", verbose=False)
+    model = L.create_model(opt)
+    model._g().load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    model.eval()
+    rng = np.random.default_rng(3)
+    frames = [random_frame(rng, topo.size, wild=0.05) for _ in range(5)]
+    c = torch.from_numpy(cand).to(gpu_device)
+    pad = (1, 0, 0, 2)
+    got = render_frames_from_landmarks(model, [f[0] for f in frames], [f[1] for f in frames], c, pad=pad, load_size=topo.size, batch=2)
+    maps = [torch.from_numpy(R.get_data_test_mode(f[0], f[1], pad, topo.size)) for f in frames]        # the host route, via the oracle
+    want = render_frames(model, maps, c, batch=2)
+    assert len(got) == 5 and all(np.array_equal(a, b) for a, b in zip(got, want))
