@@ -61,6 +61,11 @@ typedef enum lspf2f_dtype {
                                               liveness-based reuse */
 #define LSPF2F_FLAG_NO_GRAPH 2u            /* launch every kernel eagerly instead of replaying a
                                               cached hipGraph (also: env LSP_HIP_GRAPH=0) */
+#define LSPF2F_FLAG_INSTANCE_NORM 4u       /* the norm_layer=nn.InstanceNorm2d variant of the generators (constructor argument,
+                                              models/networks.py:459 / :555): every norm is InstanceNorm2d(affine=False,
+                                              eps=1e-5) computed at run time per (frame, channel); the level convs carry a
+                                              bias (use_bias, :494 / :590) and the state dict holds `<conv>.bias` instead of
+                                              the BatchNorm tensors.  fp32 only. */
 
 /* Mirrors the option fields the reference reads on this path
  * (options/base_options_feature2face.py:49-50 ngf / n_downsample_G, :40 loadSize; the

@@ -23,6 +23,8 @@ ERR_NAMES = {
 VARIANT_IDS = {"normal": 0, "large": 1}
 DTYPE_IDS = {"f32": 0, "bf16": 1}
 FLAG_KEEP_INTERMEDIATES = 1
+FLAG_INSTANCE_NORM = 4
+NORM_IDS = {"batch": 0, "instance": 1}
 
 
 class NativeLibraryError(RuntimeError):

@@ -89,7 +89,8 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     h->cfg = *cfg;
     const std::string e = h->plan.build(cfg->variant, cfg->input_nc, cfg->feat_nc, cfg->output_nc, cfg->ngf,
                                         cfg->num_downs, cfg->height,
-                                        (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0, cfg->dtype);
+                                        (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0, cfg->dtype,
+                                        (cfg->flags & LSPF2F_FLAG_INSTANCE_NORM) ? 1 : 0);
     if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
@@ -193,7 +194,10 @@ static const char *kernel_name(const LayerDesc &l)
     switch (l.kind) {
     case kFirstConv: return "first_conv";
     case kLastConv: return l.wgemm_off >= 0 ? "last_conv (igemm3x3 + pixel_shuffle_tanh)" : "last_conv";
-    default: return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3+splitk_reduce" : "igemm3x3");
+    default:
+        if (l.inorm) return l.smallm ? "conv3x3_smallm+in_small" : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
+                          : l.in_route == kInSmall ? "igemm3x3+in_small" : "igemm3x3+in_reduce_stats+in_finalize+in_apply";
+        return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3+splitk_reduce" : "igemm3x3");
     }
 }
 
@@ -251,6 +255,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.B = batch; p.H = l.hs; p.W = l.hs; p.feat_nc = P.feat_nc; p.cand_nc = P.input_nc - P.feat_nc;
         p.cand_batch = cand_batch; p.Cout = l.cout; p.dtype = P.dtype;
         p.ci_begin = 0; p.ci_end = P.input_nc; p.base = nullptr; p.relu = 1;
+        p.bias = bptr(l.shift_off);          // InstanceNorm plans: the conv bias (scale is 1); nullptr otherwise
         // two slots at the head of the workspace: [0] lspf2f_set_candidates' per-person cache, [1] the per-forward share of a
         // broadcast stack -- separate, so a broadcast forward never overwrites what the cache holds
         float *cache = reinterpret_cast<float *>(cand != nullptr ? h->ws + P.cand_cache_bytes() : h->ws);
@@ -261,7 +266,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             // feature-map channels
             if (cand != nullptr) {
                 FirstConvParams c = p;
-                c.B = 1; c.cand_batch = 1; c.ci_begin = P.feat_nc; c.out = cache; c.relu = 0;
+                c.B = 1; c.cand_batch = 1; c.ci_begin = P.feat_nc; c.out = cache; c.relu = 0; c.bias = nullptr;
                 e = launch_first_conv(c, s);
             }
             p.ci_end = P.feat_nc; p.base = cache;
@@ -288,14 +293,21 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.out = out;
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out; p.out_u8 = out_u8; p.dtype = P.dtype;
         p.route = h->last_route;
+        p.bias = bptr(l.shift_off);
         e = launch_last_conv(p, s);
     } else if (l.smallm) {
         SmallMParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
-        p.residual = tptr(l.res); p.out = tptr(l.out);
+        p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.Cin = l.cin; p.Cout = l.cout;
-        p.stride = l.stride; p.up = l.up; p.relu = l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
+        p.stride = l.stride; p.up = l.up; p.relu = l.inorm ? 0 : l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
         e = launch_smallm(p, s);
+        if (e == hipSuccess && l.inorm) {          // raw conv output (+ bias) -> statistics + normalisation (+ residual, ReLU) in one launch
+            InstNormParams q{};
+            q.x = tptr(l.out); q.partial = nullptr; q.splits = 1; q.bias = nullptr; q.residual = tptr(l.res); q.relu = l.relu;
+            q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
+            e = launch_in_small(q, s);
+        }
     } else {
         IgemmParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off);
@@ -312,8 +324,41 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.ktiles_total = (l.up4 ? 4 : 9) * l.cin / P.ktile_channels();
         p.splits = l.splits;
         p.ktiles_per_split = (p.ktiles_total + l.splits - 1) / l.splits;
-        e = launch_igemm(p, l.bm, l.bn, l.group, s);
-        if (e == hipSuccess && l.splits > 1) e = launch_splitk_reduce(p, s);
+        if (l.inorm) {
+            // InstanceNorm follows: the conv writes its raw output (+ bias); residual add and ReLU move behind the normalisation
+            float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
+            const size_t slab = (size_t)batch * P.stats_groups_max;            // [B][groups][C] with C <= the plan's widest layer
+            InstNormParams q{};
+            q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu;
+            q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
+            q.psum = st; q.psq = st + slab * l.cout;
+            q.mean = st + 2 * slab * l.cout; q.rstd = q.mean + (size_t)batch * l.cout;
+            p.residual = nullptr; p.relu = 0;
+            if (l.in_route == kInFused) {
+                const int rhw = l.up4 ? l.hs * l.hs : l.ho * l.ho;
+                q.groups = (l.up4 ? 4 : 1) * rhw / (l.bm == 32 ? 32 : l.bm / 2);
+                p.psum = q.psum; p.psq = q.psq; p.in_groups = q.groups;
+                e = launch_igemm(p, l.bm, l.bn, l.group, s);
+                if (e == hipSuccess) e = launch_in_finalize(q, s);
+                if (e == hipSuccess) e = launch_in_apply(q, s);
+            } else {
+                e = launch_igemm(p, l.bm, l.bn, l.group, s);
+                q.splits = l.splits;
+                q.partial = l.splits > 1 ? p.partial : nullptr;
+                q.bias = bptr(l.shift_off);
+                if (l.in_route == kInSmall) {
+                    if (e == hipSuccess) e = launch_in_small(q, s);
+                } else {
+                    q.groups = (q.hw + 63) / 64;
+                    if (e == hipSuccess) e = launch_in_reduce_stats(q, s);
+                    if (e == hipSuccess) e = launch_in_finalize(q, s);
+                    if (e == hipSuccess) e = launch_in_apply(q, s);
+                }
+            }
+        } else {
+            e = launch_igemm(p, l.bm, l.bn, l.group, s);
+            if (e == hipSuccess && l.splits > 1) e = launch_splitk_reduce(p, s);
+        }
     }
     if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
     return LSPF2F_OK;
@@ -332,7 +377,7 @@ static int check_forward_args(lspf2f_handle *h, const float *feat, const float *
     if (!h->blob) return fail(LSPF2F_ERR_STATE, "weights not bound (lspf2f_bind_weights)");
     if (!h->ws) return fail(LSPF2F_ERR_STATE, "workspace not bound (lspf2f_bind_workspace)");
     h->plan.plan_batch(batch);
-    if (h->ws_size < h->plan.act_bytes + h->plan.partial_bytes)
+    if (h->ws_size < h->plan.act_bytes + h->plan.partial_bytes + h->plan.stats_bytes)
         return fail(LSPF2F_ERR_STATE, "workspace too small for this batch (lspf2f_workspace_bytes)");
     return LSPF2F_OK;
 }

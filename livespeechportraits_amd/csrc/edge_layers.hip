@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
 #pragma unroll
         for (int t = 0; t < 9; ++t) v[t] = vn[t];
     }
+    if (p.bias)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] += p.bias[co0 + j];
     T *o = static_cast<T *>(p.out) + (size_t)gid * p.Cout + co0;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
                 acc.x += v * w[ci][t].x; acc.y += v * w[ci][t].y; acc.z += v * w[ci][t].z; acc.w += v * w[ci][t].w;
             }
         }
+        if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + j * 4); acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
         if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         store4(static_cast<T *>(p.out) + (size_t)g * p.Cout + j * 4, acc);
     }
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(256) void last_conv(const LastConvParams p)
 #pragma unroll
     for (int co = 0; co < CO; ++co)
     {
-        const float v = p.apply_tanh ? tanhf(acc[co]) : acc[co];
+        const float pre = acc[co] + (p.bias ? p.bias[co] : 0.f);
+        const float v = p.apply_tanh ? tanhf(pre) : pre;
         if (p.out) p.out[(((size_t)b * CO + co) * H + 2 * y + py) * W + 2 * x + px] = v;
         if (p.out_u8) p.out_u8[(((size_t)b * H + 2 * y + py) * W + 2 * x + px) * CO + co] = to_u8(v);
     }
@@ -344,6 +349,7 @@ __global__ __launch_bounds__(256) void last_conv_rows(const LastConvParams p)
             float r = acc[0];
 #pragma unroll
             for (int co = 1; co < CO; ++co) r = (j == co) ? acc[co] : r;
+            if (p.bias) r += p.bias[j];
             r = p.apply_tanh ? tanhf(r) : r;
             if (outp) outp[(((size_t)b * CO + j) * H + 2 * y + py) * W + 2 * x + px] = r;
             if (p.out_u8) p.out_u8[(((size_t)b * H + 2 * y + py) * W + 2 * x + px) * CO + j] = to_u8(r);
@@ -467,6 +473,7 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
                 float r = acc[par][0];
 #pragma unroll
                 for (int co = 1; co < CO; ++co) r = (j == co) ? acc[par][co] : r;
+                if (p.bias) r += p.bias[j];
                 r = p.apply_tanh ? tanhf(r) : r;
                 const int Y = 2 * y + (par >> 1), X = 2 * x + (par & 1);
                 if (p.out) p.out[(((size_t)b * CO + j) * H + Y) * W + X] = r;

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             sc = *reinterpret_cast<const float4 *>(p.scale + n);
             sh = *reinterpret_cast<const float4 *>(p.shift + n);
         }
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);   // InstanceNorm: sum x, sum x^2 of this lane's rows
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -364,7 +365,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (p.out_f32) store4(static_cast<float *>(p.out) + orow * p.Cout + n, v);
                     else store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
+                    if (p.psum) {
+                        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                    }
                 }
+            }
+        }
+        if (p.psum) {
+            // InstanceNorm statistics of this wave's TM*32 rows (all inside one frame: the planner checks divisibility) for its 32
+            // channels of column block j: the 8 lanes that share a channel quad hold 4 rows each -> xor-shuffle over lane bits 3..5
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
+                s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
+            }
+            const int mw = m0 + wm * TM * 32;
+            if (erow == 0 && nok && mw < p.M) {
+                const int b = (int)p.div_rhw.div((unsigned)mw);
+                const int gpp = rhw / (TM * 32);                                   // groups per frame and parity
+                const size_t g = (size_t)b * p.in_groups + par * gpp + (mw - b * rhw) / (TM * 32);
+                *reinterpret_cast<float4 *>(p.psum + g * p.Cout + n) = s1;
+                *reinterpret_cast<float4 *>(p.psq + g * p.Cout + n) = s2;
             }
         }
     }

@@ -52,6 +52,8 @@ struct IgemmParams {
     int ktiles_per_split;
     int splits;
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
+    float *psum, *psq;          // InstanceNorm plans, fused route: per-wave partial sums of the output and its square,
+    int in_groups;              //   [B][in_groups][Cout] each (in_groups = wave row-groups per frame); nullptr otherwise
     int out_f32;                // write fp32 output whatever the storage type (GEMM form of the last conv)
     int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
     int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,
@@ -105,6 +107,7 @@ struct FirstConvParams {
     int ci_begin, ci_end;   // input-channel range of this pass ([0, feat_nc+cand_nc) = the whole layer)
     const float *base;      // optional pre-activation partial sums [1][H/2][W/2][Cout] to start from
     int relu;
+    const float *bias;      // [Cout] conv bias (InstanceNorm plans: use_bias, networks.py:590) or nullptr; final pass only
 };
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
 
@@ -118,6 +121,7 @@ struct LastConvParams {
     int apply_tanh;
     unsigned char *out_u8;     // optional HWC uint8 frame [B][2Hs][2Ws][Cout] = tensor2im(out); out may then be nullptr
     int route;                 // 0 = kernel chosen by size; 1 strip, 2 rows, 3 generic (forced per handle, tests only)
+    const float *bias;         // [Cout] conv bias added before tanh (InstanceNorm plans) or nullptr
 };
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);
 
@@ -130,6 +134,24 @@ struct ShuffleParams {
     int B, Hs, Ws, Cout, apply_tanh;
 };
 hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s);
+
+// InstanceNorm2d(affine=False, eps=1e-5) after a conv, fp32 NHWC (instnorm.hip).  `x` holds the raw conv output (bias included)
+// and is normalised in place: x = relu?((x - mean[b][c]) * rstd[b][c] + residual?).
+struct InstNormParams {
+    float *x;                  // [B][hw][C]
+    const float *partial;      // split-K partials [splits][B*hw][C] to fold into x first (splits > 1), else nullptr
+    int splits;
+    const float *bias;         // [C] added while folding the partials (the igemm epilogue adds it itself when splits == 1)
+    const float *residual;     // [B][hw][C] or nullptr
+    int relu;
+    float *psum, *psq;         // partial sums [B][groups][C]
+    float *mean, *rstd;        // [B][C]
+    int B, hw, C, groups;
+};
+hipError_t launch_in_reduce_stats(const InstNormParams &p, hipStream_t s);   // fold partials, write raw x, 64-row partial sums
+hipError_t launch_in_finalize(const InstNormParams &p, hipStream_t s);       // partial sums -> mean, rstd (double)
+hipError_t launch_in_apply(const InstNormParams &p, hipStream_t s);          // streaming normalise (+ residual) (+ ReLU)
+hipError_t launch_in_small(const InstNormParams &p, hipStream_t s);          // hw <= 1024: everything in one launch
 
 // elementwise pass of the 'small' U-Net: space-to-depth (+ LeakyReLU) for the next 4x4 s2 conv, ReLU copy for the skip
 struct PrepareParams {

@@ -109,21 +109,23 @@ struct Builder {
     // ResidualBlock (networks.py:650-675): conv-BN-ReLU-conv-BN, += x, ReLU
     int res_block(const std::string &lname, const std::string &key, int x, int c, int h)
     {
+        // with norm_layer = InstanceNorm2d the block keeps bias=False convs (networks.py:662-668) and the norms own no tensors
+        const bool in = p.norm == 1;
         add_param(key + ".block.0.weight", {c, c, 3, 3});
-        add_bn(key + ".block.1", c);
+        if (!in) add_bn(key + ".block.1", c);
         add_param(key + ".block.3.weight", {c, c, 3, 3});
-        add_bn(key + ".block.4", c);
+        if (!in) add_bn(key + ".block.4", c);
         LayerDesc a;
         a.name = lname + ".a"; a.kind = kIgemm; a.src0 = x; a.cin = a.c0 = c; a.cout = c;
         a.hs = a.ho = h; a.stride = 1; a.relu = true;
-        a.wkey = key + ".block.0.weight"; a.bnkey = key + ".block.1";
+        a.wkey = key + ".block.0.weight"; a.bnkey = in ? "" : key + ".block.1"; a.inorm = in;
         a.out = add_tensor(a.name, c, h, (int)p.layers.size());
         const int ta = a.out;
         add_layer(a);
         LayerDesc b;
         b.name = lname + ".b"; b.kind = kIgemm; b.src0 = ta; b.res = x; b.cin = b.c0 = c; b.cout = c;
         b.hs = b.ho = h; b.stride = 1; b.relu = true; b.residual = true;
-        b.wkey = key + ".block.3.weight"; b.bnkey = key + ".block.4";
+        b.wkey = key + ".block.3.weight"; b.bnkey = in ? "" : key + ".block.4"; b.inorm = in;
         b.out = add_tensor(b.name, c, h, (int)p.layers.size());
         const int tb = b.out;
         add_layer(b);
@@ -147,8 +149,13 @@ struct Builder {
         d.cin = d.c0 = cin; d.cout = inner; d.hs = h_in; d.ho = hd; d.stride = 2; d.relu = true;
         d.wkey = key(i) + ".weight";
         add_param(d.wkey, {inner, cin, 3, 3});
+        const bool in = p.norm == 1;          // use_bias = norm_layer == nn.InstanceNorm2d (networks.py:590)
+        if (in) { d.biaskey = key(i) + ".bias"; add_param(d.biaskey, {inner}); }
         ++i;
-        if (!outer && !innermost) { d.bnkey = key(i); add_bn(d.bnkey, inner); ++i; }
+        if (!outer && !innermost) {
+            if (in) d.inorm = true; else { d.bnkey = key(i); add_bn(d.bnkey, inner); }
+            ++i;
+        }
         ++i;  // ReLU
         d.out = add_tensor(d.name, inner, hd, (int)p.layers.size());
         int cur = d.out;
@@ -166,8 +173,12 @@ struct Builder {
         u.relu = !outer; u.tanh_out = outer;
         u.wkey = key(i) + ".weight";
         add_param(u.wkey, {cout, u.cin, 3, 3});
+        if (in) { u.biaskey = key(i) + ".bias"; add_param(u.biaskey, {cout}); }
         ++i;
-        if (!outer) { u.bnkey = key(i); add_bn(u.bnkey, cout); i += 2; }
+        if (!outer) {
+            if (in) u.inorm = true; else { u.bnkey = key(i); add_bn(u.bnkey, cout); }
+            i += 2;
+        }
         if (outer) { u.out = -1; add_layer(u); return -1; }
         u.out = add_tensor(u.name, cout, h_in, (int)p.layers.size());
         cur = u.out;
@@ -179,8 +190,11 @@ struct Builder {
 }  // namespace
 
 std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc_, int ngf_, int num_downs_,
-                        int size_, bool keep, int dtype_)
+                        int size_, bool keep, int dtype_, int norm_)
 {
+    if (norm_ != 0 && norm_ != 1) return "norm must be 0 (BatchNorm2d, eval) or 1 (InstanceNorm2d)";
+    if (norm_ == 1 && dtype_ != 0) return "the InstanceNorm variant is fp32 only";
+    norm = norm_;
     if (dtype_ != 0 && dtype_ != 1) return "dtype must be 0 (fp32) or 1 (bf16)";
     if (dtype_ == 1 && ngf_ % 64 != 0) return "bf16 needs ngf % 64 == 0 (a K-tile is 64 bf16 channels)";
     dtype = dtype_;
@@ -214,7 +228,7 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
         }
-        if (!l.bnkey.empty()) {
+        if (!l.bnkey.empty() || !l.biaskey.empty()) {   // a conv bias travels as (scale 1, shift bias)
             off = align_up(off, 256);
             l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
             off = align_up(off, 256);
@@ -278,7 +292,7 @@ struct Arena {
     }
 };
 
-struct BatchLayout { size_t act_bytes, partial_bytes; };
+struct BatchLayout { size_t act_bytes, partial_bytes, stats_bytes; int groups_max; };
 
 BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, std::vector<LayerDesc> *tiled)
 {
@@ -288,6 +302,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
         return align_up((size_t)t.c * t.h * t.h * (size_t)batch * p.elt(), 256);
     };
     size_t partial = 0;
+    int groups_max = 0, cmax = 0;
     for (int li = 0; li < (int)p.layers.size(); ++li) {
         const LayerDesc &l = p.layers[li];
         if (l.out >= 0) off[l.out] = a.alloc(bytes_of(p.tensors[l.out]));
@@ -305,9 +320,26 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, p.dtype, &bm, &bn, &splits, &group);
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
+            int route = kInNone;
+            if (l.inorm) {
+                // rows of one wave (32 per 32x32 tile row, bm / 2 waves... = bm / 2 for the 2x2-wave tiles) must stay inside one
+                // frame for the epilogue sums; tiny levels do statistics + normalisation in one workgroup per channel slab
+                const int hw = l.ho * l.ho, rhw = l.up4 ? l.hs * l.hs : hw;
+                const int wave_rows = bm == 32 ? 32 : bm / 2;
+                if (!smallm && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
+                    route = kInFused;
+                    groups_max = std::max(groups_max, (l.up4 ? 4 : 1) * rhw / wave_rows);
+                } else if (hw <= 1024) {
+                    route = kInSmall;
+                } else {
+                    route = kInReduce;
+                    groups_max = std::max(groups_max, (hw + 63) / 64);
+                }
+                cmax = std::max(cmax, l.cout);
+            }
             if (tiled) {
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
-                (*tiled)[li].smallm = smallm;
+                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route;
             }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }
@@ -315,7 +347,9 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
         if (p.last_as_gemm(l)) partial = std::max(partial, (size_t)batch * l.hs * l.hs * 4 * l.cout * sizeof(float));
     }
     if (offsets) *offsets = off;
-    return {align_up(a.end, 256), align_up(partial, 256)};
+    // InstanceNorm statistics: partial sums [2][batch][groups_max][cmax] and the finalised (mean, rstd) [2][batch][cmax]
+    const size_t stats = cmax ? align_up((size_t)2 * batch * ((size_t)groups_max + 1) * cmax * sizeof(float), 256) : 0;
+    return {align_up(a.end, 256), align_up(partial, 256), stats, groups_max};
 }
 }  // namespace
 
@@ -328,13 +362,16 @@ void Plan::plan_batch(int batch)
     act_bytes = persistent_bytes() + bl.act_bytes;
     partial_bytes = bl.partial_bytes;
     partial_offset = act_bytes;
+    stats_bytes = bl.stats_bytes;
+    stats_offset = partial_offset + partial_bytes;
+    stats_groups_max = bl.groups_max;
     planned_batch = batch;
 }
 
 size_t Plan::workspace_bytes(int batch) const
 {
     const BatchLayout bl = layout_for(*this, batch, nullptr, nullptr);
-    return persistent_bytes() + bl.act_bytes + bl.partial_bytes;
+    return persistent_bytes() + bl.act_bytes + bl.partial_bytes + bl.stats_bytes;
 }
 
 std::string Plan::pack(void *blob, size_t bytes) const
@@ -412,6 +449,12 @@ std::string Plan::pack(void *blob, size_t bytes) const
                 u += 0x7fffu + ((u >> 16) & 1u);             // round to nearest even
                 d16[i] = (uint16_t)(u >> 16);
             }
+        }
+        if (!l.biaskey.empty()) {
+            const float *bv = get(l.biaskey).data.data();
+            float *sc = reinterpret_cast<float *>(base + l.scale_off);
+            float *sh = reinterpret_cast<float *>(base + l.shift_off);
+            for (int c = 0; c < cout; ++c) { sc[c] = 1.0f; sh[c] = bv[c]; }
         }
         if (!l.bnkey.empty()) {
             // eval-mode BatchNorm2d folded to y = x*scale + shift, applied AFTER accumulation

@@ -14,6 +14,9 @@
 namespace lspf2f {
 
 enum LayerKind { kFirstConv = 0, kIgemm = 1, kLastConv = 2 };
+// InstanceNorm plans, per layer and batch: kInFused = sums in the igemm epilogue (wave shuffles), kInReduce = a streaming pass
+// that also folds the split-K partials, kInSmall = one workgroup per (frame, 32 channels) does statistics + normalisation
+enum InRoute { kInNone = 0, kInFused = 1, kInReduce = 2, kInSmall = 3 };
 
 struct TensorDesc {        // an activation tensor in the workspace (NHWC)
     std::string name;
@@ -35,6 +38,9 @@ struct LayerDesc {
     bool up4 = false;      // upsample conv executed in sub-pixel form (4 parities x 2x2 taps)
     std::string wkey;      // state-dict key of the OIHW weight
     std::string bnkey;     // state-dict prefix of the following BatchNorm2d ("" = none)
+    std::string biaskey;   // state-dict key of the conv bias ("" = none; InstanceNorm plans: the level convs, networks.py:590)
+    bool inorm = false;    // an InstanceNorm2d (affine=False, eps 1e-5) follows the conv: per-(frame, channel) statistics at run time
+    int in_route = 0;      // per-batch: how those statistics are gathered (kInFused / kInReduce / kInSmall)
     int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
     int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
@@ -54,6 +60,8 @@ struct Plan {
     int variant = 1, nres = 2, input_nc = 13, feat_nc = 1, output_nc = 3, ngf = 64, num_downs = 8, size = 512;
     bool keep_intermediates = false;
     int dtype = 0;             // 0: fp32 activations + weights; 1: bf16 storage (fp32 accumulate), first/last-layer weights fp32
+    int norm = 0;              // 0: BatchNorm2d in eval mode (folded, the shipped checkpoints); 1: InstanceNorm2d (norm_layer argument
+                               // of the reference constructors, networks.py:555 / :459): conv biases on, statistics at run time, fp32 only
     size_t elt() const { return dtype == 1 ? 2 : 4; }
     int ktile_channels() const { return dtype == 1 ? 64 : 32; }   // a K-tile is 128 B of channels
     bool layer_weights_typed(const LayerDesc &l) const { return l.kind == kIgemm; }   // else fp32
@@ -70,6 +78,9 @@ struct Plan {
     size_t act_bytes = 0;       // activation arena
     size_t partial_bytes = 0;   // split-K scratch
     size_t partial_offset = 0;
+    size_t stats_bytes = 0;     // InstanceNorm plans: per-wave partial sums [2][B][groups][C] + the finalised [2][B][C]
+    size_t stats_offset = 0;
+    int stats_groups_max = 0;
     // persistent region at workspace offset 0: pre-activation contribution of the candidate channels to the
     // first conv, [H/2][W/2][ngf] fp32 (constant per person: demo.py:89-95 builds img_candidates once)
     size_t cand_cache_bytes() const { return ((size_t)(size / 2) * (size / 2) * ngf * sizeof(float) + 255) / 256 * 256; }
@@ -78,7 +89,7 @@ struct Plan {
     size_t persistent_bytes() const { return 2 * cand_cache_bytes(); }
 
     std::string build(int variant, int input_nc, int feat_nc, int output_nc, int ngf, int num_downs,
-                      int size, bool keep, int dtype = 0);   // returns "" or an error message
+                      int size, bool keep, int dtype = 0, int norm = 0);   // returns "" or an error message
     void plan_batch(int batch);
     size_t workspace_bytes(int batch) const;   // without mutating the current plan
     std::string pack(void *blob, size_t bytes) const;   // "" or error

@@ -22,19 +22,21 @@ from . import _native as N
 class Engine:
     def __init__(self, variant: str = "large", input_nc: int = 13, feat_nc: int = 1,
                  output_nc: int = 3, ngf: int = 64, num_downs: int = 8, size: int = 512,
-                 max_batch: int = 1, keep_intermediates: bool = False, dtype: str = "f32"):
+                 max_batch: int = 1, keep_intermediates: bool = False, dtype: str = "f32", norm: str = "batch"):
         if variant not in N.VARIANT_IDS:
             raise ValueError("opt.size must be 'normal' or 'large' for the HIP renderer "
                              "(got %r; the 'small' U-Net is not on the shipped path)" % (variant,))
         if dtype not in N.DTYPE_IDS:
             raise ValueError("dtype must be 'f32' or 'bf16'")
-        self.dtype = dtype
+        if norm not in N.NORM_IDS:
+            raise ValueError("norm must be 'batch' (BatchNorm2d, the shipped checkpoints) or 'instance' (norm_layer=nn.InstanceNorm2d)")
+        self.dtype, self.norm = dtype, norm
         self.lib = N.load()
         self.variant, self.input_nc, self.feat_nc, self.output_nc = variant, input_nc, feat_nc, output_nc
         self.ngf, self.num_downs, self.size, self.max_batch = ngf, num_downs, size, max_batch
         cfg = N.Config(N.ABI_VERSION, N.VARIANT_IDS[variant], input_nc, feat_nc, output_nc, ngf,
                        num_downs, size, size, max_batch, N.DTYPE_IDS[dtype],
-                       N.FLAG_KEEP_INTERMEDIATES if keep_intermediates else 0)
+                       (N.FLAG_KEEP_INTERMEDIATES if keep_intermediates else 0) | (N.FLAG_INSTANCE_NORM if norm == "instance" else 0))
         h = ctypes.c_void_p()
         N.check(self.lib.lspf2f_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h

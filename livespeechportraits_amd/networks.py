@@ -28,38 +28,55 @@ class _Slot(nn.Identity):
     reference (stands where it has nn.ReLU / nn.Upsample)."""
 
 
-def _conv(cin: int, cout: int, stride: int) -> nn.Conv2d:
-    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+def _conv(cin: int, cout: int, stride: int, bias: bool = False) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=bias)
+
+
+def _norm_kind(norm_layer) -> str:
+    """The reference constructors take ``norm_layer`` (networks.py:459, :555): BatchNorm2d (default) or InstanceNorm2d."""
+    if norm_layer in (None, nn.BatchNorm2d, "batch"):
+        if norm_layer is None:
+            raise NotImplementedError("norm_layer=None (no normalisation) is not supported by the HIP renderer")
+        return "batch"
+    if norm_layer in (nn.InstanceNorm2d, "instance"):
+        return "instance"
+    raise NotImplementedError("norm_layer must be nn.BatchNorm2d or nn.InstanceNorm2d, got %r" % (norm_layer,))
+
+
+def _norm(kind: str, channels: int) -> nn.Module:
+    # InstanceNorm2d(affine=False, track_running_stats=False) owns no tensors: a parameter-free slot keeps the index
+    return nn.BatchNorm2d(channels) if kind == "batch" else _Slot()
 
 
 class ResidualBlock(nn.Module):
-    """Container for conv-BN-ReLU-conv-BN (+x, ReLU) -- keys block.{0,1,3,4}."""
+    """Container for conv-norm-ReLU-conv-norm (+x, ReLU) -- keys block.{0,1,3,4}; the convs never have a bias."""
 
-    def __init__(self, channels: int):
+    def __init__(self, channels: int, norm: str = "batch"):
         super().__init__()
-        self.block = nn.Sequential(_conv(channels, channels, 1), nn.BatchNorm2d(channels), _Slot(),
-                                   _conv(channels, channels, 1), nn.BatchNorm2d(channels))
+        self.block = nn.Sequential(_conv(channels, channels, 1), _norm(norm, channels), _Slot(),
+                                   _conv(channels, channels, 1), _norm(norm, channels))
 
 
 class ResUnetSkipConnectionBlock(nn.Module):
     """One nesting level; ``model`` mirrors the reference's Sequential index by index."""
 
-    def __init__(self, depth: int, num_downs: int, nres: int, ngf: int, input_nc: int, output_nc: int):
+    def __init__(self, depth: int, num_downs: int, nres: int, ngf: int, input_nc: int, output_nc: int, norm: str = "batch"):
         super().__init__()
         outer, innermost = depth == 0, depth == num_downs - 1
         cin, inner, cout = level_channels(depth, ngf, input_nc, output_nc)
-        seq = [_conv(cin, inner, 2)]
+        use_bias = norm == "instance"                         # networks.py:494 / :590
+        seq = [_conv(cin, inner, 2, use_bias)]
         if not (outer or innermost):
-            seq.append(nn.BatchNorm2d(inner))
+            seq.append(_norm(norm, inner))
         seq.append(_Slot())                                   # ReLU
-        seq += [ResidualBlock(inner) for _ in range(nres)]
+        seq += [ResidualBlock(inner, norm) for _ in range(nres)]
         if not innermost:
-            seq.append(ResUnetSkipConnectionBlock(depth + 1, num_downs, nres, ngf, input_nc, output_nc))
+            seq.append(ResUnetSkipConnectionBlock(depth + 1, num_downs, nres, ngf, input_nc, output_nc, norm))
         seq.append(_Slot())                                   # Upsample
-        seq.append(_conv(inner if innermost else 2 * inner, cout, 1))
+        seq.append(_conv(inner if innermost else 2 * inner, cout, 1, use_bias))
         if not outer:
-            seq += [nn.BatchNorm2d(cout), _Slot()]
-            seq += [ResidualBlock(cout) for _ in range(nres)]
+            seq += [_norm(norm, cout), _Slot()]
+            seq += [ResidualBlock(cout, norm) for _ in range(nres)]
         self.model = nn.Sequential(*seq)
 
 
@@ -67,11 +84,12 @@ class Feature2FaceGenerator(nn.Module):
     """Feature2FaceGenerator_{normal,large}: parameters here, arithmetic in liblspf2f."""
 
     def __init__(self, variant: str, input_nc: int = 13, output_nc: int = 3, num_downs: int = 8,
-                 ngf: int = 64, feat_nc: int = 1):
+                 ngf: int = 64, feat_nc: int = 1, norm_layer=nn.BatchNorm2d):
         super().__init__()
         self.variant, self.input_nc, self.output_nc = variant, input_nc, output_nc
         self.num_downs, self.ngf, self.feat_nc = num_downs, ngf, feat_nc
-        self.model = ResUnetSkipConnectionBlock(0, num_downs, VARIANTS[variant], ngf, input_nc, output_nc)
+        self.norm = _norm_kind(norm_layer)
+        self.model = ResUnetSkipConnectionBlock(0, num_downs, VARIANTS[variant], ngf, input_nc, output_nc, self.norm)
         self._engine: Optional[Engine] = None
         self._blob: Optional[torch.Tensor] = None      # packed weights on the device
         self._dirty = True
@@ -90,7 +108,7 @@ class Feature2FaceGenerator(nn.Module):
             same_size = e is not None and e.size == size
             mb = max(batch, e.max_batch) if same_size else batch
             e = Engine(self.variant, self.input_nc, self.feat_nc, self.output_nc, self.ngf,
-                       self.num_downs, size, mb)
+                       self.num_downs, size, mb, norm=self.norm)
             # The packed layout depends on the frame size (an up-conv switches to the 16-tap sub-pixel form once it writes
             # >= 32x32, plan.cpp), not on the batch: the blob is reused only when just max_batch grew.
             if same_size and not self._dirty and self._blob is not None and self._blob.device == device \
@@ -129,12 +147,14 @@ class Feature2FaceGenerator(nn.Module):
         return self.render(feat, cand)
 
 
-def Feature2FaceGenerator_normal(input_nc=13, output_nc=3, num_downs=8, ngf=64):
-    return Feature2FaceGenerator("normal", input_nc, output_nc, num_downs, ngf)
+def Feature2FaceGenerator_normal(input_nc=13, output_nc=3, num_downs=8, ngf=64, norm_layer=nn.BatchNorm2d):
+    """networks.py:458-483; ``norm_layer=nn.InstanceNorm2d`` selects the run-time normalisation variant"""
+    return Feature2FaceGenerator("normal", input_nc, output_nc, num_downs, ngf, norm_layer=norm_layer)
 
 
-def Feature2FaceGenerator_large(input_nc=13, output_nc=3, num_downs=8, ngf=64):
-    return Feature2FaceGenerator("large", input_nc, output_nc, num_downs, ngf)
+def Feature2FaceGenerator_large(input_nc=13, output_nc=3, num_downs=8, ngf=64, norm_layer=nn.BatchNorm2d):
+    """networks.py:554-579"""
+    return Feature2FaceGenerator("large", input_nc, output_nc, num_downs, ngf, norm_layer=norm_layer)
 
 
 def init_weights(net: nn.Module, init_type: str = "normal", init_gain: float = 0.02) -> None:

@@ -82,6 +82,16 @@ def make_state_dict(topo: Topology, seed: int = 1234) -> Dict[str, np.ndarray]:
     return sd
 
 
+def scale_last_conv(sd: Dict[str, np.ndarray], topo: Topology, gain: float) -> Dict[str, np.ndarray]:
+    """Scale the weight of the outermost up-conv (the layer in front of tanh).  With run-time normalisation (InstanceNorm
+    variant) the activations in front of it have unit variance, and the N(0, 0.02)-like weights of the recipe would push a
+    percent of the output into tanh saturation, where errors hide."""
+    key = topo.convs[-1].weight_key
+    out = dict(sd)
+    out[key] = (sd[key] * np.float32(gain)).astype(np.float32)
+    return out
+
+
 def make_inputs(batch: int, size: int = 512, seed: int = 99, cand_batch: int = 1,
                 cand_channels: int = 12) -> Tuple[np.ndarray, np.ndarray]:
     """(feature_map [B,1,S,S] with exact {0,1} values -- face_dataset.py:280 divides a

@@ -69,6 +69,7 @@ class Topology:
     size: int
     convs: List[ConvSpec] = field(default_factory=list)
     tensors: Dict[str, Tuple[int, ...]] = field(default_factory=dict)   # state-dict key -> shape
+    norm: str = "batch"       # "batch": nn.BatchNorm2d (the default of the constructors); "instance": norm_layer=nn.InstanceNorm2d
 
     @property
     def nres(self) -> int:
@@ -105,7 +106,13 @@ def level_channels(depth: int, ngf: int, input_nc: int, output_nc: int) -> Tuple
 
 def build_topology(variant: str = "large", input_nc: int = 13, output_nc: int = 3,
                    ngf: int = 64, num_downs: int = 8, size: int = 512,
-                   prefix: str = "netG.model") -> Topology:
+                   prefix: str = "netG.model", norm: str = "batch") -> Topology:
+    """``norm="instance"`` describes the same nets built with ``norm_layer=nn.InstanceNorm2d`` (networks.py:459, :555): the
+    norms own no tensors (affine=False, no running stats) and the level convs -- not the ResidualBlock convs -- have a bias
+    (``use_bias``, networks.py:494 / :590)."""
+    if norm not in ("batch", "instance"):
+        raise ValueError("norm must be 'batch' or 'instance'")
+    inst = norm == "instance"
     if variant not in VARIANTS:
         raise ValueError("variant must be 'normal' or 'large' (the 'small' pix2pix U-Net of "
                          "networks.py:680-769 is not on the shipped path), got %r" % (variant,))
@@ -113,10 +120,12 @@ def build_topology(variant: str = "large", input_nc: int = 13, output_nc: int = 
         raise ValueError("num_downs must be >= 5 (networks.py:563 builds num_downs-5 middle blocks)")
     if size % (1 << num_downs) != 0:
         raise ValueError("size must be a multiple of 2**num_downs")
-    topo = Topology(variant, input_nc, output_nc, ngf, num_downs, size)
+    topo = Topology(variant, input_nc, output_nc, ngf, num_downs, size, norm=norm)
     nres = topo.nres
 
     def add_bn(key: str, c: int):
+        if inst:
+            return
         topo.tensors[key + ".weight"] = (c,)
         topo.tensors[key + ".bias"] = (c,)
         topo.tensors[key + ".running_mean"] = (c,)
@@ -141,6 +150,8 @@ def build_topology(variant: str = "large", input_nc: int = 13, output_nc: int = 
         i = 0
         wk = "%s.model.%d.weight" % (pfx, i)
         topo.tensors[wk] = (inner, cin, 3, 3)
+        if inst:
+            topo.tensors["%s.model.%d.bias" % (pfx, i)] = (inner,)
         i += 1
         bn_key = None
         if not (outermost or innermost):
@@ -160,6 +171,8 @@ def build_topology(variant: str = "large", input_nc: int = 13, output_nc: int = 
         up_cin = inner if innermost else inner * 2
         wk = "%s.model.%d.weight" % (pfx, i)
         topo.tensors[wk] = (cout, up_cin, 3, 3)
+        if inst:
+            topo.tensors["%s.model.%d.bias" % (pfx, i)] = (cout,)
         i += 1
         bn_key = None
         if not outermost:

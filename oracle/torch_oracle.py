@@ -39,6 +39,9 @@ BN_EPS = 1e-5
 
 
 def _bn(x: torch.Tensor, sd: Dict[str, torch.Tensor], key: str) -> torch.Tensor:
+    if (key + ".running_mean") not in sd:
+        # norm_layer=nn.InstanceNorm2d (networks.py:459, :555): affine=False, track_running_stats=False, eps=1e-5 -> no tensors
+        return F.instance_norm(x, None, None, None, None, True, 0.1, BN_EPS)
     return F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"],
                         sd[key + ".weight"], sd[key + ".bias"], training=False, eps=BN_EPS)
 
@@ -64,7 +67,7 @@ def generator_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, nres: int, n
         outer = depth == 0
         inner = depth == num_downs - 1
         i = 0
-        h = F.conv2d(x, sd["%s.model.%d.weight" % (pfx, i)], None, 2, 1)
+        h = F.conv2d(x, sd["%s.model.%d.weight" % (pfx, i)], sd.get("%s.model.%d.bias" % (pfx, i)), 2, 1)   # bias: InstanceNorm variant
         i += 1
         if not (outer or inner):
             h = _bn(h, sd, "%s.model.%d" % (pfx, i))
@@ -79,7 +82,7 @@ def generator_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, nres: int, n
             i += 1
         h = F.interpolate(h, scale_factor=2, mode="nearest")
         i += 1
-        h = F.conv2d(h, sd["%s.model.%d.weight" % (pfx, i)], None, 1, 1)
+        h = F.conv2d(h, sd["%s.model.%d.weight" % (pfx, i)], sd.get("%s.model.%d.bias" % (pfx, i)), 1, 1)
         i += 1
         if outer:
             return h

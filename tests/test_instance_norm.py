@@ -1,0 +1,99 @@
+"""The norm_layer=nn.InstanceNorm2d variant of the generators (reference constructors
+models/networks.py:459, :555, use_bias :494 / :590, ResidualBlock :650-668).  Goldens = outputs of the REFERENCE modules built
+with that argument (oracle/make_golden_in.py asserts the oracle bit-identical to them).  Tolerance: the north-star 1e-3 max-abs
+fp32; measured error is printed and also held to 2e-4."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import GOLDEN
+
+CASES = ["in_large_s128_b2", "in_normal_s192_b3", "in_normal_512", "in_large_512"]
+TOL, TIGHT = 1e-3, 2e-4
+
+
+def problem(case):
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.topology import build_topology
+    meta = json.load(open(os.path.join(GOLDEN, case + ".json")))
+    ref = np.load(os.path.join(GOLDEN, case + ".npz"))["out"]
+    topo = build_topology(meta["variant"], ngf=meta["ngf"], num_downs=meta["num_downs"], size=meta["size"], norm="instance")
+    sd = synth.scale_last_conv(synth.make_state_dict(topo, meta["weight_seed"]), topo, meta["last_gain"])
+    feat, cand = synth.make_inputs(meta["batch"], meta["size"], meta["input_seed"], 1)
+    return meta, ref, topo, sd, feat, cand
+
+
+# ---- CPU -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", CASES[:2])
+def test_oracle_reproduces_the_reference_golden(case):
+    from oracle import torch_oracle
+    meta, ref, topo, sd, feat, cand = problem(case)
+    x = torch.cat([torch.from_numpy(feat), torch.from_numpy(cand).expand(meta["batch"], -1, -1, -1)], 1)
+    out = torch_oracle.generator_forward(torch_oracle.to_torch(sd), x, topo.nres, topo.num_downs).numpy()
+    assert np.abs(out - ref).max() <= 1e-6            # bit-identical under the torch build that made the fixture
+    assert np.abs(ref).max() < 0.99
+
+
+def test_plan_and_containers_carry_the_reference_keys():
+    from livespeechportraits_amd import networks
+    from livespeechportraits_amd.engine import Engine
+    for case in ("in_large_512", "in_normal_512"):
+        meta = json.load(open(os.path.join(GOLDEN, case + ".json")))
+        e = Engine(meta["variant"], norm="instance")
+        want = {"netG." + k: tuple(v) for k, v in meta["keys"].items()}           # dumped from the reference module
+        assert e.expected_tensors() == want
+        ctor = networks.Feature2FaceGenerator_large if meta["variant"] == "large" else networks.Feature2FaceGenerator_normal
+        g = ctor(13, 3, 8, 64, norm_layer=nn.InstanceNorm2d)
+        assert {k: tuple(v.shape) for k, v in g.state_dict().items()} == {k: tuple(v) for k, v in meta["keys"].items()}
+        routes = {l["kernel"] for l in e.layers(1)}
+        assert any("stats" in r for r in routes) and any("in_small" in r for r in routes) and any("in_reduce_stats" in r for r in routes)
+    with pytest.raises(Exception):
+        Engine("normal", norm="instance", dtype="bf16")            # fp32 only
+    with pytest.raises(NotImplementedError):
+        networks.Feature2FaceGenerator_normal(norm_layer=nn.GroupNorm)
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_matches_reference_golden(case, gpu_device):
+    from livespeechportraits_amd.engine import Engine
+    meta, ref, topo, sd, feat, cand = problem(case)
+    e = Engine(meta["variant"], 13, 1, 3, meta["ngf"], meta["num_downs"], meta["size"], max_batch=meta["batch"], norm="instance")
+    assert not e.load_state_dict(sd)
+    e.bind(e.pack(), gpu_device)
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+    out = e.forward(f, c)
+    err = np.abs(out.cpu().numpy() - ref)
+    print("\n%s: max-abs vs the reference module %.2e (mean %.2e); routes %s" % (
+        case, err.max(), err.mean(), sorted({l["kernel"] for l in e.layers(meta["batch"]) if "in_" in l["kernel"]})))
+    assert err.max() <= TOL and err.max() <= TIGHT
+    assert torch.equal(e.forward(f, c), out)                    # fixed summation order: bit-reproducible
+    # frames are independent: statistics are per (frame, channel)
+    if meta["batch"] > 1:
+        one = e.forward(f[1:2].contiguous(), c)
+        assert (one[0] - out[1]).abs().max().item() <= 2e-5
+    u8 = e.forward_image(f, c)
+    want = ((out.permute(0, 2, 3, 1) + 1.0) / 2.0 * 255.0).clamp(0, 255).to(torch.uint8)
+    assert (u8.int() - want.int()).abs().max().item() <= 1
+
+
+@pytest.mark.gpu
+def test_batch8_and_the_parameter_container(gpu_device):
+    """the reference-named constructor with norm_layer=nn.InstanceNorm2d, batch 8 at full size vs the live oracle (every frame)"""
+    from livespeechportraits_amd import networks, synth
+    from oracle import torch_oracle
+    meta, ref, topo, sd, _, cand = problem("in_normal_512")
+    g = networks.Feature2FaceGenerator_normal(13, 3, 8, 64, norm_layer=nn.InstanceNorm2d)
+    g.load_state_dict({k[len("netG."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    g = g.to(gpu_device)
+    feat, _ = synth.make_inputs(8, 512, seed=7, cand_batch=1)
+    out = g.render(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
+    sdt = torch_oracle.to_torch(sd)
+    for i in range(8):
+        want = torch_oracle.inference(sdt, torch.from_numpy(feat[i:i + 1]), torch.from_numpy(cand), 1, 8).numpy()
+        assert np.abs(out[i:i + 1] - want).max() <= TIGHT, i
