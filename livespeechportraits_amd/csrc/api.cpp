@@ -331,13 +331,14 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             InstNormParams q{};
             q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu;
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
-            q.psum = st; q.psq = st + slab * l.cout;
-            q.mean = st + 2 * slab * l.cout; q.rstd = q.mean + (size_t)batch * l.cout;
+            q.psum = st; q.psq = st + slab * l.cout; q.pshift = st + 2 * slab * l.cout;
+            q.mean = st + 3 * slab * l.cout; q.rstd = q.mean + (size_t)batch * l.cout;
             p.residual = nullptr; p.relu = 0;
             if (l.in_route == kInFused) {
                 const int rhw = l.up4 ? l.hs * l.hs : l.ho * l.ho;
-                q.groups = (l.up4 ? 4 : 1) * rhw / (l.bm == 32 ? 32 : l.bm / 2);
-                p.psum = q.psum; p.psq = q.psq; p.in_groups = q.groups;
+                q.rows_per_group = l.bm == 32 ? 32 : l.bm / 2;                  // rows of one wave
+                q.groups = (l.up4 ? 4 : 1) * rhw / q.rows_per_group;
+                p.psum = q.psum; p.psq = q.psq; p.pshift = q.pshift; p.in_groups = q.groups;
                 e = launch_igemm(p, l.bm, l.bn, l.group, s);
                 if (e == hipSuccess) e = launch_in_finalize(q, s);
                 if (e == hipSuccess) e = launch_in_apply(q, s);
@@ -349,7 +350,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
                 if (l.in_route == kInSmall) {
                     if (e == hipSuccess) e = launch_in_small(q, s);
                 } else {
-                    q.groups = (q.hw + 63) / 64;
+                    q.groups = (q.hw + 63) / 64; q.rows_per_group = 64;
                     if (e == hipSuccess) e = launch_in_reduce_stats(q, s);
                     if (e == hipSuccess) e = launch_in_finalize(q, s);
                     if (e == hipSuccess) e = launch_in_apply(q, s);

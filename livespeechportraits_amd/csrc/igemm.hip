@@ -335,7 +335,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             sc = *reinterpret_cast<const float4 *>(p.scale + n);
             sh = *reinterpret_cast<const float4 *>(p.shift + n);
         }
-        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);   // InstanceNorm: sum x, sum x^2 of this lane's rows
+        // InstanceNorm plans: sums of (x - c) and (x - c)^2 over this lane's rows, c = the value in the wave's first row (a shift
+        // close to the mean keeps var = E[d^2] - E[d]^2 free of cancellation; in_finalize merges the groups in double)
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f), c4 = s1;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -346,47 +348,56 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                 const int row = pass * 8 + erow;
                 float4 v = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
                 const int m = m0 + (wm * TM + i) * 32 + row;
-                if (m >= p.M || !nok) continue;
+                const bool ok = m < p.M && nok;
                 size_t orow = (size_t)m;                     // output pixel index (NHWC row)
-                if (p.up4) {
+                if (p.up4 && ok) {
                     const int b = (int)p.div_rhw.div((unsigned)m);
                     const int rr = m - b * rhw;
                     const int y = (int)p.div_rw.div((unsigned)rr), x = rr - y * rw;
                     orow = ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
                 }
                 if (p.splits > 1) {
-                    *reinterpret_cast<float4 *>(p.partial + ((size_t)z * p.Mout + orow) * p.Cout + n) = v;
+                    if (ok) *reinterpret_cast<float4 *>(p.partial + ((size_t)z * p.Mout + orow) * p.Cout + n) = v;
                 } else {
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                    if (p.residual) {
+                    if (p.residual && ok) {
                         const float4 rv = load4(static_cast<const T *>(p.residual) + orow * p.Cout + n);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (p.out_f32) store4(static_cast<float *>(p.out) + orow * p.Cout + n, v);
-                    else store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
-                    if (p.psum) {
-                        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                    if (ok) {
+                        if (p.out_f32) store4(static_cast<float *>(p.out) + orow * p.Cout + n, v);
+                        else store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
+                    }
+                    if (p.psum) {                            // wave-uniform
+                        if (i == 0 && pass == 0) {           // row 0 of the wave's rows sits in the lanes with erow == 0
+                            c4.x = __shfl(v.x, lane & 7); c4.y = __shfl(v.y, lane & 7);
+                            c4.z = __shfl(v.z, lane & 7); c4.w = __shfl(v.w, lane & 7);
+                        }
+                        if (ok) {
+                            const float4 d = make_float4(v.x - c4.x, v.y - c4.y, v.z - c4.z, v.w - c4.w);
+                            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                            s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+                        }
                     }
                 }
             }
         }
         if (p.psum) {
-            // InstanceNorm statistics of this wave's TM*32 rows (all inside one frame: the planner checks divisibility) for its 32
-            // channels of column block j: the 8 lanes that share a channel quad hold 4 rows each -> xor-shuffle over lane bits 3..5
+            // the 8 lanes that share a channel quad hold 4 rows each per tile -> xor-shuffle over lane bits 3..5
 #pragma unroll
             for (int o = 8; o < 64; o <<= 1) {
                 s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
                 s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
             }
-            const int mw = m0 + wm * TM * 32;
+            const int mw = m0 + wm * TM * 32;               // all TM*32 rows lie inside one frame (the planner checks divisibility)
             if (erow == 0 && nok && mw < p.M) {
                 const int b = (int)p.div_rhw.div((unsigned)mw);
                 const int gpp = rhw / (TM * 32);                                   // groups per frame and parity
-                const size_t g = (size_t)b * p.in_groups + par * gpp + (mw - b * rhw) / (TM * 32);
-                *reinterpret_cast<float4 *>(p.psum + g * p.Cout + n) = s1;
-                *reinterpret_cast<float4 *>(p.psq + g * p.Cout + n) = s2;
+                const size_t g = ((size_t)b * p.in_groups + par * gpp + (mw - b * rhw) / (TM * 32)) * p.Cout + n;
+                *reinterpret_cast<float4 *>(p.psum + g) = s1;
+                *reinterpret_cast<float4 *>(p.psq + g) = s2;
+                *reinterpret_cast<float4 *>(p.pshift + g) = c4;
             }
         }
     }

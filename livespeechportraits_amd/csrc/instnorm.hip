@@ -3,13 +3,17 @@
 //
 // Unlike eval-mode BatchNorm this is a run-time reduction over H*W per (frame, channel).  Three routes, chosen per layer by the
 // planner (plan.cpp, InRoute):
-//   fused   the igemm epilogue already produced per-wave sums of x and x^2 (xor-shuffles over the 8 lanes sharing a channel
+//   fused   the igemm epilogue already produced per-wave shifted sums (xor-shuffles over the 8 lanes sharing a channel
 //           quad, igemm.hip) -> in_finalize -> in_apply
 //   reduce  split-K layers / extents the epilogue cannot partition: in_reduce_stats folds the partials (+ bias), writes the raw
 //           tensor and 64-row partial sums -> in_finalize -> in_apply
 //   small   H*W <= 1024: in_small, one workgroup per (frame, 32 channels), does fold + statistics + normalisation
-// Partial sums are fp32 over <= 64 rows, combined in double in a fixed order (bit-reproducible); var = E[x^2] - mean^2 in double
-// (ATen accumulates these statistics in double on the CPU as well).  The normalised tensor overwrites the raw one.
+// Numerics: a channel whose H*W values are nearly equal has var << mean^2, and 1/sqrt(var + 1e-5) then amplifies any error in
+// var up to 316x (this is what happens at the 2x2 / 4x4 levels) -- so var is never formed as E[x^2] - mean^2 of raw values.
+// Every group of <= 64 rows sums d = x - c with c = the group's first row (fp32; d is small where it matters), the groups are
+// merged in double with the pairwise update of Chan et al. in a fixed order (bit-reproducible), and the one-launch route makes
+// two passes (mean, then sum (x - mean)^2).  ATen accumulates these statistics in double on the CPU as well.
+// The normalised tensor overwrites the raw one.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -45,10 +49,12 @@ __global__ __launch_bounds__(256) void in_reduce_stats(const InstNormParams p)
     const int rl_n = 256 / cq, tid = threadIdx.x;
     const int rl = tid / cq, q = tid - rl * cq;
     const int b = blockIdx.y, row0 = blockIdx.x * 64;
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, c4 = s1;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.splits > 1 && p.bias && rl < rl_n) bias = *reinterpret_cast<const float4 *>(p.bias + q * 4);
-    if (rl < rl_n)
+    if (rl < rl_n) {
+        c4 = fold_row(p, ((size_t)b * p.hw + row0) * p.C + q * 4);          // the shift: this group's first row (every row lane reads it)
+        if (p.splits > 1) { c4.x += bias.x; c4.y += bias.y; c4.z += bias.z; c4.w += bias.w; }
         for (int r = rl; r < 64 && row0 + r < p.hw; r += rl_n) {
             const size_t e = ((size_t)b * p.hw + row0 + r) * p.C + q * 4;
             float4 v = fold_row(p, e);
@@ -56,9 +62,11 @@ __global__ __launch_bounds__(256) void in_reduce_stats(const InstNormParams p)
                 v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
                 *reinterpret_cast<float4 *>(p.x + e) = v;
             }
-            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            const float4 d = make_float4(v.x - c4.x, v.y - c4.y, v.z - c4.z, v.w - c4.w);
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
         }
+    }
     red[0][tid] = s1;
     red[1][tid] = s2;
     __syncthreads();
@@ -71,35 +79,61 @@ __global__ __launch_bounds__(256) void in_reduce_stats(const InstNormParams p)
         const size_t g = ((size_t)b * p.groups + blockIdx.x) * p.C + q * 4;
         *reinterpret_cast<float4 *>(p.psum + g) = s1;
         *reinterpret_cast<float4 *>(p.psq + g) = s2;
+        *reinterpret_cast<float4 *>(p.pshift + g) = c4;
     }
 }
 
-// one wave per (frame, channel quad): lanes stride over the groups, double accumulation, xor-shuffle tree
+// running statistics of a set of values: count, mean, sum of squared deviations; merge = Chan, Golub & LeVeque's pairwise update
+struct Moments { double n, mean, m2; };
+__device__ __forceinline__ Moments merge(Moments a, Moments b)
+{
+    if (b.n == 0.0) return a;
+    if (a.n == 0.0) return b;
+    const double n = a.n + b.n, delta = b.mean - a.mean;
+    return {n, a.mean + delta * (b.n / n), a.m2 + b.m2 + delta * delta * (a.n * b.n / n)};
+}
+__device__ __forceinline__ Moments group_moments(float s1, float s2, float c, double n)
+{
+    const double m = (double)s1 / n;                            // mean of d = x - c
+    return {n, (double)c + m, (double)s2 - (double)s1 * m};     // sum (d - m)^2 = sum d^2 - (sum d)^2 / n
+}
+
+// one wave per (frame, channel quad): lanes stride over the groups, then an xor-shuffle merge tree; everything in double
 __global__ __launch_bounds__(256) void in_finalize(const InstNormParams p)
 {
     const int cq = p.C >> 2;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= p.B * cq) return;
     const int b = wave / cq, q = wave - b * cq;
-    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+    Moments acc[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    // a frame's rows are covered by hw / rows_per_group groups (x4 for the sub-pixel up-convs, whose groups are per parity and
+    // cover hw / 4 rows each); only the reduce route can end on a short group
+    const int full = p.hw / p.rows_per_group, tail = p.hw - full * p.rows_per_group;
     for (int g = lane; g < p.groups; g += 64) {
         const size_t o = ((size_t)b * p.groups + g) * p.C + q * 4;
         const float4 a = *reinterpret_cast<const float4 *>(p.psum + o), c = *reinterpret_cast<const float4 *>(p.psq + o);
-        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
-        t[0] += c.x; t[1] += c.y; t[2] += c.z; t[3] += c.w;
+        const float4 sh = *reinterpret_cast<const float4 *>(p.pshift + o);
+        const double n = (tail && g == p.groups - 1) ? (double)tail : (double)p.rows_per_group;
+        acc[0] = merge(acc[0], group_moments(a.x, c.x, sh.x, n));
+        acc[1] = merge(acc[1], group_moments(a.y, c.y, sh.y, n));
+        acc[2] = merge(acc[2], group_moments(a.z, c.z, sh.z, n));
+        acc[3] = merge(acc[3], group_moments(a.w, c.w, sh.w, n));
     }
 #pragma unroll
-    for (int o = 32; o; o >>= 1)
+    for (int o = 1; o < 64; o <<= 1)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s[k] += shfl_xor_d(s[k], o); t[k] += shfl_xor_d(t[k], o); }
+        for (int k = 0; k < 4; ++k) {
+            Moments t = {shfl_xor_d(acc[k].n, o), shfl_xor_d(acc[k].mean, o), shfl_xor_d(acc[k].m2, o)};
+            // both partners must compute the same value: merge in a canonical order (lower lane first)
+            acc[k] = (lane & o) ? merge(t, acc[k]) : merge(acc[k], t);
+        }
     if (lane == 0) {
         float m[4], r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const double mean = s[k] / p.hw;
-            double var = t[k] / p.hw - mean * mean;             // biased variance, as instance_norm uses
+            double var = acc[k].m2 / acc[k].n;                  // biased variance, as instance_norm uses
             var = var < 0.0 ? 0.0 : var;
-            m[k] = (float)mean;
+            m[k] = (float)acc[k].mean;
             r[k] = (float)(1.0 / sqrt(var + kInEps));
         }
         *reinterpret_cast<float4 *>(p.mean + (size_t)b * p.C + q * 4) = make_float4(m[0], m[1], m[2], m[3]);
@@ -136,13 +170,26 @@ __global__ __launch_bounds__(256) void in_apply(const InstNormParams p)
 // grid (C / 32, B), 256 threads = 32 row lanes x 8 channel quads: fold, statistics and normalisation of one 32-channel slab
 __global__ __launch_bounds__(256) void in_small(const InstNormParams p)
 {
-    __shared__ float4 red[2][4][8];
+    __shared__ float4 red[1][4][8];
     const int tid = threadIdx.x, q = tid & 7, rl = tid >> 3, wave = tid >> 6;
     const int b = blockIdx.y, c0 = blockIdx.x * 32 + q * 4;
     const bool live = c0 < p.C;                                // C % 32 != 0 cannot happen (ngf % 32 == 0), kept for safety
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live && p.splits > 1 && p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + c0);
+    // block-wide sum of a float4 per channel quad, in double: the 8 row lanes of a wave (xor-shuffle over lane bits 3..5), then the 4
+    // waves through LDS in a fixed order.  Called by all 256 threads.
+    auto block_sum = [&](float4 v, double (&out)[4]) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o); }
+        __syncthreads();                                       // the previous round's readers are done with `red`
+        if ((tid & 63) < 8) red[0][wave][q] = v;
+        __syncthreads();
+        out[0] = out[1] = out[2] = out[3] = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const float4 a = red[0][w][q]; out[0] += a.x; out[1] += a.y; out[2] += a.z; out[3] += a.w; }
+    };
+    // pass 1: fold the split-K partials (+ bias) into x, mean
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live)
         for (int r = rl; r < p.hw; r += 32) {
             const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
@@ -152,34 +199,24 @@ __global__ __launch_bounds__(256) void in_small(const InstNormParams p)
                 *reinterpret_cast<float4 *>(p.x + e) = v;      // re-read below by the SAME thread
             }
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
         }
-    // the 8 row lanes of a wave that share a channel quad: xor-shuffle over lane bits 3..5, then the 4 waves through LDS
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-        s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
-        s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
-    }
-    if ((tid & 63) < 8) { red[0][wave][q] = s1; red[1][wave][q] = s2; }
-    __syncthreads();
-    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float4 a = red[0][w][q], c = red[1][w][q];
-        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
-        t[0] += c.x; t[1] += c.y; t[2] += c.z; t[3] += c.w;
-    }
-    float m[4], rs[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double mean = s[k] / p.hw;
-        double var = t[k] / p.hw - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        m[k] = (float)mean;
-        rs[k] = (float)(1.0 / sqrt(var + kInEps));
-    }
+    double sum[4];
+    block_sum(s1, sum);
+    const float4 m4 = make_float4((float)(sum[0] / p.hw), (float)(sum[1] / p.hw), (float)(sum[2] / p.hw), (float)(sum[3] / p.hw));
+    // pass 2: sum of squared deviations from that mean (two-pass variance: no cancellation)
+    float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live)
+        for (int r = rl; r < p.hw; r += 32) {
+            const float4 v = *reinterpret_cast<const float4 *>(p.x + ((size_t)b * p.hw + r) * p.C + c0);
+            const float4 d = make_float4(v.x - m4.x, v.y - m4.y, v.z - m4.z, v.w - m4.w);
+            s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+        }
+    double ssq[4];
+    block_sum(s2, ssq);
     if (!live) return;
-    const float4 m4 = make_float4(m[0], m[1], m[2], m[3]), r4 = make_float4(rs[0], rs[1], rs[2], rs[3]);
+    const float4 r4 = make_float4((float)(1.0 / sqrt(ssq[0] / p.hw + kInEps)), (float)(1.0 / sqrt(ssq[1] / p.hw + kInEps)),
+                                  (float)(1.0 / sqrt(ssq[2] / p.hw + kInEps)), (float)(1.0 / sqrt(ssq[3] / p.hw + kInEps)));
+    // pass 3: normalise (+ residual) (+ ReLU) in place
     for (int r = rl; r < p.hw; r += 32) {
         const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
         float4 *px = reinterpret_cast<float4 *>(p.x + e);
@@ -198,7 +235,7 @@ hipError_t launch_in_reduce_stats(const InstNormParams &p, hipStream_t s)
 
 hipError_t launch_in_finalize(const InstNormParams &p, hipStream_t s)
 {
-    if (!in_shape_ok(p) || p.groups < 1) return hipErrorInvalidValue;
+    if (!in_shape_ok(p) || p.groups < 1 || p.rows_per_group < 1) return hipErrorInvalidValue;
     const int waves = p.B * (p.C / 4);
     hipLaunchKernelGGL(in_finalize, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p);
     return hipGetLastError();

@@ -52,8 +52,8 @@ struct IgemmParams {
     int ktiles_per_split;
     int splits;
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
-    float *psum, *psq;          // InstanceNorm plans, fused route: per-wave partial sums of the output and its square,
-    int in_groups;              //   [B][in_groups][Cout] each (in_groups = wave row-groups per frame); nullptr otherwise
+    float *psum, *psq, *pshift; // InstanceNorm plans, fused route: per-wave sums of (x - c), (x - c)^2 and the shift c (= the group's
+    int in_groups;              //   first row), [B][in_groups][Cout] each (in_groups = wave row-groups per frame); nullptr otherwise
     int out_f32;                // write fp32 output whatever the storage type (GEMM form of the last conv)
     int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
     int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,
@@ -144,9 +144,10 @@ struct InstNormParams {
     const float *bias;         // [C] added while folding the partials (the igemm epilogue adds it itself when splits == 1)
     const float *residual;     // [B][hw][C] or nullptr
     int relu;
-    float *psum, *psq;         // partial sums [B][groups][C]
+    float *psum, *psq, *pshift;   // per group: sums of (x - c), (x - c)^2 and the shift c (the group's first row), [B][groups][C]
     float *mean, *rstd;        // [B][C]
     int B, hw, C, groups;
+    int rows_per_group;        // rows behind one group's sums (the last group of a frame may hold fewer: hw - g * rows_per_group)
 };
 hipError_t launch_in_reduce_stats(const InstNormParams &p, hipStream_t s);   // fold partials, write raw x, 64-row partial sums
 hipError_t launch_in_finalize(const InstNormParams &p, hipStream_t s);       // partial sums -> mean, rstd (double)

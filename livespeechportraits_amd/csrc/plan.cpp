@@ -347,8 +347,8 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
         if (p.last_as_gemm(l)) partial = std::max(partial, (size_t)batch * l.hs * l.hs * 4 * l.cout * sizeof(float));
     }
     if (offsets) *offsets = off;
-    // InstanceNorm statistics: partial sums [2][batch][groups_max][cmax] and the finalised (mean, rstd) [2][batch][cmax]
-    const size_t stats = cmax ? align_up((size_t)2 * batch * ((size_t)groups_max + 1) * cmax * sizeof(float), 256) : 0;
+    // InstanceNorm statistics: per-group (sum d, sum d^2, shift) [3][batch][groups_max][cmax] and the finalised (mean, rstd) [2][batch][cmax]
+    const size_t stats = cmax ? align_up(((size_t)3 * groups_max + 2) * batch * cmax * sizeof(float), 256) : 0;
     return {align_up(a.end, 256), align_up(partial, 256), stats, groups_max};
 }
 }  // namespace

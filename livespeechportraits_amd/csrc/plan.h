@@ -78,7 +78,7 @@ struct Plan {
     size_t act_bytes = 0;       // activation arena
     size_t partial_bytes = 0;   // split-K scratch
     size_t partial_offset = 0;
-    size_t stats_bytes = 0;     // InstanceNorm plans: per-wave partial sums [2][B][groups][C] + the finalised [2][B][C]
+    size_t stats_bytes = 0;     // InstanceNorm plans: per-group sums and shifts [3][B][groups][C] + the finalised (mean, rstd) [2][B][C]
     size_t stats_offset = 0;
     int stats_groups_max = 0;
     // persistent region at workspace offset 0: pre-activation contribution of the candidate channels to the

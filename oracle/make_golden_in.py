@@ -65,6 +65,17 @@ def main():
         taps = {}
         ora = torch_oracle.generator_forward(torch_oracle.to_torch(sd), x, topo.nres, nd, taps=taps)
         assert torch.equal(ora, ref), "oracle differs from the reference module: %g" % (ora - ref).abs().max().item()
+        # The reference's own reproducibility on this case.  InstanceNorm over the 4 / 16 values of the 2x2 / 4x4 levels amplifies fp32
+        # rounding differences by up to 1/sqrt(eps) = 316, so two evaluations of the SAME module with different CPU kernels differ
+        # far more than in the BatchNorm plans: (a) oneDNN convolutions vs ATen's native ones, (b) fp32 vs a float64 evaluation.
+        with torch.backends.mkldnn.flags(enabled=False):
+            with torch.no_grad():
+                alt = net(x)
+        d_alt = (alt - ref).abs()
+        sd64 = {k: v.double() for k, v in torch_oracle.to_torch(sd).items()}
+        d_64 = (torch_oracle.generator_forward(sd64, x.double(), topo.nres, nd).float() - ref).abs()
+        print("   reference vs itself with oneDNN off: max %.2e mean %.2e; vs float64: max %.2e mean %.2e"
+              % (d_alt.max(), d_alt.mean(), d_64.max(), d_64.mean()))
         sat = (ref.abs() > 0.99).float().mean().item()
         print("%-18s %s ngf %d downs %d size %d batch %d: |out| max %.3f std %.3f sat %.4f%%, pre-tanh absmax %.2f; oracle bit-exact; %d keys"
               % (name, variant, ngf, nd, size, batch, ref.abs().max(), ref.std(), 100 * sat, taps["pre_tanh"].abs().max(), len(ref_keys)))
@@ -72,6 +83,8 @@ def main():
         np.savez_compressed(os.path.join(a.out, name + ".npz"), out=ref.numpy())      # no saturation (asserted above): tanh hides nothing
         with open(os.path.join(a.out, name + ".json"), "w") as f:
             json.dump({"variant": variant, "ngf": ngf, "num_downs": nd, "size": size, "batch": batch, "cand_batch": 1, "norm": "instance", "last_gain": LAST_GAIN,
+                       "reference_self_distance": {"onednn_off_max": d_alt.max().item(), "onednn_off_mean": d_alt.mean().item(),
+                                                   "float64_max": d_64.max().item(), "float64_mean": d_64.mean().item()},
                        "weight_seed": 1234, "input_seed": 99, "torch": torch.__version__, "keys": ref_keys}, f, indent=0)
 
 
