@@ -112,4 +112,6 @@ def test_batch8_and_the_parameter_container(gpu_device):
     sdt = torch_oracle.to_torch(sd)
     for i in range(8):
         want = torch_oracle.inference(sdt, torch.from_numpy(feat[i:i + 1]), torch.from_numpy(cand), 1, 8).numpy()
-        assert np.abs(out[i:i + 1] - want).max() <= 1.5 * meta["reference_self_distance"]["onednn_off_max"], i
+        err = np.abs(out[i:i + 1] - want).max()
+        print("frame %d: %.2e" % (i, err))
+        assert err <= TOL, i            # other inputs than the fixture's: the contract itself (the `normal` nets leave room for it)
