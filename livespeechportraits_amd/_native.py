@@ -1,4 +1,4 @@
-"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h, include/lsprnn.h, include/lspraster.h).
+"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h, include/lsprnn.h, include/lspraster.h, include/lspmel.h).
 
 There is deliberately no fallback: if the shared library is missing or does not
 load, importing the hot path raises -- a GPU box must never silently run
@@ -163,6 +163,16 @@ RASTER_SIGNATURES = {
 }
 RASTER_POINT_DTYPES = {"int32": 0, "float32": 1, "float64": 2}
 
+# every symbol include/lspmel.h declares
+MEL_SIGNATURES = {
+    "lspmel_last_error": (c_char_p, []),
+    "lspmel_num_windows": (c_int, [c_int64]),
+    "lspmel_basis_floats": (c_size_t, []),
+    "lspmel_make_basis": (c_int, [c_void_p, c_size_t]),
+    "lspmel_workspace_bytes": (c_size_t, [c_int]),
+    "lspmel_compute": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
 _lib = None
 
 
@@ -180,7 +190,7 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e)) from e
-    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()) + list(RNN_SIGNATURES.items()) + list(RASTER_SIGNATURES.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()) + list(RNN_SIGNATURES.items()) + list(RASTER_SIGNATURES.items()) + list(MEL_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
@@ -249,3 +259,15 @@ def check_raster(rc: int) -> None:
     if rc != OK:
         msg = load().lspraster_last_error()
         raise LsprasterError(rc, msg.decode() if msg else "")
+
+
+class LspmelError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lspmel error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check_mel(rc: int) -> None:
+    if rc != OK:
+        msg = load().lspmel_last_error()
+        raise LspmelError(rc, msg.decode() if msg else "")
