@@ -53,8 +53,8 @@ def test_host_side_basis_matches_the_oracle():
     want = mel_oracle.slaney_mel_filterbank()
     assert (fb[:, 257:] == 0).all()
     assert np.abs(fb[:, :257] - want).max() <= 1e-9 and (fb[:, :257] > 0).sum() == (want > 0).sum()
-    # every filter is a single triangle with unit-ish area: sum(w) * (bin spacing) == 1 for interior filters (Slaney normalisation)
-    assert np.allclose(want.sum(1)[2:-2] * (8000 / 256), 1.0, atol=0.1)
+    # Slaney normalisation: every triangle has unit area, i.e. sum(w) * bin spacing ~ 1 (sampled on a 31.25 Hz grid, so only roughly)
+    assert (np.abs(want.sum(1) * (8000 / 256) - 1.0) < 0.15).all() and (want >= 0).all()
     dft = blob[:514 * 268].reshape(514, 268).astype(np.float64)
     rng = np.random.default_rng(0)
     clip = rng.uniform(-1, 1, 266).astype(np.float32)
