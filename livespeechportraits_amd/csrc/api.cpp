@@ -195,6 +195,8 @@ static const char *kernel_name(const LayerDesc &l)
     case kFirstConv: return "first_conv";
     case kLastConv: return l.wgemm_off >= 0 ? "last_conv (igemm3x3 + pixel_shuffle_tanh)" : "last_conv";
     default:
+        if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
+        if (l.fullk) return "conv3x3_fullk";
         if (l.inorm) return l.smallm ? "conv3x3_smallm+in_small" : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
                           : l.in_route == kInSmall ? "igemm3x3+in_small" : "igemm3x3+in_reduce_stats+in_finalize+in_apply";
         return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3+splitk_reduce" : "igemm3x3");
@@ -303,6 +305,19 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.stride = l.stride; p.up = l.up; p.relu = l.inorm ? 0 : l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
         e = launch_smallm(p, s);
         if (e == hipSuccess && l.inorm) {          // raw conv output (+ bias) -> statistics + normalisation (+ residual, ReLU) in one launch
+            InstNormParams q{};
+            q.x = tptr(l.out); q.partial = nullptr; q.splits = 1; q.bias = nullptr; q.residual = tptr(l.res); q.relu = l.relu;
+            q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
+            e = launch_in_small(q, s);
+        }
+    } else if (l.fullk) {
+        FullKParams p{};
+        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout;
+        p.up = l.up; p.relu = l.inorm ? 0 : l.relu;
+        e = launch_fullk(p, l.fullk, s);
+        if (e == hipSuccess && l.inorm) {          // InstanceNorm plans: H*W <= 256 here, the one-launch statistics route
             InstNormParams q{};
             q.x = tptr(l.out); q.partial = nullptr; q.splits = 1; q.bias = nullptr; q.residual = tptr(l.res); q.relu = l.relu;
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
@@ -540,6 +555,27 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             return LSPF2F_OK;
         }
         if (tile_m == 1 && tile_n == 1) return fail(LSPF2F_ERR_UNSUPPORTED, "tiny-M kernel does not support this shape");
+    }
+    {
+        // tile (16 | 32) x 16 forces the full-K single-launch kernel; tile 0x0 + split 0 lets the planner's rule pick it
+        const int ho_ = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
+        int pb = 0;
+        if ((tile_m == 16 || tile_m == 32) && tile_n == 16) pb = tile_m / 16;
+        else if (tile_m == 0 && tile_n == 0 && split_k == 0)
+            pb = fullk_choice(batch, hs, ho_, c0, c1, cout, stride, upsample == 1, upsample == 2, dtype);
+        if (pb) {
+            FullKParams q{};
+            q.src0 = static_cast<const float *>(src0); q.src1 = c1 ? static_cast<const float *>(src1) : nullptr;
+            q.w = static_cast<const float *>(w_packed); q.scale = scale; q.shift = shift;
+            q.residual = static_cast<const float *>(residual); q.out = static_cast<float *>(out);
+            q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = ho_; q.Wo = ho_; q.C0 = c0; q.C1 = c1; q.Cout = cout;
+            q.up = upsample == 1; q.relu = relu;
+            if (dtype != 0 || stride != 1 || upsample == 2 || !fullk_supported(q, pb))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "full-K kernel does not support this shape");
+            e = launch_fullk(q, pb, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (full-K) launch");
+            return LSPF2F_OK;
+        }
     }
     IgemmParams p{};
     p.src0 = src0; p.src1 = c1 ? src1 : nullptr; p.w = w_packed; p.scale = scale; p.shift = shift;

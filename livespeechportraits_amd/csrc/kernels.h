@@ -96,6 +96,21 @@ struct SmallMParams {
 bool smallm_supported(const SmallMParams &p);
 hipError_t launch_smallm(const SmallMParams &p, hipStream_t s);
 
+// Full-K single-launch conv for the 16x16 / 8x8 levels at small batch (fullk.hip): fp32, stride 1, optional 9-tap nearest x2
+// upsample and concat; a workgroup owns 16*pb pixels x 16 channels over the whole K, no split-K, no reduce launch.
+struct FullKParams {
+    const float *src0, *src1;    // NHWC [B][Hs][Ws][C0|C1]; src1 == nullptr when C1 == 0
+    const float *w;              // [Cout][9][C0 + C1]
+    const float *scale, *shift;  // [Cout] or nullptr
+    const float *residual;       // [B][Ho][Wo][Cout] or nullptr
+    float *out;                  // [B][Ho][Wo][Cout]
+    int B, Hs, Ws, Ho, Wo, C0, C1, Cout;
+    int up, relu;
+    int ntm, ntn, tiles_per_img; // filled by launch_fullk
+};
+bool fullk_supported(const FullKParams &p, int pb);
+hipError_t launch_fullk(const FullKParams &p, int pb, hipStream_t s);
+
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
 struct FirstConvParams {
     const float *feat;   // [B][feat_nc][H][W]

@@ -320,13 +320,15 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, p.dtype, &bm, &bn, &splits, &group);
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
+            const int fullk = smallm ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
+            if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
             int route = kInNone;
             if (l.inorm) {
                 // rows of one wave (32 per 32x32 tile row, bm / 2 waves... = bm / 2 for the 2x2-wave tiles) must stay inside one
                 // frame for the epilogue sums; tiny levels do statistics + normalisation in one workgroup per channel slab
                 const int hw = l.ho * l.ho, rhw = l.up4 ? l.hs * l.hs : hw;
                 const int wave_rows = bm == 32 ? 32 : bm / 2;
-                if (!smallm && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
+                if (!smallm && !fullk && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
                     route = kInFused;
                     groups_max = std::max(groups_max, (l.up4 ? 4 : 1) * rhw / wave_rows);
                 } else if (hw <= 1024) {
@@ -339,7 +341,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             }
             if (tiled) {
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
-                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route;
+                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk;
             }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }

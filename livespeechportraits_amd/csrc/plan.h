@@ -46,6 +46,7 @@ struct LayerDesc {
     // per-batch tiling decision
     int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
     bool smallm = false;   // executed by the single-launch tiny-M kernel (M <= 16) instead of the igemm
+    int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
 };
 
 struct ParamDesc {         // an expected state-dict entry
@@ -103,6 +104,22 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
 inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes)
 {
     return M <= 16 && c1 == 0 && cin % 256 == 0 && 9 * (cin / 4) <= 5 * 256 && in_bytes <= 64 * 1024 && cout % 2 == 0;
+}
+// full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0
+inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype)
+{
+    if (dtype != 0 || stride != 1 || up4) return 0;
+    if (ho != 2 && ho != 4 && ho != 8 && ho != 16) return 0;
+    if (up ? 2 * hs != ho : hs != ho) return 0;
+    if ((c0 != 128 && c0 != 256 && c0 != 512) || (c1 != 0 && c1 != c0) || cout % 128) return 0;
+    // whole tiles must fit one dispatch wave of the chip with room to spare: <= 512 workgroups (2 per CU on 256 CUs)
+    const int ntn = cout / 16;
+    for (int pb = 1; pb <= (ho == 16 ? 2 : 1); ++pb) {
+        const int nr = pb * (16 / ho);
+        const long tiles = (long)batch * ((ho + nr - 1) / nr) * ntn;
+        if (tiles <= 256 || (pb == (ho == 16 ? 2 : 1) && tiles <= 512)) return pb;
+    }
+    return 0;
 }
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 

@@ -130,6 +130,41 @@ def test_conv3x3_k_groups(cfg, gpu_device):
     assert (got - ref).abs().max().item() <= 2e-5
 
 
+FULLK_CASES = [
+    # b, c0, c1, cout, hs, up, bn, res, relu, tile       (tile 16x16 / 32x16 = the full-K single-launch kernel)
+    (1, 512, 0, 512, 16, False, True, True, True, (32, 16)),      # L4 / L5 res conv b at batch 1: 256 tiles of 32 px x 16 ch
+    (1, 512, 0, 512, 16, False, True, False, True, (16, 16)),     # the same layer in 16-pixel tiles
+    (1, 512, 0, 512, 8, False, True, True, True, (16, 16)),       # 8x8 res conv: a 16-pixel block is two rows
+    (1, 512, 512, 512, 8, True, True, False, True, (32, 16)),     # L5.up: nearest x2 (8 -> 16) + concat, two staged sources
+    (1, 512, 512, 512, 4, True, True, False, True, (16, 16)),     # L6.up: 4 -> 8
+    (2, 256, 0, 128, 4, False, True, True, False, (16, 16)),      # 4x4: one block per frame, G = 4, no ReLU
+    (3, 128, 0, 256, 2, False, False, False, True, (16, 16)),     # 2x2: 4 of a block's 16 pixels are real; G = 2; no BN
+    (2, 256, 256, 128, 2, True, True, False, True, (16, 16)),     # 2 -> 4 with concat
+    (5, 128, 0, 128, 16, False, True, True, True, (32, 16)),      # batch 5: tiles index (frame, row pair)
+    (1, 512, 0, 512, 16, False, True, True, True, (0, 0)),        # planner's own choice for the batch-1 16x16 layer
+]
+
+
+@pytest.mark.parametrize("cfg", FULLK_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d%s_t%dx%d" % (
+    c[0], c[1], c[2], c[3], c[4], "up" if c[5] else "", c[9][0], c[9][1]))
+def test_conv3x3_full_k_kernel(cfg, gpu_device):
+    b, c0, c1, cout, hs, up, bn, res, relu, tile = cfg
+    x0 = rnd(b, c0, hs, hs, seed=31)
+    x1 = rnd(b, c1, hs, hs, seed=32) if c1 else None
+    w = rnd(cout, c0 + c1, 3, 3, seed=33) * 0.05
+    scale = rnd(cout, seed=34) * 0.5 + 1.0 if bn else None
+    shift = rnd(cout, seed=35) * 0.1 if bn else None
+    ho = 2 * hs if up else hs
+    r = rnd(b, cout, ho, ho, seed=36) if res else None
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, up, relu, tile)
+    ref = ref_conv(x0, x1, w, scale, shift, r, 1, up, relu)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 3e-5, err                       # K up to 9216 fp32 products of O(0.05) weights
+    again = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, up, relu, tile)
+    assert torch.equal(again, got)                # fixed summation order
+
+
 TINY_CASES = [
     # b, cin, cout, hs, stride, up, bn, res, relu     (tile 1x1 = the single-launch tiny-M kernel)
     (1, 512, 512, 4, 1, False, True, True, True),     # L6 res conv b
