@@ -199,7 +199,9 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
  *   per pipeline step: 1, 2 or 4); scratch is needed when split_k != 1
  *   (size from lspf2f_conv3x3_scratch_bytes).  Special tiles: 1 x 1 = the tiny-M kernel (<= 16 output pixels);
  *   16 x 16 / 32 x 16 = the full-K single-launch kernel of the 16x16 / 8x8 levels (fp32, stride 1, extents 2..16,
- *   c0 in {128, 256, 512}, c1 in {0, c0}, cout % 128 == 0; no scratch). */
+ *   c0 in {128, 256, 512}, c1 in {0, c0}, cout % 128 == 0; no scratch).  With k_group == -1 the full-K kernel takes w_packed in
+ *   its own tile-blocked layout, [cout/16][source][tap][4 waves][g][64 lanes][4] with lane (li, kq) of block (nt, T, w, g) holding
+ *   channels 4 * (kq * 4G + w * G + g) .. + 3 (G = c0 / 64) of output row 16 nt + li -- the copy the packer adds for those layers. */
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride,
                                     int upsample, int tile_m, int tile_n, int split_k, int k_group, int dtype);
 int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, const float *scale,

@@ -312,7 +312,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         }
     } else if (l.fullk) {
         FullKParams p{};
-        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wfk_off); p.wtile = 1; p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout;
         p.up = l.up; p.relu = l.inorm ? 0 : l.relu;
@@ -570,6 +570,10 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             q.residual = static_cast<const float *>(residual); q.out = static_cast<float *>(out);
             q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = ho_; q.Wo = ho_; q.C0 = c0; q.C1 = c1; q.Cout = cout;
             q.up = upsample == 1; q.relu = relu;
+            q.wtile = k_group == -1 ? 1 : 0;       // -1: w_packed is already in the full-K kernel's tile-blocked layout
+#ifdef LSPF2F_FULLK_STAMPS
+            q.stamps = scratch_bytes >= (size_t)512 * 4 * 16 * 8 ? static_cast<unsigned long long *>(scratch) : nullptr;
+#endif
             if (dtype != 0 || stride != 1 || upsample == 2 || !fullk_supported(q, pb))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "full-K kernel does not support this shape");
             e = launch_fullk(q, pb, static_cast<hipStream_t>(hip_stream));

@@ -36,43 +36,6 @@ static constexpr int LDK = 32;   // LDS row pitch in floats (128 B, unpadded: th
 // flight per thread).  G = 1 for long K loops; G = 4 turns a short split-K range (<= 4 tiles)
 // into a single load -> LDS -> MFMA pass, which is what the latency-bound <= 8x8 levels need.
 // UP = the 9-tap nearest-x2 gather form (only the small, weight-streaming up-convs use it).
-// buffer resource descriptor (raw buffer, stride 0) from wave-uniform values
-__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes)
-{
-    const unsigned long long a = (unsigned long long)base;
-    i32x4 r;
-    r.x = (int)(unsigned)a;
-    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
-    r.z = (int)bytes;
-    r.w = 0x00020000;
-    return r;
-}
-
-// One LDS-DMA piece: 64 lanes x 16 B -> LDS[lds_addr + lane*16]; out-of-range voffset lands as zeros.
-// Issued from inline asm on purpose: a compiler-visible LDS-DMA makes hipcc wait vmcnt(0) before the
-// next ds_read (it cannot disambiguate LDS addresses), which serialises the copy with the MFMAs.  The
-// kernel waits for its DMAs itself (dma_wait) right before the barrier that publishes the buffer.
-// M0 is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 srd, int soff)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %1\n\t"
-                 "s_nop 4\n\t"
-                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
-                 : "memory");
-}
-// wait until at most N of this wave's DMA pieces are still in flight (they complete in order)
-template <int N>
-__device__ __forceinline__ void dma_wait()
-{
-    __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs issued so far ABOVE the wait (they cover the copy)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // T = storage type of activations and weights: float (exact fp32 MFMA, v_mfma_f32_32x32x2_f32) or bf16_t
 // (v_mfma_f32_32x32x16_bf16, fp32 accumulate and epilogue).  A K-tile is always 128 B of channels (32 fp32 /
 // 64 bf16), so the LDS geometry, the DMA pieces and the swizzle are identical for both.

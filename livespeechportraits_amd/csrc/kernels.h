@@ -106,10 +106,13 @@ struct FullKParams {
     float *out;                  // [B][Ho][Wo][Cout]
     int B, Hs, Ws, Ho, Wo, C0, C1, Cout;
     int up, relu;
-    int ntm, ntn, tiles_per_img; // filled by launch_fullk
+    int ntm, ntn, tiles_per_img, wo_log2; // filled by launch_fullk
+    int wtile;                   // weights in the tile-blocked layout of pack_fullk_weights() (the shipped path) instead of [Cout][9][Cin]
+    unsigned long long *stamps;  // -DLSPF2F_FULLK_STAMPS builds: [blocks][4 waves][16] cycle counters
 };
 bool fullk_supported(const FullKParams &p, int pb);
 hipError_t launch_fullk(const FullKParams &p, int pb, hipStream_t s);
+void pack_fullk_weights(const float *rows, int c0, int nch, int cout, float *out);   // host: [Cout][9][nch * c0] -> tile-blocked
 
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
 struct FirstConvParams {

@@ -1,4 +1,5 @@
 #include "plan.h"
+#include "kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -228,6 +229,13 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
         }
+        if (l.kind == kIgemm && fullk_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype)) {
+            // HBM is plentiful (288 GB): the 16x16 / 8x8 layers keep a second, tile-blocked copy for the full-K kernel of the
+            // small-batch plans next to the row layout the implicit-GEMM kernel of the large-batch plans reads
+            off = align_up(off, 256);
+            l.wfk_off = (int64_t)off;
+            off += (size_t)l.cout * 9 * l.cin * sizeof(float);
+        }
         if (!l.bnkey.empty() || !l.biaskey.empty()) {   // a conv bias travels as (scale 1, shift bias)
             off = align_up(off, 256);
             l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
@@ -320,7 +328,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, p.dtype, &bm, &bn, &splits, &group);
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
-            const int fullk = smallm ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
+            const int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
             if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
             int route = kInNone;
             if (l.inorm) {
@@ -436,6 +444,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < 9; ++t)
                         dst[((size_t)co * 9 + t) * cin + ci] = W[((size_t)co * cin + ci) * 9 + t];
+            if (l.wfk_off >= 0) pack_fullk_weights(dst, l.c0, l.c1 ? 2 : 1, cout, reinterpret_cast<float *>(base + l.wfk_off));
         } else if (l.kind == kFirstConv) {
             // [ci][tap][co]  -- broadcast rows for the direct first-layer kernel
             for (int co = 0; co < cout; ++co)

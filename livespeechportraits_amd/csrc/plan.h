@@ -42,6 +42,7 @@ struct LayerDesc {
     bool inorm = false;    // an InstanceNorm2d (affine=False, eps 1e-5) follows the conv: per-(frame, channel) statistics at run time
     int in_route = 0;      // per-batch: how those statistics are gathered (kInFused / kInReduce / kInSmall)
     int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
+    int64_t wfk_off = -1;    // fp32 plans, 16x16 / 8x8 stride-1 layers: a second copy of the weights in the tile-blocked layout of the full-K kernel
     int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
     int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
@@ -106,10 +107,17 @@ inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes)
     return M <= 16 && c1 == 0 && cin % 256 == 0 && 9 * (cin / 4) <= 5 * 256 && in_bytes <= 64 * 1024 && cout % 2 == 0;
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0
+// which layers get the tile-blocked weight copy at pack time (independent of the batch: the blob layout must not depend on it)
+inline bool fullk_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype)
+{
+    if (dtype != 0 || stride != 1 || up4) return false;
+    if (ho != 8 && ho != 16) return false;                    // 4x4 / 2x2 belong to the tiny-M kernel at batch 1
+    if (up ? 2 * hs != ho : hs != ho) return false;
+    return (c0 == 128 || c0 == 256 || c0 == 512) && (c1 == 0 || c1 == c0) && cout % 128 == 0;
+}
 inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype)
 {
-    if (dtype != 0 || stride != 1 || up4) return 0;
-    if (ho != 2 && ho != 4 && ho != 8 && ho != 16) return 0;
+    if (!fullk_layer(hs, ho, c0, c1, cout, stride, up, up4, dtype)) return 0;
     if (up ? 2 * hs != ho : hs != ho) return 0;
     if ((c0 != 128 && c0 != 256 && c0 != 512) || (c1 != 0 && c1 != c0) || cout % 128) return 0;
     // whole tiles must fit one dispatch wave of the chip with room to spare: <= 512 workgroups (2 per CU on 256 CUs)

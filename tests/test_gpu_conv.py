@@ -25,7 +25,9 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev).to(tdt)
     d0 = nhwc(x0)
     d1 = nhwc(x1) if x1 is not None else None
-    if up == 2:
+    if k_group == -1:
+        wp = pack_fullk(w, c0, 2 if c1 else 1).to(dev)       # the full-K kernel's tile-blocked layout
+    elif up == 2:
         wp = pack_subpixel(w).to(dev).to(tdt)                # [parity][co][a][b][ci]
     else:
         wp = w.permute(0, 2, 3, 1).contiguous().to(dev).to(tdt)   # [co][ky][kx][ci]
@@ -43,6 +45,21 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     N.check(rc)
     torch.cuda.synchronize()
     return out.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def pack_fullk(w, c0, nch):
+    """Independent (torch indexing) statement of the tile-blocked weight layout of conv3x3_fullk:
+    [cout/16][source * 9 + tap][wave 4][g][lane 64][4], lane = li + 16 kq holds channels 4 (kq 4G + wave G + g) .. + 3 of source
+    `source`, tap `tap`, output row 16 nt + li.  w: OIHW."""
+    cout = w.shape[0]
+    G = c0 // 64
+    rows = w.permute(0, 2, 3, 1).reshape(cout, 9, nch, c0)                                  # [n][tap][source][c]
+    nt, T, wv, g, lane = torch.meshgrid(torch.arange(cout // 16), torch.arange(nch * 9), torch.arange(4), torch.arange(G),
+                                        torch.arange(64), indexing="ij")
+    li, kq = lane % 16, lane // 16
+    c = 4 * (kq * 4 * G + wv * G + g)
+    n, src, tap = nt * 16 + li, T // 9, T % 9
+    return torch.stack([rows[n, tap, src, c + e] for e in range(4)], -1).contiguous().float()
 
 
 def pack_subpixel(w):
@@ -163,6 +180,10 @@ def test_conv3x3_full_k_kernel(cfg, gpu_device):
     assert err <= 3e-5, err                       # K up to 9216 fp32 products of O(0.05) weights
     again = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, up, relu, tile)
     assert torch.equal(again, got)                # fixed summation order
+    if tile != (0, 0):
+        # the shipped form: weights in the tile-blocked layout (k_group = -1); same K order, so bit-identical to the row-layout form
+        tiled = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, up, relu, tile, k_group=-1)
+        assert torch.equal(tiled, got)
 
 
 TINY_CASES = [

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Time ONE conv shape through lspf2f_conv3x3 with a forced tile (GPU): median of hipEvent pairs, eager launches.
+  python tools/time_conv.py c0 c1 cout hs up tile_m tile_n [batch]"""
+import ctypes, sys
+import torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from livespeechportraits_amd import _native as N
+
+def main():
+    c0, c1, cout, hs, up, tm, tn = [int(x) for x in sys.argv[1:8]]
+    b = int(sys.argv[8]) if len(sys.argv) > 8 else 1
+    kg = int(sys.argv[9]) if len(sys.argv) > 9 else 0        # -1: full-K tile-blocked weight layout (timing only: same bytes)
+    lib = N.load(); dev = torch.device("cuda:0")
+    ho = 2 * hs if up else hs
+    d0 = torch.randn(b, hs, hs, c0, device=dev); d1 = torch.randn(b, hs, hs, c1, device=dev) if c1 else None
+    w = torch.randn(cout, 3, 3, c0 + c1, device=dev) * 0.02
+    sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    out = torch.empty(b, ho, ho, cout, device=dev)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, up, tm, tn, 0, 0, 0)
+    scratch = torch.zeros(max(sb, 512 * 4 * 16 * 8), dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def run():
+        N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(w), p(sc), p(sh), None, p(out), b, hs, hs, c0, c1, cout, 1, up, 1, tm, tn, 0, kg, 0, p(scratch), scratch.numel(), st))
+    for _ in range(5): run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(30):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 100)
+    ts.sort()
+    st64 = scratch[:512 * 4 * 16 * 8].view(torch.int64).view(512, 4, 16).cpu().numpy()
+    if st64.any():
+        import numpy as np
+        nb = (st64[:, 0, 0] != 0).sum()
+        d = (st64[:nb] - st64[:nb, :, :1]).astype(np.float64)
+        names = ["start", "dma issued", "6 taps issued", "dma landed", "barrier", "tap0", "tap1", "tap2", "tap3", "tap4", "tap5", "tap6", "tap7", "tap8", "k done", "end"]
+        print("stamps (shader cycles since kernel entry of the wave; median / p90 over %d blocks x 4 waves):" % nb)
+        for i, n_ in enumerate(names):
+            print("   %-14s %8.0f %8.0f" % (n_, np.median(d[:, :, i]), np.percentile(d[:, :, i], 90)))
+        t0 = st64[:nb, :, 0].min(); print("   first wave start -> last wave end: %d cycles; spread of starts %d" % (st64[:nb, :, 15].max() - t0, st64[:nb, :, 0].max() - t0))
+    gf = 2 * cout * (c0 + c1) * 9 * ho * ho * b / 1e9
+    print("c%d+%d o%d h%d%s b%d tile %dx%d: %.1f us per launch (10 back-to-back), %.1f TFLOP/s" % (c0, c1, cout, hs, "up" if up else "", b, tm, tn, ts[len(ts)//2], gf / ts[len(ts)//2] * 1e3 / 1e3))
+
+main()
