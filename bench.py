@@ -124,49 +124,79 @@ def main():
     fps = world * B * a.steps / elapsed
     flops_step = topo.flops_per_frame() * B
 
-    # per-layer timing (hipEvent pair around every launch, on the launch stream)
+    # ---- roofline: live, per kernel class.  ROCm 7.2 cannot time events recorded by graph nodes, so a kernel cannot be bracketed inside
+    # the replay of the whole forward; instead the launches of ONE class (in network order, reading what the last forward left in the
+    # workspace) are captured into their own graph and replayed between two hipEvents on the launch stream (lspf2f_subset_timed):
+    # no host gaps, kernel boundaries included, the same launches the timed region replays.  The classes partition the forward, their
+    # times add up to <= the timed step, and each class's average launch duration is what the committed rocprofv3 summary
+    # (profiles/r02_kernel_stats_*.txt) shows for that kernel name.
     layers = eng.layers(B)
-    reps = 5
-    acc = np.zeros(len(layers))
-    for _ in range(reps):
-        _, ms = eng.forward_timed(feat, cand, out)
-        acc += np.array(ms)
-    acc /= reps
-    ig = [i for i, l in enumerate(layers) if l["kernel"].startswith("igemm") or l["kernel"] == "conv3x3_smallm"]
-    ig_ms = float(acc[ig].sum())
-    ig_flops = sum(layers[i]["flops_per_frame"] for i in ig) * B          # algorithmic
-    ig_exec = sum(layers[i]["exec_flops_per_frame"] for i in ig) * B       # issued to the MFMA pipe
-    achieved = ig_flops / (ig_ms * 1e-3) / 1e12
-    executed = ig_exec / (ig_ms * 1e-3) / 1e12
+    eng.forward(feat, cand, out)
+
+    def cls_of(l):
+        k = l["kernel"]
+        if k.startswith("igemm3x3"):
+            return "igemm3x3<%dx%d,g%d>" % (l["tile_m"], l["tile_n"], l["k_group"])
+        return k.split(" ")[0]
+    classes = {}
+    for i, l in enumerate(layers):
+        classes.setdefault(cls_of(l), []).append(i)
+    table = []
+    elt = 4 if a.dtype == "f32" else 2
+
+    def add_row(name, idxs, part, flops, exec_flops, nbytes, launches):
+        sel = [0] * len(layers)
+        for i in idxs:
+            sel[i] = part
+        ms = eng.subset_timed(feat, cand, sel, out, reps=10)
+        table.append({"kernel": name, "launches": launches, "flops": int(flops), "exec_flops": int(exec_flops), "bytes": int(nbytes),
+                      "ms": round(ms, 5), "us_per_launch": round(1e3 * ms / launches, 2),
+                      "tflops": round(flops / (ms * 1e-3) / 1e12, 2), "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                      "frac_mfma": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "frac_hbm": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+    for name, idxs in classes.items():
+        fl = sum(layers[i]["flops_per_frame"] for i in idxs) * B
+        ex = sum(layers[i]["exec_flops_per_frame"] for i in idxs) * B
+        by = sum(layers[i]["act_bytes_per_frame"] for i in idxs) * B + sum(layers[i]["weight_bytes"] for i in idxs)
+        add_row(name, idxs, 1 if name.startswith("igemm3x3") else 3, fl, ex, by, len(idxs))
+    split = [i for i, l in enumerate(layers) if l["split_k"] > 1 and l["kernel"].startswith("igemm3x3")]
+    if split:
+        # the reduce launches: no arithmetic; bytes = the fp32 partial slabs they read + the tensor they write
+        by = sum((layers[i]["split_k"] * 4 + elt) * layers[i]["cout"] * layers[i]["h_out"] ** 2 for i in split) * B
+        add_row("splitk_reduce*", split, 2, 0, 0, by, len(split))
+    table.sort(key=lambda r: -r["ms"])
+    dom = table[0]
+    class_ms = sum(r["ms"] for r in table)
     if a.layers:
         with open(a.layers, "w") as f:
-            f.write("# per-layer hipEvent timing, %s batch %d, mean of %d passes\n" % (a.variant, B, reps))
-            f.write("%-16s %-28s %5s %5s %4s %4s %9s %3s %9s %8s %8s\n" % (
-                "layer", "kernel", "cin", "cout", "hin", "hout", "tile", "spl", "GFLOP", "us", "TFLOP/s"))
-            for l, m in zip(layers, acc):
-                gf = l["flops_per_frame"] * B / 1e9
-                f.write("%-16s %-28s %5d %5d %4d %4d %4dx%-4d %3d %9.3f %8.1f %8.2f\n" % (
-                    l["name"], l["kernel"], l["cin"], l["cout"], l["h_in"], l["h_out"], l["tile_m"], l["tile_n"],
-                    l["split_k"], gf, m * 1e3, gf / m if m > 0 else 0))
-            f.write("# sum %.3f ms; igemm family %.3f ms = %.2f TFLOP/s\n" % (acc.sum(), ig_ms, achieved))
+            f.write("# per kernel class, %s batch %d %s: launches of one class replayed from their own graph between two hipEvents (bench.py)\n" % (a.variant, B, a.dtype))
+            f.write("%-28s %8s %10s %10s %9s %9s %9s %8s %9s %9s\n" % ("kernel class", "launches", "GFLOP", "MB", "ms", "us/launch", "TFLOP/s", "GB/s", "frac_mfma", "frac_hbm"))
+            for r in table:
+                f.write("%-28s %8d %10.3f %10.2f %9.4f %9.2f %9.2f %8.1f %9.4f %9.4f\n" % (
+                    r["kernel"], r["launches"], r["flops"] / 1e9, r["bytes"] / 1e6, r["ms"], r["us_per_launch"], r["tflops"], r["gbs"], r["frac_mfma"], r["frac_hbm"]))
+            f.write("# sum of classes %.4f ms; timed step (graph replay of the whole forward) %.4f ms\n" % (class_ms, ms_per_step))
 
-    # HBM traffic of the same launch set from the committed PMC passes (offline: rocprofv3 --pmc cannot
-    # run inside this process); only quoted for the workload it was measured on
+    # HBM traffic of the dominant kernel from the committed PMC passes (offline: rocprofv3 --pmc cannot run inside this process);
+    # only quoted for the workload it was measured on
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_large_b1.json")
-    if a.variant == "large" and B == 1 and a.size == 512 and a.dtype == "f32" and os.path.exists(pmc_path):
-        pj = json.load(open(pmc_path))["per_forward_bytes"]["conv_family"]
-        traffic = int(pj["fetch_x2"] + pj["write"])
-        traffic_src = "profiles/r01_pmc_large_b1.json (FETCH_SIZE x2 + WRITE_SIZE per forward, rocprofv3 --pmc)"
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_%s_b%d_%s.json" % (a.variant, B, a.dtype))
+    if a.size == 512 and os.path.exists(pmc_path):
+        pj = json.load(open(pmc_path))
+        fam = pj["per_forward_bytes"].get("igemm3x3")
+        if fam:
+            traffic = int(fam["fetch_x2"] + fam["write"])
+            traffic_src = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE of the igemm3x3 launches of one forward, rocprofv3 --pmc, separate passes)" % os.path.basename(pmc_path)
 
     roofline = {
-        "bound": "mfma", "kernel": "igemm3x3 family incl. split-K reduce and tiny-M conv (all %d conv layers of one frame batch except first/last)" % len(ig),
-        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-        "algorithmic_bytes": int(sum(layers[i]["act_bytes_per_frame"] for i in ig) * B + sum(layers[i]["weight_bytes"] for i in ig)),
-        "flops_per_launch_set": ig_flops, "ms_per_launch_set": round(ig_ms, 4),
-        "executed": {"tflops": round(executed, 2), "frac": round(executed / peak, 4),
+        "bound": "mfma",
+        "kernel": "%s: the %d launches per forward of the dominant kernel (all conv layers it executes; split-K reduce launches are their own row)" % (dom["kernel"], dom["launches"]),
+        "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac_mfma"],
+        "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": dom["bytes"],
+        "flops_per_launch_set": dom["flops"], "ms_per_launch_set": dom["ms"], "us_per_launch": dom["us_per_launch"],
+        "executed": {"tflops": round(dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12, 2), "frac": round(dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12 / peak, 4),
                      "note": "MFMA FLOPs actually issued: the sub-pixel up-convs need 4/9 of the algorithmic count"},
+        "method": "launches of one kernel class replayed from their own hipGraph between two hipEvents on the launch stream (lspf2f_subset_timed); "
+                  "agrees with the rocprofv3 --kernel-trace --stats averages committed under profiles/",
+        "per_class": table, "sum_of_classes_ms": round(class_ms, 4),
         "whole_forward": {"achieved": round(flops_step / (ev_ms * 1e-3) / 1e12, 2),
                           "frac": round(flops_step / (ev_ms * 1e-3) / 1e12 / peak, 4),
                           "ms_device": round(ev_ms, 4)},

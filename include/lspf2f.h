@@ -184,6 +184,15 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *out)
 int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *cand_dev,
                          int cand_batch, float *out_dev, int batch, void *hip_stream,
                          float *ms_per_layer);
+/* Duration of a SUBSET of the forward's launches without host gaps (profiling aid): the selected layers are captured in network
+ * order into one graph, replayed `reps` times between two events on hip_stream; *ms_per_replay = elapsed / reps.  part[num_layers]:
+ * 0 skip, 1 the layer's main kernel(s) only (a split-K layer without its reduce launch), 2 only its split-K reduce launch, 3 all of
+ * it.  Run a forward first (the layers read what it left in the workspace).  This is how bench.py times one kernel class inside
+ * otherwise unchanged launches: ROCm 7.2 cannot time events recorded by graph nodes, so a kernel cannot be bracketed inside the
+ * replay of the whole forward.  Synchronises the stream. */
+int lspf2f_subset_timed(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch, float *out_dev,
+                        int batch, void *hip_stream, const int *part, int reps, float *ms_per_replay,
+                        int *launches_per_replay);
 
 /* Single fused 3x3 convolution, the unit the generator is made of, exposed for per-kernel
  * parity tests against torch.nn.functional.conv2d (+ batch_norm eval + relu).

@@ -77,6 +77,8 @@ SIGNATURES = {
     "lspf2f_layer_info_get": (c_int, [c_void_p, c_int, POINTER(LayerInfo)]),
     "lspf2f_forward_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                      POINTER(c_float)]),
+    "lspf2f_subset_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, POINTER(c_int), c_int,
+                                    POINTER(c_float), POINTER(c_int)]),
     "lspf2f_conv3x3_scratch_bytes": (c_size_t, [c_int] * 13),
     "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p, c_size_t, c_void_p]),
     "lspf2f_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),

@@ -48,6 +48,7 @@ struct lspf2f_handle {
     bool packed = false;
     bool use_graph = true;
     bool last_direct = false;     // bf16 plans: direct last-conv kernel instead of the GEMM form (LSP_HIP_LASTCONV_DIRECT, read at create)
+    int timing_part = 3;          // lspf2f_subset_timed: 1 = main kernels only, 2 = split-K reduce only, 3 = everything (always 3 on the hot path)
     int last_route = 0;           // forced direct last-conv kernel (LSP_HIP_LASTCONV_{STRIP,ROWS,GENERIC}, read at create; tests only)
     const void *cand_cached = nullptr;   // candidate stack whose first-conv contribution sits in the workspace cache
     hipStream_t cap_stream = nullptr;
@@ -372,8 +373,8 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
                 }
             }
         } else {
-            e = launch_igemm(p, l.bm, l.bn, l.group, s);
-            if (e == hipSuccess && l.splits > 1) e = launch_splitk_reduce(p, s);
+            if (h->timing_part & 1) e = launch_igemm(p, l.bm, l.bn, l.group, s);
+            if (e == hipSuccess && l.splits > 1 && (h->timing_part & 2)) e = launch_splitk_reduce(p, s);
         }
     }
     if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
@@ -479,6 +480,62 @@ int lspf2f_set_candidates(lspf2f_handle *h, const float *cand_dev, void *hip_str
     if (e != hipSuccess) return hipfail(e, "lspf2f_set_candidates launch");
     h->cand_cached = cand_dev;
     return LSPF2F_OK;
+}
+
+// Duration of a SUBSET of the forward's launches without host gaps: the selected layers are captured, in network order, into one graph
+// that is replayed `reps` times between two ordinary events on `hip_stream` (events recorded by graph nodes cannot be timed on ROCm 7.2,
+// so a kernel cannot be bracketed inside the replay of the whole forward).  part[i]: 0 = skip layer i, 1 = its main kernel(s) only (a
+// split-K layer without its reduce launch), 2 = only its split-K reduce launch, 3 = everything the layer launches.  The layers read
+// what the last forward left in the workspace (run one first); results are not meaningful, durations are.
+int lspf2f_subset_timed(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch, float *out_dev, int batch,
+                        void *hip_stream, const int *part, int reps, float *ms_per_replay, int *launches_per_replay)
+{
+    if (!part || !ms_per_replay || reps < 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null part / ms_per_replay, or reps < 1");
+    int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev, batch);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int n = (int)h->plan.layers.size();
+    if (!h->cap_stream) {
+        const hipError_t e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithFlags");
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int launches = 0;
+    hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < n && !rc && e == hipSuccess; ++i) {
+        if (!part[i]) continue;
+        h->timing_part = part[i];
+        rc = run_layer(h, h->plan.layers[i], feat_dev, cand_dev, cand_batch, out_dev, nullptr, batch, h->cap_stream);
+        ++launches;
+    }
+    h->timing_part = 3;
+    const hipError_t e2 = hipStreamEndCapture(h->cap_stream, &graph);
+    if (!rc && e != hipSuccess) rc = hipfail(e, "hipStreamBeginCapture");
+    if (!rc && e2 != hipSuccess) rc = hipfail(e2, "hipStreamEndCapture");
+    if (!rc && !launches) rc = fail(LSPF2F_ERR_INVALID_ARGUMENT, "empty selection");
+    if (!rc && (e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) rc = hipfail(e, "hipGraphInstantiate");
+    if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(LSPF2F_ERR_HIP, "hipEventCreate failed");
+    if (!rc && (e = hipGraphLaunch(exec, s)) != hipSuccess) rc = hipfail(e, "hipGraphLaunch");          // warm-up replay
+    if (!rc) {
+        (void)hipEventRecord(e0, s);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) e = hipGraphLaunch(exec, s);
+        (void)hipEventRecord(e1, s);
+        if (e != hipSuccess) rc = hipfail(e, "hipGraphLaunch");
+    }
+    if (!rc && (e = hipStreamSynchronize(s)) != hipSuccess) rc = hipfail(e, "hipStreamSynchronize");
+    if (!rc) {
+        float ms = 0.f;
+        if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) rc = hipfail(e, "hipEventElapsedTime");
+        *ms_per_replay = ms / (float)reps;
+        if (launches_per_replay) *launches_per_replay = launches;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
 }
 
 int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch,

@@ -228,6 +228,24 @@ class Engine:
                                                   ctypes.c_void_p(stream), ms))
         return out, [float(x) for x in ms]
 
+    def subset_timed(self, feat, cand, part, out=None, reps: int = 10) -> float:
+        """milliseconds per replay of a graph holding only the selected layers' launches (part[i]: 0 skip, 1 main kernels, 2 split-K
+        reduce only, 3 all) -- no host gaps; run forward() first"""
+        b = self._check_inputs(feat, cand)
+        if out is None:
+            out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device)
+        n = self.lib.lspf2f_num_layers(self._h)
+        if len(part) != n:
+            raise ValueError("part needs one entry per layer (%d)" % n)
+        arr = (ctypes.c_int * n)(*[int(x) for x in part])
+        ms, cnt = ctypes.c_float(), ctypes.c_int()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            N.check(self.lib.lspf2f_subset_timed(self._h, feat.data_ptr(), cand.data_ptr() if cand is not None else None,
+                                                 cand.shape[0] if cand is not None else 0, out.data_ptr(), b,
+                                                 ctypes.c_void_p(stream), arr, reps, ctypes.byref(ms), ctypes.byref(cnt)))
+        return float(ms.value)
+
     # ---- introspection -------------------------------------------------------------------
     def layers(self, batch: Optional[int] = None) -> List[dict]:
         if batch is not None:

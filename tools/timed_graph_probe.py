@@ -1,0 +1,24 @@
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from livespeechportraits_amd import synth
+from livespeechportraits_amd.engine import Engine
+from livespeechportraits_amd.topology import build_topology
+dev = torch.device("cuda:0")
+topo = build_topology("large"); sd = synth.make_state_dict(topo, 1234)
+e = Engine("large"); e.load_state_dict(sd); e.bind(e.pack(), dev)
+f, c = synth.make_inputs(1, 512, 99, 1); f, c = torch.from_numpy(f).to(dev), torch.from_numpy(c).to(dev)
+out = e.forward(f, c); torch.cuda.synchronize()
+L = e.layers(1)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(50): e.forward(f, c)
+ev1.record(); torch.cuda.synchronize()
+print("plain replay %.4f ms" % (ev0.elapsed_time(ev1) / 50))
+print("all layers, subset graph: %.4f ms" % e.subset_timed(f, c, [3] * len(L)))
+dom = [1 if (l["kernel"].startswith("igemm3x3") and l["tile_m"] == 64 and l["tile_n"] == 64 and l["k_group"] == 1) else 0 for l in L]
+t = e.subset_timed(f, c, dom); print("igemm 64x64 g1 main kernels: %d launches %.4f ms = %.2f us each" % (sum(dom), t, 1e3 * t / sum(dom)))
+red = [2 if l["split_k"] > 1 else 0 for l in L]
+t = e.subset_timed(f, c, red); print("split-K reduces: %d launches %.4f ms" % (sum(1 for x in red if x), t))
+for k in ("conv3x3_fullk", "conv3x3_smallm", "first_conv", "last_conv"):
+    m = [3 if l["kernel"] == k else 0 for l in L]
+    t = e.subset_timed(f, c, m); print("%s: %d launches %.4f ms = %.2f us each" % (k, sum(1 for x in m if x), t, 1e3 * t / sum(1 for x in m if x)))
