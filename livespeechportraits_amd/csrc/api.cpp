@@ -48,6 +48,7 @@ struct lspf2f_handle {
     bool packed = false;
     bool use_graph = true;
     bool last_direct = false;     // bf16 plans: direct last-conv kernel instead of the GEMM form (LSP_HIP_LASTCONV_DIRECT, read at create)
+    bool first_direct = false;    // LSP_HIP_FIRSTCONV_DIRECT (read at create): vector-ALU first conv instead of the matrix-core kernel
     int timing_part = 3;          // lspf2f_subset_timed: 1 = main kernels only, 2 = split-K reduce only, 3 = everything (always 3 on the hot path)
     int last_route = 0;           // forced direct last-conv kernel (LSP_HIP_LASTCONV_{STRIP,ROWS,GENERIC}, read at create; tests only)
     const void *cand_cached = nullptr;   // candidate stack whose first-conv contribution sits in the workspace cache
@@ -98,6 +99,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     // environment switches are read HERE, once per handle, never on the launch path
     if (const char *env = std::getenv("LSP_HIP_GRAPH")) h->use_graph = h->use_graph && std::strcmp(env, "0") != 0;
     h->last_direct = std::getenv("LSP_HIP_LASTCONV_DIRECT") != nullptr;
+    h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") != nullptr;
     h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
                   : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : 0;
     *out = h;
@@ -262,7 +264,10 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         // two slots at the head of the workspace: [0] lspf2f_set_candidates' per-person cache, [1] the per-forward share of a
         // broadcast stack -- separate, so a broadcast forward never overwrites what the cache holds
         float *cache = reinterpret_cast<float *>(cand != nullptr ? h->ws + P.cand_cache_bytes() : h->ws);
-        const bool shared = p.cand_nc > 0 && P.feat_nc > 0 && (cand == nullptr || (cand_batch == 1 && batch > 1));
+        p.force_direct = h->first_direct ? 1 : 0;
+        // a candidate stack shared by the batch (cand_batch == 1) is simply broadcast by the matrix-core kernel (it is read from L2);
+        // only the vector-ALU route still splits the layer into a once-per-batch candidate pass and a per-frame feature pass
+        const bool shared = p.cand_nc > 0 && P.feat_nc > 0 && (cand == nullptr || (h->first_direct && cand_batch == 1 && batch > 1));
         if (shared) {
             // candidate stack shared by the whole batch: its contribution is computed once (or taken
             // from lspf2f_set_candidates' cache when cand == NULL), each frame then adds its own
@@ -476,6 +481,7 @@ int lspf2f_set_candidates(lspf2f_handle *h, const float *cand_dev, void *hip_str
     c.out = reinterpret_cast<float *>(h->ws);
     c.B = 1; c.H = l.hs; c.W = l.hs; c.feat_nc = P.feat_nc; c.cand_nc = P.input_nc - P.feat_nc; c.cand_batch = 1;
     c.Cout = l.cout; c.ci_begin = P.feat_nc; c.ci_end = P.input_nc; c.base = nullptr; c.relu = 0;
+    c.force_direct = h->first_direct ? 1 : 0;
     const hipError_t e = launch_first_conv(c, static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return hipfail(e, "lspf2f_set_candidates launch");
     h->cand_cached = cand_dev;

@@ -151,6 +151,117 @@ __global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// First layer on the matrix cores.  The direct kernel above issues 0.98 GFLOP per frame on the vector ALU behind LDS weight
+// broadcasts and sits at 36 us per frame (10 % of the HBM roofline of its 30 MB); as an implicit GEMM -- M = output pixels, N = Cout,
+// K = 13 x 9 = 117 (padded to 118) -- the arithmetic is 6 us of v_mfma_f32_32x32x2_f32 and the layer becomes a streaming kernel.
+//   * tile = 2 output rows x 64 columns (128 pixels, one 32-pixel run per wave); its 5 x 129 input window of every channel is
+//     staged from the two NCHW API tensors into LDS once (zero padding written there: no branches later), the 117 x Cout weights too;
+//   * A fragment: lane (pixel m, k parity) reads ONE float at [ci][2 r + ky][2 m + kx] -- a stride-2 ds_read_b32 (2-way conflict,
+//     4 cycles against 64 x NH cycles of MFMA per K step); B fragment: weights [k][n], conflict-free;
+//   * epilogue straight from the accumulators: for a fixed register the 32 lanes of a half-wave hold 32 consecutive channels of
+//     one pixel -> 128-byte NHWC segments; + bias (InstanceNorm plans), ReLU, fp32 or bf16 store.
+// Channel range [ci_begin, ci_end) as in the direct kernel (candidate-share pass of lspf2f_set_candidates: weights outside the
+// range are zeroed in LDS, their inputs never read).
+template <typename T, int NH>
+__global__ __launch_bounds__(256) void first_conv_mfma(const FirstConvParams p)
+{
+    constexpr int CIN = 13, KS = (CIN * 9 + 1) / 2;          // 59 K steps of 2
+    constexpr int LDW = 132;                                  // LDS row pitch of the input window (129 used)
+    constexpr int N = NH * 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *win = sm;                                          // [13][5][LDW]
+    float *wl = sm + CIN * 5 * LDW;                           // [118][N]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const int tiles_x = (Wo + 63) / 64, tiles_y = (Ho + 1) / 2;
+    int t = blockIdx.x;
+    const int b = t / (tiles_x * tiles_y);
+    t -= b * tiles_x * tiles_y;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * 2, ox0 = tx * 64;
+
+    // weights: blob layout [(ci * 9 + tap)][Cout]; rows outside [ci_begin, ci_end) and the pad row 117 are zero
+    for (int i = tid; i < 2 * KS * N; i += 256) {
+        const int k = i / N, n = i - k * N;
+        const int ci = k / 9;
+        wl[i] = (k < CIN * 9 && ci >= p.ci_begin && ci < p.ci_end && ci < p.feat_nc + p.cand_nc) ? p.w[(size_t)k * p.Cout + n] : 0.f;
+    }
+    // input window: rows 2 oy0 - 1 .. + 3, columns 2 ox0 - 1 .. + 127 of every channel in range (others: zeros)
+    const size_t plane = (size_t)p.H * p.W;
+    for (int i = tid; i < CIN * 5 * 129; i += 256) {
+        const int ci = i / (5 * 129), r = (i - ci * 5 * 129) / 129, c = i - ci * 5 * 129 - r * 129;
+        const int iy = 2 * oy0 - 1 + r, ix = 2 * ox0 - 1 + c;
+        float v = 0.f;
+        if (ci >= p.ci_begin && ci < p.ci_end && ci < p.feat_nc + p.cand_nc && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+            const float *src = ci < p.feat_nc ? p.feat + ((size_t)b * p.feat_nc + ci) * plane
+                                              : p.cand + ((size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc + (ci - p.feat_nc)) * plane;
+            v = src[(size_t)iy * p.W + ix];
+        }
+        win[(ci * 5 + r) * LDW + c] = v;
+    }
+    __syncthreads();
+
+    // wave -> 32 pixels: output row oy0 + (wave >> 1), columns ox0 + 32 (wave & 1) + m
+    const int m = lane & 31, kp = lane >> 5;
+    const int orow = wave >> 1, ocol = 32 * (wave & 1) + m;
+    const float *abase = win + (2 * orow) * LDW + 2 * ocol;  // + (ci * 5 + ky) * LDW + kx
+    f32x16 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+        // k = 2 s2 + kp -> (ci, ky, kx); both parities' offsets are compile-time constants, the lane picks its own
+        constexpr int dummy = 0; (void)dummy;
+        const int k0 = 2 * s2, k1 = 2 * s2 + 1;
+        const int o0 = ((k0 / 9) * 5 + (k0 % 9) / 3) * LDW + (k0 % 9) % 3;
+        const int o1 = k1 < CIN * 9 ? ((k1 / 9) * 5 + (k1 % 9) / 3) * LDW + (k1 % 9) % 3 : 0;   // k = 117: weight row is zero
+        const float a = abase[kp ? o1 : o0];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float bw = wl[(2 * s2 + kp) * N + h * 32 + m];
+            acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw, acc[h], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D layout row (pixel) = (r & 3) + 8 (r >> 2) + 4 kp, col (channel) = m
+    const int oy = oy0 + orow;
+    if (oy >= Ho) return;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int n = h * 32 + m;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = 32 * (wave & 1) + (r & 3) + 8 * (r >> 2) + 4 * kp;
+            const int ox = ox0 + px;
+            if (ox >= Wo) continue;
+            float v = acc[h][r] + bias;
+            if (p.relu) v = fmaxf(v, 0.f);
+            const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * p.Cout + n;
+            if constexpr (sizeof(T) == 4) static_cast<float *>(p.out)[o] = v;
+            else static_cast<bf16_t *>(p.out)[o] = f2bf(v);
+        }
+    }
+}
+
+template <typename T, int NH>
+static hipError_t launch_first_conv_mfma(const FirstConvParams &p, hipStream_t s)
+{
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const long tiles = (long)p.B * ((Wo + 63) / 64) * ((Ho + 1) / 2);
+    const size_t smem = (size_t)(13 * 5 * 132 + 118 * NH * 32) * sizeof(float);
+    static unsigned long long attr_mask = 0;
+    if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&first_conv_mfma<T, NH>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((first_conv_mfma<T, NH>), dim3((unsigned)tiles), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
 {
     if (p.base && p.ci_begin == 0 && p.ci_end == 1 && p.feat_nc == 1 && 64 % (p.Cout / 4) == 0 && p.Cout <= 256) {
@@ -162,6 +273,17 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
         if (p.dtype == 1) hipLaunchKernelGGL((first_conv_feat<bf16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((first_conv_feat<float, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         return hipGetLastError();
+    }
+    // matrix-core form: no partial sums to start from, 13 input channels (the only count feature2face_G.py builds), Cout a multiple
+    // of 32 up to 128; bf16 output only for the layer itself (the candidate cache is fp32)
+    const bool cache_pass = p.relu == 0 && p.base == nullptr && p.ci_begin > 0;
+    if (!p.base && !p.force_direct && p.feat_nc + p.cand_nc == 13 && (p.Cout == 32 || p.Cout == 64 || p.Cout == 128)) {
+        const bool bf = p.dtype == 1 && !cache_pass;
+        switch (p.Cout / 32) {
+        case 1: return bf ? launch_first_conv_mfma<bf16_t, 1>(p, s) : launch_first_conv_mfma<float, 1>(p, s);
+        case 2: return bf ? launch_first_conv_mfma<bf16_t, 2>(p, s) : launch_first_conv_mfma<float, 2>(p, s);
+        default: return bf ? launch_first_conv_mfma<bf16_t, 4>(p, s) : launch_first_conv_mfma<float, 4>(p, s);
+        }
     }
     const long total = (long)p.B * (p.H / 2) * (p.W / 2);
     const int K = (p.ci_end - p.ci_begin) * 9;

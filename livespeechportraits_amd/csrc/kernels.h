@@ -126,6 +126,7 @@ struct FirstConvParams {
     const float *base;      // optional pre-activation partial sums [1][H/2][W/2][Cout] to start from
     int relu;
     const float *bias;      // [Cout] conv bias (InstanceNorm plans: use_bias, networks.py:590) or nullptr; final pass only
+    int force_direct;       // tests / A-B runs: the vector-ALU kernel instead of the matrix-core one
 };
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
 
