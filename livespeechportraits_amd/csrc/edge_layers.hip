@@ -181,24 +181,50 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FirstConvParams p)
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int oy0 = ty * 2, ox0 = tx * 64;
 
-    // weights: blob layout [(ci * 9 + tap)][Cout]; rows outside [ci_begin, ci_end) and the pad row 117 are zero
-    for (int i = tid; i < 2 * KS * N; i += 256) {
-        const int k = i / N, n = i - k * N;
-        const int ci = k / 9;
-        wl[i] = (k < CIN * 9 && ci >= p.ci_begin && ci < p.ci_end && ci < p.feat_nc + p.cand_nc) ? p.w[(size_t)k * p.Cout + n] : 0.f;
-    }
-    // input window: rows 2 oy0 - 1 .. + 3, columns 2 ox0 - 1 .. + 127 of every channel in range (others: zeros)
-    const size_t plane = (size_t)p.H * p.W;
-    for (int i = tid; i < CIN * 5 * 129; i += 256) {
-        const int ci = i / (5 * 129), r = (i - ci * 5 * 129) / 129, c = i - ci * 5 * 129 - r * 129;
-        const int iy = 2 * oy0 - 1 + r, ix = 2 * ox0 - 1 + c;
-        float v = 0.f;
-        if (ci >= p.ci_begin && ci < p.ci_end && ci < p.feat_nc + p.cand_nc && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-            const float *src = ci < p.feat_nc ? p.feat + ((size_t)b * p.feat_nc + ci) * plane
-                                              : p.cand + ((size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc + (ci - p.feat_nc)) * plane;
-            v = src[(size_t)iy * p.W + ix];
+    // weights: blob layout [(ci * 9 + tap)][Cout]; rows outside [ci_begin, ci_end) and the pad row 117 are zero.  All loads of a
+    // thread are issued before its LDS writes (a load -> write loop would be a chain of serial round trips).
+    {
+        constexpr int W4 = 2 * KS * N / 4, PER = (W4 + 255) / 256;
+        float4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * 256, k = (i * 4) / N, ci = k / 9;
+            const bool ok = i < W4 && k < CIN * 9 && ci >= p.ci_begin && ci < p.ci_end;
+            v[u] = ok ? *reinterpret_cast<const float4 *>(p.w + (size_t)k * p.Cout + (i * 4 - k * N)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        win[(ci * 5 + r) * LDW + c] = v;
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (tid + u * 256 < W4) *reinterpret_cast<float4 *>(wl + (tid + u * 256) * 4) = v[u];
+    }
+    // input window: rows 2 oy0 - 1 .. + 3, columns 2 ox0 - 1 .. + 127 of every channel in range (others: zeros).  A wave takes the
+    // (channel, row) lines q = wave, wave + 4, ...; a line is 129 floats = lanes 0..63 twice plus one
+    {
+        const size_t plane = (size_t)p.H * p.W;
+        constexpr int LINES = CIN * 5, PERW = (LINES + 3) / 4;         // 17 lines per wave
+        float v[PERW][3];
+#pragma unroll
+        for (int j = 0; j < PERW; ++j) {
+            const int q = wave + 4 * j, ci = q / 5, r = q - ci * 5;
+            const int iy = 2 * oy0 - 1 + r;
+            const bool rok = q < LINES && ci >= p.ci_begin && ci < p.ci_end && (unsigned)iy < (unsigned)p.H;
+            const float *src = nullptr;
+            if (rok)
+                src = (ci < p.feat_nc ? p.feat + ((size_t)b * p.feat_nc + ci) * plane
+                                      : p.cand + ((size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc + (ci - p.feat_nc)) * plane) + (size_t)iy * p.W;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int c = lane + 64 * u, ix = 2 * ox0 - 1 + c;
+                v[j][u] = (rok && c < 129 && (unsigned)ix < (unsigned)p.W) ? src[ix] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PERW; ++j) {
+            const int q = wave + 4 * j;
+            if (q < LINES)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (lane + 64 * u < 129) win[q * LDW + lane + 64 * u] = v[j][u];
+        }
     }
     __syncthreads();
 
@@ -211,19 +237,33 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FirstConvParams p)
     for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
-#pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-        // k = 2 s2 + kp -> (ci, ky, kx); both parities' offsets are compile-time constants, the lane picks its own
-        constexpr int dummy = 0; (void)dummy;
+    // k = 2 s + kp -> (ci, ky, kx): both parities' window offsets are compile-time constants, the lane picks its own.  Operands of
+    // step s + 1 are read from LDS before the MFMAs of step s are issued (pinned with scheduling barriers: the compiler otherwise
+    // sinks each read to its use and every K step pays the LDS latency).
+    auto a_off = [&](int s2) {
         const int k0 = 2 * s2, k1 = 2 * s2 + 1;
         const int o0 = ((k0 / 9) * 5 + (k0 % 9) / 3) * LDW + (k0 % 9) % 3;
         const int o1 = k1 < CIN * 9 ? ((k1 / 9) * 5 + (k1 % 9) / 3) * LDW + (k1 % 9) % 3 : 0;   // k = 117: weight row is zero
-        const float a = abase[kp ? o1 : o0];
+        return kp ? o1 : o0;
+    };
+    float a_cur = abase[a_off(0)], a_nxt = 0.f;
+    float b_cur[NH], b_nxt[NH];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const float bw = wl[(2 * s2 + kp) * N + h * 32 + m];
-            acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw, acc[h], 0, 0, 0);
+    for (int h = 0; h < NH; ++h) { b_cur[h] = wl[kp * N + h * 32 + m]; b_nxt[h] = 0.f; }
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+        if (s2 + 1 < KS) {
+            a_nxt = abase[a_off(s2 + 1)];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) b_nxt[h] = wl[(2 * (s2 + 1) + kp) * N + h * 32 + m];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[h], acc[h], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) b_cur[h] = b_nxt[h];
     }
     // epilogue: C/D layout row (pixel) = (r & 3) + 8 (r >> 2) + 4 kp, col (channel) = m
     const int oy = oy0 + orow;

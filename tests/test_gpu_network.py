@@ -148,10 +148,10 @@ def test_shared_candidate_paths_agree(gpu_device):
     e = make_engine(topo, sd, gpu_device, B)
     f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
     per_frame = e.forward(f, c.expand(B, -1, -1, -1).contiguous()).clone()      # one-kernel first layer
-    shared = e.forward(f, c).clone()                                            # cand pass + feature pass
+    shared = e.forward(f, c).clone()                                            # candidate share once + per-frame feature pass
     assert (shared - per_frame).abs().max().item() <= 2e-6
     e.set_candidates(c)
-    cached = e.forward(f, c).clone()                                            # feature pass only
+    cached = e.forward(f, c).clone()                                            # feature pass only, on top of the cached share
     assert torch.equal(cached, shared)
     single = e.forward(f[1:2].contiguous(), c)                                  # batch 1 through the cache
     assert (single[0] - shared[1]).abs().max().item() <= 2e-6
