@@ -248,6 +248,38 @@ def main():
             hout.copy_(du8, non_blocking=True)
             torch.cuda.synchronize()
         extra["pcie_inclusive_frames_per_s_batch1_uint8"] = round(nl / (time.perf_counter() - t2), 2)
+        # the same loop with the edge map drawn on the device: per frame ~1.5 KB of landmarks + shoulder points go
+        # H2D instead of a host-rasterised 1 MiB feature map (datasets/face_dataset.py:276-323 + demo.py:262-265)
+        from livespeechportraits_amd.feature_map import FeatureMapRasteriser
+        rast = FeatureMapRasteriser(a.size, 18, dev)
+        rng = np.random.default_rng(0)
+        lm = (a.size * 0.5 + rng.normal(0, a.size * 0.12, (1, 73, 2))).astype(np.float32)
+        sh = np.stack([np.linspace(0, a.size, 18), np.full(18, a.size * 0.9)], 1)[None].astype(np.float32)
+        hpts = torch.from_numpy(np.concatenate([lm, sh], 1)).pin_memory()
+        dpts = torch.empty((1, 91, 2), device=dev)
+        for _ in range(3):
+            dpts.copy_(hpts, non_blocking=True)
+            rast.rasterise_points(dpts, out=dfeat); eng.forward_image(dfeat, cand, du8); hout.copy_(du8, non_blocking=True)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(nl):
+            dpts.copy_(hpts, non_blocking=True)                 # 728 bytes H2D instead of the 1 MiB feature map
+            rast.rasterise_points(dpts, out=dfeat)
+            eng.forward_image(dfeat, cand, du8)
+            hout.copy_(du8, non_blocking=True)
+            torch.cuda.synchronize()
+        extra["pcie_inclusive_frames_per_s_batch1_uint8_landmarks_in"] = round(nl / (time.perf_counter() - t3), 2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        l8 = torch.from_numpy(np.repeat(lm, 8, 0)).to(dev); s8 = torch.from_numpy(np.repeat(sh, 8, 0)).to(dev)
+        m8 = torch.empty((8, 1, a.size, a.size), device=dev)
+        rast.rasterise(l8, s8, out=m8); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            rast.rasterise(l8, s8, out=m8)
+        e1.record(); torch.cuda.synchronize()
+        extra["edge_map_rasteriser"] = {"us_per_frame_batch8": round(e0.elapsed_time(e1) * 1e3 / 160, 2),
+                                        "hbm_frac_of_8TBs": round(8 * a.size * a.size * 4 / (e0.elapsed_time(e1) * 1e-3 / 20) / 8e12, 4),
+                                        "note": "lspraster_edge_maps: 88 thick edges per frame -> fp32 [8,1,512,512]; parity unpinned vs cv2 (bit-exact to oracle/raster_oracle.c)"}
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
@@ -321,12 +353,12 @@ def headpose_extra(dev, cpu_threads):
 
 def pipeline_extra(dev, eng, cand):
     """BASELINE.json configs[4] shape, PLUMBING ONLY: the device stages of demo.py chained on one stream for a 687-frame clip
-    (data/Input/00083.wav is 687 frames at 60 fps = 11.45 s) with synthetic weights and stand-in data -- APC encoder ->
-    manifold projection -> Audio2Feature and Audio2Headpose -> renderer (batch 8, fused tensor2im, uint8 frames left on the
-    device).  NOT in it, because the reference does them on the CPU with libraries absent here (librosa, cv2) or with
-    per-person assets that cannot be obtained: mel spectrogram, smoothing / head-pose post-processing, 3-D projection,
-    landmark rasterisation (the feature maps are synthetic), JPEG / video writing.  One number: clip frames per second of
-    wall-clock over those device stages."""
+    (data/Input/00083.wav is 687 frames at 60 fps = 11.45 s) with synthetic weights and stand-in data -- waveform -> mel -> APC
+    encoder -> manifold projection -> Audio2Feature and Audio2Headpose -> (stand-in landmarks) -> edge-map rasteriser -> renderer
+    (batch 8, fused tensor2im, uint8 frames left on the device).  NOT in it, because the reference does them on the CPU with
+    per-person assets that cannot be obtained: smoothing / head-pose post-processing, the 3-D projection that turns mouth
+    features and poses into the 73 landmarks (random stand-in landmarks are rasterised instead), JPEG / video writing.  One
+    number: clip frames per second of wall-clock over those device stages."""
     from livespeechportraits_amd import manifold, synth
     from livespeechportraits_amd.a2h_engine import HeadposeEngine
     from livespeechportraits_amd.apc import APC_encoder
@@ -343,13 +375,20 @@ def pipeline_extra(dev, eng, cand):
     a2h = HeadposeEngine(max_audio_frames=nframe + ff_head)
     a2h.load_state_dict(synth.make_a2h_state_dict(cfg)); a2h.bind(dev)
     db = torch.from_numpy(synth.make_feature_database(30000, 8, 512, 24)[0]).to(dev)
-    mel = torch.from_numpy(synth.make_mel(2 * nframe)).to(dev).unsqueeze(0)
+    from livespeechportraits_amd import mel as mel_mod
+    from livespeechportraits_amd.feature_map import FeatureMapRasteriser
+    wave = torch.from_numpy((0.1 * np.random.default_rng(1).standard_normal(int(nframe / 60 * 16000) + 8)).astype(np.float32)).to(dev)   # 11.45 s at 16 kHz
+    rast = FeatureMapRasteriser(eng.size, 18, dev)
+    rng = np.random.default_rng(2)
+    lms = torch.from_numpy((eng.size * 0.5 + rng.normal(0, eng.size * 0.12, (nframe, 73, 2))).astype(np.float32)).to(dev)      # stand-in landmarks
+    shs = torch.from_numpy(np.tile(np.stack([np.linspace(0, eng.size, 18), np.full(18, eng.size * 0.9)], 1)[None], (nframe, 1, 1)).astype(np.float32)).to(dev)
     pre = torch.zeros(12, device=dev)
     noise = torch.from_numpy(synth.symmetric(nframe * 12, 1.0, 5).reshape(nframe, 12)).to(dev)
-    maps = torch.from_numpy(synth.make_inputs(8, eng.size, seed=7, cand_batch=1)[0]).to(dev)     # stand-in edge maps, reused per batch
+    maps = torch.empty((8, 1, eng.size, eng.size), device=dev)
     frames = torch.empty((8, eng.size, eng.size, 3), dtype=torch.uint8, device=dev)
 
     def clip():
+        mel = mel_mod.compute_mel(wave).unsqueeze(0)                                            # [1, 1374, 80] from the waveform, on the device
         feats = apc.forward(mel, torch.Tensor([2 * nframe]))[0]                                 # [1374, 512]
         feats = manifold.project(feats.contiguous(), db, 10, 1.0)
         tail = feats[-1:].expand(2 * ff_feat, -1)
@@ -358,6 +397,7 @@ def pipeline_extra(dev, eng, cand):
         poses = a2h.generate(a2h_in, pre, noise, None, 0.3, ff_head)                            # [687, 12]
         for i in range(0, nframe, 8):
             b = min(8, nframe - i)
+            rast.rasterise(lms[i:i + b], shs[i:i + b], out=maps[:b])                            # edge maps drawn on the device
             eng.forward_image(maps[:b], cand, frames[:b])
         return mouth, poses
 

@@ -59,7 +59,15 @@ class FeatureMapRasteriser:
         device) -> float32 [B, 1, H, W] in {0, 1} on the device (uint8 [B, H, W] in {0, 255} when ``as_uint8``).
         ``pad`` = (top, bottom, left, right) shifts the shoulders by (right - left, top - bottom) as get_feature_image does
         (face_dataset.py:287-292; applied to a copy, the reference shifts its argument in place)."""
-        pts = self._points(landmarks, shoulders, pad)
+        return self.rasterise_points(self._points(landmarks, shoulders, pad), out, as_uint8)
+
+    def rasterise_points(self, pts: torch.Tensor, out: Optional[torch.Tensor] = None, as_uint8: bool = False) -> torch.Tensor:
+        """The same with the points already laid out as the kernel wants them: ONE device tensor [B, 73 + n_shoulder, 2] (landmarks
+        then shoulder points, pad shift applied), int32 / float32 / float64 -- a render loop that keeps such a buffer moves one
+        ~1.5 KB H2D copy per frame and launches nothing else."""
+        if pts.device != self.device or pts.dim() != 3 or pts.shape[1] != N_LANDMARKS + self.n_shoulder or pts.shape[2] != 2 \
+                or not pts.is_contiguous() or pts.dtype not in (torch.int32, torch.float32, torch.float64):
+            raise ValueError("points must be a contiguous [B, %d, 2] int32/float32/float64 tensor on %s" % (N_LANDMARKS + self.n_shoulder, self.device))
         b = pts.shape[0]
         s = self.load_size
         if as_uint8:
