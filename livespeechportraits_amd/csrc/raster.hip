@@ -1,10 +1,12 @@
 // gfx950: the landmark edge map of the render loop on the device (include/lspraster.h).
 //
-// One workgroup rasterises one 64-row band of one frame.  Every thread takes whole edges (thick lines) of the frame's
-// ~106-edge list and runs the integer scan conversion of that edge on its own -- the primitives only ever write one value,
-// so the image is the union of their pixel sets and the order is irrelevant -- setting bits of the band's bitmask in LDS
-// (64 rows x W bits = 4 KB at W = 512) with ds_or.  The band is then expanded to the output tensor with coalesced 16-byte
-// stores: the kernel's HBM traffic is the output itself (1 MiB fp32 per frame) plus ~1 KB of points.
+// One workgroup rasterises one 64-row band of one frame.  A WAVE takes one edge (thick line) of the frame's ~88-edge list at a time:
+// the set-up (perpendicular offset, clipping, the per-edge divisions) is wave-uniform, and the per-pixel / per-row work is spread over
+// the 64 lanes in closed form -- a DDA step k is x0 + k, (y0 + k * step) >> 16; a scanline y of the fill is xs + (y - y_event) * dx
+// on each chain, exactly what the sequential `x += dx` reaches -- so an edge costs a few hundred instructions instead of a loop over
+// its length.  The primitives only ever write one value, so the image is the union of their pixel sets and the order is irrelevant:
+// lanes set bits of the band's bitmask in LDS (64 rows x W bits = 4 KB at W = 512) with ds_or.  The band is then expanded to the
+// output tensor with coalesced 16-byte stores: the kernel's HBM traffic is the output itself (1 MiB fp32 per frame) plus ~1 KB of points.
 //
 // The scan conversion follows OpenCV 4.4.0's cv::line for thickness > 1 (modules/imgproc/src/drawing.cpp: ThickLine ->
 // FillConvexPoly with a Line2 outline, Circle end caps) in 16.16 fixed point with 64-bit intermediates; doubles are used
@@ -85,8 +87,9 @@ __device__ bool clip(long long width, long long height, P2 &p1, P2 &p2)
     return (c1 | c2) == 0;
 }
 
-// sub-pixel DDA between two 16.16 points: one pixel per step along the major axis, plus the rounded far end point
-__device__ void dda(const Band &b, P2 a, P2 e)
+// sub-pixel DDA between two 16.16 points: one pixel per step along the major axis, plus the rounded far end point.  Arguments are
+// wave-uniform; step k goes to lane k % 64.
+__device__ void dda(const Band &b, P2 a, P2 e, int lane)
 {
     if (!clip((long long)b.w << SHIFT, (long long)b.h << SHIFT, a, e)) return;
     long long dx = e.x - a.x, dy = e.y - a.y;
@@ -97,21 +100,22 @@ __device__ void dda(const Band &b, P2 a, P2 e)
         dx = -dx; dy = -dy;
     }
     const long long step = xmajor ? (dy * ONE) / (ax | 1) : (dx * ONE) / (ay | 1);
-    int count = (int)((xmajor ? e.x - a.x : e.y - a.y) >> SHIFT);
+    const int count = (int)((xmajor ? e.x - a.x : e.y - a.y) >> SHIFT);
     a.x += ONE >> 1;
     a.y += ONE >> 1;
-    dot(b, (int)((e.x + (ONE >> 1)) >> SHIFT), (int)((e.y + (ONE >> 1)) >> SHIFT));
+    if (lane == 0) dot(b, (int)((e.x + (ONE >> 1)) >> SHIFT), (int)((e.y + (ONE >> 1)) >> SHIFT));
     if (xmajor) {
-        int x = (int)(a.x >> SHIFT);
-        for (; count >= 0; --count, ++x, a.y += step) dot(b, x, (int)(a.y >> SHIFT));
+        const int x0 = (int)(a.x >> SHIFT);
+        for (int k = lane; k <= count; k += 64) dot(b, x0 + k, (int)((a.y + k * step) >> SHIFT));
     } else {
-        int y = (int)(a.y >> SHIFT);
-        for (; count >= 0; --count, ++y, a.x += step) dot(b, (int)(a.x >> SHIFT), y);
+        const int y0 = (int)(a.y >> SHIFT);
+        for (int k = lane; k <= count; k += 64) dot(b, (int)((a.x + k * step) >> SHIFT), y0 + k);
     }
 }
 
-// convex quad in 16.16: outline through the DDA, interior by walking the left and right edge chains from the top vertex
-__device__ void fill_quad(const Band &b, const P2 (&v)[4])
+// convex quad in 16.16: outline through the DDA, interior by walking the left and right edge chains from the top vertex.  The chains
+// change edge at a handful of event rows (wave-uniform, simulated in order); the rows between two events go to the lanes.
+__device__ void fill_quad(const Band &b, const P2 (&v)[4], int lane)
 {
     constexpr int N = 4;
     constexpr long long HALF = ONE >> 1;
@@ -124,7 +128,7 @@ __device__ void fill_quad(const Band &b, const P2 (&v)[4])
         ymax = v[i].y > ymax ? v[i].y : ymax;
         xmax = v[i].x > xmax ? v[i].x : xmax;
         xmin = v[i].x < xmin ? v[i].x : xmin;
-        dda(b, prev, v[i]);
+        dda(b, prev, v[i], lane);
         prev = v[i];
     }
     xmin = (xmin + HALF) >> SHIFT; xmax = (xmax + HALF) >> SHIFT;
@@ -138,7 +142,8 @@ __device__ void fill_quad(const Band &b, const P2 (&v)[4])
     // vertex access with a runtime index: 4 entries, resolved with selects (no scratch)
     auto vx = [&](int i) { return i == 0 ? v[0].x : i == 1 ? v[1].x : i == 2 ? v[2].x : v[3].x; };
     auto vy = [&](int i) { return i == 0 ? v[0].y : i == 1 ? v[1].y : i == 2 ? v[2].y : v[3].y; };
-    do {
+    while (y <= (int)ymax) {
+        // edge changes due at row y (the sequential algorithm checks them at every row; they can only fire at y == ye[i])
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (y < ye[i]) continue;
@@ -160,18 +165,29 @@ __device__ void fill_quad(const Band &b, const P2 (&v)[4])
             }
         }
         if (edges < 0) break;
-        if (y >= 0) {
-            const long long lo = x[0] > x[1] ? x[1] : x[0], hi = x[0] > x[1] ? x[0] : x[1];
-            int x1 = (int)((lo + HALF) >> SHIFT), x2 = (int)((hi + HALF) >> SHIFT);
-            if (x2 >= 0 && x1 < b.w) span(b, y, x1 < 0 ? 0 : x1, x2 >= b.w ? b.w - 1 : x2);
+        // rows [y, ynext) see no further change: row y + k has x[i] + k * dxr[i] on chain i, as k sequential `x += dx` would give.
+        // A chain whose edge list is exhausted keeps ye[i] <= y forever; the next check then drives `edges` below zero and ends the
+        // walk, exactly as the row-by-row loop does -- so only ONE row may be emitted in that state.
+        int ynext = (int)ymax + 1;
+        if (ye[0] > y && ye[0] < ynext) ynext = ye[0];
+        if (ye[1] > y && ye[1] < ynext) ynext = ye[1];
+        if (ye[0] <= y || ye[1] <= y) ynext = y + 1;
+        for (int k = lane; k < ynext - y; k += 64) {
+            const int yy = y + k;
+            if (yy < 0) continue;
+            const long long x0 = x[0] + k * dxr[0], x1 = x[1] + k * dxr[1];
+            const long long lo = x0 > x1 ? x1 : x0, hi = x0 > x1 ? x0 : x1;
+            const int xa = (int)((lo + HALF) >> SHIFT), xb = (int)((hi + HALF) >> SHIFT);
+            if (xb >= 0 && xa < b.w) span(b, yy, xa < 0 ? 0 : xa, xb >= b.w ? b.w - 1 : xb);
         }
-        x[0] += dxr[0];
-        x[1] += dxr[1];
-    } while (++y <= (int)ymax);
+        x[0] += (long long)(ynext - y) * dxr[0];
+        x[1] += (long long)(ynext - y) * dxr[1];
+        y = ynext;
+    }
 }
 
-// filled midpoint circle: horizontal spans
-__device__ void disc(const Band &b, int cx, int cy, int radius)
+// filled midpoint circle: horizontal spans; the walk is short (radius <= 16) and wave-uniform, lanes 0..3 write its four spans
+__device__ void disc(const Band &b, int cx, int cy, int radius, int lane)
 {
     int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
     auto row = [&](int y, int xl, int xr) {
@@ -180,10 +196,10 @@ __device__ void disc(const Band &b, int cx, int cy, int radius)
     };
     if (!(cx - radius < b.w && cx + radius >= 0 && cy - radius < b.h && cy + radius >= 0)) return;
     while (dx >= dy) {
-        row(cy - dy, cx - dx, cx + dx);
-        row(cy + dy, cx - dx, cx + dx);
-        row(cy - dx, cx - dy, cx + dy);
-        row(cy + dx, cx - dy, cx + dy);
+        if (lane < 4) {
+            const int ry = (lane & 2) ? dx : dy, rx = (lane & 2) ? dy : dx;      // lanes 0,1: rows cy -/+ dy, half-width dx; 2,3: rows cy -/+ dx, half-width dy
+            row((lane & 1) ? cy + ry : cy - ry, cx - rx, cx + rx);
+        }
         ++dy;
         err += plus;
         plus += 2;
@@ -194,7 +210,7 @@ __device__ void disc(const Band &b, int cx, int cy, int radius)
     }
 }
 
-__device__ void thick_line(const Band &b, int x0, int y0, int x1, int y1, int thickness)
+__device__ void thick_line(const Band &b, int x0, int y0, int x1, int y1, int thickness, int lane)
 {
     const P2 p0 = {(long long)x0 * ONE, (long long)y0 * ONE}, p1 = {(long long)x1 * ONE, (long long)y1 * ONE};
     const double dx = (double)(p0.x - p1.x) * (1.0 / (double)ONE), dy = (double)(p1.y - p0.y) * (1.0 / (double)ONE);
@@ -205,11 +221,11 @@ __device__ void thick_line(const Band &b, int x0, int y0, int x1, int y1, int th
         r = ((double)half + (double)odd * (double)ONE * 0.5) / __dsqrt_rn(r);
         const long long ox = __double2ll_rn(dy * r), oy = __double2ll_rn(dx * r);      // round half to even, like cvRound
         const P2 q[4] = {{p0.x + ox, p0.y + oy}, {p0.x - ox, p0.y - oy}, {p1.x - ox, p1.y - oy}, {p1.x + ox, p1.y + oy}};
-        fill_quad(b, q);
+        fill_quad(b, q, lane);
     }
     const int radius = (half + (int)(ONE >> 1)) >> SHIFT;
-    disc(b, x0, y0, radius);
-    disc(b, x1, y1, radius);
+    disc(b, x0, y0, radius, lane);
+    disc(b, x1, y1, radius, lane);
 }
 
 struct Params {
@@ -239,14 +255,15 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
     __syncthreads();
     const size_t base = (size_t)frame * p.npoints * 2;
     const int reach = (p.thickness >> 1) + 2;                  // a primitive never leaves its end points' box by more than this
-    for (int s = tid; s < p.nseg; s += 256) {
+    const int lane = tid & 63;
+    for (int s = __builtin_amdgcn_readfirstlane(tid >> 6); s < p.nseg; s += 4) {       // one edge per wave at a time
         const int ia = p.segments[2 * s], ib = p.segments[2 * s + 1];
         if ((unsigned)ia >= (unsigned)p.npoints || (unsigned)ib >= (unsigned)p.npoints) continue;
         const int x0 = coord(p, base + 2 * ia), y0 = coord(p, base + 2 * ia + 1);
         const int x1 = coord(p, base + 2 * ib), y1 = coord(p, base + 2 * ib + 1);
         const int lo = (y0 < y1 ? y0 : y1) - reach, hi = (y0 < y1 ? y1 : y0) + reach;
         if (hi < b.y0 || lo >= b.y0 + b.rows) continue;        // this edge does not touch the band
-        thick_line(b, x0, y0, x1, y1, p.thickness);
+        thick_line(b, x0, y0, x1, y1, p.thickness, lane);
     }
     __syncthreads();
     // expand the band: 4 pixels per thread and step
