@@ -1,10 +1,11 @@
 // gfx950: the landmark edge map of the render loop on the device (include/lspraster.h).
 //
-// One workgroup rasterises one 64-row band of one frame.  A WAVE takes one edge (thick line) of the frame's ~88-edge list at a time:
-// the set-up (perpendicular offset, clipping, the per-edge divisions) is wave-uniform, and the per-pixel / per-row work is spread over
-// the 64 lanes in closed form -- a DDA step k is x0 + k, (y0 + k * step) >> 16; a scanline y of the fill is xs + (y - y_event) * dx
-// on each chain, exactly what the sequential `x += dx` reaches -- so an edge costs a few hundred instructions instead of a loop over
-// its length.  The primitives only ever write one value, so the image is the union of their pixel sets and the order is irrelevant:
+// One workgroup rasterises one 64-row band of one frame, in two phases.  Phase 1, one THREAD per edge of the frame's ~88-edge list:
+// the sequential, per-edge part of the scan conversion -- the perpendicular offset (double sqrt / divide), clipping, the emulated 64-bit
+// divisions behind the DDA steps and scanline slopes, the order in which the fill's two edge chains advance -- is evaluated once into a
+// small plan in LDS (measured: done per wave instead, these ~2500 instructions per edge made the kernel 120 us whatever the edge length).
+// Phase 2, one WAVE per edge: pixels and scanlines are closed forms of the plan -- DDA step k is (base + k, (minor + k * step) >> 16), row
+// y0 + k of a fill piece has x_i + k * d_i on chain i, exactly what the sequential `x += dx` reaches -- and go to the 64 lanes.  The primitives only ever write one value, so the image is the union of their pixel sets and the order is irrelevant:
 // lanes set bits of the band's bitmask in LDS (64 rows x W bits = 4 KB at W = 512) with ds_or.  The band is then expanded to the
 // output tensor with coalesced 16-byte stores: the kernel's HBM traffic is the output itself (1 MiB fp32 per frame) plus ~1 KB of points.
 //
@@ -87,10 +88,28 @@ __device__ bool clip(long long width, long long height, P2 &p1, P2 &p2)
     return (c1 | c2) == 0;
 }
 
-// sub-pixel DDA between two 16.16 points: one pixel per step along the major axis, plus the rounded far end point.  Arguments are
-// wave-uniform; step k goes to lane k % 64.
-__device__ void dda(const Band &b, P2 a, P2 e, int lane)
+// ---- phase 1, one THREAD per edge: everything that is per-edge and sequential (the perpendicular offset, clipping, the 64-bit
+// divisions behind the DDA steps and the scanline slopes, the order in which the fill's two chains change edge) becomes a plan ----
+struct DdaRec {            // one outline piece: pixel k is (base + k, (minor + k * step) >> 16) (x-major) or transposed
+    int valid, xmajor, count, base;
+    long long minor, step;
+    int ex, ey;            // the rounded far end point, drawn once
+};
+struct Piece {             // scanlines y0 .. y0 + n - 1 of the fill: chain i sits at x_i + k * d_i on row y0 + k
+    int y0, n;
+    long long x0, d0, x1, d1;
+};
+constexpr int MAX_PIECES = 6;      // every piece but the last ends at an edge change, and a quad has 4 edges to spend
+struct EdgePlan {
+    int skip, npieces, radius, hasquad;
+    int cx0, cy0, cx1, cy1;
+    DdaRec dda[4];
+    Piece pc[MAX_PIECES];
+};
+
+__device__ void plan_dda(const Band &b, P2 a, P2 e, DdaRec &r)
 {
+    r.valid = 0;
     if (!clip((long long)b.w << SHIFT, (long long)b.h << SHIFT, a, e)) return;
     long long dx = e.x - a.x, dy = e.y - a.y;
     const long long ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
@@ -99,23 +118,22 @@ __device__ void dda(const Band &b, P2 a, P2 e, int lane)
         const P2 t = a; a = e; e = t;
         dx = -dx; dy = -dy;
     }
-    const long long step = xmajor ? (dy * ONE) / (ax | 1) : (dx * ONE) / (ay | 1);
-    const int count = (int)((xmajor ? e.x - a.x : e.y - a.y) >> SHIFT);
+    r.step = xmajor ? (dy * ONE) / (ax | 1) : (dx * ONE) / (ay | 1);
+    r.count = (int)((xmajor ? e.x - a.x : e.y - a.y) >> SHIFT);
     a.x += ONE >> 1;
     a.y += ONE >> 1;
-    if (lane == 0) dot(b, (int)((e.x + (ONE >> 1)) >> SHIFT), (int)((e.y + (ONE >> 1)) >> SHIFT));
-    if (xmajor) {
-        const int x0 = (int)(a.x >> SHIFT);
-        for (int k = lane; k <= count; k += 64) dot(b, x0 + k, (int)((a.y + k * step) >> SHIFT));
-    } else {
-        const int y0 = (int)(a.y >> SHIFT);
-        for (int k = lane; k <= count; k += 64) dot(b, (int)((a.x + k * step) >> SHIFT), y0 + k);
-    }
+    r.ex = (int)((e.x + (ONE >> 1)) >> SHIFT);
+    r.ey = (int)((e.y + (ONE >> 1)) >> SHIFT);
+    r.xmajor = xmajor ? 1 : 0;
+    r.base = (int)((xmajor ? a.x : a.y) >> SHIFT);
+    r.minor = xmajor ? a.y : a.x;
+    r.valid = 1;
 }
 
 // convex quad in 16.16: outline through the DDA, interior by walking the left and right edge chains from the top vertex.  The chains
-// change edge at a handful of event rows (wave-uniform, simulated in order); the rows between two events go to the lanes.
-__device__ void fill_quad(const Band &b, const P2 (&v)[4], int lane)
+// change edge at a handful of event rows; between two events row y + k has x_i + k * d_i on chain i, exactly what k sequential
+// `x += dx` give -- one Piece per stretch.
+__device__ void plan_quad(const Band &b, const P2 (&v)[4], EdgePlan &pl)
 {
     constexpr int N = 4;
     constexpr long long HALF = ONE >> 1;
@@ -128,7 +146,7 @@ __device__ void fill_quad(const Band &b, const P2 (&v)[4], int lane)
         ymax = v[i].y > ymax ? v[i].y : ymax;
         xmax = v[i].x > xmax ? v[i].x : xmax;
         xmin = v[i].x < xmin ? v[i].x : xmin;
-        dda(b, prev, v[i], lane);
+        plan_dda(b, prev, v[i], pl.dda[i]);
         prev = v[i];
     }
     xmin = (xmin + HALF) >> SHIFT; xmax = (xmax + HALF) >> SHIFT;
@@ -142,7 +160,7 @@ __device__ void fill_quad(const Band &b, const P2 (&v)[4], int lane)
     // vertex access with a runtime index: 4 entries, resolved with selects (no scratch)
     auto vx = [&](int i) { return i == 0 ? v[0].x : i == 1 ? v[1].x : i == 2 ? v[2].x : v[3].x; };
     auto vy = [&](int i) { return i == 0 ? v[0].y : i == 1 ? v[1].y : i == 2 ? v[2].y : v[3].y; };
-    while (y <= (int)ymax) {
+    while (y <= (int)ymax && pl.npieces < MAX_PIECES) {
         // edge changes due at row y (the sequential algorithm checks them at every row; they can only fire at y == ye[i])
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -165,24 +183,65 @@ __device__ void fill_quad(const Band &b, const P2 (&v)[4], int lane)
             }
         }
         if (edges < 0) break;
-        // rows [y, ynext) see no further change: row y + k has x[i] + k * dxr[i] on chain i, as k sequential `x += dx` would give.
-        // A chain whose edge list is exhausted keeps ye[i] <= y forever; the next check then drives `edges` below zero and ends the
-        // walk, exactly as the row-by-row loop does -- so only ONE row may be emitted in that state.
         int ynext = (int)ymax + 1;
         if (ye[0] > y && ye[0] < ynext) ynext = ye[0];
         if (ye[1] > y && ye[1] < ynext) ynext = ye[1];
-        if (ye[0] <= y || ye[1] <= y) ynext = y + 1;
-        for (int k = lane; k < ynext - y; k += 64) {
-            const int yy = y + k;
-            if (yy < 0) continue;
-            const long long x0 = x[0] + k * dxr[0], x1 = x[1] + k * dxr[1];
-            const long long lo = x0 > x1 ? x1 : x0, hi = x0 > x1 ? x0 : x1;
-            const int xa = (int)((lo + HALF) >> SHIFT), xb = (int)((hi + HALF) >> SHIFT);
-            if (xb >= 0 && xa < b.w) span(b, yy, xa < 0 ? 0 : xa, xb >= b.w ? b.w - 1 : xb);
-        }
+        if (ye[0] <= y || ye[1] <= y) ynext = y + 1;         // cannot happen (an exhausted chain ends the walk above); one row if it did
+        Piece &q = pl.pc[pl.npieces++];
+        q.y0 = y; q.n = ynext - y; q.x0 = x[0]; q.d0 = dxr[0]; q.x1 = x[1]; q.d1 = dxr[1];
         x[0] += (long long)(ynext - y) * dxr[0];
         x[1] += (long long)(ynext - y) * dxr[1];
         y = ynext;
+    }
+}
+
+__device__ void plan_edge(const Band &b, int x0, int y0, int x1, int y1, int thickness, EdgePlan &pl)
+{
+    pl.npieces = 0; pl.hasquad = 0;
+    pl.cx0 = x0; pl.cy0 = y0; pl.cx1 = x1; pl.cy1 = y1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pl.dda[i].valid = 0;
+    const P2 p0 = {(long long)x0 * ONE, (long long)y0 * ONE}, p1 = {(long long)x1 * ONE, (long long)y1 * ONE};
+    const double dx = (double)(p0.x - p1.x) * (1.0 / (double)ONE), dy = (double)(p1.y - p0.y) * (1.0 / (double)ONE);
+    double r = dx * dx + dy * dy;
+    const int odd = thickness & 1;
+    const int half = thickness << (SHIFT - 1);               // half the width, 16.16
+    if (fabs(r) > 2.2204460492503131e-16) {
+        r = ((double)half + (double)odd * (double)ONE * 0.5) / __dsqrt_rn(r);
+        const long long ox = __double2ll_rn(dy * r), oy = __double2ll_rn(dx * r);      // round half to even, like cvRound
+        const P2 q[4] = {{p0.x + ox, p0.y + oy}, {p0.x - ox, p0.y - oy}, {p1.x - ox, p1.y - oy}, {p1.x + ox, p1.y + oy}};
+        pl.hasquad = 1;
+        plan_quad(b, q, pl);
+    }
+    pl.radius = (half + (int)(ONE >> 1)) >> SHIFT;
+}
+
+// ---- phase 2, one WAVE per edge: the plan is wave-uniform, pixels and scanlines go to the lanes ----
+__device__ void draw_dda(const Band &b, const DdaRec &r, int lane)
+{
+    if (!r.valid) return;
+    if (lane == 0) dot(b, r.ex, r.ey);
+    if (r.xmajor)
+        for (int k = lane; k <= r.count; k += 64) dot(b, r.base + k, (int)((r.minor + k * r.step) >> SHIFT));
+    else
+        for (int k = lane; k <= r.count; k += 64) dot(b, (int)((r.minor + k * r.step) >> SHIFT), r.base + k);
+}
+
+__device__ void draw_piece(const Band &b, const Piece &q, int lane)
+{
+    constexpr long long HALF = ONE >> 1;
+    // only the rows inside this band matter: start the lanes at the band's first row of the piece
+    int k0 = b.y0 - q.y0;
+    if (k0 < 0) k0 = 0;
+    int k1 = b.y0 + b.rows - q.y0;
+    if (k1 > q.n) k1 = q.n;
+    for (int k = k0 + lane; k < k1; k += 64) {
+        const int yy = q.y0 + k;
+        if (yy < 0) continue;
+        const long long xa = q.x0 + k * q.d0, xb = q.x1 + k * q.d1;
+        const long long lo = xa > xb ? xb : xa, hi = xa > xb ? xa : xb;
+        const int xl = (int)((lo + HALF) >> SHIFT), xr = (int)((hi + HALF) >> SHIFT);
+        if (xr >= 0 && xl < b.w) span(b, yy, xl < 0 ? 0 : xl, xr >= b.w ? b.w - 1 : xr);
     }
 }
 
@@ -210,24 +269,6 @@ __device__ void disc(const Band &b, int cx, int cy, int radius, int lane)
     }
 }
 
-__device__ void thick_line(const Band &b, int x0, int y0, int x1, int y1, int thickness, int lane)
-{
-    const P2 p0 = {(long long)x0 * ONE, (long long)y0 * ONE}, p1 = {(long long)x1 * ONE, (long long)y1 * ONE};
-    const double dx = (double)(p0.x - p1.x) * (1.0 / (double)ONE), dy = (double)(p1.y - p0.y) * (1.0 / (double)ONE);
-    double r = dx * dx + dy * dy;
-    const int odd = thickness & 1;
-    const int half = thickness << (SHIFT - 1);               // half the width, 16.16
-    if (fabs(r) > 2.2204460492503131e-16) {
-        r = ((double)half + (double)odd * (double)ONE * 0.5) / __dsqrt_rn(r);
-        const long long ox = __double2ll_rn(dy * r), oy = __double2ll_rn(dx * r);      // round half to even, like cvRound
-        const P2 q[4] = {{p0.x + ox, p0.y + oy}, {p0.x - ox, p0.y - oy}, {p1.x - ox, p1.y - oy}, {p1.x + ox, p1.y + oy}};
-        fill_quad(b, q, lane);
-    }
-    const int radius = (half + (int)(ONE >> 1)) >> SHIFT;
-    disc(b, x0, y0, radius, lane);
-    disc(b, x1, y1, radius, lane);
-}
-
 struct Params {
     const void *points;
     const int *segments;
@@ -243,27 +284,51 @@ __device__ __forceinline__ int coord(const Params &p, size_t i)
     return (int)static_cast<const double *>(p.points)[i];
 }
 
+constexpr int EDGE_CHUNK = 96;             // edges planned per round (41 KB of plans in LDS)
+
 __global__ __launch_bounds__(256) void edge_map_band(const Params p)
 {
-    extern __shared__ unsigned bits[];
-    const int tid = threadIdx.x, frame = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    EdgePlan *plans = reinterpret_cast<EdgePlan *>(lds);                       // [EDGE_CHUNK]
+    unsigned *bits = reinterpret_cast<unsigned *>(lds + sizeof(EdgePlan) * EDGE_CHUNK);
+    const int tid = threadIdx.x, lane = tid & 63, frame = blockIdx.y;
     Band b;
     b.bits = bits; b.w = p.w; b.h = p.h; b.words = p.w >> 5;
     b.y0 = blockIdx.x * BAND;
     b.rows = p.h - b.y0 < BAND ? p.h - b.y0 : BAND;
     for (int i = tid; i < BAND * b.words; i += 256) bits[i] = 0u;
-    __syncthreads();
     const size_t base = (size_t)frame * p.npoints * 2;
     const int reach = (p.thickness >> 1) + 2;                  // a primitive never leaves its end points' box by more than this
-    const int lane = tid & 63;
-    for (int s = __builtin_amdgcn_readfirstlane(tid >> 6); s < p.nseg; s += 4) {       // one edge per wave at a time
-        const int ia = p.segments[2 * s], ib = p.segments[2 * s + 1];
-        if ((unsigned)ia >= (unsigned)p.npoints || (unsigned)ib >= (unsigned)p.npoints) continue;
-        const int x0 = coord(p, base + 2 * ia), y0 = coord(p, base + 2 * ia + 1);
-        const int x1 = coord(p, base + 2 * ib), y1 = coord(p, base + 2 * ib + 1);
-        const int lo = (y0 < y1 ? y0 : y1) - reach, hi = (y0 < y1 ? y1 : y0) + reach;
-        if (hi < b.y0 || lo >= b.y0 + b.rows) continue;        // this edge does not touch the band
-        thick_line(b, x0, y0, x1, y1, p.thickness, lane);
+    for (int c0 = 0; c0 < p.nseg; c0 += EDGE_CHUNK) {
+        const int nc = p.nseg - c0 < EDGE_CHUNK ? p.nseg - c0 : EDGE_CHUNK;
+        __syncthreads();                                       // bits zeroed / the previous chunk's plans are no longer read
+        if (tid < nc) {
+            EdgePlan &pl = plans[tid];
+            const int s = c0 + tid;
+            const int ia = p.segments[2 * s], ib = p.segments[2 * s + 1];
+            pl.skip = 1;
+            if ((unsigned)ia < (unsigned)p.npoints && (unsigned)ib < (unsigned)p.npoints) {
+                const int x0 = coord(p, base + 2 * ia), y0 = coord(p, base + 2 * ia + 1);
+                const int x1 = coord(p, base + 2 * ib), y1 = coord(p, base + 2 * ib + 1);
+                const int lo = (y0 < y1 ? y0 : y1) - reach, hi = (y0 < y1 ? y1 : y0) + reach;
+                if (!(hi < b.y0 || lo >= b.y0 + b.rows)) {     // the edge touches this band
+                    pl.skip = 0;
+                    plan_edge(b, x0, y0, x1, y1, p.thickness, pl);
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < nc; e += 4) {
+            const EdgePlan &pl = plans[e];
+            if (pl.skip) continue;
+            if (pl.hasquad) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) draw_dda(b, pl.dda[i], lane);
+                for (int i = 0; i < pl.npieces; ++i) draw_piece(b, pl.pc[i], lane);
+            }
+            disc(b, pl.cx0, pl.cy0, pl.radius, lane);
+            disc(b, pl.cx1, pl.cy1, pl.radius, lane);
+        }
     }
     __syncthreads();
     // expand the band: 4 pixels per thread and step
@@ -302,7 +367,7 @@ int lspraster_edge_maps(const void *points_dev, int point_dtype, int batch, int 
         return fail(LSPRASTER_ERR_UNSUPPORTED, "thickness must be in 2..32 (thickness 1 is a different OpenCV routine; the reference uses 2)");
     if (height < 1 || width < 32 || width % 32 || width > LSPRASTER_MAX_WIDTH) return fail(LSPRASTER_ERR_UNSUPPORTED, "width must be a multiple of 32, <= 4096");
     Params p{points_dev, segments_dev, out_f32_dev, out_u8_dev, point_dtype, npoints, nsegments, thickness, height, width};
-    const size_t smem = (size_t)BAND * (width / 32) * sizeof(unsigned);
+    const size_t smem = sizeof(EdgePlan) * EDGE_CHUNK + (size_t)BAND * (width / 32) * sizeof(unsigned);      // <= 41 KB + 32 KB
     hipLaunchKernelGGL(edge_map_band, dim3((height + BAND - 1) / BAND, batch), dim3(256), smem, static_cast<hipStream_t>(hip_stream), p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LSPRASTER_ERR_HIP, std::string("edge_map_band launch: ") + hipGetErrorString(e));
