@@ -158,7 +158,7 @@ def main():
         ex = sum(layers[i]["exec_flops_per_frame"] for i in idxs) * B
         by = sum(layers[i]["act_bytes_per_frame"] for i in idxs) * B + sum(layers[i]["weight_bytes"] for i in idxs)
         add_row(name, idxs, 1 if name.startswith("igemm3x3") else 3, fl, ex, by, len(idxs))
-    split = [i for i, l in enumerate(layers) if l["split_k"] > 1 and l["kernel"].startswith("igemm3x3")]
+    split = [i for i, l in enumerate(layers) if "+splitk_reduce" in l["kernel"]]
     if split:
         # the reduce launches: no arithmetic; bytes = the fp32 partial slabs they read + the tensor they write
         by = sum((layers[i]["split_k"] * 4 + elt) * layers[i]["cout"] * layers[i]["h_out"] ** 2 for i in split) * B

@@ -48,6 +48,8 @@ struct lspf2f_handle {
     bool packed = false;
     bool use_graph = true;
     bool last_direct = false;     // bf16 plans: direct last-conv kernel instead of the GEMM form (LSP_HIP_LASTCONV_DIRECT, read at create)
+    bool fuse_splitk = true;      // LSP_HIP_FUSED_SPLITK=0 (read at create): always combine split-K slabs with a separate launch
+    bool counters_clean = false;  // the arrival counters at the head of the workspace were zeroed since it was bound
     bool first_direct = false;    // LSP_HIP_FIRSTCONV_DIRECT (read at create): vector-ALU first conv instead of the matrix-core kernel
     int timing_part = 3;          // lspf2f_subset_timed: 1 = main kernels only, 2 = split-K reduce only, 3 = everything (always 3 on the hot path)
     int last_route = 0;           // forced direct last-conv kernel (LSP_HIP_LASTCONV_{STRIP,ROWS,GENERIC}, read at create; tests only)
@@ -100,6 +102,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_GRAPH")) h->use_graph = h->use_graph && std::strcmp(env, "0") != 0;
     h->last_direct = std::getenv("LSP_HIP_LASTCONV_DIRECT") != nullptr;
     h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") != nullptr;
+    if (const char *env = std::getenv("LSP_HIP_FUSED_SPLITK")) h->fuse_splitk = std::strcmp(env, "0") != 0;
     h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
                   : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : 0;
     *out = h;
@@ -178,6 +181,7 @@ int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes)
     if ((uintptr_t)dev_workspace % 256) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
     h->drop_graphs();
     h->cand_cached = nullptr;
+    h->counters_clean = false;
     h->ws = static_cast<char *>(dev_workspace);
     h->ws_size = bytes;
     return LSPF2F_OK;
@@ -202,7 +206,7 @@ static const char *kernel_name(const LayerDesc &l)
         if (l.fullk) return "conv3x3_fullk";
         if (l.inorm) return l.smallm ? "conv3x3_smallm+in_small" : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
                           : l.in_route == kInSmall ? "igemm3x3+in_small" : "igemm3x3+in_reduce_stats+in_finalize+in_apply";
-        return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? "igemm3x3+splitk_reduce" : "igemm3x3");
+        return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? (l.fused_splitk ? "igemm3x3 (split-K combined in the launch)" : "igemm3x3+splitk_reduce") : "igemm3x3");
     }
 }
 
@@ -379,11 +383,27 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
                 }
             }
         } else {
+            const bool fused = l.fused_splitk && h->fuse_splitk;
+            if (fused) {
+                p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
+                p.slab_bytes = (size_t)l.splits * p.Mout * l.cout * sizeof(float);
+            }
             if (h->timing_part & 1) e = launch_igemm(p, l.bm, l.bn, l.group, s);
-            if (e == hipSuccess && l.splits > 1 && (h->timing_part & 2)) e = launch_splitk_reduce(p, s);
+            if (e == hipSuccess && l.splits > 1 && !fused && (h->timing_part & 2)) e = launch_splitk_reduce(p, s);
         }
     }
     if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
+    return LSPF2F_OK;
+}
+
+// the arrival counters of the in-launch split-K combine must be zero before the first launch that uses them; every last arriver
+// resets its own, so once per workspace binding is enough
+static int clean_counters(lspf2f_handle *h, hipStream_t s)
+{
+    if (h->counters_clean) return LSPF2F_OK;
+    const hipError_t e = hipMemsetAsync(h->ws + h->plan.counters_offset(), 0, Plan::kTileCounters * sizeof(unsigned), s);
+    if (e != hipSuccess) return hipfail(e, "hipMemsetAsync (split-K arrival counters)");
+    h->counters_clean = true;
     return LSPF2F_OK;
 }
 
@@ -420,6 +440,8 @@ int lspf2f_forward_ex(lspf2f_handle *h, const float *feat_dev, const float *cand
     int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev ? out_dev : reinterpret_cast<float *>(out_u8_dev), batch);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    rc = clean_counters(h, s);
+    if (rc) return rc;
 
     // The ~80-150 launches of one forward are replayed from a hipGraph (captured once per
     // distinct set of pointers on a private stream), which removes the per-launch host cost that
@@ -501,6 +523,7 @@ int lspf2f_subset_timed(lspf2f_handle *h, const float *feat_dev, const float *ca
     int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev, batch);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if ((rc = clean_counters(h, s)) != 0) return rc;
     const int n = (int)h->plan.layers.size();
     if (!h->cap_stream) {
         const hipError_t e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
@@ -552,6 +575,7 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
     int rc = check_forward_args(h, feat_dev, cand_dev, cand_batch, out_dev, batch);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if ((rc = clean_counters(h, s)) != 0) return rc;
     const int n = (int)h->plan.layers.size();
     std::vector<hipEvent_t> ev(n + 1);
     for (auto &e : ev)

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     // float4 residual loads / stores, 8 lanes per 128-B row segment, 4 instead of 16 memory
     // instructions per tile.  Same-wave LDS traffic needs no barrier (a wave's DS ops execute in order).
     if (ABL(p, 16)) return;
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.tile_cnt ? (int)p.slab_bytes : 0, 0x00020000);
     constexpr int EP = 36;                                   // patch row pitch (floats), keeps rows 16-B aligned
     float *patch = smem + wave * (32 * EP);
     const int ccol = lane & 31, crow = 4 * (lane >> 5);
@@ -320,7 +321,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                     orow = ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
                 }
                 if (p.splits > 1) {
-                    if (ok) *reinterpret_cast<float4 *>(p.partial + ((size_t)z * p.Mout + orow) * p.Cout + n) = v;
+                    if (ok) {
+                        const size_t e = ((size_t)z * p.Mout + orow) * p.Cout + n;
+                        // fused combine: the slab is published to whichever workgroup arrives last at this tile, possibly on another XCD
+                        // (private L2s) -> write-through (sc1) stores, no release fence needed (guide: Guideline 16, R1)
+                        if (p.tile_cnt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab_rsrc, (unsigned)(e * 4), 0, 16);
+                        else *reinterpret_cast<float4 *>(p.partial + e) = v;
+                    }
                 } else {
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                     if (p.residual && ok) {
@@ -363,6 +370,60 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                 *reinterpret_cast<float4 *>(p.pshift + g) = c4;
             }
         }
+    }
+
+    // ---- fused split-K combine (2 <= splits <= 8): the workgroup that arrives LAST at a tile sums the slabs in z order and runs the epilogue,
+    // instead of a separate reduce launch.  Protocol of the guide (Guideline 16, counter form): write-through slab stores above -> every wave
+    // drains its stores -> barrier -> one relaxed agent-scope ticket; the last arriver reads the slabs with sc1 loads (past its L1 / any stale
+    // line), in a fixed order -> bit-reproducible, independent of which slice arrives last.  The counter is reset by the last arriver (and zeroed
+    // once per workspace binding by the host).
+    if (p.tile_cnt == nullptr || p.splits == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                          // also: every wave is done with its epilogue patch (smem reused below)
+    unsigned *flag = reinterpret_cast<unsigned *>(smem);
+    const unsigned tile = (unsigned)(lin - (unsigned)z * gridDim.x);          // logical (parity, M-tile, N-tile) id, the same for every z
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag[0] != (unsigned)p.splits - 1u) return;
+    if (tid == 0) __hip_atomic_store(p.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // tile = BM x BN fp32: thread -> (row r0 + 16 i... ) 16 float4 columns x NT / 16 rows per pass
+    constexpr int C4 = BN / 4, RPP2 = NT / C4;               // float4 columns, rows per pass
+    const int c4i = tid % C4, rr = tid / C4;
+    const int ncol = n0 + c4i * 4;
+    if (ncol >= p.Cout) return;
+    float4 sc2 = make_float4(1.f, 1.f, 1.f, 1.f), sh2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) {
+        sc2 = *reinterpret_cast<const float4 *>(p.scale + ncol);
+        sh2 = *reinterpret_cast<const float4 *>(p.shift + ncol);
+    }
+#pragma unroll 2
+    for (int r = rr; r < BM; r += RPP2) {
+        const int m = m0 + r;
+        if (m >= p.M) break;
+        size_t orow = (size_t)m;
+        if (p.up4) {
+            const int b = (int)p.div_rhw.div((unsigned)m);
+            const int q = m - b * rhw;
+            const int y = (int)p.div_rw.div((unsigned)q), x = q - y * rw;
+            orow = ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
+        }
+        const size_t e = orow * p.Cout + ncol;
+        float4 t[8];
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz)
+            if (zz < p.splits)
+                t[zz] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, (unsigned)(((size_t)zz * p.Mout * p.Cout + e) * 4), 0, 16));
+        float4 v = t[0];
+#pragma unroll
+        for (int zz = 1; zz < 8; ++zz)
+            if (zz < p.splits) { v.x += t[zz].x; v.y += t[zz].y; v.z += t[zz].z; v.w += t[zz].w; }
+        v.x = v.x * sc2.x + sh2.x; v.y = v.y * sc2.y + sh2.y; v.z = v.z * sc2.z + sh2.z; v.w = v.w * sc2.w + sh2.w;
+        if (p.residual) {
+            const float4 rv = load4(static_cast<const T *>(p.residual) + e);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        store4(static_cast<T *>(p.out) + e, v);
     }
 }
 

@@ -54,6 +54,9 @@ struct IgemmParams {
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
     float *psum, *psq, *pshift; // InstanceNorm plans, fused route: per-wave sums of (x - c), (x - c)^2 and the shift c (= the group's
     int in_groups;              //   first row), [B][in_groups][Cout] each (in_groups = wave row-groups per frame); nullptr otherwise
+    size_t slab_bytes;          // bytes of the split-K scratch (buffer-descriptor range of the fused combine)
+    unsigned *tile_cnt;         // fused split-K: one arrival counter per (parity, M-tile, N-tile), zero between launches; nullptr = the
+                                //   partial slabs are combined by a separate splitk_reduce launch
     int out_f32;                // write fp32 output whatever the storage type (GEMM form of the last conv)
     int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
     int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,

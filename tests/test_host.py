@@ -91,7 +91,7 @@ def test_workspace_reuse_and_growth():
     keep = Engine("large", max_batch=8, keep_intermediates=True)
     w1, w8 = e.workspace_bytes(1), e.workspace_bytes(8)
     assert w1 < keep.workspace_bytes(1) / 2, "liveness reuse should at least halve the arena"
-    fixed = 2 * 256 * 256 * 64 * 4        # batch-independent head: the two candidate-share slots (plan.h persistent_bytes)
+    fixed = 2 * 256 * 256 * 64 * 4 + 16384 * 4   # batch-independent head: two candidate-share slots + split-K arrival counters (plan.h)
     assert 6 * (w1 - fixed) < w8 - fixed < 9 * (w1 - fixed)
     # every layer output lies inside the arena, 256-byte aligned
     for l in keep.layers(2):
