@@ -703,6 +703,9 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
 #ifdef LSPF2F_ABLATE
     if (const char *env = std::getenv("LSP_HIP_DBG")) p.dbg = std::atoi(env);   // tools/ablate.sh builds only
 #endif
+#ifdef LSPF2F_IGEMM_STAMPS
+    if (sp == 1 && scratch && scratch_bytes >= (size_t)2048 * 4 * 16 * 8) p.stamps = static_cast<unsigned long long *>(scratch);
+#endif
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     e = launch_igemm(p, bm, bn, grp, s);
     if (e == hipSuccess && sp > 1) e = launch_splitk_reduce(p, s);

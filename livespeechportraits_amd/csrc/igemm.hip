@@ -24,6 +24,13 @@
 
 namespace lspf2f {
 
+// phase timestamps (tools/time_conv.py; builds with -DLSPF2F_IGEMM_STAMPS only)
+#ifdef LSPF2F_IGEMM_STAMPS
+#define ISTAMP(i) do { if (p.stamps && (threadIdx.x & 63) == 0) p.stamps[((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ISTAMP(i) do {} while (0)
+#endif
+
 static constexpr unsigned kOOB = 0x80000000u;   // voffset beyond any num_records: buffer load returns 0
 
 static constexpr int BK = 32;    // K-tile (floats); Cin % 32 == 0 so a K-tile never straddles a tap
@@ -64,6 +71,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
+    ISTAMP(0);
 
     // up4 (sub-pixel form of Upsample x2 + Conv3x3): blockIdx.x also enumerates the 4 output
     // parities (py, px); each is a 2x2-tap conv over the LOW-res source with pre-summed weights,
@@ -251,13 +259,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     if (kt_begin < kt_end && !ABL(p, 32)) {
         constexpr int PIECES = G * (PA + PB);      // DMA instructions this wave issues per step
         const int nsteps = (kt_end - kt_begin + G - 1) / G;
+        ISTAMP(1);
         fetch(kt_begin, 0);
+        ISTAMP(2);
         if (NS > 2 && nsteps > 1) fetch(kt_begin + G, 1);
         if (NS > 2 && nsteps > 1) dma_wait<PIECES>(); else dma_wait<0>();
         __syncthreads();
+        ISTAMP(3);
         int cur = 0;
         read_frag(0, 0, 0);
         for (int t = 0; t < nsteps; ++t) {
+            if (t == 1) ISTAMP(4);
+            if (t == 2) ISTAMP(5);
             // ring slot (cur + NS-1) % NS was last read in step t-1; every wave has passed that barrier
             const int ahead = t + NS - 1;
             const bool issue = ahead < nsteps && !ABL(p, 1);
@@ -283,6 +296,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     // are free after the last barrier) so every lane ends up with 4 consecutive channels of a row:
     // float4 residual loads / stores, 8 lanes per 128-B row segment, 4 instead of 16 memory
     // instructions per tile.  Same-wave LDS traffic needs no barrier (a wave's DS ops execute in order).
+    ISTAMP(6);
     if (ABL(p, 16)) return;
     const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.tile_cnt ? (int)p.slab_bytes : 0, 0x00020000);
     constexpr int EP = 36;                                   // patch row pitch (floats), keeps rows 16-B aligned
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     // drains its stores -> barrier -> one relaxed agent-scope ticket; the last arriver reads the slabs with sc1 loads (past its L1 / any stale
     // line), in a fixed order -> bit-reproducible, independent of which slice arrives last.  The counter is reset by the last arriver (and zeroed
     // once per workspace binding by the host).
+    ISTAMP(7);
     if (p.tile_cnt == nullptr || p.splits == 1) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                          // also: every wave is done with its epilogue patch (smem reused below)

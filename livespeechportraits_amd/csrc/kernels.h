@@ -59,6 +59,7 @@ struct IgemmParams {
                                 //   partial slabs are combined by a separate splitk_reduce launch
     int out_f32;                // write fp32 output whatever the storage type (GEMM form of the last conv)
     int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
+    unsigned long long *stamps; // -DLSPF2F_IGEMM_STAMPS builds: [blocks][4 waves][16] cycle counters (tools/time_conv.py)
     int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,
                                 // 4 no barrier, 8 no buffer flip, 16 no epilogue, 32 no K loop
 };

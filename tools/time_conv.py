@@ -17,7 +17,7 @@ def main():
     sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     out = torch.empty(b, ho, ho, cout, device=dev)
     sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, up, tm, tn, 0, 0, 0)
-    scratch = torch.zeros(max(sb, 512 * 4 * 16 * 8), dtype=torch.uint8, device=dev)
+    scratch = torch.zeros(max(sb, 2048 * 4 * 16 * 8), dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run():
@@ -31,12 +31,14 @@ def main():
         for _ in range(10): run()
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 100)
     ts.sort()
-    st64 = scratch[:512 * 4 * 16 * 8].view(torch.int64).view(512, 4, 16).cpu().numpy()
+    st64 = scratch[:2048 * 4 * 16 * 8].view(torch.int64).view(2048, 4, 16).cpu().numpy()
     if st64.any():
         import numpy as np
         nb = (st64[:, 0, 0] != 0).sum()
         d = (st64[:nb] - st64[:nb, :, :1]).astype(np.float64)
         names = ["start", "dma issued", "6 taps issued", "dma landed", "barrier", "tap0", "tap1", "tap2", "tap3", "tap4", "tap5", "tap6", "tap7", "tap8", "k done", "end"]
+        if tm >= 64:
+            names = ["start", "descriptors done", "first fetch issued", "first tile landed+barrier", "K step 1", "K step 2", "K loop done", "epilogue done"] + ["-"] * 8
         print("stamps (shader cycles since kernel entry of the wave; median / p90 over %d blocks x 4 waves):" % nb)
         for i, n_ in enumerate(names):
             print("   %-14s %8.0f %8.0f" % (n_, np.median(d[:, :, i]), np.percentile(d[:, :, i], 90)))
