@@ -24,11 +24,17 @@
 
 namespace lspf2f {
 
-// phase timestamps (tools/time_conv.py; builds with -DLSPF2F_IGEMM_STAMPS only)
+// phase timestamps (tools/time_conv.py; builds with -DLSPF2F_IGEMM_STAMPS only): s_memtime values are wave-uniform scalars kept in
+// registers and written once at the end, so the instrumented kernel keeps its control flow
 #ifdef LSPF2F_IGEMM_STAMPS
-#define ISTAMP(i) do { if (p.stamps && (threadIdx.x & 63) == 0) p.stamps[((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define ISTAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ISTAMP_DECL unsigned long long stamp_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define ISTAMP_FLUSH do { if (p.stamps && (threadIdx.x & 63) == 0) { unsigned long long *q_ = p.stamps + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + (threadIdx.x >> 6)) * 16; \
+    for (int i_ = 0; i_ < 16; ++i_) q_[i_] = stamp_t[i_]; } } while (0)
 #else
 #define ISTAMP(i) do {} while (0)
+#define ISTAMP_DECL do {} while (0)
+#define ISTAMP_FLUSH do {} while (0)
 #endif
 
 static constexpr unsigned kOOB = 0x80000000u;   // voffset beyond any num_records: buffer load returns 0
@@ -71,33 +77,44 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
+    ISTAMP_DECL;
     ISTAMP(0);
+    // The argument block is read with scalar loads that miss the scalar cache once per launch and CU (~650 cycles each round trip).  Left alone,
+    // the compiler sinks the loads next to their uses, i.e. into three dependent round trips spread over the prologue; naming the fields here
+    // keeps all of them in the entry block -> one round trip (tools/time_conv.py stamps: -1300 cycles of ~4000 before the first fetch).
+    asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.partial));
+    asm volatile("" :: "s"(p.B), "s"(p.Hs), "s"(p.Ws), "s"(p.Ho), "s"(p.Wo), "s"(p.C0), "s"(p.C1), "s"(p.Cin), "s"(p.Cout), "s"(p.stride),
+                       "s"(p.up4), "s"(p.relu), "s"(p.M), "s"(p.Mout), "s"(p.ktiles_total), "s"(p.ktiles_per_split), "s"(p.splits));
+    asm volatile("" :: "s"(p.div_rhw.m), "s"(p.div_rhw.s1), "s"(p.div_rhw.s2), "s"(p.div_rw.m), "s"(p.div_rw.s1), "s"(p.div_rw.s2),
+                       "s"(p.div_gx.m), "s"(p.div_gx.s1), "s"(p.div_gx.s2), "s"(p.div_tile.m), "s"(p.div_tile.s1), "s"(p.div_tile.s2),
+                       "s"(p.div_cin.m), "s"(p.div_cin.s1), "s"(p.div_cin.s2), "s"(p.ntm), "s"(p.ntn), "s"(p.gx), "s"(p.gy), "s"(p.psum), "s"(p.tile_cnt),
+                       "s"(p.out_f32), "s"(p.xcd));
 
     // up4 (sub-pixel form of Upsample x2 + Conv3x3): blockIdx.x also enumerates the 4 output
     // parities (py, px); each is a 2x2-tap conv over the LOW-res source with pre-summed weights,
     // M counts low-res positions, and row m lands on output pixel (2y+py, 2x+px).
-    const int ntn = (p.Cout + BN - 1) / BN;
     // XCD-aware order: the dispatcher deals workgroups round-robin over the 8 XCDs (private L2s),
     // so logical tile ids are handed out in 8 contiguous chunks -- one XCD works on one band of
     // image rows (m-major: activations fetched once, weights by every XCD) or on one band of
     // output channels / K-splits (n-major, weight-heavy layers: weights fetched once).
-    unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    unsigned lin = blockIdx.x + blockIdx.y * (unsigned)p.gx;
     if (p.xcd) {
-        const unsigned total = gridDim.x * gridDim.y, q = total >> 3, r = total & 7, x = lin & 7;
+        const unsigned total = (unsigned)(p.gx * p.gy), q = total >> 3, r = total & 7, x = lin & 7;
         lin = x * q + (x < r ? x : r) + (lin >> 3);
     }
-    const int z = (int)(lin / gridDim.x);
-    int bx = (int)(lin - (unsigned)z * gridDim.x), par = 0;
+    const int z = (int)p.div_gx.div(lin);                // the scalar divisions of this prologue are multiplies by launch constants
+    int bx = (int)(lin - (unsigned)(z * p.gx)), par = 0;
     if (p.up4) { par = bx & 3; bx >>= 2; }
     const int py = par >> 1, px = par & 1;
     int mt, nt;
-    if (p.xcd == 2) { const int ntm = (p.M + BM - 1) / BM; nt = bx / ntm; mt = bx - nt * ntm; }
-    else { mt = bx / ntn; nt = bx - mt * ntn; }
+    if (p.xcd == 2) { nt = (int)p.div_tile.div((unsigned)bx); mt = bx - nt * p.ntm; }
+    else { mt = (int)p.div_tile.div((unsigned)bx); nt = bx - mt * p.ntn; }
     const int m0 = mt * BM, n0 = nt * BN;
     const int kt_begin = z * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split;
     if (kt_end > p.ktiles_total) kt_end = p.ktiles_total;
 
+    ISTAMP(8);
     const int lrow = tid >> 3;
     // staging: thread = (row lrow of each 8-row wave stripe, 16-B slot tid&7); it fetches the k-quad that
     // belongs in its slot
@@ -145,6 +162,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             a_mask[i] = mask;
         }
     }
+    ISTAMP(9);
     const int K = ntap * p.Cin;
     const T *wbase = static_cast<const T *>(p.w) + (size_t)par * p.Cout * K;
     unsigned b_off[PB];                                  // byte offset of this thread's weight row, or OOB
@@ -158,9 +176,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
 
     // K-tile cursor of the NEXT tile to fetch: tap = ky*tw+kx, c = channel offset inside the
     // concatenated input
-    int tap = (kt_begin * BKE) / p.Cin;
+    int tap = (int)p.div_cin.div((unsigned)(kt_begin * BKE));
     int c = kt_begin * BKE - tap * p.Cin;
-    int ky = tap / tw, kx = tap - ky * tw;
+    int ky = p.up4 ? tap >> 1 : (tap * 11) >> 5, kx = tap - ky * tw;     // tap / tw for tap <= 8
 
     // Stage K-tiles kt .. kt+G-1 into LDS buffer `buf` with buffer_load ... lds (LDS-DMA): no staging
     // registers, no ds_write; invalid taps / ragged rows use an out-of-range voffset and land as zeros
@@ -204,6 +222,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
         }
     };
 
+    // Epilogue operands fetched before the K loop: the folded-BN scale / shift of this lane's channel quad and (tiles of <= 2 MFMA blocks per wave)
+    // the residual rows.  Issued in the epilogue they are dependent global-load round trips with the MFMA pipe already idle (~2 us of a ~47-us
+    // launch); issued here they ride under the first fetch.  They are OLDER than every LDS-DMA piece, and loads return in order, so the counted
+    // vmcnt waits of the K loop are unaffected.
+    const int erow = lane >> 3, ecol = (lane & 7) * 4;      // epilogue role of this lane: row within an 8-row pass, first channel of its quad
+    constexpr bool PRE = TM * TN <= 2;
+    const bool pre_res = PRE && p.residual != nullptr && p.splits == 1 && !p.up4;
+    float4 scv[TN], shv[TN];
+    float4 rpre[PRE ? TM : 1][PRE ? TN : 1][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + ecol;
+        scv[j] = make_float4(1.f, 1.f, 1.f, 1.f); shv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.splits == 1 && p.scale && n < p.Cout) {
+            scv[j] = *reinterpret_cast<const float4 *>(p.scale + n);
+            shv[j] = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int m = m0 + (wm * TM + i) * 32 + pass * 8 + erow;
+                    rpre[i][j][pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pre_res && m < p.M && n < p.Cout)
+                        rpre[i][j][pass] = load4(static_cast<const T *>(p.residual) + (size_t)m * p.Cout + n);
+                }
+        }
+    }
+    ISTAMP(10);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -269,8 +317,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
         int cur = 0;
         read_frag(0, 0, 0);
         for (int t = 0; t < nsteps; ++t) {
-            if (t == 1) ISTAMP(4);
-            if (t == 2) ISTAMP(5);
+
             // ring slot (cur + NS-1) % NS was last read in step t-1; every wave has passed that barrier
             const int ahead = t + NS - 1;
             const bool issue = ahead < nsteps && !ABL(p, 1);
@@ -302,17 +349,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     constexpr int EP = 36;                                   // patch row pitch (floats), keeps rows 16-B aligned
     float *patch = smem + wave * (32 * EP);
     const int ccol = lane & 31, crow = 4 * (lane >> 5);
-    const int erow = lane >> 3, ecol = (lane & 7) * 4;      // this lane's (row within 8-row pass, first channel)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nb = n0 + (wn * TN + j) * 32;              // first channel of the tile
         const int n = nb + ecol;
         const bool nok = n < p.Cout;                         // Cout % 4 == 0: a float4 is all-in or all-out
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.splits == 1 && p.scale && nok) {
-            sc = *reinterpret_cast<const float4 *>(p.scale + n);
-            sh = *reinterpret_cast<const float4 *>(p.shift + n);
-        }
+        const float4 sc = scv[j], sh = shv[j];
         // InstanceNorm plans: sums of (x - c) and (x - c)^2 over this lane's rows, c = the value in the wave's first row (a shift
         // close to the mean keeps var = E[d^2] - E[d]^2 free of cancellation; in_finalize merges the groups in double)
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f), c4 = s1;
@@ -344,7 +386,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                     }
                 } else {
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                    if (p.residual && ok) {
+                    if (pre_res) {
+                        if constexpr (PRE) { const float4 rv = rpre[i][j][pass]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                    } else if (p.residual && ok) {
                         const float4 rv = load4(static_cast<const T *>(p.residual) + orow * p.Cout + n);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
@@ -392,11 +436,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     // line), in a fixed order -> bit-reproducible, independent of which slice arrives last.  The counter is reset by the last arriver (and zeroed
     // once per workspace binding by the host).
     ISTAMP(7);
+    ISTAMP_FLUSH;
     if (p.tile_cnt == nullptr || p.splits == 1) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                          // also: every wave is done with its epilogue patch (smem reused below)
     unsigned *flag = reinterpret_cast<unsigned *>(smem);
-    const unsigned tile = (unsigned)(lin - (unsigned)z * gridDim.x);          // logical (parity, M-tile, N-tile) id, the same for every z
+    const unsigned tile = (unsigned)(lin - (unsigned)(z * p.gx));          // logical (parity, M-tile, N-tile) id, the same for every z
     if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (flag[0] != (unsigned)p.splits - 1u) return;
@@ -533,8 +578,13 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
         if (e != hipSuccess) return e;
     }
+    IgemmParams q = p;
+    q.ntm = ntm; q.ntn = ntn; q.gx = ntm * ntn * npar; q.gy = p.splits;
+    q.div_gx = FastDiv::make((unsigned)(ntm * ntn * npar));
+    q.div_tile = FastDiv::make((unsigned)(p.xcd == 2 ? ntm : ntn));
+    q.div_cin = FastDiv::make((unsigned)p.Cin);
     hipLaunchKernelGGL((igemm3x3<T, BM, BN, WGM, WGN, G, UP>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
-                       smem, s, p);
+                       smem, s, q);
     return hipGetLastError();
 }
 

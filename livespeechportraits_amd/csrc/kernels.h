@@ -52,6 +52,8 @@ struct IgemmParams {
     int ktiles_per_split;
     int splits;
     FastDiv div_rhw, div_rw;    // dividers by the M-space extents (filled by launch_igemm)
+    FastDiv div_gx, div_tile, div_cin;   // by gridDim.x, by the tile count of the fast-running tile index (ntn, or ntm when xcd == 2), by Cin:
+    int ntm, ntn, gx, gy;       //   the per-block scalar divisions of the prologue as multiplies; gx, gy = the grid (filled by the launcher)
     float *psum, *psq, *pshift; // InstanceNorm plans, fused route: per-wave sums of (x - c), (x - c)^2 and the shift c (= the group's
     int in_groups;              //   first row), [B][in_groups][Cout] each (in_groups = wave row-groups per frame); nullptr otherwise
     size_t slab_bytes;          // bytes of the split-K scratch (buffer-descriptor range of the fused combine)

@@ -38,11 +38,14 @@ def main():
         d = (st64[:nb] - st64[:nb, :, :1]).astype(np.float64)
         names = ["start", "dma issued", "6 taps issued", "dma landed", "barrier", "tap0", "tap1", "tap2", "tap3", "tap4", "tap5", "tap6", "tap7", "tap8", "k done", "end"]
         if tm >= 64:
-            names = ["start", "descriptors done", "first fetch issued", "first tile landed+barrier", "K step 1", "K step 2", "K loop done", "epilogue done"] + ["-"] * 8
+            names = ["start", "descriptors done", "first fetch issued", "first tile landed+barrier", "-", "-", "K loop done", "epilogue done", "tile ids done", "row descriptors done", "weight offsets done"] + ["-"] * 5
         print("stamps (shader cycles since kernel entry of the wave; median / p90 over %d blocks x 4 waves):" % nb)
         for i, n_ in enumerate(names):
             print("   %-14s %8.0f %8.0f" % (n_, np.median(d[:, :, i]), np.percentile(d[:, :, i], 90)))
-        t0 = st64[:nb, :, 0].min(); print("   first wave start -> last wave end: %d cycles; spread of starts %d" % (st64[:nb, :, 15].max() - t0, st64[:nb, :, 0].max() - t0))
+        last = 7 if tm >= 64 else 15
+        for x in range(8):      # each XCD has its own counter: dispatch order deals block i to XCD i % 8
+            sub = st64[x:nb:8]
+            t0 = sub[:, :, 0].min(); print("   XCD %d: first wave start -> last wave end %d cycles; spread of starts %d" % (x, sub[:, :, last].max() - t0, sub[:, :, 0].max() - t0))
     gf = 2 * cout * (c0 + c1) * 9 * ho * ho * b / 1e9
     print("c%d+%d o%d h%d%s b%d tile %dx%d: %.1f us per launch (10 back-to-back), %.1f TFLOP/s" % (c0, c1, cout, hs, "up" if up else "", b, tm, tn, ts[len(ts)//2], gf / ts[len(ts)//2] * 1e3 / 1e3))
 
