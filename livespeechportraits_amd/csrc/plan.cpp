@@ -236,6 +236,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wfk_off = (int64_t)off;
             off += (size_t)l.cout * 9 * l.cin * sizeof(float);
         }
+        if (l.kind == kIgemm && rowconv_layer(l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+            off = align_up(off, 256);
+            l.wrc_off = (int64_t)off;
+            off += (size_t)l.cout * 9 * l.cin * elt();
+        }
         if (!l.bnkey.empty() || !l.biaskey.empty()) {   // a conv bias travels as (scale 1, shift bias)
             off = align_up(off, 256);
             l.scale_off = (int64_t)off; off += (size_t)l.cout * sizeof(float);
@@ -330,6 +335,8 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             const int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
             if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
+            const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho) : 0;
+            if (rowconv) { bm = 64 * rowconv; bn = 64; splits = 1; group = 1; }
             int route = kInNone;
             if (l.inorm) {
                 // rows of one wave (32 per 32x32 tile row, bm / 2 waves... = bm / 2 for the 2x2-wave tiles) must stay inside one
@@ -352,7 +359,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 (*tiled)[li].fused_splitk = p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
                                             (size_t)splits * Mout * l.cout * sizeof(float) < (size_t)0x7fffffff;
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
-                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk;
+                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv;
             }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }
@@ -464,6 +471,8 @@ std::string Plan::pack(void *blob, size_t bytes) const
                 d16[i] = (uint16_t)(u >> 16);
             }
         }
+        if (l.wrc_off >= 0)     // the same bf16 values, regrouped into the MFMA A-fragments the row kernel keeps in registers
+            pack_rowconv_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wrc_off));
         if (!l.biaskey.empty()) {
             const float *bv = get(l.biaskey).data.data();
             float *sc = reinterpret_cast<float *>(base + l.scale_off);

@@ -1,0 +1,334 @@
+// gfx950: weights-stationary 3x3 convolution for the 64 -> 64 channel layers in bf16 storage (the 256x256 level).  DESIGN.md section 4.4.
+//
+// In bf16 these layers are HBM-bound (algorithmic: 128 B in + 128 B out per pixel for 73.7 kFLOP; the MFMA time is half the transfer time
+// at 8 frames), and the implicit-GEMM kernel runs them at a fifth of the HBM roofline because im2col pulls every input pixel through the
+// CU's vector-memory path nine times.  Here every input pixel enters the CU ONCE:
+//   * a workgroup owns a strip of R output rows x 64 pixels; wave (pg, nb) computes pixels pg*32 .. +31 x channels nb*32 .. +31 of every row
+//     and sweeps down the R + 2 input rows it needs.  Each wave copies ITS 34-pixel window of an input row global -> LDS by LDS-DMA into a
+//     private ring (RC_PF rows ahead; 128-B pixel records, 16-B chunks XOR-swizzled exactly as the igemm's K-tiles).  Private rings cost the
+//     second wave of a pixel group a re-read (an L1 hit), and buy a kernel without a single barrier: a wave waits on its own vmcnt only, and
+//     the first fragments of the next row are read while the last MFMAs of this row run;
+//   * the whole weight tensor (64 x 576 bf16 = 72 KB) lives in REGISTERS: a wave holds the 36 A-fragments of its 32 output channels
+//     (144 VGPRs) for the lifetime of the workgroup and multiplies them with pixel fragments read from its ring
+//     (v_mfma_f32_32x32x16_bf16, A = weights [32 ch x 16 k], B = pixels [16 k x 32 px]);
+//   * one fragment read of input row i feeds three MFMAs -- tap rows ky = 0, 1, 2 go to the accumulators of output rows i, i-1, i-2 --
+//     so LDS traffic is a third of a tap-by-tap loop; accumulators rotate by unrolling the row loop three times;
+//   * when input row i has been consumed output row i-2 is complete: the wave parks its 32 px x 32 ch tile (fp32) in a private LDS patch
+//     and finishes it DURING the next step, between that step's MFMAs (one wave per SIMD: nothing else would cover the epilogue): read
+//     the patch transposed (a lane then owns 8 consecutive channels of a pixel), add the residual row (fetched by LDS-DMA into a per-wave
+//     ring RC_PF steps earlier), scale / shift / ReLU in the igemm epilogue's operation order, store 16 B per lane.
+// Every wave issues the same number of vector-memory operations per row step (5 input pieces, 2 residual pieces, 2 stores; out-of-range
+// ones are addressed outside their buffer and dropped by the hardware), so the LDS-DMA waits are counted vmcnt waits (loads and stores
+// retire in order on gfx9).  Same packed weights [Cout][9][Cin] as the igemm; same accumulation order (ky, kx, channel block) -> same bits.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace lspf2f {
+
+namespace {
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+constexpr int RC_TW = 64;                 // output pixels per strip row
+constexpr int RC_ROWB = 5120;             // bytes per ring row of a wave: 40 pixel records of 128 B = 5 DMA pieces (34 are real)
+constexpr int RC_NR = 5;                  // ring rows per wave; rows are fetched RC_NR - 1 steps ahead
+constexpr int RC_PF = RC_NR - 1;
+constexpr int RC_RES_SLOT = 2048;         // per-wave residual slot: 32 px x 64 B
+constexpr int RC_RES_NR = RC_PF + 1;      // a residual row is fetched RC_PF steps before its epilogue
+constexpr int RC_PATCH = 32 * 144;        // per-wave epilogue patch: 32 px x (128 B + 16 B pad), fp32
+constexpr int RC_IN = 5, RC_RP = 2, RC_ST = 2;          // vector-memory operations per step and wave: input pieces, residual pieces, stores
+constexpr int RC_OPS = RC_IN + RC_RP + RC_ST;
+constexpr unsigned kOOB = 0x80000000u;
+
+// Counted-wait bound for the rows issued by the prologue (RC_PF statements, statement k = input row k then residual row k - 3).  Row k
+// is waited for after k complete steps; the bound is the number of operations issued after it (and after residual row k - 3, which the
+// same step finishes), minimised over k < RC_PF (a smaller count only waits longer).
+constexpr int rc_early_wait()
+{
+    int best = 1 << 20;
+    for (int k = 0; k < RC_PF; ++k) {
+        const int after_res = (RC_IN + RC_RP) * (RC_PF - 1 - k) + RC_OPS * k;      // the residual pieces close statement k
+        if (after_res < best) best = after_res;
+    }
+    return best;
+}
+static_assert(RC_PF >= 3 && (RC_PF - 1) * RC_OPS < 64, "vmcnt is a 6-bit counter");
+
+template <int N> __device__ __forceinline__ void vm_wait()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+}  // namespace
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void rowconv64(const RowConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = wave & 1, pg = wave >> 1;           // this wave: output channels nb*32.., pixels pg*32.. of the strip
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    asm volatile("" :: "s"(p.src), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.R),
+                       "s"(p.relu), "s"(p.wfrag), "s"(p.nsx), "s"(p.nsy), "s"(p.nblocks), "s"(p.div_sx.m), "s"(p.div_sx.s1), "s"(p.div_sx.s2),
+                       "s"(p.div_sy.m), "s"(p.div_sy.s1), "s"(p.div_sy.s2));
+
+    // strip of this workgroup; XCD-aware order: each XCD (private L2) works on vertically adjacent strips, which share their halo rows
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned total = (unsigned)p.nblocks, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const unsigned t1 = p.div_sx.div(lin);
+    const int sx = (int)(lin - t1 * (unsigned)p.nsx);
+    const int b = (int)p.div_sy.div(t1);
+    const int sy = (int)(t1 - (unsigned)b * (unsigned)p.nsy);
+    const int x0 = sx * RC_TW, y0 = sy * p.R;
+    const unsigned imgbytes = (unsigned)(p.H * p.W) * 128u;
+    const i32x4 srd_in = make_srd(static_cast<const char *>(p.src) + (size_t)b * imgbytes, imgbytes);
+    const i32x4 srd_res = make_srd(RES ? static_cast<const char *>(p.residual) + (size_t)b * imgbytes : static_cast<const char *>(p.src), RES ? imgbytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<char *>(p.out) + (size_t)b * imgbytes, 0, (int)imgbytes, 0x00020000);
+
+    // LDS map: per wave [RC_NR] input rows | per wave [RC_RES_NR] residual slots | per wave patch
+    const unsigned lds_ring = lds0 + (unsigned)wave * (RC_NR * RC_ROWB);
+    const unsigned lds_res = lds0 + 4 * RC_NR * RC_ROWB + (unsigned)wave * (RC_RES_NR * RC_RES_SLOT);
+    float *patch = smem + (4 * RC_NR * RC_ROWB + 4 * RC_RES_NR * RC_RES_SLOT) / 4 + wave * (RC_PATCH / 4);
+
+    // ---- DMA roles.  Input row: piece q moves record slots q*64 + lane (a slot = one 16-B chunk of a pixel record; record r = pixel
+    // x0 + pg*32 - 1 + r); the lane fetches the chunk that belongs in its slot under the swizzle  slot c of record r <- chunk c ^ ((r >> 1) & 7).
+    unsigned in_col[RC_IN];                  // byte offset of (x, chunk) inside an image row, or kOOB (padding column / filler record)
+#pragma unroll
+    for (int q = 0; q < RC_IN; ++q) {
+        const int sl = q * 64 + lane, r = sl >> 3, c = sl & 7;
+        const int x = x0 + pg * 32 - 1 + r;
+        in_col[q] = (r < 34 && (unsigned)x < (unsigned)p.W) ? (unsigned)(x * 128 + ((c ^ ((r >> 1) & 7)) << 4)) : kOOB;
+    }
+    // Residual row (private ring): piece q, lane i <- pixel 16q + (i >> 2), 16-B chunk (i & 3) of this wave's 64 B per pixel --
+    // the ownership the epilogue has after its transpose (lane i: pixel 16*pass + (i >> 2), channels (i & 3)*8 .. +7), so it reads slot + lane*16.
+    unsigned res_col[RC_RP];
+#pragma unroll
+    for (int q = 0; q < RC_RP; ++q)
+        res_col[q] = (unsigned)((x0 + pg * 32 + 16 * q + (lane >> 2)) * 128 + nb * 64 + (lane & 3) * 16);
+    const unsigned rowbytes = (unsigned)p.W * 128u;
+
+    // The 5 + 2 pieces of one step in ONE statement: M0 (LDS base of an LDS-DMA) is compiler-reserved, so it is saved and restored once
+    // per step instead of once per piece (7 pieces: 23 instead of 35 issue slots, and this kernel is issue-bound, see the end of the header)
+    auto dma_step = [&](int i, int j) {      // input row i of the strip (image row y0 - 1 + i) -> ring slot i % RC_NR; residual row j -> slot j % RC_RES_NR
+        const int gyi = y0 - 1 + i, gyj = y0 + j;
+        const bool oki = (unsigned)gyi < (unsigned)p.H && i < p.R + 2;
+        const bool okj = RES && j >= 0 && j < p.R && gyj < p.H;
+        const int soffi = oki ? gyi * (int)rowbytes : 0, soffj = okj ? gyj * (int)rowbytes : 0;
+        const unsigned basei = lds_ring + (unsigned)(i % RC_NR) * RC_ROWB;
+        const unsigned basej = lds_res + (unsigned)(((j % RC_RES_NR) + RC_RES_NR) % RC_RES_NR) * RC_RES_SLOT;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %8, %9 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %8, %9 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %5, %8, %9 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %6, %8, %9 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %7, %8, %9 offen lds\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %11, %12, %13 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(basei), "s"(basej),
+                       "v"(oki ? in_col[0] : kOOB), "v"(oki ? in_col[1] : kOOB), "v"(oki ? in_col[2] : kOOB), "v"(oki ? in_col[3] : kOOB), "v"(oki ? in_col[4] : kOOB),
+                       "s"(srd_in), "s"(soffi),
+                       "v"(okj ? res_col[0] : kOOB), "v"(okj ? res_col[1] : kOOB), "s"(srd_res), "s"(soffj)
+                     : "memory", "scc");
+    };
+    static_assert(RC_IN == 5 && RC_RP == 2, "dma_step is written out for 5 + 2 pieces");
+
+    // ---- weights -> registers: A-fragment (tap, kc) of this wave's 32 channels: lane = channel nb*32 + l31, k = kc*16 + 8*hi .. +7
+    bf16x8 wf[9][4];
+    if (p.wfrag) {                           // fragment order: 1 KB per instruction, coalesced (72 KB per workgroup in ~1200 cycles)
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(p.w) + (size_t)nb * 36 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                wf[t][kc] = wp[(t * 4 + kc) * 64];
+    } else {                                 // row layout [64][9][64] (single-layer entry point): 16 B per 1152-B row and lane
+        const bf16_t *wrow = static_cast<const bf16_t *>(p.w) + (size_t)(nb * 32 + l31) * 576 + hi * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                wf[t][kc] = *reinterpret_cast<const bf16x8 *>(wrow + t * 64 + kc * 16);
+    }
+    // epilogue constants of this lane's 8 channels (after the transpose): nb*32 + (lane & 3)*8 ..
+    float sc[8], sh[8];
+    {
+        const int c0 = nb * 32 + (lane & 3) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sc[t] = p.scale ? p.scale[c0 + t] : 1.f; sh[t] = p.scale ? p.shift[c0 + t] : 0.f; }
+    }
+    // make sure the weights have landed before the counted waits start (they count every vector-memory operation of the wave)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // B-fragment addresses inside a ring row: pixel record r = l31 + kx, chunk kc*2 + hi, swizzled
+    unsigned boff[3][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int r = l31 + kx;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) boff[kx][kc] = (unsigned)(r * 128 + (((kc * 2 + hi) ^ ((r >> 1) & 7)) << 4));
+    }
+    auto frag = [&](int i, int f) {          // fragment f = kx*4 + kc of input row i
+        return *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(smem) + (lds_ring - lds0) + (unsigned)(i % RC_NR) * RC_ROWB + boff[f >> 2][f & 3]);
+    };
+
+    f32x16 acc0, acc1, acc2;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    // second half of the epilogue of output row j (its tile sits in the patch): one pass = 16 pixels of the tile
+    auto finish = [&](int j, int pass) {
+        const bool live = j >= 0 && j < p.R && y0 + j < p.H;
+        const unsigned resbase = (lds_res - lds0) + (unsigned)(((j % RC_RES_NR) + RC_RES_NR) % RC_RES_NR) * RC_RES_SLOT;
+        const int px = 16 * pass + (lane >> 2);
+        const char *src = reinterpret_cast<const char *>(patch) + px * 144 + (lane & 3) * 32;
+        const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 16);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = v[t] * sc[t] + sh[t];
+        if (RES) {
+            const u32x4 rv = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(smem) + resbase + pass * 1024 + lane * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v[2 * t] += __uint_as_float(rv[t] << 16);
+                v[2 * t + 1] += __uint_as_float(rv[t] & 0xffff0000u);
+            }
+        }
+        // ReLU on the rounded pair: a bf16 is negative iff it is negative as a 16-bit integer, and rounding keeps sign and zero, so
+        // max(., 0) on the packed halves (v_pk_max_i16) equals rounding fmaxf(v, 0) -- one instruction per pair instead of two
+        unsigned o0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned w = pack_bf16x2(v[2 * t], v[2 * t + 1]);
+            if (RELU) w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0}));
+            o0[t] = w;
+        }
+        const u32x4 o = {o0[0], o0[1], o0[2], o0[3]};
+        const unsigned off = live ? (unsigned)(((y0 + j) * p.W + x0 + pg * 32 + px) * 128 + nb * 64 + (lane & 3) * 16) : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+    };
+
+    // One step = input row i: its three tap rows go to output rows i (an, started here), i-1 (am) and i-2 (ao, complete after this step);
+    // the tile of output row i-3, parked in the patch by the previous step, is finished between the MFMAs.  The fragment registers are a
+    // ring of 3 read two fragments ahead; the first two fragments of a row are read by the PREVIOUS step (f0, f1), after it has waited for
+    // the row: input row i+1 and residual row i-2 were both issued RC_PF - 1 steps before this one, so once this step has issued all its
+    // own operations, at most the operations of the last RC_PF - 1 steps may still be in flight.
+    bf16x8 f0, f1;
+    auto step = [&](int i, f32x16 &an, f32x16 &am, f32x16 &ao) {
+        dma_step(i + RC_PF, i + RC_PF - 3);
+        bf16x8 bfr[3];
+        bfr[0] = f0; bfr[1] = f1;
+#pragma unroll
+        for (int f = 0; f < 12; ++f) {
+            if (f + 2 < 12) bfr[(f + 2) % 3] = frag(i, f + 2);
+            const int kx = f >> 2, kc = f & 3;
+            ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[6 + kx][kc], bfr[f % 3], ao, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[3 + kx][kc], bfr[f % 3], am, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0 + kx][kc], bfr[f % 3], f == 0 ? zero16 : an, 0, 0, 0);   // output row i starts here: C = 0
+            if (f == 1) finish(i - 3, 0);
+            if (f == 5) finish(i - 3, 1);
+            if (f == 8) {
+                if (i + 1 < RC_PF) vm_wait<rc_early_wait()>(); else vm_wait<(RC_PF - 1) * RC_OPS>();
+            }
+            if (f == 9) f0 = frag(i + 1, 0);
+            if (f == 10) f1 = frag(i + 1, 1);
+        }
+        // park the tile of output row i - 2.  D layout: lane = pixel l31, register r = channel 8*(r >> 2) + 4*hi + (r & 3); the patch is
+        // pixel-major fp32, so reading it back 32 B per lane transposes the tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(patch) + l31 * 144 + g * 32 + hi * 16) = make_float4(ao[4 * g], ao[4 * g + 1], ao[4 * g + 2], ao[4 * g + 3]);
+    };
+
+    // ---- prologue: the first RC_PF input rows and the residual rows whose epilogue comes within the first RC_PF steps
+    // (output row j is complete after step j + 2 and finished during step j + 3, so its residual is fetched at step j + 3 - RC_PF)
+    // (issued as RC_PF full steps: the residual half of a statement that has no row to fetch is addressed out of range, like every filler)
+#pragma unroll
+    for (int i = 0; i < RC_PF; ++i) dma_step(i, i - 3);
+    vm_wait<rc_early_wait()>();
+    f0 = frag(0, 0); f1 = frag(0, 1);
+
+    const int nsteps = p.R + 2;               // rounded up to a multiple of 3 by the rotation; the extra steps move zeros and store nothing
+    int i = 0;
+    for (; i < nsteps; i += 3) {
+        step(i, acc0, acc2, acc1);
+        step(i + 1, acc1, acc0, acc2);
+        step(i + 2, acc2, acc1, acc0);
+    }
+    // the tile parked by the last step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    finish(i - 3, 0);
+    finish(i - 3, 1);
+}
+
+void pack_rowconv_weights(const unsigned short *rows, unsigned short *out)
+{
+    // A-fragment (nb, tap, kc): lane = channel nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7
+    for (int nb = 0; nb < 2; ++nb)
+        for (int t = 0; t < 9; ++t)
+            for (int kc = 0; kc < 4; ++kc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e)
+                        out[((((size_t)nb * 9 + t) * 4 + kc) * 64 + lane) * 8 + e] =
+                            rows[((size_t)(nb * 32 + (lane & 31)) * 9 + t) * 64 + kc * 16 + 8 * (lane >> 5) + e];
+}
+
+bool rowconv_supported(const RowConvParams &p)
+{
+    return p.B >= 1 && p.H >= 1 && p.W % RC_TW == 0 && p.R >= 1 && (size_t)p.H * p.W * 128 < 0x7fffffffull;
+}
+
+int rowconv_rows(int batch, int h, int w)
+{
+    // rows per strip: the largest that still gives every CU a workgroup (one workgroup per CU fits: 288 registers per lane)
+    const int cand[] = {32, 16, 8, 4, 2, 1};
+    for (int r : cand)
+        if ((long)batch * (w / RC_TW) * ((h + r - 1) / r) >= 256) return r;
+    return 1;
+}
+
+hipError_t launch_rowconv(const RowConvParams &p_in, hipStream_t s)
+{
+    if (!rowconv_supported(p_in)) return hipErrorInvalidValue;
+    RowConvParams p = p_in;
+    p.nsx = p.W / RC_TW; p.nsy = (p.H + p.R - 1) / p.R;
+    p.nblocks = p.B * p.nsx * p.nsy;
+    p.div_sx = FastDiv::make((unsigned)p.nsx);
+    p.div_sy = FastDiv::make((unsigned)p.nsy);
+    const size_t smem = 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH);
+    typedef void (*kern_t)(const RowConvParams);
+    static const kern_t kern[4] = {rowconv64<false, false>, rowconv64<false, true>, rowconv64<true, false>, rowconv64<true, true>};
+    static unsigned long long attr_mask = 0;
+    if (attr_needed_on_this_device(attr_mask))
+        for (kern_t k : kern) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+        }
+    hipLaunchKernelGGL(kern[(p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace lspf2f
