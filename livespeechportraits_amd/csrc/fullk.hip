@@ -43,6 +43,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     STAMP(0);
+    // one scalar-load round trip for the whole argument block (see igemm.hip): left alone the compiler fetches the source pointers in a second,
+    // dependent round trip right before the first LDS-DMA piece
+    asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.Hs), "s"(p.Ws),
+                       "s"(p.Ho), "s"(p.Wo), "s"(p.C0), "s"(p.C1), "s"(p.Cout), "s"(p.up), "s"(p.relu), "s"(p.ntm), "s"(p.ntn), "s"(p.tiles_per_img),
+                       "s"(p.wo_log2));
 
     // tile: the N-slices of one XCD are contiguous, every M-tile of an N-slice lands on that XCD (blocks are dealt round-robin).
     // (integer division runs on the vector ALU: readfirstlane tells the compiler the results are wave-uniform, which the LDS-DMA

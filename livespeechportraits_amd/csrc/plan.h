@@ -49,7 +49,8 @@ struct LayerDesc {
     int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
     bool smallm = false;   // executed by the single-launch tiny-M kernel (M <= 16) instead of the igemm
     bool fused_splitk = false;   // fp32 plans: 2..8 K-splits combined inside the igemm launch by the last-arriving workgroup (no splitk_reduce
-                                 // launch): +1.0 % at fp32 batch 1, none at batch 8, -2.4 % on bf16 batch 8 (A-B-A-B, one session)
+                                 // launch): +1.0 % at fp32 batch 1, none at batch 8, -2.4 % on bf16 batch 8 (A-B-A-B, one session; restricted
+                                 // to the <= 16x16 / <= 8x8 levels of a bf16 plan it still loses 0.7-0.9 %)
     int rowconv = 0;       // > 0: executed by the weights-stationary 64 -> 64 bf16 kernel (rowconv.hip) with this many output rows per strip
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
 };

@@ -23,6 +23,10 @@ __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
     float *act = sm + 160;                                 // [B*Hs*Ws + 1][Cin] (last pixel = zeros); later red[MM*NC][RS]
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * NC;
+    // one scalar-load round trip for the whole argument block (see igemm.hip), so nothing scalar sits between the weight requests and the
+    // activation requests
+    asm volatile("" :: "s"(p.src), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.Hs), "s"(p.Ws), "s"(p.Ho),
+                       "s"(p.Wo), "s"(p.Cin), "s"(p.Cout), "s"(p.stride), "s"(p.up), "s"(p.relu), "s"(p.M));
     const int C4 = p.Cin >> 2, K4 = 9 * C4;
 
     // 1. weights of this workgroup's channels: issue first
