@@ -249,3 +249,37 @@ def test_batched_render_loop_bookkeeping():
     seen = []
     render_frames(Fake(), iter(maps), torch.zeros(1, 12, 4, 4), batch=4, on_frame=lambda i, a: seen.append((i, int(a[0, 0, 0]))))
     assert seen == [(i, 10 * i) for i in range(7)]
+
+
+def test_bf16_plans_route_64_channel_layers_to_the_row_kernel(monkeypatch):
+    """in bf16 plans the 64 -> 64 stride-1 convs run on rowconv64 (strip height by batch), nothing else does, fp32 plans never do,
+    and LSP_HIP_ROWCONV=0 (read at create) puts them back on the implicit GEMM.  The packer's fragment-ordered copy of their weights (right
+    behind the row layout in the blob, plan.cpp) is checked against the numpy restatement used by the GPU test."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("normal", dtype="bf16", max_batch=8)
+    for batch, rows in ((1, 4), (2, 8), (8, 32)):
+        names = [(l["name"], l["tile_m"] // 64) for l in e.layers(batch) if l["kernel"] == "rowconv64"]
+        assert [n for n, _ in names] == ["L0.d.res0.a", "L0.d.res0.b", "L1.u.res0.a", "L1.u.res0.b"]
+        assert all(r == rows for _, r in names)
+    for l in e.layers(8):
+        if l["kernel"] == "rowconv64":
+            assert (l["cin"], l["cout"], l["stride"], l["upsample"], l["h_out"]) == (64, 64, 1, 0, 256)
+    assert not any(l["kernel"] == "rowconv64" for l in Engine("normal", max_batch=8).layers(8))
+    monkeypatch.setenv("LSP_HIP_ROWCONV", "0")
+    assert not any(l["kernel"] == "rowconv64" for l in Engine("normal", dtype="bf16", max_batch=8).layers(8))
+    monkeypatch.delenv("LSP_HIP_ROWCONV")
+
+    topo, sd = synth.synthetic("normal", ngf=64, num_downs=5, size=128)      # 64-channel level at 64x64
+    s = Engine("normal", ngf=64, num_downs=5, size=128, dtype="bf16")
+    s.load_state_dict(sd)
+    blob = s.pack().numpy()
+    checked = 0
+    for l, c in zip(s.layers(1), topo.convs):
+        if l["kernel"] != "rowconv64":
+            continue
+        rows = blob[l["w_offset"]: l["w_offset"] + 64 * 576 * 2].view(np.uint16).reshape(2, 32, 9, 4, 2, 8)   # [nb][ch][tap][kc][hi][e]
+        frag = blob[l["w_offset"] + 64 * 576 * 2: l["w_offset"] + 2 * 64 * 576 * 2].view(np.uint16).reshape(2, 9, 4, 2, 32, 8)
+        assert np.array_equal(frag, rows.transpose(0, 2, 3, 4, 1, 5)), l["name"]
+        checked += 1
+    assert checked >= 2
