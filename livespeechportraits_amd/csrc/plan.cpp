@@ -46,7 +46,8 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
         }
         if (tiles < (bm == 128 ? 512 : want)) {
             // workgroups to aim for when splitting K.  fp32: 768 beats 512 (batch 1 `large` 388.8-389.5 -> 392.3-393.2 frames/s,
-            // `normal` 633.5-635.0 -> 638.5-640.9, batch 8 +0.4 %; 1024 is slightly below 768).  bf16 keeps 512 (768: batch 8
+            // `normal` 633.5-635.0 -> 638.5-640.9, batch 8 +0.4 %; 1024 is slightly below 768).  Splitting the 512-tile layers of the 128x128 level
+            // in two as well (2 -> 4 waves per SIMD) was measured in round 2: the K loop gains what the 8.4-MB slabs cost, 52 -> 55 us per layer.  bf16 keeps 512 (768: batch 8
             // `large` -0.7 %, `normal` no change).  Same session, 3 runs per arm.
             const int target = dtype == 0 ? 768 : 512;
             splits = (int)((target + tiles - 1) / tiles);
