@@ -205,7 +205,7 @@ static const char *kernel_name(const LayerDesc &l)
     default:
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
         if (l.fullk) return "conv3x3_fullk";
-        if (l.rowconv) return "rowconv64";
+        if (l.rowconv) return l.c0 == 64 ? "rowconv64" : "rowconv128";
         if (l.inorm) return l.smallm ? "conv3x3_smallm+in_small" : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
                           : l.in_route == kInSmall ? "igemm3x3+in_small" : "igemm3x3+in_reduce_stats+in_finalize+in_apply";
         return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? (l.fused_splitk ? "igemm3x3 (split-K combined in the launch)" : "igemm3x3+splitk_reduce") : "igemm3x3");
@@ -327,7 +327,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         RowConvParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.wrc_off); p.wfrag = 1; p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.residual = tptr(l.res); p.out = tptr(l.out);
-        p.B = batch; p.H = l.ho; p.W = l.ho; p.R = l.rowconv; p.relu = l.relu;
+        p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.c0; p.R = l.rowconv; p.relu = l.relu;
         e = launch_rowconv(p, s);
     } else if (l.fullk) {
         FullKParams p{};
@@ -655,13 +655,13 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     {
         // tile (16 | 32) x 16 forces the full-K single-launch kernel; tile 0x0 + split 0 lets the planner's rule pick it
         const int ho_ = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
-        if (tile_m > 1000 && tile_n == 64) {       // 1000 + R: the weights-stationary 64 -> 64 bf16 kernel with R output rows per strip
+        if (tile_m > 1000 && (tile_n == 64 || tile_n == 128)) {   // 1000 + R: the weights-stationary bf16 kernel (tile_n channels in and out) with R output rows per strip
             RowConvParams q{};
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
-            q.B = batch; q.H = hs; q.W = ws; q.R = tile_m - 1000; q.relu = relu;
+            q.B = batch; q.H = hs; q.W = ws; q.C = tile_n; q.R = tile_m - 1000; q.relu = relu;
             q.wfrag = k_group == -1 ? 1 : 0;     // -1: w_packed is already in the row kernel's fragment order
-            if (!rowconv_layer(hs, c0, c1, cout, stride, upsample == 1, upsample == 2, dtype, false) || hs != ws || !rowconv_supported(q))
-                return fail(LSPF2F_ERR_UNSUPPORTED, "the 64 -> 64 bf16 row kernel does not support this shape");
+            if (!rowconv_layer(hs, c0, c1, cout, stride, upsample == 1, upsample == 2, dtype, false) || c0 != tile_n || hs != ws || !rowconv_supported(q))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 row kernel does not support this shape");
             e = launch_rowconv(q, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (rowconv) launch");
             return LSPF2F_OK;

@@ -120,13 +120,14 @@ bool fullk_supported(const FullKParams &p, int pb);
 hipError_t launch_fullk(const FullKParams &p, int pb, hipStream_t s);
 void pack_fullk_weights(const float *rows, int c0, int nch, int cout, float *out);   // host: [Cout][9][nch * c0] -> tile-blocked
 
-// Weights-stationary conv for the 64 -> 64 channel layers in bf16 storage (rowconv.hip): stride 1, one source, W % 64 == 0.
+// Weights-stationary conv for the 64 -> 64 and 128 -> 128 channel layers in bf16 storage (rowconv.hip): stride 1, one source,
+// W % 64 == 0 (64 channels) / W % 32 == 0 (128 channels).
 struct RowConvParams {
-    const void *src, *w;          // NHWC bf16 [B][H][W][64]; weights bf16 [64][9][64]
+    const void *src, *w;          // NHWC bf16 [B][H][W][C]; weights bf16 [C][9][C]
     const float *scale, *shift;   // [64] or nullptr
     const void *residual;         // NHWC bf16 or nullptr
     void *out;                    // NHWC bf16
-    int B, H, W;
+    int B, H, W, C;               // C = 64 | 128 channels in and out
     int R;                        // output rows per workgroup strip (rowconv_rows())
     int relu;
     int wfrag;                    // weights in the fragment order of pack_rowconv_weights() (the shipped path) instead of [64][9][64]
@@ -134,9 +135,9 @@ struct RowConvParams {
     FastDiv div_sx, div_sy;
 };
 bool rowconv_supported(const RowConvParams &p);
-int rowconv_rows(int batch, int h, int w);
+int rowconv_rows(int batch, int h, int w, int c);
 hipError_t launch_rowconv(const RowConvParams &p, hipStream_t s);
-void pack_rowconv_weights(const unsigned short *rows, unsigned short *out);   // host: bf16 [64][9][64] -> [nb 2][tap 9][kc 4][lane 64][8]
+void pack_rowconv_weights(const unsigned short *rows, unsigned short *out, int c);   // host: bf16 [c][9][c] -> [nb c/32][tap 9][kc c/16][lane 64][8]
 
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
 struct FirstConvParams {

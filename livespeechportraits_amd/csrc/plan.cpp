@@ -336,8 +336,8 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             const int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
             if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
-            const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho) : 0;
-            if (rowconv) { bm = 64 * rowconv; bn = 64; splits = 1; group = 1; }
+            const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho, l.c0) : 0;
+            if (rowconv) { bm = (l.c0 == 64 ? 64 : 32) * rowconv; bn = l.c0; splits = 1; group = 1; }
             int route = kInNone;
             if (l.inorm) {
                 // rows of one wave (32 per 32x32 tile row, bm / 2 waves... = bm / 2 for the 2x2-wave tiles) must stay inside one
@@ -473,7 +473,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
             }
         }
         if (l.wrc_off >= 0)     // the same bf16 values, regrouped into the MFMA A-fragments the row kernel keeps in registers
-            pack_rowconv_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wrc_off));
+            pack_rowconv_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wrc_off), l.c0);
         if (!l.biaskey.empty()) {
             const float *bv = get(l.biaskey).data.data();
             float *sc = reinterpret_cast<float *>(base + l.scale_off);

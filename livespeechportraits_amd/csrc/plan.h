@@ -115,11 +115,12 @@ inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes)
 {
     return M <= 16 && c1 == 0 && cin % 256 == 0 && 9 * (cin / 4) <= 5 * 256 && in_bytes <= 64 * 1024 && cout % 2 == 0;
 }
-// weights-stationary 64 -> 64 kernel eligibility (mirrors rowconv_supported() in rowconv.hip): bf16 storage, one 64-channel source,
-// stride 1, no upsample, BatchNorm (folded) plans
+// weights-stationary kernel eligibility (mirrors rowconv_supported() in rowconv.hip): bf16 storage, one source of 64 or 128 channels,
+// as many out, stride 1, no upsample, BatchNorm (folded) plans
 inline bool rowconv_layer(int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
 {
-    return dtype == 1 && c0 == 64 && c1 == 0 && cout == 64 && stride == 1 && !up && !up4 && !inorm && ho % 64 == 0;
+    if (dtype != 1 || c1 != 0 || cout != c0 || stride != 1 || up || up4 || inorm) return false;
+    return (c0 == 64 && ho % 64 == 0) || (c0 == 128 && ho % 32 == 0);
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0
 // which layers get the tile-blocked weight copy at pack time (independent of the batch: the blob layout must not depend on it)

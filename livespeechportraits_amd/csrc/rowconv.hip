@@ -284,29 +284,236 @@ __global__ __launch_bounds__(256) void rowconv64(const RowConvParams p)
     finish(i - 3, 1);
 }
 
-void pack_rowconv_weights(const unsigned short *rows, unsigned short *out)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same idea for the 128 -> 128 layers (the 128x128 level).  72 A-fragments per wave (9 taps x 8 channel blocks = 288 registers: the kernel
+// runs one wave per SIMD on the 512-register budget), wave = one of the 4 blocks of 32 output channels, all four waves on the SAME 32
+// pixels of a row.  The 34-pixel input window (256-B pixel records) is therefore shared: one ring for the workgroup, each wave copying a
+// quarter of a row, one barrier per row step; residual rows and the epilogue are per wave exactly as above.
+namespace {
+constexpr int RD_TW = 32;                 // output pixels per strip row
+constexpr int RD_PITCH = 12288;           // bytes per ring row: 48 pixel records of 256 B = 3 DMA passes of the workgroup (34 are real)
+constexpr int RD_NR = 6;                  // ring rows; rows are fetched RD_NR - 1 steps ahead
+constexpr int RD_PF = RD_NR - 1;
+constexpr int RD_RES_NR = RD_PF + 1;
+constexpr int RD_IN = 3, RD_RP = 2, RD_ST = 2;
+constexpr int RD_OPS = RD_IN + RD_RP + RD_ST;
+static_assert((RD_PF - 1) * RD_OPS < 64, "vmcnt is a 6-bit counter");
+}  // namespace
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void rowconv128(const RowConvParams p)
 {
-    // A-fragment (nb, tap, kc): lane = channel nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7
-    for (int nb = 0; nb < 2; ++nb)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nb = __builtin_amdgcn_readfirstlane(tid >> 6);      // this wave: output channels nb*32 .. +31
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    asm volatile("" :: "s"(p.src), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.R),
+                       "s"(p.relu), "s"(p.wfrag), "s"(p.nsx), "s"(p.nsy), "s"(p.nblocks), "s"(p.div_sx.m), "s"(p.div_sx.s1), "s"(p.div_sx.s2),
+                       "s"(p.div_sy.m), "s"(p.div_sy.s1), "s"(p.div_sy.s2));
+
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned total = (unsigned)p.nblocks, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const unsigned t1 = p.div_sx.div(lin);
+    const int sx = (int)(lin - t1 * (unsigned)p.nsx);
+    const int b = (int)p.div_sy.div(t1);
+    const int sy = (int)(t1 - (unsigned)b * (unsigned)p.nsy);
+    const int x0 = sx * RD_TW, y0 = sy * p.R;
+    const unsigned imgbytes = (unsigned)(p.H * p.W) * 256u;
+    const i32x4 srd_in = make_srd(static_cast<const char *>(p.src) + (size_t)b * imgbytes, imgbytes);
+    const i32x4 srd_res = make_srd(RES ? static_cast<const char *>(p.residual) + (size_t)b * imgbytes : static_cast<const char *>(p.src), RES ? imgbytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<char *>(p.out) + (size_t)b * imgbytes, 0, (int)imgbytes, 0x00020000);
+
+    // LDS map: [RD_NR] shared input rows | per wave [RD_RES_NR] residual slots | per wave patch
+    const unsigned lds_ring = lds0;
+    const unsigned lds_res = lds0 + RD_NR * RD_PITCH + (unsigned)nb * (RD_RES_NR * RC_RES_SLOT);
+    float *patch = smem + (RD_NR * RD_PITCH + 4 * RD_RES_NR * RC_RES_SLOT) / 4 + nb * (RC_PATCH / 4);
+
+    // DMA roles.  Input row: pass q moves record slots q*256 + tid (16 slots per 256-B record; record r = pixel x0 - 1 + r), swizzled in the low
+    // three bits of the chunk index like the 128-B records of the other kernels: slot c of record r <- chunk c ^ ((r >> 1) & 7).
+    unsigned in_col[RD_IN];
+#pragma unroll
+    for (int q = 0; q < RD_IN; ++q) {
+        const int sl = q * 256 + tid, r = sl >> 4, c = sl & 15;
+        const int x = x0 - 1 + r;
+        in_col[q] = (r < RD_TW + 2 && (unsigned)x < (unsigned)p.W) ? (unsigned)(x * 256 + ((c ^ ((r >> 1) & 7)) << 4)) : kOOB;
+    }
+    unsigned res_col[RD_RP];
+#pragma unroll
+    for (int q = 0; q < RD_RP; ++q)
+        res_col[q] = (unsigned)((x0 + 16 * q + (lane >> 2)) * 256 + nb * 64 + (lane & 3) * 16);
+    const unsigned rowbytes = (unsigned)p.W * 256u;
+
+    auto dma_step = [&](int i, int j) {      // input row i -> ring slot i % RD_NR (this wave's quarter of each pass); residual row j -> slot j % RD_RES_NR
+        const int gyi = y0 - 1 + i, gyj = y0 + j;
+        const bool oki = (unsigned)gyi < (unsigned)p.H && i < p.R + 2;
+        const bool okj = RES && j >= 0 && j < p.R && gyj < p.H;
+        const int soffi = oki ? gyi * (int)rowbytes : 0, soffj = okj ? gyj * (int)rowbytes : 0;
+        const unsigned basei = lds_ring + (unsigned)(i % RD_NR) * RD_PITCH + (unsigned)nb * 1024u;
+        const unsigned basej = lds_res + (unsigned)(((j % RD_RES_NR) + RD_RES_NR) % RD_RES_NR) * RC_RES_SLOT;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %6, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %6, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %5, %6, %7 offen lds\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %8, %10, %11 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %9, %10, %11 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(basei), "s"(basej),
+                       "v"(oki ? in_col[0] : kOOB), "v"(oki ? in_col[1] : kOOB), "v"(oki ? in_col[2] : kOOB), "s"(srd_in), "s"(soffi),
+                       "v"(okj ? res_col[0] : kOOB), "v"(okj ? res_col[1] : kOOB), "s"(srd_res), "s"(soffj)
+                     : "memory", "scc");
+    };
+
+    // weights -> registers: A-fragment (tap, kc) of this wave's 32 channels: lane = channel nb*32 + l31, k = kc*16 + 8*hi .. +7
+    bf16x8 wf[9][8];
+    if (p.wfrag) {
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(p.w) + (size_t)nb * 72 * 64 + lane;
+#pragma unroll
         for (int t = 0; t < 9; ++t)
-            for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc)
+                wf[t][kc] = wp[(t * 8 + kc) * 64];
+    } else {
+        const bf16_t *wrow = static_cast<const bf16_t *>(p.w) + (size_t)(nb * 32 + l31) * 1152 + hi * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc)
+                wf[t][kc] = *reinterpret_cast<const bf16x8 *>(wrow + t * 128 + kc * 16);
+    }
+    float sc[8], sh[8];
+    {
+        const int c0 = nb * 32 + (lane & 3) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sc[t] = p.scale ? p.scale[c0 + t] : 1.f; sh[t] = p.scale ? p.shift[c0 + t] : 0.f; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // B-fragment addresses inside a ring row: record r = l31 + kx, chunk kc*2 + hi, swizzled; computed per use from three per-kx bases
+    unsigned rbase[3], rswz[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) { const int r = l31 + kx; rbase[kx] = (unsigned)(r * 256); rswz[kx] = (unsigned)((r >> 1) & 7); }
+    auto frag = [&](int i, int f) {          // fragment f = kx*8 + kc of input row i
+        const int kx = f >> 3, kc = f & 7;
+        const unsigned off = (unsigned)(i % RD_NR) * RD_PITCH + rbase[kx] + ((((unsigned)(kc * 2 + hi)) ^ rswz[kx]) << 4);
+        return *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(smem) + off);
+    };
+
+    f32x16 acc0, acc1, acc2;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    auto finish = [&](int j, int pass) {     // second half of the epilogue of output row j (its tile sits in the patch): 16 pixels
+        const bool live = j >= 0 && j < p.R && y0 + j < p.H;
+        const unsigned resbase = (lds_res - lds0) + (unsigned)(((j % RD_RES_NR) + RD_RES_NR) % RD_RES_NR) * RC_RES_SLOT;
+        const int px = 16 * pass + (lane >> 2);
+        const char *src = reinterpret_cast<const char *>(patch) + px * 144 + (lane & 3) * 32;
+        const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 16);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = v[t] * sc[t] + sh[t];
+        if (RES) {
+            const u32x4 rv = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(smem) + resbase + pass * 1024 + lane * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v[2 * t] += __uint_as_float(rv[t] << 16);
+                v[2 * t + 1] += __uint_as_float(rv[t] & 0xffff0000u);
+            }
+        }
+        unsigned o0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned w = pack_bf16x2(v[2 * t], v[2 * t + 1]);
+            if (RELU) w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0}));
+            o0[t] = w;
+        }
+        const u32x4 o = {o0[0], o0[1], o0[2], o0[3]};
+        const unsigned off = live ? (unsigned)(((y0 + j) * p.W + x0 + px) * 256 + nb * 64 + (lane & 3) * 16) : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+    };
+
+    // One step = input row i (see rowconv64); the row and residual row i - 3 were issued RD_PF steps ago, so at most the operations of the
+    // RD_PF - 1 steps since may be in flight (the first RD_PF rows come from the prologue: statement k = row k + residual row k - 3, 5 operations)
+    auto step = [&](int i, f32x16 &an, f32x16 &am, f32x16 &ao) {
+        if (i < RD_PF) vm_wait<(RD_IN + RD_RP) * (RD_PF - 1)>(); else vm_wait<(RD_PF - 1) * RD_OPS>();
+        __syncthreads();                      // row i visible to every wave; ring slot (i - 1) % RD_NR released by every wave
+        dma_step(i + RD_PF, i + RD_PF - 3);
+        bf16x8 bfr[3];
+        bfr[0] = frag(i, 0); bfr[1] = frag(i, 1);
+#pragma unroll
+        for (int f = 0; f < 24; ++f) {
+            if (f + 2 < 24) bfr[(f + 2) % 3] = frag(i, f + 2);
+            const int kx = f >> 3, kc = f & 7;
+            ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[6 + kx][kc], bfr[f % 3], ao, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[3 + kx][kc], bfr[f % 3], am, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0 + kx][kc], bfr[f % 3], f == 0 ? zero16 : an, 0, 0, 0);
+            if (f == 3) finish(i - 3, 0);
+            if (f == 11) finish(i - 3, 1);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(patch) + l31 * 144 + g * 32 + hi * 16) = make_float4(ao[4 * g], ao[4 * g + 1], ao[4 * g + 2], ao[4 * g + 3]);
+    };
+
+#pragma unroll
+    for (int i = 0; i < RD_PF; ++i) dma_step(i, i - 3);
+    const int nsteps = p.R + 2;
+    int i = 0;
+    for (; i < nsteps; i += 3) {
+        step(i, acc0, acc2, acc1);
+        step(i + 1, acc1, acc0, acc2);
+        step(i + 2, acc2, acc1, acc0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    finish(i - 3, 0);
+    finish(i - 3, 1);
+}
+
+void pack_rowconv_weights(const unsigned short *rows, unsigned short *out, int c)
+{
+    // A-fragment (nb, tap, kc): lane = channel nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7; c = 64 | 128 channels in and out
+    const int nkc = c / 16;
+    for (int nb = 0; nb < c / 32; ++nb)
+        for (int t = 0; t < 9; ++t)
+            for (int kc = 0; kc < nkc; ++kc)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e)
-                        out[((((size_t)nb * 9 + t) * 4 + kc) * 64 + lane) * 8 + e] =
-                            rows[((size_t)(nb * 32 + (lane & 31)) * 9 + t) * 64 + kc * 16 + 8 * (lane >> 5) + e];
+                        out[((((size_t)nb * 9 + t) * nkc + kc) * 64 + lane) * 8 + e] =
+                            rows[((size_t)(nb * 32 + (lane & 31)) * 9 + t) * c + kc * 16 + 8 * (lane >> 5) + e];
 }
 
 bool rowconv_supported(const RowConvParams &p)
 {
-    return p.B >= 1 && p.H >= 1 && p.W % RC_TW == 0 && p.R >= 1 && (size_t)p.H * p.W * 128 < 0x7fffffffull;
+    if (p.C != 64 && p.C != 128) return false;
+    const int tw = p.C == 64 ? RC_TW : RD_TW;
+    return p.B >= 1 && p.H >= 1 && p.W % tw == 0 && p.R >= 1 && (size_t)p.H * p.W * p.C * 2 < 0x7fffffffull;
 }
 
-int rowconv_rows(int batch, int h, int w)
+int rowconv_rows(int batch, int h, int w, int c)
 {
-    // rows per strip: the largest that still gives every CU a workgroup (one workgroup per CU fits: 288 registers per lane)
+    // rows per strip: the largest that still gives every CU a workgroup (one workgroup per CU fits: ~290-450 registers per lane)
+    const int tw = c == 64 ? RC_TW : RD_TW;
     const int cand[] = {32, 16, 8, 4, 2, 1};
     for (int r : cand)
-        if ((long)batch * (w / RC_TW) * ((h + r - 1) / r) >= 256) return r;
+        if ((long)batch * (w / tw) * ((h + r - 1) / r) >= 256) return r;
     return 1;
 }
 
@@ -314,20 +521,25 @@ hipError_t launch_rowconv(const RowConvParams &p_in, hipStream_t s)
 {
     if (!rowconv_supported(p_in)) return hipErrorInvalidValue;
     RowConvParams p = p_in;
-    p.nsx = p.W / RC_TW; p.nsy = (p.H + p.R - 1) / p.R;
+    const bool wide = p.C == 128;
+    p.nsx = p.W / (wide ? RD_TW : RC_TW); p.nsy = (p.H + p.R - 1) / p.R;
     p.nblocks = p.B * p.nsx * p.nsy;
     p.div_sx = FastDiv::make((unsigned)p.nsx);
     p.div_sy = FastDiv::make((unsigned)p.nsy);
-    const size_t smem = 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH);
+    const size_t smem = wide ? (size_t)RD_NR * RD_PITCH + 4 * ((size_t)RD_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH)
+                             : 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH);
     typedef void (*kern_t)(const RowConvParams);
-    static const kern_t kern[4] = {rowconv64<false, false>, rowconv64<false, true>, rowconv64<true, false>, rowconv64<true, true>};
+    static const kern_t kern[8] = {rowconv64<false, false>, rowconv64<false, true>, rowconv64<true, false>, rowconv64<true, true>,
+                                   rowconv128<false, false>, rowconv128<false, true>, rowconv128<true, false>, rowconv128<true, true>};
     static unsigned long long attr_mask = 0;
     if (attr_needed_on_this_device(attr_mask))
-        for (kern_t k : kern) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        for (int k = 0; k < 8; ++k) {
+            const size_t need = k < 4 ? 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH)
+                                      : (size_t)RD_NR * RD_PITCH + 4 * ((size_t)RD_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[k]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
             if (e != hipSuccess) return e;
         }
-    hipLaunchKernelGGL(kern[(p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(kern[(wide ? 4 : 0) + (p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 

@@ -65,9 +65,10 @@ def pack_fullk(w, c0, nch):
 
 
 def pack_rowconv(w):
-    """OIHW [64][64][3][3] -> bf16 [nb 2][tap 9][kc 4][lane 64][8]: A-fragment (nb, tap, kc), lane = channel nb*32 + (lane & 31),
-    k = kc*16 + 8*(lane >> 5) .. +7 (Plan::pack does the same on the host, pack_rowconv_weights)"""
-    rows = w.permute(0, 2, 3, 1).reshape(2, 32, 9, 4, 2, 8)          # [nb][ch][tap][kc][hi][e]
+    """OIHW [C][C][3][3] (C = 64 | 128) -> bf16 [nb C/32][tap 9][kc C/16][lane 64][8]: A-fragment (nb, tap, kc), lane = channel
+    nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7 (Plan::pack does the same on the host, pack_rowconv_weights)"""
+    c = w.shape[0]
+    rows = w.permute(0, 2, 3, 1).reshape(c // 32, 32, 9, c // 16, 2, 8)      # [nb][ch][tap][kc][hi][e]
     return rows.permute(0, 2, 3, 4, 1, 5).contiguous().to(torch.bfloat16)   # [nb][tap][kc][hi][ch][e]: lane = hi*32 + ch
 
 
@@ -353,39 +354,46 @@ def test_conv3x3_bf16_storage(cfg, gpu_device):
 
 
 ROWCONV_CASES = [
-    # b, h, rows per strip, residual, relu
-    (1, 64, 16, True, True),      # 4 strips per column
-    (2, 64, 7, False, True),      # ragged: the last strip has one real row
-    (1, 128, 4, True, False),
-    (1, 64, 1, True, True),       # one row per strip: every input row is a halo row of its neighbours
-    (1, 256, 32, True, True),     # the shipped size: 8 strips of 32 rows x 4 columns of 64-pixel strips (34 row steps, rounded to 36)
+    # channels, b, h, rows per strip, residual, relu
+    (64, 1, 64, 16, True, True),      # 4 strips per column
+    (64, 2, 64, 7, False, True),      # ragged: the last strip has one real row
+    (64, 1, 128, 4, True, False),
+    (64, 1, 64, 1, True, True),       # one row per strip: every input row is a halo row of its neighbours
+    (64, 1, 256, 32, True, True),     # the shipped size: 8 strips of 32 rows x 4 columns of 64-pixel strips (34 row steps, rounded to 36)
+    (128, 1, 32, 16, True, True),     # 128 -> 128: one column of 32-pixel strips
+    (128, 2, 64, 7, False, True),     # ragged
+    (128, 1, 64, 1, True, False),
+    (128, 1, 128, 16, True, True),    # the shipped size at batch 8: 8 strips of 16 rows x 4 columns
 ]
 
 
-@pytest.mark.parametrize("cfg", ROWCONV_CASES, ids=lambda c: "b%d_h%d_r%d_res%d_relu%d" % c)
+@pytest.mark.parametrize("cfg", ROWCONV_CASES, ids=lambda c: "c%d_b%d_h%d_r%d_res%d_relu%d" % c)
 def test_conv3x3_rows_kernel_bf16(cfg, gpu_device):
-    """The weights-stationary 64 -> 64 kernel of the bf16 plans (rowconv.hip) against the fp64 conv of the bf16-rounded operands (one bf16
-    ulp of the result), and against the implicit-GEMM kernel on the same inputs: same MFMA, same accumulation order -> the same bits."""
-    b, h, rows, res, relu = cfg
-    x0 = bf16r(rnd(b, 64, h, h, seed=71))
-    w = rnd(64, 64, 3, 3, seed=72) * 0.05
-    scale, shift = rnd(64, seed=73) * 0.5 + 1.0, rnd(64, seed=74) * 0.1
-    r = bf16r(rnd(b, 64, h, h, seed=75)) if res else None
-    got = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (1000 + rows, 64), 0, 0, dtype=1)
+    """The weights-stationary kernels of the bf16 plans (rowconv.hip, 64 -> 64 and 128 -> 128) against the fp64 conv of the bf16-rounded
+    operands (one bf16 ulp of the result), and against the implicit-GEMM kernel on the same inputs: same MFMA, same accumulation order ->
+    the same bits."""
+    c, b, h, rows, res, relu = cfg
+    x0 = bf16r(rnd(b, c, h, h, seed=71))
+    w = rnd(c, c, 3, 3, seed=72) * 0.05
+    scale, shift = rnd(c, seed=73) * 0.5 + 1.0, rnd(c, seed=74) * 0.1
+    r = bf16r(rnd(b, c, h, h, seed=75)) if res else None
+    got = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (1000 + rows, c), 0, 0, dtype=1)
     ref = ref_conv(x0, None, bf16r(w), scale, shift, r, 1, False, relu)
     assert torch.isfinite(got).all()
     tol = (ref.abs() * 2.0 ** -8 + 1e-3)
     assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
     other = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (64, 64), 1, 1, dtype=1)
     assert torch.equal(got, other), (got - other).abs().max().item()
-    frag = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (1000 + rows, 64), 0, -1, dtype=1)   # the shipped weight layout
+    frag = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (1000 + rows, c), 0, -1, dtype=1)   # the shipped weight layout
     assert torch.equal(got, frag)
 
 
 def test_conv3x3_rows_kernel_rejects_other_shapes(gpu_device):
     from livespeechportraits_amd import _native as N
     x = bf16r(rnd(1, 128, 64, 64))
-    with pytest.raises(N.Lspf2fError):
+    with pytest.raises(N.Lspf2fError):       # 128 in, 64 out
         run_conv(gpu_device, x, None, rnd(64, 128, 3, 3), None, None, None, 1, 0, False, (1016, 64), 0, 0, dtype=1)
+    with pytest.raises(N.Lspf2fError):       # 128 -> 128 data on the 64-channel kernel
+        run_conv(gpu_device, x, None, rnd(128, 128, 3, 3), None, None, None, 1, 0, False, (1016, 64), 0, 0, dtype=1)
     with pytest.raises(N.Lspf2fError):       # fp32 storage
         run_conv(gpu_device, rnd(1, 64, 64, 64), None, rnd(64, 64, 3, 3), None, None, None, 1, 0, False, (1016, 64), 0, 0, dtype=0)

@@ -252,7 +252,7 @@ def test_batched_render_loop_bookkeeping():
 
 
 def test_bf16_plans_route_64_channel_layers_to_the_row_kernel(monkeypatch):
-    """in bf16 plans the 64 -> 64 stride-1 convs run on rowconv64 (strip height by batch), nothing else does, fp32 plans never do,
+    """in bf16 plans the 64 -> 64 and 128 -> 128 stride-1 convs run on rowconv64 / rowconv128 (strip height by batch), nothing else does, fp32 plans never do,
     and LSP_HIP_ROWCONV=0 (read at create) puts them back on the implicit GEMM.  The packer's fragment-ordered copy of their weights (right
     behind the row layout in the blob, plan.cpp) is checked against the numpy restatement used by the GPU test."""
     from livespeechportraits_amd import synth
@@ -262,12 +262,16 @@ def test_bf16_plans_route_64_channel_layers_to_the_row_kernel(monkeypatch):
         names = [(l["name"], l["tile_m"] // 64) for l in e.layers(batch) if l["kernel"] == "rowconv64"]
         assert [n for n, _ in names] == ["L0.d.res0.a", "L0.d.res0.b", "L1.u.res0.a", "L1.u.res0.b"]
         assert all(r == rows for _, r in names)
+    wide = [(l["name"], l["tile_m"] // 32) for l in e.layers(8) if l["kernel"] == "rowconv128"]
+    assert wide == [(n, 16) for n in ("L1.d.res0.a", "L1.d.res0.b", "L2.u.res0.a", "L2.u.res0.b")]
     for l in e.layers(8):
         if l["kernel"] == "rowconv64":
             assert (l["cin"], l["cout"], l["stride"], l["upsample"], l["h_out"]) == (64, 64, 1, 0, 256)
-    assert not any(l["kernel"] == "rowconv64" for l in Engine("normal", max_batch=8).layers(8))
+        if l["kernel"] == "rowconv128":
+            assert (l["cin"], l["cout"], l["stride"], l["upsample"], l["h_out"]) == (128, 128, 1, 0, 128)
+    assert not any(l["kernel"].startswith("rowconv") for l in Engine("normal", max_batch=8).layers(8))
     monkeypatch.setenv("LSP_HIP_ROWCONV", "0")
-    assert not any(l["kernel"] == "rowconv64" for l in Engine("normal", dtype="bf16", max_batch=8).layers(8))
+    assert not any(l["kernel"].startswith("rowconv") for l in Engine("normal", dtype="bf16", max_batch=8).layers(8))
     monkeypatch.delenv("LSP_HIP_ROWCONV")
 
     topo, sd = synth.synthetic("normal", ngf=64, num_downs=5, size=128)      # 64-channel level at 64x64
@@ -275,11 +279,15 @@ def test_bf16_plans_route_64_channel_layers_to_the_row_kernel(monkeypatch):
     s.load_state_dict(sd)
     blob = s.pack().numpy()
     checked = 0
+    kinds = set()
     for l, c in zip(s.layers(1), topo.convs):
-        if l["kernel"] != "rowconv64":
+        if not l["kernel"].startswith("rowconv"):
             continue
-        rows = blob[l["w_offset"]: l["w_offset"] + 64 * 576 * 2].view(np.uint16).reshape(2, 32, 9, 4, 2, 8)   # [nb][ch][tap][kc][hi][e]
-        frag = blob[l["w_offset"] + 64 * 576 * 2: l["w_offset"] + 2 * 64 * 576 * 2].view(np.uint16).reshape(2, 9, 4, 2, 32, 8)
+        ch = l["cin"]
+        nbytes = ch * 9 * ch * 2
+        rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(ch // 32, 32, 9, ch // 16, 2, 8)   # [nb][ch][tap][kc][hi][e]
+        frag = blob[l["w_offset"] + nbytes: l["w_offset"] + 2 * nbytes].view(np.uint16).reshape(ch // 32, 9, ch // 16, 2, 32, 8)
         assert np.array_equal(frag, rows.transpose(0, 2, 3, 4, 1, 5)), l["name"]
         checked += 1
-    assert checked >= 2
+        kinds.add(l["kernel"])
+    assert checked >= 4 and kinds == {"rowconv64", "rowconv128"}
