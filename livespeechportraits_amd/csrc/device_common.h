@@ -70,6 +70,48 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 sr
                  : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
                  : "memory");
 }
+// N pieces of one operand in ONE statement (N = 1, 2, 4, 8): consecutive pieces land STRIDE bytes apart in LDS and share descriptor and scalar
+// offset, so M0 is saved, advanced and restored once per group instead of once per piece (2 + 3N instead of 5N issue slots; the bf16 K loop
+// is issue-bound).  One wait state between an M0 write and the LDS-DMA that uses it is what the hazard table asks for.
+template <int N, int STRIDE>
+__device__ __forceinline__ void dma16_group(unsigned lds_addr, const unsigned (&voff)[N], i32x4 srd, int soff)
+{
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8, "piece counts of the shipped tiles");
+    unsigned keep;
+    if constexpr (N == 1) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_addr), "v"(voff[0]), "s"(srd), "s"(soff) : "memory");
+    } else if constexpr (N == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %4, %5 offen lds\n\ts_add_u32 m0, m0, %6\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "s"(srd), "s"(soff), "n"(STRIDE) : "memory", "scc");
+    } else if constexpr (N == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %6, %7 offen lds\n\ts_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %6, %7 offen lds\n\ts_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %6, %7 offen lds\n\ts_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %5, %6, %7 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(srd), "s"(soff), "n"(STRIDE) : "memory", "scc");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %10, %11 offen lds\n\ts_add_u32 m0, m0, %12\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %10, %11 offen lds\n\ts_add_u32 m0, m0, %12\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %10, %11 offen lds\n\ts_add_u32 m0, m0, %12\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %5, %10, %11 offen lds\n\ts_add_u32 m0, m0, %12\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %6, %10, %11 offen lds\n\ts_add_u32 m0, m0, %12\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %7, %10, %11 offen lds\n\ts_add_u32 m0, m0, %12\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %8, %10, %11 offen lds\n\ts_add_u32 m0, m0, %12\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %9, %10, %11 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7]),
+                       "s"(srd), "s"(soff), "n"(STRIDE) : "memory", "scc");
+    }
+}
 // wait until at most N of this wave's DMA pieces are still in flight (they complete in order)
 template <int N>
 __device__ __forceinline__ void dma_wait()

@@ -201,17 +201,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             const unsigned csb = (unsigned)cs * (unsigned)EB;
             const unsigned A = lds_a + (unsigned)(((buf * G + g) * TILE_A + wstripe * LDK) * 4);
             const unsigned Bq = lds_b + (unsigned)(((buf * G + g) * TILE_B + wstripe * LDK) * 4);
+            unsigned va[PA], vb[PB];
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 const bool ok = live && ((a_mask[i] >> tap) & 1u);
                 const int pix = UP ? a_pix0[i] + ((a_oy[i] + ky) >> 1) * p.Ws + ((a_ox[i] + kx) >> 1)
                                    : a_pix0[i] + tapdelta;
-                const unsigned voff = ok ? (unsigned)pix * csb + (unsigned)lqb : kOOB;
-                dma16(A + i * RPP * LDK * 4, voff, rs, soff);
+                va[i] = ok ? (unsigned)pix * csb + (unsigned)lqb : kOOB;
             }
 #pragma unroll
-            for (int i = 0; i < PB; ++i)
-                dma16(Bq + i * RPP * LDK * 4, live ? b_off[i] : kOOB, rsw, (kt + g) * (BK * 4));
+            for (int i = 0; i < PB; ++i) vb[i] = live ? b_off[i] : kOOB;
+            // one statement per operand: M0 saved / restored once per group (same session, grouped vs one statement per piece: fp32 batch 8
+            // +1.3 %, bf16 `large` batch 8 +1.0 %, fp32 batch 1 +0.4 %)
+            dma16_group<PA, RPP * LDK * 4>(A, va, rs, soff);
+            dma16_group<PB, RPP * LDK * 4>(Bq, vb, rsw, (kt + g) * (BK * 4));
             if (live) {
                 c += BKE;
                 if (c == p.Cin) {
