@@ -96,6 +96,8 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
                                         (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0, cfg->dtype,
                                         (cfg->flags & LSPF2F_FLAG_INSTANCE_NORM) ? 1 : 0);
     if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
+    if (const char *env = std::getenv("LSP_HIP_BANDCONV")) h->plan.use_bandconv = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_BLOCKS")) h->plan.bandconv_min_blocks = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
@@ -205,6 +207,7 @@ static const char *kernel_name(const LayerDesc &l)
     default:
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
         if (l.fullk) return "conv3x3_fullk";
+        if (l.bandconv) return "bandconv512";
         if (l.rowconv) return l.c0 == 64 ? "rowconv64" : "rowconv128";
         if (l.inorm) return l.smallm ? "conv3x3_smallm+in_small" : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
                           : l.in_route == kInSmall ? "igemm3x3+in_small" : "igemm3x3+in_reduce_stats+in_finalize+in_apply";
@@ -323,6 +326,12 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             e = launch_in_small(q, s);
         }
+    } else if (l.bandconv) {
+        BandConvParams p{};
+        p.src = tptr(l.src0); p.w = bptr(l.wbc_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.W = l.ho; p.Cout = l.cout; p.relu = l.relu;
+        e = launch_bandconv(p, s);
     } else if (l.rowconv) {
         RowConvParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.wrc_off); p.wfrag = 1; p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
@@ -655,6 +664,16 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     {
         // tile (16 | 32) x 16 forces the full-K single-launch kernel; tile 0x0 + split 0 lets the planner's rule pick it
         const int ho_ = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
+        if (tile_m == 2000 && k_group == -1) {     // the activation-stationary bf16 kernel of the 16x16 / 8x8 levels; weights in its fragment order
+            BandConvParams q{};
+            q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
+            q.B = batch; q.W = hs; q.Cout = cout; q.relu = relu;
+            if (!bandconv_layer(hs, c0, c1, cout, stride, upsample == 1, upsample == 2, dtype, false) || hs != ws || !bandconv_supported(q))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 band kernel does not support this shape");
+            e = launch_bandconv(q, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (bandconv) launch");
+            return LSPF2F_OK;
+        }
         if (tile_m > 1000 && (tile_n == 64 || tile_n == 128)) {   // 1000 + R: the weights-stationary bf16 kernel (tile_n channels in and out) with R output rows per strip
             RowConvParams q{};
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;

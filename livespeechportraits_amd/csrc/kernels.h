@@ -139,6 +139,21 @@ int rowconv_rows(int batch, int h, int w, int c);
 hipError_t launch_rowconv(const RowConvParams &p, hipStream_t s);
 void pack_rowconv_weights(const unsigned short *rows, unsigned short *out, int c);   // host: bf16 [c][9][c] -> [nb c/32][tap 9][kc c/16][lane 64][8]
 
+// Activation-stationary conv for the 512 -> Cout layers of the 16x16 / 8x8 levels in bf16 storage (bandconv.hip): stride 1, one source of
+// 512 channels, square frames of width 16 or 8, Cout % 32 == 0; weights in the fragment order of pack_bandconv_weights().
+struct BandConvParams {
+    const void *src, *w;          // NHWC bf16 [B][W][W][512]; weights bf16 [Cout/32][4][9][8][64][8]
+    const float *scale, *shift;   // [Cout] or nullptr
+    const void *residual;         // NHWC bf16 or nullptr
+    void *out;                    // NHWC bf16 [B][W][W][Cout]
+    int B, W, Cout, relu;
+    int ntiles, nblocks;          // filled by launch_bandconv
+    FastDiv div_tiles;
+};
+bool bandconv_supported(const BandConvParams &p);
+hipError_t launch_bandconv(const BandConvParams &p, hipStream_t s);
+void pack_bandconv_weights(const unsigned short *rows, unsigned short *out, int cout);   // host: bf16 [cout][9][512] -> fragment order
+
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
 struct FirstConvParams {
     const float *feat;   // [B][feat_nc][H][W]

@@ -43,6 +43,7 @@ struct LayerDesc {
     int in_route = 0;      // per-batch: how those statistics are gathered (kInFused / kInReduce / kInSmall)
     int64_t w_off = -1, scale_off = -1, shift_off = -1;   // byte offsets in the packed blob
     int64_t wfk_off = -1;    // fp32 plans, 16x16 / 8x8 stride-1 layers: a second copy of the weights in the tile-blocked layout of the full-K kernel
+    int64_t wbc_off = -1;    // bf16 plans, 512 -> Cout stride-1 layers at 16x16 / 8x8: a copy of the weights in the fragment order of bandconv.hip
     int64_t wrc_off = -1;    // bf16 plans, 64 -> 64 stride-1 layers: a copy of the weights in the fragment order of the weights-stationary kernel (rowconv.hip)
     int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
@@ -51,6 +52,7 @@ struct LayerDesc {
     bool fused_splitk = false;   // fp32 plans: 2..8 K-splits combined inside the igemm launch by the last-arriving workgroup (no splitk_reduce
                                  // launch): +1.0 % at fp32 batch 1, none at batch 8, -2.4 % on bf16 batch 8 (A-B-A-B, one session; restricted
                                  // to the <= 16x16 / <= 8x8 levels of a bf16 plan it still loses 0.7-0.9 %)
+    bool bandconv = false;  // executed by the activation-stationary kernel of the 16x16 / 8x8 levels (bandconv.hip, bf16 plans)
     int rowconv = 0;       // > 0: executed by the weights-stationary 64 -> 64 bf16 kernel (rowconv.hip) with this many output rows per strip
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
 };
@@ -69,6 +71,8 @@ struct Plan {
     int dtype = 0;             // 0: fp32 activations + weights; 1: bf16 storage (fp32 accumulate), first/last-layer weights fp32
     int norm = 0;              // 0: BatchNorm2d in eval mode (folded, the shipped checkpoints); 1: InstanceNorm2d (norm_layer argument
                                // of the reference constructors, networks.py:555 / :459): conv biases on, statistics at run time, fp32 only
+    bool use_bandconv = true;  // bf16 plans: LSP_HIP_BANDCONV=0 at create puts the 16x16 / 8x8 layers back on the implicit GEMM (A-B runs)
+    int bandconv_min_blocks = 128;   // ... and they only leave it when the launch has at least this many workgroups
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
     size_t elt() const { return dtype == 1 ? 2 : 4; }
     int ktile_channels() const { return dtype == 1 ? 64 : 32; }   // a K-tile is 128 B of channels
@@ -121,6 +125,11 @@ inline bool rowconv_layer(int ho, int c0, int c1, int cout, int stride, bool up,
 {
     if (dtype != 1 || c1 != 0 || cout != c0 || stride != 1 || up || up4 || inorm) return false;
     return (c0 == 64 && ho % 64 == 0) || (c0 == 128 && ho % 32 == 0);
+}
+// activation-stationary kernel eligibility (mirrors bandconv_supported() in bandconv.hip)
+inline bool bandconv_layer(int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
+{
+    return dtype == 1 && c0 == 512 && c1 == 0 && cout % 32 == 0 && stride == 1 && !up && !up4 && !inorm && (ho == 16 || ho == 8);
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0
 // which layers get the tile-blocked weight copy at pack time (independent of the batch: the blob layout must not depend on it)

@@ -25,7 +25,9 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev).to(tdt)
     d0 = nhwc(x0)
     d1 = nhwc(x1) if x1 is not None else None
-    if k_group == -1 and tile[0] > 1000:
+    if k_group == -1 and tile[0] == 2000:
+        wp = pack_bandconv(w).to(dev)                         # the band kernel's fragment order (bf16)
+    elif k_group == -1 and tile[0] > 1000:
         wp = pack_rowconv(w).to(dev)                          # the row kernel's MFMA-fragment order (bf16)
     elif k_group == -1:
         wp = pack_fullk(w, c0, 2 if c1 else 1).to(dev)       # the full-K kernel's tile-blocked layout
@@ -70,6 +72,14 @@ def pack_rowconv(w):
     c = w.shape[0]
     rows = w.permute(0, 2, 3, 1).reshape(c // 32, 32, 9, c // 16, 2, 8)      # [nb][ch][tap][kc][hi][e]
     return rows.permute(0, 2, 3, 4, 1, 5).contiguous().to(torch.bfloat16)   # [nb][tap][kc][hi][ch][e]: lane = hi*32 + ch
+
+
+def pack_bandconv(w):
+    """OIHW [Cout][512][3][3] -> bf16 [slice Cout/32][K quarter 4][tap 9][kc 8][lane 64][8]: lane = channel slice*32 + (lane & 31),
+    k = input channel q*128 + kc*16 + 8*(lane >> 5) .. +7 of the tap (pack_bandconv_weights on the host)"""
+    cout = w.shape[0]
+    rows = w.permute(0, 2, 3, 1).reshape(cout // 32, 32, 9, 4, 8, 2, 8)        # [cs][ch][tap][q][kc][hi][e]
+    return rows.permute(0, 3, 2, 4, 5, 1, 6).contiguous().to(torch.bfloat16)    # [cs][q][tap][kc][hi][ch][e]
 
 
 def pack_subpixel(w):
@@ -397,3 +407,40 @@ def test_conv3x3_rows_kernel_rejects_other_shapes(gpu_device):
         run_conv(gpu_device, x, None, rnd(128, 128, 3, 3), None, None, None, 1, 0, False, (1016, 64), 0, 0, dtype=1)
     with pytest.raises(N.Lspf2fError):       # fp32 storage
         run_conv(gpu_device, rnd(1, 64, 64, 64), None, rnd(64, 64, 3, 3), None, None, None, 1, 0, False, (1016, 64), 0, 0, dtype=0)
+
+
+BANDCONV_CASES = [
+    # b, h (= w), cout, residual, relu
+    (1, 16, 64, True, True),
+    (2, 16, 512, False, True),     # 2 frames x 4 tiles x 16 slices
+    (3, 8, 96, True, False),       # 8x8 level: 2 tiles per frame
+    (8, 8, 512, True, True),       # the shipped shapes at 8 frames
+    (8, 16, 512, True, True),
+]
+
+
+@pytest.mark.parametrize("cfg", BANDCONV_CASES, ids=lambda c: "b%d_h%d_o%d_res%d_relu%d" % c)
+def test_conv3x3_band_kernel_bf16(cfg, gpu_device):
+    """The activation-stationary kernel of the bf16 plans for the 512-channel layers at 16x16 / 8x8 (bandconv.hip) against the fp64 conv of
+    the bf16-rounded operands: one bf16 ulp of the result (its K split by channel quarter is a different fp32 summation order from the
+    implicit GEMM's, so the two agree to that ulp, not bit for bit)."""
+    b, h, cout, res, relu = cfg
+    x0 = bf16r(rnd(b, 512, h, h, seed=81))
+    w = rnd(cout, 512, 3, 3, seed=82) * 0.02
+    scale, shift = rnd(cout, seed=83) * 0.5 + 1.0, rnd(cout, seed=84) * 0.1
+    r = bf16r(rnd(b, cout, h, h, seed=85)) if res else None
+    got = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (2000, 32), 0, -1, dtype=1)
+    ref = ref_conv(x0, None, bf16r(w), scale, shift, r, 1, False, relu)
+    assert torch.isfinite(got).all()
+    tol = (ref.abs() * 2.0 ** -8 + 1e-3)
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
+    again = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (2000, 32), 0, -1, dtype=1)
+    assert torch.equal(got, again)                                   # fixed summation order
+
+
+def test_conv3x3_band_kernel_rejects_other_shapes(gpu_device):
+    from livespeechportraits_amd import _native as N
+    with pytest.raises(N.Lspf2fError):       # 32x32 frames
+        run_conv(gpu_device, bf16r(rnd(1, 512, 32, 32)), None, rnd(64, 512, 3, 3), None, None, None, 1, 0, False, (2000, 32), 0, -1, dtype=1)
+    with pytest.raises(N.Lspf2fError):       # stride 2
+        run_conv(gpu_device, bf16r(rnd(1, 512, 16, 16)), None, rnd(64, 512, 3, 3), None, None, None, 2, 0, False, (2000, 32), 0, -1, dtype=1)
