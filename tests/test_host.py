@@ -291,3 +291,37 @@ def test_bf16_plans_route_64_channel_layers_to_the_row_kernel(monkeypatch):
         checked += 1
         kinds.add(l["kernel"])
     assert checked >= 4 and kinds == {"rowconv64", "rowconv128"}
+
+
+def test_bf16_plans_route_small_512_channel_layers_to_the_band_kernel(monkeypatch):
+    """from 128 workgroups up, bf16 plans run the 512 -> 512 stride-1 convs of the 16x16 / 8x8 levels on bandconv512; the
+    packer's fragment-ordered copy (right behind the row layout in the blob) equals the numpy restatement the GPU test uses."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("normal", dtype="bf16", max_batch=8)
+    band = [l["name"] for l in e.layers(8) if l["kernel"] == "bandconv512"]
+    assert band == ["L4.d.res0.a", "L4.d.res0.b", "L5.d.res0.a", "L5.d.res0.b", "L6.u.res0.a", "L6.u.res0.b", "L5.u.res0.a", "L5.u.res0.b"]
+    for l in e.layers(8):
+        if l["kernel"] == "bandconv512":
+            assert (l["cin"], l["cout"], l["stride"], l["upsample"]) == (512, 512, 1, 0) and l["h_out"] in (8, 16)
+    assert not any(l["kernel"] == "bandconv512" for l in e.layers(1))            # 64 / 32 workgroups: stays on the implicit GEMM
+    assert [l["name"] for l in e.layers(2) if l["kernel"] == "bandconv512"] == ["L4.d.res0.a", "L4.d.res0.b", "L5.u.res0.a", "L5.u.res0.b"]
+    assert not any(l["kernel"] == "bandconv512" for l in Engine("normal", max_batch=8).layers(8))
+    monkeypatch.setenv("LSP_HIP_BANDCONV", "0")
+    assert not any(l["kernel"] == "bandconv512" for l in Engine("normal", dtype="bf16", max_batch=8).layers(8))
+    monkeypatch.delenv("LSP_HIP_BANDCONV")
+
+    topo, sd = synth.synthetic("normal", ngf=64, num_downs=6, size=256)      # 512 channels at 16x16 and 8x8
+    s = Engine("normal", ngf=64, num_downs=6, size=256, dtype="bf16", max_batch=8)
+    s.load_state_dict(sd)
+    blob = s.pack().numpy()
+    checked = 0
+    for l in s.layers(8):
+        if l["kernel"] != "bandconv512":
+            continue
+        cout, nbytes = l["cout"], l["cout"] * 9 * 512 * 2
+        rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(cout // 32, 32, 9, 4, 8, 2, 8)   # [cs][ch][tap][q][kc][hi][e]
+        frag = blob[l["w_offset"] + nbytes: l["w_offset"] + 2 * nbytes].view(np.uint16).reshape(cout // 32, 4, 9, 8, 2, 32, 8)
+        assert np.array_equal(frag, rows.transpose(0, 3, 2, 4, 5, 1, 6)), l["name"]
+        checked += 1
+    assert checked >= 2
