@@ -174,3 +174,39 @@ def test_lle_refuses_out_of_range_neighbours_and_knn_marks_nan_rows(gpu_device):
     qn[3] = np.nan
     indn = manifold.knn(torch.from_numpy(qn).to(gpu_device), torch.from_numpy(db).to(gpu_device), 4).cpu().numpy()
     assert (indn[3] == -1).all() and (indn[[0, 1, 2, 4]] == ind.cpu().numpy()[[0, 1, 2, 4]]).all()
+
+
+@pytest.mark.parametrize("size,batch", [(256, 4), (768, 1), (256, 1)])
+def test_bf16_own_kernels_agree_with_the_implicit_gemm_at_other_sizes(size, batch, gpu_device, monkeypatch):
+    """The kernels bf16 plans use instead of the implicit GEMM (rowconv64 / rowconv128 / bandconv512) at frame sizes
+    other than 512: strips, ragged strip heights and level widths change with the size.  Reference = the SAME plan with those kernels
+    switched off (LSP_HIP_ROWCONV=0, LSP_HIP_BANDCONV=0, read at create).  Layer by layer the kernels agree to a bf16 ulp (tests/test_gpu_conv.py);
+    through the network a different fp32 summation order becomes isolated one-ulp flips that compound, as between any two bf16 plans."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.topology import build_topology
+    topo = build_topology("normal", size=size)
+    sd = synth.make_state_dict(topo, 4321)
+    feat, cand = synth.make_inputs(batch, size, seed=5, cand_batch=1)
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+
+    def run(own):
+        if not own:
+            monkeypatch.setenv("LSP_HIP_ROWCONV", "0"); monkeypatch.setenv("LSP_HIP_BANDCONV", "0")
+        e = Engine("normal", size=size, max_batch=batch, dtype="bf16")
+        monkeypatch.delenv("LSP_HIP_ROWCONV", raising=False); monkeypatch.delenv("LSP_HIP_BANDCONV", raising=False)
+        e.load_state_dict(sd)
+        e.bind(e.pack(), gpu_device)
+        kinds = sorted({l["kernel"].split(" ")[0] for l in e.layers(batch)})
+        return e.forward(f, c).cpu().numpy(), kinds
+    got, kinds = run(True)
+    ref, kinds_ref = run(False)
+    print("\nsize %d batch %d: kernels %s" % (size, batch, kinds))
+    assert not any(k.startswith(("rowconv", "bandconv")) for k in kinds_ref)
+    if size >= 256:
+        assert "rowconv64" in kinds and "rowconv128" in kinds
+    d = np.abs(got - ref)
+    print("   max-abs %.3g mean-abs %.3g vs the igemm-only plan" % (d.max(), d.mean()))
+    assert np.isfinite(got).all()
+    # (not bit-identical even without the band kernel: the igemm-only plan splits K for some of these layers, another fp32 summation order)
+    assert d.max() <= 2e-2 and d.mean() <= 1e-3
