@@ -98,6 +98,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
     if (const char *env = std::getenv("LSP_HIP_BANDCONV")) h->plan.use_bandconv = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_BLOCKS")) h->plan.bandconv_min_blocks = std::atoi(env);
+    if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_FRAMES")) h->plan.bandconv_min_frames_small = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;

@@ -29,9 +29,11 @@ constexpr int BC_PATCH = 32 * 144;        // per wave and pixel block: 32 px x (
 template <int W, int PXB, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
 {
-    constexpr int TR = 32 * PXB / W;                  // output rows per tile
-    constexpr int BW = W + 2, BR = TR + 2;            // band extent incl. halo
-    constexpr int NSLOT = BR * BW * 64;               // 16-B slots of the band (64 per 1024-B pixel record)
+    constexpr bool MULTI = W * W < 32 * PXB;          // 4x4 / 2x2 levels: a tile is FR whole frames (2 / 8), each with its own halo
+    constexpr int FR = MULTI ? 32 * PXB / (W * W) : 1;
+    constexpr int TR = MULTI ? W : 32 * PXB / W;      // output rows per tile and frame
+    constexpr int BW = W + 2, BR = TR + 2;            // band extent per frame incl. halo
+    constexpr int NSLOT = FR * BR * BW * 64;          // 16-B slots of the band (64 per 1024-B pixel record)
     constexpr int NPASS = (NSLOT + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef __attribute__((address_space(3))) float lds_float;
@@ -52,21 +54,21 @@ __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
     }
     const int cs = (int)p.div_tiles.div(lin);
     const int tile = (int)(lin - (unsigned)cs * (unsigned)p.ntiles);
-    constexpr int TPI = W / TR;                        // tiles per frame
-    const int b = tile / TPI, ty = tile - b * TPI;
-    const int y0 = ty * TR;
-    const unsigned imgbytes = (unsigned)(W * W) * 1024u;
-    const i32x4 srd_in = make_srd(static_cast<const char *>(p.src) + (size_t)b * imgbytes, imgbytes);
+    constexpr int TPI = MULTI ? 1 : W / TR;            // tiles per frame
+    const int b0 = MULTI ? tile * FR : tile / TPI;     // first frame of the tile
+    const int y0 = MULTI ? 0 : (tile - b0 * TPI) * TR;
+    const i32x4 srd_in = make_srd(p.src, (unsigned)(p.B * W * W) * 1024u);
 
-    // ---- 1. band -> LDS (once).  Slot s = pass*256 + tid: band pixel bp = s >> 6 (row bp / BW, column bp % BW), slot c = s & 63 holds
-    // chunk c ^ (bp & 7); the pixel is (y0 - 1 + row, column - 1), zeros outside the frame.
+    // ---- 1. band -> LDS (once).  Slot s = pass*256 + tid: band pixel bp = s >> 6 (frame bp / (BR*BW) of the tile, then row, column), slot
+    // c = s & 63 holds chunk c ^ (bp & 7); the pixel is (y0 - 1 + row, column - 1) of that frame, zeros outside the frame / past the batch.
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
         const int s = q * 256 + tid, bp = s >> 6, c = s & 63;
-        const int br = bp / BW, bc = bp - br * BW;
-        const int y = y0 - 1 + br, x = bc - 1;
-        const bool ok = s < NSLOT && (unsigned)y < (unsigned)W && (unsigned)x < (unsigned)W;
-        dma16(lds0 + (unsigned)(q * 4096 + wave * 1024), ok ? (unsigned)((y * W + x) * 1024 + ((c ^ (bp & 7)) << 4)) : kOOBb, srd_in, 0);
+        const int fr = bp / (BR * BW), rem = bp - fr * (BR * BW);
+        const int br = rem / BW, bc = rem - br * BW;
+        const int y = y0 - 1 + br, x = bc - 1, b = b0 + fr;
+        const bool ok = s < NSLOT && b < p.B && (unsigned)y < (unsigned)W && (unsigned)x < (unsigned)W;
+        dma16(lds0 + (unsigned)(q * 4096 + wave * 1024), ok ? (unsigned)(((b * W + y) * W + x) * 1024 + ((c ^ (bp & 7)) << 4)) : kOOBb, srd_in, 0);
     }
 
     // ---- 2. weight stream: fragment f = tap*8 + kc of this wave's K quarter, 1 KB per fragment, ring of BC_RING
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
     unsigned bp0[PXB];
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb) {
-        const int tp = pb * 32 + l31, tr = tp / W, tc = tp - tr * W;
-        bp0[pb] = (unsigned)(tr * BW + tc);
+        const int tp = pb * 32 + l31, fr = tp / (TR * W), rem = tp - fr * (TR * W), tr = rem / W, tc = rem - tr * W;
+        bp0[pb] = (unsigned)(fr * (BR * BW) + tr * BW + tc);
     }
     f32x16 acc[PXB];
 #pragma unroll
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
             v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
         }
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        const int tp = pb * 32 + px, tr = tp / W, tc = tp - tr * W;
+        const int tp = pb * 32 + px, fr = tp / (TR * W), rem = tp - fr * (TR * W), tr = rem / W, tc = rem - tr * W;
+        const int b = b0 + fr;
+        if (b >= p.B) continue;                        // a tile of whole frames past the batch
         const size_t e = ((size_t)(b * W + y0 + tr) * W + tc) * (size_t)p.Cout + n;
         if (RES) {
             const float4 rv = load4(static_cast<const bf16_t *>(p.residual) + e);
@@ -155,32 +159,38 @@ void pack_bandconv_weights(const unsigned short *rows, unsigned short *out, int 
 
 bool bandconv_supported(const BandConvParams &p)
 {
-    return p.B >= 1 && (p.W == 16 || p.W == 8) && p.Cout % 32 == 0 && p.Cout >= 32;
+    return p.B >= 1 && (p.W == 16 || p.W == 8 || p.W == 4 || p.W == 2) && p.Cout % 32 == 0 && p.Cout >= 32 &&
+           (size_t)p.B * p.W * p.W * 1024 < 0x7fffffffull;
 }
 
 hipError_t launch_bandconv(const BandConvParams &p_in, hipStream_t s)
 {
     if (!bandconv_supported(p_in)) return hipErrorInvalidValue;
     BandConvParams p = p_in;
-    const int pxb = p.W == 16 ? 2 : 1, tr = 32 * pxb / p.W;
-    p.ntiles = p.B * (p.W / tr);
+    const int pxb = p.W == 16 ? 2 : 1;
+    const int fr = p.W >= 8 ? 1 : 32 / (p.W * p.W);                  // frames per tile at the 4x4 / 2x2 levels
+    const int tr = p.W >= 8 ? 32 * pxb / p.W : p.W;
+    p.ntiles = p.W >= 8 ? p.B * (p.W / tr) : (p.B + fr - 1) / fr;
     p.nblocks = p.ntiles * (p.Cout / 32);
     p.div_tiles = FastDiv::make((unsigned)p.ntiles);
-    const size_t band = (size_t)(tr + 2) * (p.W + 2) * 1024;
+    const size_t band = (size_t)fr * (tr + 2) * (p.W + 2) * 1024;
     const size_t pass_bytes = ((band / 16 + 255) / 256) * 4096;      // the copy writes whole passes (filler slots land as zeros)
     const size_t red = (size_t)4 * pxb * BC_PATCH;
     const size_t smem = pass_bytes > red ? pass_bytes : red;
     typedef void (*kern_t)(const BandConvParams);
-    static const kern_t k16[4] = {bandconv512<16, 2, false, false>, bandconv512<16, 2, false, true>, bandconv512<16, 2, true, false>, bandconv512<16, 2, true, true>};
-    static const kern_t k8[4] = {bandconv512<8, 1, false, false>, bandconv512<8, 1, false, true>, bandconv512<8, 1, true, false>, bandconv512<8, 1, true, true>};
+    static const kern_t kern[4][4] = {
+        {bandconv512<16, 2, false, false>, bandconv512<16, 2, false, true>, bandconv512<16, 2, true, false>, bandconv512<16, 2, true, true>},
+        {bandconv512<8, 1, false, false>, bandconv512<8, 1, false, true>, bandconv512<8, 1, true, false>, bandconv512<8, 1, true, true>},
+        {bandconv512<4, 1, false, false>, bandconv512<4, 1, false, true>, bandconv512<4, 1, true, false>, bandconv512<4, 1, true, true>},
+        {bandconv512<2, 1, false, false>, bandconv512<2, 1, false, true>, bandconv512<2, 1, true, false>, bandconv512<2, 1, true, true>}};
     static unsigned long long attr_mask = 0;
     if (attr_needed_on_this_device(attr_mask))
-        for (int k = 0; k < 8; ++k) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k < 4 ? k16[k] : k8[k - 4]), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+        for (int k = 0; k < 16; ++k) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[k >> 2][k & 3]), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
         }
-    const int sel = (p.residual ? 2 : 0) + (p.relu ? 1 : 0);
-    hipLaunchKernelGGL(p.W == 16 ? k16[sel] : k8[sel], dim3(p.nblocks), dim3(256), smem, s, p);
+    const int lvl = p.W == 16 ? 0 : p.W == 8 ? 1 : p.W == 4 ? 2 : 3;
+    hipLaunchKernelGGL(kern[lvl][(p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 

@@ -343,8 +343,9 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
             const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho, l.c0) : 0;
             if (rowconv) { bm = (l.c0 == 64 ? 64 : 32) * rowconv; bn = l.c0; splits = 1; group = 1; }
-            const bool bandconv = p.use_bandconv && l.wbc_off >= 0 &&
-                                  (long)batch * (l.ho == 16 ? 4 : 2) * (l.cout / 32) >= p.bandconv_min_blocks;
+            const bool bandconv = p.use_bandconv && l.wbc_off >= 0 && !smallm &&
+                                  (l.ho >= 8 ? (long)batch * (l.ho == 16 ? 4 : 2) * (l.cout / 32) >= p.bandconv_min_blocks
+                                             : batch >= p.bandconv_min_frames_small);
             if (bandconv) { bm = l.ho == 16 ? 64 : 32; bn = 32; splits = 1; group = 1; }
             int route = kInNone;
             if (l.inorm) {

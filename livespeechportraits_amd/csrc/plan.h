@@ -72,7 +72,10 @@ struct Plan {
     int norm = 0;              // 0: BatchNorm2d in eval mode (folded, the shipped checkpoints); 1: InstanceNorm2d (norm_layer argument
                                // of the reference constructors, networks.py:555 / :459): conv biases on, statistics at run time, fp32 only
     bool use_bandconv = true;  // bf16 plans: LSP_HIP_BANDCONV=0 at create puts the 16x16 / 8x8 layers back on the implicit GEMM (A-B runs)
-    int bandconv_min_blocks = 128;   // ... and they only leave it when the launch has at least this many workgroups
+    int bandconv_min_blocks = 128;  // (16x16 / 8x8 levels; the 4x4 / 2x2 levels, one tile per 2 / 8 frames, have their own bound below)
+    int bandconv_min_frames_small = 1 << 30;   // 4x4 / 2x2 levels (a tile = 2 / 8 whole frames): never by default -- at 8 frames the 64 / 16
+                                               // workgroups of such a launch lose to the igemm (normal 4460 -> 4388, large 2881 -> 2840 frames/s,
+                                               // A-B-A-B); LSP_HIP_BANDCONV_MIN_FRAMES lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
     size_t elt() const { return dtype == 1 ? 2 : 4; }
     int ktile_channels() const { return dtype == 1 ? 64 : 32; }   // a K-tile is 128 B of channels
@@ -129,7 +132,7 @@ inline bool rowconv_layer(int ho, int c0, int c1, int cout, int stride, bool up,
 // activation-stationary kernel eligibility (mirrors bandconv_supported() in bandconv.hip)
 inline bool bandconv_layer(int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
 {
-    return dtype == 1 && c0 == 512 && c1 == 0 && cout % 32 == 0 && stride == 1 && !up && !up4 && !inorm && (ho == 16 || ho == 8);
+    return dtype == 1 && c0 == 512 && c1 == 0 && cout % 32 == 0 && stride == 1 && !up && !up4 && !inorm && (ho == 16 || ho == 8 || ho == 4 || ho == 2);
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0
 // which layers get the tile-blocked weight copy at pack time (independent of the batch: the blob layout must not depend on it)

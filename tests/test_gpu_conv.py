@@ -416,6 +416,11 @@ BANDCONV_CASES = [
     (3, 8, 96, True, False),       # 8x8 level: 2 tiles per frame
     (8, 8, 512, True, True),       # the shipped shapes at 8 frames
     (8, 16, 512, True, True),
+    (8, 4, 512, True, True),       # 4x4 level: a tile = 2 whole frames
+    (3, 4, 64, False, True),       # ... the second tile half empty
+    (8, 2, 512, True, False),      # 2x2 level: a tile = 8 whole frames
+    (5, 2, 96, True, True),        # ... 5 of them real
+    (9, 2, 32, False, False),      # ... two tiles
 ]
 
 
