@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
     // ---- 2. weight stream: fragment f = tap*8 + kc of this wave's K quarter, 1 KB per fragment, ring of BC_RING
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(p.w) + ((size_t)(cs * 4 + wave) * 72) * 64 + lane;
     bf16x8 ring[BC_RING];
+    constexpr int BC_PRE = BC_RING < 56 ? BC_RING : 56;      // requested before the band wait (vmcnt counts to 63)
 #pragma unroll
-    for (int f = 0; f < BC_RING; ++f) ring[f] = wp[f * 64];
+    for (int f = 0; f < BC_PRE; ++f) ring[f] = wp[f * 64];
 
     // pixel fragment addressing: tile pixel pb*32 + l31 -> band pixel (row + ky, column + kx)
     unsigned bp0[PXB];
@@ -90,8 +91,12 @@ __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the band (and the first ring fill) has landed
+    // the band has landed once at most the BC_PRE weight loads issued after it are outstanding (loads retire in order): the K loop then starts on
+    // the first fragments while the rest of the weights are still streaming in
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BC_PRE) : "memory");
     __syncthreads();
+#pragma unroll
+    for (int f = BC_PRE; f < BC_RING; ++f) ring[f] = wp[f * 64];
 
     // ---- 3. K loop of this wave: 9 taps x 8 channel blocks of 16, no barrier
 #pragma unroll
