@@ -99,6 +99,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_BANDCONV")) h->plan.use_bandconv = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_BLOCKS")) h->plan.bandconv_min_blocks = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_FRAMES")) h->plan.bandconv_min_frames_small = std::atoi(env);
+    if (const char *env = std::getenv("LSP_HIP_ROWLAST")) h->plan.use_rowlast = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
@@ -204,7 +205,7 @@ static const char *kernel_name(const LayerDesc &l)
 {
     switch (l.kind) {
     case kFirstConv: return "first_conv";
-    case kLastConv: return l.wgemm_off >= 0 ? "last_conv (igemm3x3 + pixel_shuffle_tanh)" : "last_conv";
+    case kLastConv: return l.wgemm_off >= 0 ? (l.wrl_off >= 0 ? "last_conv (rowlast128 + pixel_shuffle_tanh)" : "last_conv (igemm3x3 + pixel_shuffle_tanh)") : "last_conv";
     default:
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
         if (l.fullk) return "conv3x3_fullk";
@@ -295,6 +296,19 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         }
     } else if (l.kind == kLastConv && P.last_as_gemm(l) && !h->last_direct) {
         // bf16: 3x3 conv on the low-res source with N = 4 parities x cout through the MFMA kernel, then shuffle + tanh
+        if (l.wrl_off >= 0 && P.use_rowlast) {
+            RowLastParams q{};
+            q.src0 = tptr(l.src0); q.src1 = tptr(l.src1); q.w = h->blob + l.wrl_off;
+            q.out = reinterpret_cast<float *>(h->ws + P.partial_offset);
+            q.B = batch; q.H = l.hs; q.W = l.hs; q.R = rowlast_rows(batch, l.hs, l.hs);
+            e = launch_rowlast(q, s);
+            if (e == hipSuccess) {
+                ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0};
+                e = launch_pixel_shuffle(sp, s);
+            }
+            if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
+            return LSPF2F_OK;
+        }
         IgemmParams g{};
         g.src0 = tptr(l.src0); g.src1 = tptr(l.src1); g.w = h->blob + l.wgemm_off;
         g.out = h->ws + P.partial_offset; g.out_f32 = 1;

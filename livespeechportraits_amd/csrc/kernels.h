@@ -154,6 +154,21 @@ bool bandconv_supported(const BandConvParams &p);
 hipError_t launch_bandconv(const BandConvParams &p, hipStream_t s);
 void pack_bandconv_weights(const unsigned short *rows, unsigned short *out, int cout);   // host: bf16 [cout][9][512] -> fragment order
 
+// The last conv of bf16 plans as a row kernel (rowconv.hip): 3x3 conv on the low-res concat of two 64-channel sources with N = 4 parities x
+// cout <= 16 outputs (the GEMM form of DESIGN.md 4.5), fp32 result [B][H][W][12] for pixel_shuffle_tanh.
+struct RowLastParams {
+    const void *src0, *src1;      // NHWC bf16 [B][H][W][64] each
+    const void *w;                // bf16, fragment order of pack_rowlast_weights()
+    float *out;                   // fp32 [B][H][W][12]
+    int B, H, W, R;
+    int nsx, nsy, nblocks;        // filled by launch_rowlast
+    FastDiv div_sx, div_sy;
+};
+bool rowlast_supported(const RowLastParams &p);
+int rowlast_rows(int batch, int h, int w);
+hipError_t launch_rowlast(const RowLastParams &p, hipStream_t s);
+void pack_rowlast_weights(const unsigned short *rows, unsigned short *out, int nout);   // host: bf16 [nout][9][128] -> [tap 9][kc 4][lane 64][8]
+
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
 struct FirstConvParams {
     const float *feat;   // [B][feat_nc][H][W]

@@ -230,6 +230,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
         }
+        if (last_as_gemm(l) && l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
+            off = align_up(off, 256);
+            l.wrl_off = (int64_t)off;
+            off += (size_t)9 * 4 * 64 * 8 * elt();
+        }
         if (l.kind == kIgemm && fullk_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype)) {
             // HBM is plentiful (288 GB): the 16x16 / 8x8 layers keep a second, tile-blocked copy for the full-K kernel of the
             // small-batch plans next to the row layout the implicit-GEMM kernel of the large-batch plans reads
@@ -457,6 +462,8 @@ std::string Plan::pack(void *blob, size_t bytes) const
                                     g[(((size_t)par * cout + co) * 9 + tap) * cin + ci] = (uint16_t)(u >> 16);
                                 }
                             }
+                if (l.wrl_off >= 0)     // (the blob is zero-filled, so the untouched taps of g are zeros)
+                    pack_rowlast_weights(g, reinterpret_cast<uint16_t *>(base + l.wrl_off), 4 * cout);
             }
         } else if (l.kind == kIgemm) {
             // [co][tap][ci]  -- the implicit-GEMM B operand, K contiguous per output channel

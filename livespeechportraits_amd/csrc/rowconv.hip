@@ -487,6 +487,187 @@ __global__ __launch_bounds__(256) void rowconv128(const RowConvParams p)
     finish(i - 3, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The last conv of bf16 plans in its GEMM form (3x3 conv on the LOW-res source with N = 4 parities x 3 channels = 12 and the pre-summed
+// sub-pixel taps scattered into a 9-tap operand), as a row kernel: 12 (padded to 16) x 1152 weights = 144 registers per wave,
+// v_mfma_f32_16x16x32_bf16 with A = weights [16 n x 32 k], B = pixels [32 k x 16 px].  All four waves hold the same weights and take 16 of
+// the strip's 64 pixels each.  The two concatenated 64-channel sources keep their own rings of 128-B pixel records (an LDS-DMA piece has one
+// buffer descriptor), swizzled like the igemm's K-tiles; one barrier per row step.  Output: fp32 [B][H][W][12] for pixel_shuffle_tanh.
+namespace {
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int RL_TW = 64;                 // low-res pixels per strip row
+constexpr int RL_PITCH = 12288;           // bytes per ring row and source: 96 records of 128 B = 3 passes of the workgroup (66 are real)
+constexpr int RL_NR = 5;
+constexpr int RL_PF = RL_NR - 1;
+constexpr int RL_OPS = 3 + 3 + 1;         // vector-memory operations per step and wave: 3 pieces per source, 1 store
+static_assert((RL_PF - 1) * RL_OPS < 64, "vmcnt is a 6-bit counter");
+}  // namespace
+
+__global__ __launch_bounds__(256) void rowlast128(const RowLastParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave: pixels wave*16 .. +15 of the strip
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.w), "s"(p.out), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.R), "s"(p.nsx), "s"(p.nsy), "s"(p.nblocks),
+                       "s"(p.div_sx.m), "s"(p.div_sx.s1), "s"(p.div_sx.s2), "s"(p.div_sy.m), "s"(p.div_sy.s1), "s"(p.div_sy.s2));
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned total = (unsigned)p.nblocks, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const unsigned t1 = p.div_sx.div(lin);
+    const int sx = (int)(lin - t1 * (unsigned)p.nsx);
+    const int b = (int)p.div_sy.div(t1);
+    const int sy = (int)(t1 - (unsigned)b * (unsigned)p.nsy);
+    const int x0 = sx * RL_TW, y0 = sy * p.R;
+    const unsigned imgbytes = (unsigned)(p.H * p.W) * 128u;
+    const i32x4 srd0 = make_srd(static_cast<const char *>(p.src0) + (size_t)b * imgbytes, imgbytes);
+    const i32x4 srd1 = make_srd(static_cast<const char *>(p.src1) + (size_t)b * imgbytes, imgbytes);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out) + (size_t)b * p.H * p.W * 48, 0, p.H * p.W * 48, 0x00020000);
+
+    // DMA roles (both sources alike): pass q moves record slots q*256 + tid, record r = pixel x0 - 1 + r, slot c <- chunk c ^ ((r >> 1) & 7)
+    unsigned in_col[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int sl = q * 256 + tid, r = sl >> 3, c = sl & 7;
+        const int x = x0 - 1 + r;
+        in_col[q] = (r < RL_TW + 2 && (unsigned)x < (unsigned)p.W) ? (unsigned)(x * 128 + ((c ^ ((r >> 1) & 7)) << 4)) : kOOB;
+    }
+    const unsigned rowbytes = (unsigned)p.W * 128u;
+    auto dma_step = [&](int i) {             // input row i of the strip (image row y0 - 1 + i) of both sources -> ring slot i % RL_NR
+        const int gy = y0 - 1 + i;
+        const bool ok = (unsigned)gy < (unsigned)p.H && i < p.R + 2;
+        const int soff = ok ? gy * (int)rowbytes : 0;
+        const unsigned base = lds0 + (unsigned)(i % RL_NR) * (2 * RL_PITCH) + (unsigned)wave * 1024u;
+        const unsigned v[3] = {ok ? in_col[0] : kOOB, ok ? in_col[1] : kOOB, ok ? in_col[2] : kOOB};
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %5, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %5, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %5, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %6, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %6, %7 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(srd0), "s"(srd1), "s"(soff)
+                     : "memory", "scc");
+    };
+
+    // weights -> registers: A-fragment (tap, kc): lane = output n = l15 (12 real), k = kc*32 + 8*g4 .. +7 of the tap
+    bf16x8 wf[9][4];
+    {
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(p.w) + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                wf[t][kc] = wp[(t * 4 + kc) * 64];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // B-fragment (kx, kc): record r = wave*16 + l15 + kx of source kc >> 1, chunk (kc & 1)*4 + g4, swizzled
+    unsigned boff[3][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int r = wave * 16 + l15 + kx;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+            boff[kx][kc] = (unsigned)((kc >> 1) * RL_PITCH + r * 128 + (((((kc & 1) * 4 + g4)) ^ ((r >> 1) & 7)) << 4));
+    }
+    f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto step = [&](int i, f32x4v &an, f32x4v &am, f32x4v &ao) {
+        if (i < RL_PF) vm_wait<6 * (RL_PF - 1)>(); else vm_wait<(RL_PF - 1) * RL_OPS>();
+        __syncthreads();
+        dma_step(i + RL_PF);
+        const char *row = reinterpret_cast<const char *>(smem) + (unsigned)(i % RL_NR) * (2 * RL_PITCH);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) {
+            const int kx = f >> 2, kc = f & 3;
+            const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(row + boff[kx][kc]);
+            ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[6 + kx][kc], bv, ao, 0, 0, 0);
+            am = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[3 + kx][kc], bv, am, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0 + kx][kc], bv, f == 0 ? zero4 : an, 0, 0, 0);
+        }
+        // output row j = i - 2 is complete.  D layout: lane = pixel l15, register r = output n = 4*g4 + r: 12 floats per pixel, lanes g4 < 3
+        const int j = i - 2;
+        const bool live = j >= 0 && j < p.R && y0 + j < p.H && g4 < 3;
+        const unsigned off = live ? (unsigned)(((y0 + j) * p.W + x0 + wave * 16 + l15) * 48 + g4 * 16) : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ao), rs_out, off, 0, 0);
+    };
+
+#pragma unroll
+    for (int i = 0; i < RL_PF; ++i) dma_step(i);
+    const int nsteps = p.R + 2;
+    for (int i = 0; i < nsteps; i += 3) {
+        step(i, acc0, acc2, acc1);
+        step(i + 1, acc1, acc0, acc2);
+        step(i + 2, acc2, acc1, acc0);
+    }
+}
+
+void pack_rowlast_weights(const unsigned short *rows, unsigned short *out, int nout)
+{
+    // rows: bf16 [nout][9][128] (nout = 4 parities x cout <= 16); fragment (tap, kc): lane = n (lane & 15, zero rows past nout),
+    // k = kc*32 + 8*(lane >> 4) .. +7 of the tap
+    for (int t = 0; t < 9; ++t)
+        for (int kc = 0; kc < 4; ++kc)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int n = lane & 15;
+                    out[(((size_t)t * 4 + kc) * 64 + lane) * 8 + e] = n < nout ? rows[((size_t)n * 9 + t) * 128 + kc * 32 + 8 * (lane >> 4) + e] : 0;
+                }
+}
+
+bool rowlast_supported(const RowLastParams &p)
+{
+    return p.B >= 1 && p.H >= 1 && p.W % RL_TW == 0 && p.R >= 1 && (size_t)p.H * p.W * 128 < 0x7fffffffull;
+}
+
+int rowlast_rows(int batch, int h, int w)
+{
+    const int cand[] = {32, 16, 8, 4, 2, 1};
+    for (int r : cand)
+        if ((long)batch * (w / RL_TW) * ((h + r - 1) / r) >= 256) return r;
+    return 1;
+}
+
+hipError_t launch_rowlast(const RowLastParams &p_in, hipStream_t s)
+{
+    if (!rowlast_supported(p_in)) return hipErrorInvalidValue;
+    RowLastParams p = p_in;
+    p.nsx = p.W / RL_TW; p.nsy = (p.H + p.R - 1) / p.R;
+    p.nblocks = p.B * p.nsx * p.nsy;
+    p.div_sx = FastDiv::make((unsigned)p.nsx);
+    p.div_sy = FastDiv::make((unsigned)p.nsy);
+    const size_t smem = (size_t)RL_NR * 2 * RL_PITCH;
+    static unsigned long long attr_mask = 0;
+    if (attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(rowlast128, dim3(p.nblocks), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
 void pack_rowconv_weights(const unsigned short *rows, unsigned short *out, int c)
 {
     // A-fragment (nb, tap, kc): lane = channel nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7; c = 64 | 128 channels in and out

@@ -270,6 +270,33 @@ def test_bf16_last_conv_gemm_and_direct_routes_agree(gpu_device, monkeypatch):
     assert np.abs(imgs[0][0] - want).max() <= 1
 
 
+def test_bf16_last_conv_row_kernel_matches_the_implicit_gemm_form(gpu_device, monkeypatch):
+    """The GEMM form of the bf16 last conv runs on rowlast128 (rowconv.hip: weights in registers, v_mfma_f32_16x16x32_bf16) when the layer
+    concatenates two 64-channel sources; LSP_HIP_ROWLAST=0 keeps it on the implicit-GEMM kernel.  Same bf16 operands, fp32 accumulation in
+    another order: the frames agree to fp32 noise, the uint8 frames to at most one level on isolated pixels."""
+    from livespeechportraits_amd.engine import Engine
+    meta, arrays, topo, sd, feat, cand = golden_problem("normal_512")
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+    outs, imgs, kinds = [], [], []
+    for row in (True, False):
+        if row:
+            monkeypatch.delenv("LSP_HIP_ROWLAST", raising=False)
+        else:
+            monkeypatch.setenv("LSP_HIP_ROWLAST", "0")
+        e = Engine(topo.variant, size=topo.size, max_batch=2, dtype="bf16")
+        e.load_state_dict(sd)
+        e.bind(e.pack(), gpu_device)
+        kinds.append(e.layers(1)[-1]["kernel"])
+        outs.append(e.forward(f, c).cpu().numpy())
+        imgs.append(e.forward_image(f, c).cpu().numpy().astype(np.int32))
+    monkeypatch.delenv("LSP_HIP_ROWLAST", raising=False)
+    assert "rowlast128" in kinds[0]
+    d = np.abs(outs[0] - outs[1])
+    print("bf16 last conv, row kernel vs implicit GEMM: max-abs %.3g, %d of %d uint8 values differ" % (d.max(), int((imgs[0] != imgs[1]).sum()), imgs[0].size))
+    assert d.max() <= 2e-6
+    assert np.abs(imgs[0] - imgs[1]).max() <= 1
+
+
 @pytest.mark.parametrize("variant,size,batch", [("normal", 1024, 2), ("large", 768, 1)])
 def test_frame_sizes_beyond_the_goldens(variant, size, batch, gpu_device):
     """Sizes larger than any golden (the index arithmetic is 32-bit with a reserved top bit): live oracle comparison."""
