@@ -99,6 +99,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_BANDCONV")) h->plan.use_bandconv = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_BLOCKS")) h->plan.bandconv_min_blocks = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_FRAMES")) h->plan.bandconv_min_frames_small = std::atoi(env);
+    if (const char *env = std::getenv("LSP_HIP_ROWUP")) h->plan.use_rowup = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_ROWLAST")) h->plan.use_rowlast = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     h->plan.plan_batch(cfg->max_batch);
@@ -209,6 +210,7 @@ static const char *kernel_name(const LayerDesc &l)
     default:
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
         if (l.fullk) return "conv3x3_fullk";
+        if (l.rowup) return "rowup256";
         if (l.bandconv) return "bandconv512";
         if (l.rowconv) return l.c0 == 64 ? "rowconv64" : "rowconv128";
         if (l.inorm) return l.smallm ? "conv3x3_smallm+in_small" : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
@@ -341,6 +343,12 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             e = launch_in_small(q, s);
         }
+    } else if (l.rowup) {
+        RowUpParams p{};
+        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wru_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.out = tptr(l.out);
+        p.B = batch; p.H = l.hs; p.W = l.hs; p.R = l.rowup; p.relu = l.relu;
+        e = launch_rowup(p, s);
     } else if (l.bandconv) {
         BandConvParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.wbc_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
@@ -679,6 +687,16 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     {
         // tile (16 | 32) x 16 forces the full-K single-launch kernel; tile 0x0 + split 0 lets the planner's rule pick it
         const int ho_ = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
+        if (tile_m > 3000 && tile_n == 64 && k_group == -1) {     // 3000 + R: the sub-pixel up-conv row kernel, weights in its fragment order
+            RowUpParams q{};
+            q.src0 = src0; q.src1 = src1; q.w = w_packed; q.scale = scale; q.shift = shift; q.out = out;
+            q.B = batch; q.H = hs; q.W = ws; q.R = tile_m - 3000; q.relu = relu;
+            if (!rowup_layer(hs, c0, c1, cout, upsample == 2, dtype, false) || residual || hs != ws || !rowup_supported(q) || (q.R & 1))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 up-conv row kernel does not support this shape");
+            e = launch_rowup(q, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (rowup) launch");
+            return LSPF2F_OK;
+        }
         if (tile_m == 2000 && k_group == -1) {     // the activation-stationary bf16 kernel of the 16x16 / 8x8 levels; weights in its fragment order
             BandConvParams q{};
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;

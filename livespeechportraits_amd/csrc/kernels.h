@@ -169,6 +169,22 @@ int rowlast_rows(int batch, int h, int w);
 hipError_t launch_rowlast(const RowLastParams &p, hipStream_t s);
 void pack_rowlast_weights(const unsigned short *rows, unsigned short *out, int nout);   // host: bf16 [nout][9][128] -> [tap 9][kc 4][lane 64][8]
 
+// Upsample x2 + conv3x3 over the concat of two 128-channel sources -> 64 channels in sub-pixel form as a row kernel (rowconv.hip; L1.up of
+// the bf16 plans).  H, W are the LOW-res extents; the output is [B][2H][2W][64].
+struct RowUpParams {
+    const void *src0, *src1;      // NHWC bf16 [B][H][W][128] each
+    const void *w;                // bf16, fragment order of pack_rowup_weights()
+    const float *scale, *shift;   // [64] or nullptr
+    void *out;                    // NHWC bf16 [B][2H][2W][64]
+    int B, H, W, R, relu;         // R = low-res rows per strip, even
+    int nsx, nsy, nblocks;        // filled by launch_rowup
+    FastDiv div_sx, div_sy;
+};
+bool rowup_supported(const RowUpParams &p);
+int rowup_rows(int batch, int h, int w);
+hipError_t launch_rowup(const RowUpParams &p, hipStream_t s);
+void pack_rowup_weights(const unsigned short *rows, unsigned short *out);   // host: bf16 [4][64][2][2][256] -> [nb 2][par 4][tap 4][kc 16][lane 64][8]
+
 // First layer: cat([feature_map, cand_image]) -> Conv 3x3 s2 p1 -> ReLU, NCHW in, NHWC out.
 struct FirstConvParams {
     const float *feat;   // [B][feat_nc][H][W]

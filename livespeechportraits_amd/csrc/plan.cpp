@@ -242,6 +242,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wfk_off = (int64_t)off;
             off += (size_t)l.cout * 9 * l.cin * sizeof(float);
         }
+        if (l.kind == kIgemm && rowup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
+            off = align_up(off, 256);
+            l.wru_off = (int64_t)off;
+            off += (size_t)16 * l.cout * l.cin * elt();
+        }
         if (l.kind == kIgemm && bandconv_layer(l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wbc_off = (int64_t)off;
@@ -348,6 +353,9 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
             const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho, l.c0) : 0;
             if (rowconv) { bm = (l.c0 == 64 ? 64 : 32) * rowconv; bn = l.c0; splits = 1; group = 1; }
+            int rowup = p.use_rowup && l.wru_off >= 0 ? rowup_rows(batch, l.hs, l.hs) : 0;
+            if (rowup < 8) rowup = 0;     // short strips (1 frame: 4 rows + 2 halo steps) do not beat the implicit GEMM: 22.4 vs 22.9 us
+            if (rowup) { bm = 32 * rowup; bn = 32; splits = 1; group = 1; }
             const bool bandconv = p.use_bandconv && l.wbc_off >= 0 && !smallm &&
                                   (l.ho >= 8 ? (long)batch * (l.ho == 16 ? 4 : 2) * (l.cout / 32) >= p.bandconv_min_blocks
                                              : batch >= p.bandconv_min_frames_small);
@@ -374,7 +382,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 (*tiled)[li].fused_splitk = p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
                                             (size_t)splits * Mout * l.cout * sizeof(float) < (size_t)0x7fffffff;
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
-                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv;
+                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv; (*tiled)[li].rowup = rowup;
             }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }
@@ -488,6 +496,8 @@ std::string Plan::pack(void *blob, size_t bytes) const
                 d16[i] = (uint16_t)(u >> 16);
             }
         }
+        if (l.wru_off >= 0)
+            pack_rowup_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wru_off));
         if (l.wbc_off >= 0)
             pack_bandconv_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wbc_off), cout);
         if (l.wrc_off >= 0)     // the same bf16 values, regrouped into the MFMA A-fragments the row kernel keeps in registers

@@ -45,6 +45,7 @@ struct LayerDesc {
     int64_t wfk_off = -1;    // fp32 plans, 16x16 / 8x8 stride-1 layers: a second copy of the weights in the tile-blocked layout of the full-K kernel
     int64_t wbc_off = -1;    // bf16 plans, 512 -> Cout stride-1 layers at 16x16 / 8x8: a copy of the weights in the fragment order of bandconv.hip
     int64_t wrc_off = -1;    // bf16 plans, 64 -> 64 stride-1 layers: a copy of the weights in the fragment order of the weights-stationary kernel (rowconv.hip)
+    int64_t wru_off = -1;    // bf16 plans, sub-pixel up-conv over two 128-channel sources -> 64 channels (L1.up): weights in the fragment order of rowup256
     int64_t wrl_off = -1;    // bf16 plans, last conv over two 64-channel sources: the GEMM-form weights in the fragment order of rowlast128 (rowconv.hip)
     int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
@@ -54,6 +55,7 @@ struct LayerDesc {
                                  // launch): +1.0 % at fp32 batch 1, none at batch 8, -2.4 % on bf16 batch 8 (A-B-A-B, one session; restricted
                                  // to the <= 16x16 / <= 8x8 levels of a bf16 plan it still loses 0.7-0.9 %)
     bool bandconv = false;  // executed by the activation-stationary kernel of the 16x16 / 8x8 levels (bandconv.hip, bf16 plans)
+    int rowup = 0;         // > 0: executed by rowup256 (rowconv.hip) with this many low-res rows per strip
     int rowconv = 0;       // > 0: executed by the weights-stationary 64 -> 64 bf16 kernel (rowconv.hip) with this many output rows per strip
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
 };
@@ -77,6 +79,7 @@ struct Plan {
     int bandconv_min_frames_small = 1 << 30;   // 4x4 / 2x2 levels (a tile = 2 / 8 whole frames): never by default -- at 8 frames the 64 / 16
                                                // workgroups of such a launch lose to the igemm (normal 4460 -> 4388, large 2881 -> 2840 frames/s,
                                                // A-B-A-B); LSP_HIP_BANDCONV_MIN_FRAMES lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
+    bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
     size_t elt() const { return dtype == 1 ? 2 : 4; }
@@ -130,6 +133,11 @@ inline bool rowconv_layer(int ho, int c0, int c1, int cout, int stride, bool up,
 {
     if (dtype != 1 || c1 != 0 || cout != c0 || stride != 1 || up || up4 || inorm) return false;
     return (c0 == 64 && ho % 64 == 0) || (c0 == 128 && ho % 32 == 0);
+}
+// row kernel of the sub-pixel up-conv (mirrors rowup_supported() in rowconv.hip)
+inline bool rowup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm)
+{
+    return dtype == 1 && up4 && c0 == 128 && c1 == 128 && cout == 64 && !inorm && hs % 32 == 0;
 }
 // activation-stationary kernel eligibility (mirrors bandconv_supported() in bandconv.hip)
 inline bool bandconv_layer(int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)

@@ -668,6 +668,209 @@ hipError_t launch_rowlast(const RowLastParams &p_in, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// L1.up of the bf16 plans (Upsample x2 + conv3x3 over the concat of two 128-channel sources -> 64 channels, in sub-pixel form: 4 output
+// parities x 2x2 taps over the LOW-res rows) as a row kernel.  A wave = one parity; a workgroup = one half (32) of the output channels, so a
+// wave keeps 4 taps x 16 channel blocks = 64 A-fragments (256 registers).  Input row i of the low-res strip feeds tap row a = 0 of output
+// row i - py and tap row a = 1 of output row i - py - 1: two accumulators per wave, rotating every step.  The four waves share the 34-pixel
+// window of both sources (one ring, one barrier per step) and write disjoint pixels of the 2x-resolution output.
+namespace {
+constexpr int RU_TW = 32;                 // low-res pixels per strip row
+constexpr int RU_PITCH = 12288;           // bytes per ring row and source: 48 records of 256 B = 3 passes of the workgroup (34 are real)
+constexpr int RU_NR = 5;
+constexpr int RU_PF = RU_NR - 1;
+constexpr int RU_OPS = 6 + 2;             // vector-memory operations per step and wave: 3 pieces per source, 2 stores
+static_assert((RU_PF - 1) * RU_OPS < 64, "vmcnt is a 6-bit counter");
+}  // namespace
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void rowup256(const RowUpParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int par = __builtin_amdgcn_readfirstlane(tid >> 6);     // this wave: output parity (py, px)
+    const int py = par >> 1, px = par & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.out), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.R), "s"(p.nsx),
+                       "s"(p.nsy), "s"(p.nblocks), "s"(p.div_sx.m), "s"(p.div_sx.s1), "s"(p.div_sx.s2), "s"(p.div_sy.m), "s"(p.div_sy.s1), "s"(p.div_sy.s2));
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned total = (unsigned)p.nblocks, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const int nb = (int)(lin & 1u);                     // half of the output channels; the two halves of a strip are neighbours on one XCD
+    const unsigned strip = lin >> 1;
+    const unsigned t1 = p.div_sx.div(strip);
+    const int sx = (int)(strip - t1 * (unsigned)p.nsx);
+    const int b = (int)p.div_sy.div(t1);
+    const int sy = (int)(t1 - (unsigned)b * (unsigned)p.nsy);
+    const int x0 = sx * RU_TW, y0 = sy * p.R;
+    const unsigned imgbytes = (unsigned)(p.H * p.W) * 256u;
+    const i32x4 srd0 = make_srd(static_cast<const char *>(p.src0) + (size_t)b * imgbytes, imgbytes);
+    const i32x4 srd1 = make_srd(static_cast<const char *>(p.src1) + (size_t)b * imgbytes, imgbytes);
+    const unsigned outbytes = (unsigned)(4 * p.H * p.W) * 128u;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<char *>(p.out) + (size_t)b * outbytes, 0, (int)outbytes, 0x00020000);
+    float *patch = smem + (RU_NR * 2 * RU_PITCH) / 4 + par * (RC_PATCH / 4);
+
+    unsigned in_col[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int sl = q * 256 + tid, r = sl >> 4, c = sl & 15;
+        const int x = x0 - 1 + r;
+        in_col[q] = (r < RU_TW + 2 && (unsigned)x < (unsigned)p.W) ? (unsigned)(x * 256 + ((c ^ ((r >> 1) & 7)) << 4)) : kOOB;
+    }
+    const unsigned rowbytes = (unsigned)p.W * 256u;
+    auto dma_step = [&](int i) {             // low-res input row i of the strip (image row y0 - 1 + i) of both sources -> ring slot i % RU_NR
+        const int gy = y0 - 1 + i;
+        const bool ok = (unsigned)gy < (unsigned)p.H && i < p.R + 2;
+        const int soff = ok ? gy * (int)rowbytes : 0;
+        const unsigned base = lds0 + (unsigned)(i % RU_NR) * (2 * RU_PITCH) + (unsigned)par * 1024u;
+        const unsigned v[3] = {ok ? in_col[0] : kOOB, ok ? in_col[1] : kOOB, ok ? in_col[2] : kOOB};
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %5, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %5, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %5, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %6, %7 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %6, %7 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(v[0]), "v"(v[1]), "v"(v[2]), "s"(srd0), "s"(srd1), "s"(soff)
+                     : "memory", "scc");
+    };
+
+    // weights -> registers: A-fragment (tap t = a*2 + b, kc): lane = channel nb*32 + l31, k = concat channel kc*16 + 8*hi .. +7
+    bf16x8 wf[4][16];
+    {
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(p.w) + ((size_t)(nb * 4 + par) * 64) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 16; ++kc)
+                wf[t][kc] = wp[(t * 16 + kc) * 64];
+    }
+    float sc[8], sh[8];
+    {
+        const int c0 = nb * 32 + (lane & 3) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sc[t] = p.scale ? p.scale[c0 + t] : 1.f; sh[t] = p.scale ? p.shift[c0 + t] : 0.f; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // B-fragment (b, kc): record r = l31 + px + b of source kc >> 3, chunk (kc & 7)*2 + hi, swizzled
+    unsigned rb[2], rs[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) { const int r = l31 + px + bb; rb[bb] = (unsigned)(r * 256); rs[bb] = (unsigned)((r >> 1) & 7); }
+
+    f32x16 acc0, acc1;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    auto step = [&](int i, f32x16 &an, f32x16 &ao) {
+        if (i < RU_PF) vm_wait<6 * (RU_PF - 1)>(); else vm_wait<(RU_PF - 1) * RU_OPS>();
+        __syncthreads();
+        dma_step(i + RU_PF);
+        const char *row = reinterpret_cast<const char *>(smem) + (unsigned)(i % RU_NR) * (2 * RU_PITCH);
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+            const int bb = f >> 4, kc = f & 15;
+            const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(row + (kc >> 3) * RU_PITCH + rb[bb] + (((unsigned)((kc & 7) * 2 + hi) ^ rs[bb]) << 4));
+            ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 + bb][kc], bv, ao, 0, 0, 0);                       // tap row a = 1: output row i - py - 1
+            an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0 + bb][kc], bv, f == 0 ? zero16 : an, 0, 0, 0);     // tap row a = 0: output row i - py
+        }
+        // low-res output row j = i - py - 1 of this parity is complete: transpose through the patch, scale / shift / ReLU, 16 B per lane
+        const int j = i - py - 1;
+        const bool live = j >= 0 && j < p.R && y0 + j < p.H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(patch) + l31 * 144 + g * 32 + hi * 16) = make_float4(ao[4 * g], ao[4 * g + 1], ao[4 * g + 2], ao[4 * g + 3]);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int pxl = 16 * pass + (lane >> 2);
+            const char *src = reinterpret_cast<const char *>(patch) + pxl * 144 + (lane & 3) * 32;
+            const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 16);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { v[t] = v[t] * sc[t] + sh[t]; if (RELU) v[t] = fmaxf(v[t], 0.f); }
+            const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            const unsigned off = live ? (unsigned)(((2 * (y0 + j) + py) * (2 * p.W) + 2 * (x0 + pxl) + px) * 128 + nb * 64 + (lane & 3) * 16) : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < RU_PF; ++i) dma_step(i);
+    const int nsteps = p.R + 2;
+    for (int i = 0; i < nsteps; i += 2) {
+        step(i, acc0, acc1);
+        step(i + 1, acc1, acc0);
+    }
+}
+
+void pack_rowup_weights(const unsigned short *rows, unsigned short *out)
+{
+    // rows: bf16 [par 4][cout 64][a 2][b 2][cin 256] (the igemm's sub-pixel layout); fragment (half nb, par, tap t = a*2 + b, kc):
+    // lane = channel nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7
+    for (int nb = 0; nb < 2; ++nb)
+        for (int par = 0; par < 4; ++par)
+            for (int t = 0; t < 4; ++t)
+                for (int kc = 0; kc < 16; ++kc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e)
+                            out[(((((size_t)nb * 4 + par) * 4 + t) * 16 + kc) * 64 + lane) * 8 + e] =
+                                rows[(((size_t)par * 64 + nb * 32 + (lane & 31)) * 4 + t) * 256 + kc * 16 + 8 * (lane >> 5) + e];
+}
+
+bool rowup_supported(const RowUpParams &p)
+{
+    return p.B >= 1 && p.H >= 1 && p.W % RU_TW == 0 && p.R >= 1 && (size_t)4 * p.H * p.W * 128 < 0x7fffffffull;
+}
+
+int rowup_rows(int batch, int h, int w)
+{
+    const int cand[] = {32, 16, 8, 4, 2};          // even step counts (the two accumulators alternate): R + 2 even
+    for (int r : cand)
+        if ((long)batch * 2 * (w / RU_TW) * ((h + r - 1) / r) >= 256) return r;
+    return 2;
+}
+
+hipError_t launch_rowup(const RowUpParams &p_in, hipStream_t s)
+{
+    if (!rowup_supported(p_in) || (p_in.R & 1)) return hipErrorInvalidValue;
+    RowUpParams p = p_in;
+    p.nsx = p.W / RU_TW; p.nsy = (p.H + p.R - 1) / p.R;
+    p.nblocks = 2 * p.B * p.nsx * p.nsy;
+    p.div_sx = FastDiv::make((unsigned)p.nsx);
+    p.div_sy = FastDiv::make((unsigned)p.nsy);
+    const size_t smem = (size_t)RU_NR * 2 * RU_PITCH + 4 * (size_t)RC_PATCH;
+    static unsigned long long attr_mask = 0;
+    if (attr_needed_on_this_device(attr_mask)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowup256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowup256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    if (p.relu) hipLaunchKernelGGL(rowup256<true>, dim3(p.nblocks), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(rowup256<false>, dim3(p.nblocks), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
 void pack_rowconv_weights(const unsigned short *rows, unsigned short *out, int c)
 {
     // A-fragment (nb, tap, kc): lane = channel nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7; c = 64 | 128 channels in and out

@@ -25,7 +25,9 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev).to(tdt)
     d0 = nhwc(x0)
     d1 = nhwc(x1) if x1 is not None else None
-    if k_group == -1 and tile[0] == 2000:
+    if k_group == -1 and tile[0] > 3000:
+        wp = pack_rowup(w).to(dev)                            # the up-conv row kernel's fragment order (bf16)
+    elif k_group == -1 and tile[0] == 2000:
         wp = pack_bandconv(w).to(dev)                         # the band kernel's fragment order (bf16)
     elif k_group == -1 and tile[0] > 1000:
         wp = pack_rowconv(w).to(dev)                          # the row kernel's MFMA-fragment order (bf16)
@@ -72,6 +74,13 @@ def pack_rowconv(w):
     c = w.shape[0]
     rows = w.permute(0, 2, 3, 1).reshape(c // 32, 32, 9, c // 16, 2, 8)      # [nb][ch][tap][kc][hi][e]
     return rows.permute(0, 2, 3, 4, 1, 5).contiguous().to(torch.bfloat16)   # [nb][tap][kc][hi][ch][e]: lane = hi*32 + ch
+
+
+def pack_rowup(w):
+    """OIHW [64][256][3][3] -> the sub-pixel form [par][co][a][b][ci] -> bf16 [nb 2][par 4][tap 4][kc 16][lane 64][8]
+    (pack_rowup_weights on the host)"""
+    sub = pack_subpixel(w).reshape(4, 2, 32, 4, 16, 2, 8)                       # [par][nb][ch][tap][kc][hi][e]
+    return sub.permute(1, 0, 3, 4, 5, 2, 6).contiguous().to(torch.bfloat16)     # [nb][par][tap][kc][hi][ch][e]
 
 
 def pack_bandconv(w):
@@ -449,3 +458,41 @@ def test_conv3x3_band_kernel_rejects_other_shapes(gpu_device):
         run_conv(gpu_device, bf16r(rnd(1, 512, 32, 32)), None, rnd(64, 512, 3, 3), None, None, None, 1, 0, False, (2000, 32), 0, -1, dtype=1)
     with pytest.raises(N.Lspf2fError):       # stride 2
         run_conv(gpu_device, bf16r(rnd(1, 512, 16, 16)), None, rnd(64, 512, 3, 3), None, None, None, 2, 0, False, (2000, 32), 0, -1, dtype=1)
+
+
+ROWUP_CASES = [
+    # b, low-res h (= w), low-res rows per strip, relu
+    (1, 32, 8, True),
+    (2, 64, 6, True),        # ragged: 64 = 10 strips of 6 + 4
+    (1, 64, 2, False),
+    (2, 128, 32, True),      # the shipped shape (8 frames: 256 workgroups)
+]
+
+
+@pytest.mark.parametrize("cfg", ROWUP_CASES, ids=lambda c: "b%d_h%d_r%d_relu%d" % c)
+def test_conv3x3_upconv_row_kernel_bf16(cfg, gpu_device):
+    """rowup256 (rowconv.hip): Upsample x2 + conv3x3 over the concat of two 128-channel sources -> 64 channels in sub-pixel form, against the
+    implicit-GEMM kernel's sub-pixel path on the same inputs (same taps, same order, same MFMA -> the same bits) and against the fp64
+    reference of the folded bf16 weights (one bf16 ulp)."""
+    b, h, rows, relu = cfg
+    x0, x1 = bf16r(rnd(b, 128, h, h, seed=91)), bf16r(rnd(b, 128, h, h, seed=92))
+    w = rnd(64, 256, 3, 3, seed=93) * 0.05
+    scale, shift = rnd(64, seed=94) * 0.5 + 1.0, rnd(64, seed=95) * 0.1
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, relu, (3000 + rows, 64), 0, -1, dtype=1)
+    other = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, relu, (128, 64), 1, 1, dtype=1)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, other), (got - other).abs().max().item()
+    wq = bf16r(pack_subpixel(w))
+    xp = F.pad(torch.cat([x0, x1], 1).double(), (1, 1, 1, 1))
+    ref = torch.zeros(b, 64, 2 * h, 2 * h, dtype=torch.float64)
+    for py in (0, 1):
+        for px in (0, 1):
+            acc = 0
+            for a in (0, 1):
+                for bb in (0, 1):
+                    acc = acc + torch.einsum("bchw,oc->bohw", xp[:, :, a + py: a + py + h, bb + px: bb + px + h], wq[py * 2 + px, :, a, bb, :].double())
+            ref[:, :, py::2, px::2] = acc
+    ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = (F.relu(ref) if relu else ref).float()
+    tol = (ref.abs() * 2.0 ** -8 + 1e-3)
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
