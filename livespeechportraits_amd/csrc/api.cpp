@@ -202,11 +202,11 @@ int lspf2f_plan_batch(lspf2f_handle *h, int batch)
     return LSPF2F_OK;
 }
 
-static const char *kernel_name(const LayerDesc &l)
+static const char *kernel_name(const LayerDesc &l, const Plan &P)
 {
     switch (l.kind) {
     case kFirstConv: return "first_conv";
-    case kLastConv: return l.wgemm_off >= 0 ? (l.wrl_off >= 0 ? "last_conv (rowlast128 + pixel_shuffle_tanh)" : "last_conv (igemm3x3 + pixel_shuffle_tanh)") : "last_conv";
+    case kLastConv: return l.wgemm_off >= 0 ? (l.wrl_off >= 0 && P.use_rowlast ? "last_conv (rowlast128 + pixel_shuffle_tanh)" : "last_conv (igemm3x3 + pixel_shuffle_tanh)") : "last_conv";
     default:
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
         if (l.fullk) return "conv3x3_fullk";
@@ -224,7 +224,7 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     if (!h || !o || i < 0 || i >= (int)h->plan.layers.size()) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "bad layer index");
     const LayerDesc &l = h->plan.layers[i];
     o->name = l.name.c_str();
-    o->kernel = kernel_name(l);
+    o->kernel = kernel_name(l, h->plan);
     o->cin = l.cin; o->cout = l.cout; o->h_in = l.hs; o->h_out = l.ho; o->stride = l.stride;
     o->upsample = l.up || l.up4; o->concat = l.concat; o->residual = l.residual; o->relu = l.relu; o->tanh_out = l.tanh_out;
     o->tile_m = l.bm; o->tile_n = l.bn; o->split_k = l.splits; o->k_group = l.group;

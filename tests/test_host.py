@@ -325,3 +325,29 @@ def test_bf16_plans_route_small_512_channel_layers_to_the_band_kernel(monkeypatc
         assert np.array_equal(frag, rows.transpose(0, 3, 2, 4, 5, 1, 6)), l["name"]
         checked += 1
     assert checked >= 2
+
+
+def test_bf16_plans_route_the_edge_layers_of_the_256_level_to_row_kernels(monkeypatch):
+    """in bf16 plans the last conv (GEMM form over two 64-channel sources) runs on rowlast128 and L1.up (two 128-channel
+    sources -> 64) on rowup256 from 8-row strips up; the fragment-ordered copy of L1.up's weights equals the numpy restatement of the GPU test."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("normal", dtype="bf16", max_batch=8)
+    l8 = e.layers(8)
+    assert "rowlast128" in l8[-1]["kernel"]
+    assert [l["name"] for l in l8 if l["kernel"] == "rowup256"] == ["L1.up"]
+    assert [l["tile_m"] // 32 for l in l8 if l["kernel"] == "rowup256"] == [32]
+    assert not any(l["kernel"] == "rowup256" for l in e.layers(1))
+    assert "rowlast128" not in Engine("normal", max_batch=8).layers(8)[-1]["kernel"]        # fp32 plans: the direct kernels
+    monkeypatch.setenv("LSP_HIP_ROWUP", "0"); monkeypatch.setenv("LSP_HIP_ROWLAST", "0")
+    off = Engine("normal", dtype="bf16", max_batch=8).layers(8)
+    monkeypatch.delenv("LSP_HIP_ROWUP"); monkeypatch.delenv("LSP_HIP_ROWLAST")
+    assert not any(l["kernel"] == "rowup256" for l in off) and "rowlast128" not in off[-1]["kernel"]
+
+    e.load_state_dict(synth.make_state_dict(__import__("livespeechportraits_amd.topology", fromlist=["build_topology"]).build_topology("normal"), 7))
+    blob = e.pack().numpy()
+    l = [x for x in l8 if x["kernel"] == "rowup256"][0]
+    nbytes = 16 * 64 * 256 * 2
+    rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(4, 2, 32, 4, 16, 2, 8)        # [par][nb][ch][tap][kc][hi][e]
+    frag = blob[l["w_offset"] + nbytes: l["w_offset"] + 2 * nbytes].view(np.uint16).reshape(2, 4, 4, 16, 2, 32, 8)
+    assert np.array_equal(frag, rows.transpose(1, 0, 3, 4, 5, 2, 6))
