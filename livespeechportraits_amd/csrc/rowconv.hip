@@ -1,5 +1,12 @@
-// gfx950: weights-stationary 3x3 convolution for the 64 -> 64 channel layers in bf16 storage (the 256x256 level).  DESIGN.md section 4.4.
+// gfx950: the row kernels of the bf16 plans -- weights-stationary 3x3 convolutions that sweep down the rows of a strip:
+//   rowconv64    64 -> 64 channels (the 256x256 level)             described below
+//   rowconv128   128 -> 128 channels (the 128x128 level)           288 weight registers per wave, shared input ring
+//   rowlast128   the last conv in its GEMM form (N = 12)           16x16x32 MFMA, two 64-channel sources
+//   rowup256     L1.up: Upsample x2 + conv over 2 x 128 channels   sub-pixel form, one output parity per wave
+// All of them keep their weights in registers for the life of a workgroup, bring every input pixel into the CU once by LDS-DMA, feed several
+// MFMAs from one LDS fragment read (the tap rows of consecutive output rows), and wait on counted vmcnt values.
 //
+// rowconv64.
 // In bf16 these layers are HBM-bound (algorithmic: 128 B in + 128 B out per pixel for 73.7 kFLOP; the MFMA time is half the transfer time
 // at 8 frames), and the implicit-GEMM kernel runs them at a fifth of the HBM roofline because im2col pulls every input pixel through the
 // CU's vector-memory path nine times.  Here every input pixel enters the CU ONCE:
