@@ -790,6 +790,22 @@ __global__ __launch_bounds__(256) void rowup256(const RowUpParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
+    // second half of the epilogue of low-res output row j of this parity (its tile sits in the patch): 16 pixels per pass
+    auto finish = [&](int j, int pass) {
+        const bool live = j >= 0 && j < p.R && y0 + j < p.H;
+        const int pxl = 16 * pass + (lane >> 2);
+        const char *src = reinterpret_cast<const char *>(patch) + pxl * 144 + (lane & 3) * 32;
+        const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 16);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { v[t] = v[t] * sc[t] + sh[t]; if (RELU) v[t] = fmaxf(v[t], 0.f); }
+        const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        const unsigned off = live ? (unsigned)(((2 * (y0 + j) + py) * (2 * p.W) + 2 * (x0 + pxl) + px) * 128 + nb * 64 + (lane & 3) * 16) : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
+    };
+
+    // One step = low-res input row i.  Output row i - py - 1 is complete after it: its tile is parked in the patch and finished between the
+    // MFMAs of the NEXT step, as in rowconv64.
     auto step = [&](int i, f32x16 &an, f32x16 &ao) {
         if (i < RU_PF) vm_wait<6 * (RU_PF - 1)>(); else vm_wait<(RU_PF - 1) * RU_OPS>();
         __syncthreads();
@@ -801,34 +817,25 @@ __global__ __launch_bounds__(256) void rowup256(const RowUpParams p)
             const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(row + (kc >> 3) * RU_PITCH + rb[bb] + (((unsigned)((kc & 7) * 2 + hi) ^ rs[bb]) << 4));
             ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 + bb][kc], bv, ao, 0, 0, 0);                       // tap row a = 1: output row i - py - 1
             an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0 + bb][kc], bv, f == 0 ? zero16 : an, 0, 0, 0);     // tap row a = 0: output row i - py
+            if (f == 3) finish(i - py - 2, 0);
+            if (f == 13) finish(i - py - 2, 1);
         }
-        // low-res output row j = i - py - 1 of this parity is complete: transpose through the patch, scale / shift / ReLU, 16 B per lane
-        const int j = i - py - 1;
-        const bool live = j >= 0 && j < p.R && y0 + j < p.H;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)      // D layout: lane = pixel l31, register r = channel 8*(r >> 2) + 4*hi + (r & 3)
             *reinterpret_cast<float4 *>(reinterpret_cast<char *>(patch) + l31 * 144 + g * 32 + hi * 16) = make_float4(ao[4 * g], ao[4 * g + 1], ao[4 * g + 2], ao[4 * g + 3]);
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int pxl = 16 * pass + (lane >> 2);
-            const char *src = reinterpret_cast<const char *>(patch) + pxl * 144 + (lane & 3) * 32;
-            const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 16);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { v[t] = v[t] * sc[t] + sh[t]; if (RELU) v[t] = fmaxf(v[t], 0.f); }
-            const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            const unsigned off = live ? (unsigned)(((2 * (y0 + j) + py) * (2 * p.W) + 2 * (x0 + pxl) + px) * 128 + nb * 64 + (lane & 3) * 16) : kOOB;
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
-        }
     };
 
 #pragma unroll
     for (int i = 0; i < RU_PF; ++i) dma_step(i);
     const int nsteps = p.R + 2;
-    for (int i = 0; i < nsteps; i += 2) {
+    int i = 0;
+    for (; i < nsteps; i += 2) {
         step(i, acc0, acc1);
         step(i + 1, acc1, acc0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    finish(i - py - 2, 0);                   // the tile parked by the last step
+    finish(i - py - 2, 1);
 }
 
 void pack_rowup_weights(const unsigned short *rows, unsigned short *out)
