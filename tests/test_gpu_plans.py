@@ -176,11 +176,11 @@ def test_lle_refuses_out_of_range_neighbours_and_knn_marks_nan_rows(gpu_device):
     assert (indn[3] == -1).all() and (indn[[0, 1, 2, 4]] == ind.cpu().numpy()[[0, 1, 2, 4]]).all()
 
 
-@pytest.mark.parametrize("size,batch", [(256, 4), (768, 1), (256, 1)])
+@pytest.mark.parametrize("size,batch", [(256, 4), (768, 1), (256, 1), (512, 12)])
 def test_bf16_own_kernels_agree_with_the_implicit_gemm_at_other_sizes(size, batch, gpu_device, monkeypatch):
-    """The kernels bf16 plans use instead of the implicit GEMM (rowconv64 / rowconv128 / bandconv512) at frame sizes
-    other than 512: strips, ragged strip heights and level widths change with the size.  Reference = the SAME plan with those kernels
-    switched off (LSP_HIP_ROWCONV=0, LSP_HIP_BANDCONV=0, read at create).  Layer by layer the kernels agree to a bf16 ulp (tests/test_gpu_conv.py);
+    """The kernels bf16 plans use instead of the implicit GEMM (rowconv64 / rowconv128 / rowlast128 / rowup256 / bandconv512, DESIGN.md
+    4.6-4.7) at frame sizes and batches other than the benchmarked ones: strips, ragged strip heights and level widths change with the size.
+    Reference = the SAME plan with those kernels switched off (LSP_HIP_{ROWCONV,BANDCONV,ROWLAST,ROWUP}=0, read at create).  Layer by layer the kernels agree to a bf16 ulp (tests/test_gpu_conv.py);
     through the network a different fp32 summation order becomes isolated one-ulp flips that compound, as between any two bf16 plans."""
     from livespeechportraits_amd import synth
     from livespeechportraits_amd.engine import Engine
@@ -190,11 +190,15 @@ def test_bf16_own_kernels_agree_with_the_implicit_gemm_at_other_sizes(size, batc
     feat, cand = synth.make_inputs(batch, size, seed=5, cand_batch=1)
     f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
 
+    SWITCHES = ("LSP_HIP_ROWCONV", "LSP_HIP_BANDCONV", "LSP_HIP_ROWLAST", "LSP_HIP_ROWUP")
+
     def run(own):
         if not own:
-            monkeypatch.setenv("LSP_HIP_ROWCONV", "0"); monkeypatch.setenv("LSP_HIP_BANDCONV", "0")
+            for k in SWITCHES:
+                monkeypatch.setenv(k, "0")
         e = Engine("normal", size=size, max_batch=batch, dtype="bf16")
-        monkeypatch.delenv("LSP_HIP_ROWCONV", raising=False); monkeypatch.delenv("LSP_HIP_BANDCONV", raising=False)
+        for k in SWITCHES:
+            monkeypatch.delenv(k, raising=False)
         e.load_state_dict(sd)
         e.bind(e.pack(), gpu_device)
         kinds = sorted({l["kernel"].split(" ")[0] for l in e.layers(batch)})
@@ -202,7 +206,7 @@ def test_bf16_own_kernels_agree_with_the_implicit_gemm_at_other_sizes(size, batc
     got, kinds = run(True)
     ref, kinds_ref = run(False)
     print("\nsize %d batch %d: kernels %s" % (size, batch, kinds))
-    assert not any(k.startswith(("rowconv", "bandconv")) for k in kinds_ref)
+    assert not any(k.startswith(("rowconv", "bandconv", "rowup")) for k in kinds_ref)
     if size >= 256:
         assert "rowconv64" in kinds and "rowconv128" in kinds
     d = np.abs(got - ref)
