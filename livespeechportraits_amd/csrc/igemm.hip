@@ -163,6 +163,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
         }
     }
     ISTAMP(9);
+    // byte offset of tap (0,0) of each staged row inside either source (modular arithmetic: a "negative" border pixel is only ever used in a
+    // sum that is valid), so a K-tile's address is one add of a scalar tap offset instead of a multiply per piece
+    unsigned a_b0[PA], a_b1[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        a_b0[i] = (unsigned)a_pix0[i] * ((unsigned)p.C0 * (unsigned)EB) + (unsigned)lqb;
+        a_b1[i] = (unsigned)a_pix0[i] * ((unsigned)p.C1 * (unsigned)EB) + (unsigned)lqb;
+    }
     const int K = ntap * p.Cin;
     const T *wbase = static_cast<const T *>(p.w) + (size_t)par * p.Cout * K;
     unsigned b_off[PB];                                  // byte offset of this thread's weight row, or OOB
@@ -205,9 +213,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 const bool ok = live && ((a_mask[i] >> tap) & 1u);
-                const int pix = UP ? a_pix0[i] + ((a_oy[i] + ky) >> 1) * p.Ws + ((a_ox[i] + kx) >> 1)
-                                   : a_pix0[i] + tapdelta;
-                va[i] = ok ? (unsigned)pix * csb + (unsigned)lqb : kOOB;
+                if constexpr (UP) {
+                    const int pix = a_pix0[i] + ((a_oy[i] + ky) >> 1) * p.Ws + ((a_ox[i] + kx) >> 1);
+                    va[i] = ok ? (unsigned)pix * csb + (unsigned)lqb : kOOB;
+                } else {
+                    va[i] = ok ? (first ? a_b0[i] : a_b1[i]) + (unsigned)tapdelta * csb : kOOB;
+                }
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i) vb[i] = live ? b_off[i] : kOOB;
