@@ -7,7 +7,10 @@ models/feature2face_G.py:16-17 with a 23-channel input) on the MI355X, built fro
   last ConvTranspose + Tanh    -> 3x3 GEMM with N = 4 parities x 3 on the low-res source + lspf2f_pixel_shuffle (tanh)
 
 No shipped configuration selects this variant, so it is sequenced from the host, one C call per launch, rather than
-planned, fused and graph-captured like 'normal' / 'large'; all arithmetic is in the HIP kernels (no CPU path).
+planned and fused like 'normal' / 'large'.  SmallUnetEngine(graph=True) captures the ~40 launches into a hipGraph per (batch, frame
+size, output kind) through torch.cuda.graphs and replays them (inputs copied into the graph's static buffer, outputs out of it); it is
+bit-identical and NOT faster (512x512: 1.04 vs 1.01 ms at one frame, 5.77 vs 5.72 ms at eight -- the launches are asynchronous and
+the device is the limiter, tools/unet_small_time.py), so it is off by default.  All arithmetic is in the HIP kernels (no CPU path).
 The mappings are documented in include/lspf2f.h next to lspf2f_unet_prepare."""
 from __future__ import annotations
 
@@ -81,10 +84,12 @@ def block_keys(num_downs: int, prefix: str = "model"):
 
 
 class SmallUnetEngine:
-    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64):
+    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, graph: bool = False):
         if ngf % 32 or num_downs < 5 or not (1 <= output_nc <= 4):
             raise ValueError("ngf must be a multiple of 32, num_downs >= 5, output_nc <= 4")
         self.lib = N.load()
+        self.use_graph = graph
+        self._graphs: Dict[tuple, tuple] = {}     # (B, S, out_u8) -> (CUDAGraph, static input, static output, scratch)
         self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
         self.chans = [ngf * min(2 ** i, 8) for i in range(num_downs)]
         self.s2d0 = (4 * input_nc + 31) // 32 * 32
@@ -93,6 +98,7 @@ class SmallUnetEngine:
         self._scratch = None
 
     def load_state_dict(self, sd: Dict[str, np.ndarray], prefix: str = "model", device="cuda:0") -> None:
+        self._graphs = {}                         # captured launches point at the previous weights
         sd = {k: (v.detach().float().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)) for k, v in sd.items()}
         keys = block_keys(self.num_downs, prefix)
         need = [k + ".weight" for blk in keys for k in (blk[0], blk[2])]
@@ -148,6 +154,28 @@ class SmallUnetEngine:
         B, _, S, _ = x.shape
         if S % (1 << self.num_downs):
             raise ValueError("frame size must be a multiple of 2**num_downs")
+        if not self.use_graph or torch.cuda.is_current_stream_capturing():
+            return self._run(x, out_u8)
+        key = (B, S, bool(out_u8))
+        if key not in self._graphs:
+            with torch.cuda.device(self.device):
+                xs = x.clone()
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):              # warm-up off the default stream: sizes the scratch, sets kernel attributes
+                    self._run(xs, out_u8)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    outs = self._run(xs, out_u8)
+            self._graphs[key] = (g, xs, outs, self._scratch)      # the scratch the captured launches point at stays alive with the graph
+        g, xs, outs, _ = self._graphs[key]
+        xs.copy_(x)
+        g.replay()
+        return outs.clone()
+
+    def _run(self, x: torch.Tensor, out_u8: bool) -> torch.Tensor:
+        B, _, S, _ = x.shape
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
         nd, L = self.num_downs, self.layers
         with torch.cuda.device(self.device):

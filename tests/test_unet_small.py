@@ -137,3 +137,21 @@ def test_prepare_and_shuffle_entry_points():
     for par in range(4):
         want[:, :, par // 2::2, par % 2::2] = torch.tanh(gq[..., par * 3:(par + 1) * 3]).permute(0, 3, 1, 2)
     assert (out.cpu() - want).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_host_sequenced_launches(gpu_device):
+    """SmallUnetEngine(graph=True) captures its ~40 launches once per (batch, size, output kind) and replays them: same bits as the
+    host-sequenced engine, for new inputs, another batch size in between (a larger split-K scratch), and the uint8 output."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    sd = synth.make_unet_small_state_dict(input_nc=5, num_downs=5, ngf=32)
+    eager, graph = SmallUnetEngine(5, 3, 5, 32), SmallUnetEngine(5, 3, 5, 32, graph=True)
+    eager.load_state_dict(sd, "model", gpu_device); graph.load_state_dict(sd, "model", gpu_device)
+    xs = [torch.from_numpy(synth.symmetric(b * 5 * 64 * 64, 0.6, 10 + i).reshape(b, 5, 64, 64)).to(gpu_device) for i, b in enumerate((1, 3, 1, 3))]
+    for x in xs:
+        assert torch.equal(graph.forward(x), eager.forward(x))
+        assert torch.equal(graph.forward(x, out_u8=True), eager.forward(x, out_u8=True))
+    assert len(graph._graphs) == 4                    # (1 | 3 frames) x (float | uint8)
+    graph.load_state_dict(sd, "model", gpu_device)
+    assert not graph._graphs                          # new weights: the captured launches are dropped
