@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- 512x512 frames/sec of the Feature2FaceGenerator forward on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or started bare,
+in which case this process becomes the launcher: it starts N rank processes of itself (one per GPU, backend nccl = RCCL), waits
+for them and exits with their status.  Fewer than N devices is an error, not a silent 1-GPU run (LSP_DIST_BACKEND=gloo lets
+ranks share devices: control-flow tests on a 1-GPU box only).
 
 A step = one pass of the hot path (lspf2f_forward) over one batch of synthetic frames per GPU,
 inputs already resident in HBM.  Default workload = BASELINE.json configs[1]: May ('large'),
@@ -26,6 +31,44 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (not the 2:1-sparse marketing 
 PEAK_HBM_GBS = 8000.0
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  One child per rank with the torchrun environment
+    contract (rendezvous on 127.0.0.1, a free port), children inherit stdout (rank 0 prints the JSON line); the first failing
+    child ends the job.  Replaces nothing in the reference (its nn.DataParallel needs no launcher: models/networks.py:392-401)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    gloo = os.environ.get("LSP_DIST_BACKEND") == "gloo"
+    if ndev < 1:
+        sys.exit("bench.py: no ROCm device visible (there is no CPU path)")
+    if ndev < n and not gloo:
+        sys.exit("bench.py: --gpus %d but only %d device(s) visible; RCCL needs one device per rank "
+                 "(LSP_DIST_BACKEND=gloo shares devices, for control-flow tests only)" % (n, ndev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r % ndev), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LSP_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, alive = 0, list(procs)
+    while alive and rc == 0:
+        time.sleep(0.2)
+        for p in list(alive):
+            if p.poll() is not None:
+                alive.remove(p)
+                rc = rc or p.returncode
+    for p in alive:          # a rank failed: stop the others (exact PIDs we started)
+        p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,16 +83,17 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--layers", default=None, help="write the per-layer timing table to this file")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)          # does not return
 
     from livespeechportraits_amd import distributed as D
     from livespeechportraits_amd import synth
     from livespeechportraits_amd.engine import Engine
     from livespeechportraits_amd.topology import build_topology
 
+    if D.env_rank()[1] != a.gpus:          # checked before the rendezvous, which would wait for ranks that never come
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the argument disagree" % (a.gpus, D.env_rank()[1]))
     rank, world, local = D.init_process_group()
-    if world != a.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     dev = torch.device("cuda:%d" % local)
     torch.cuda.set_device(dev)
@@ -61,9 +105,13 @@ def main():
     sd = synth.make_state_dict(topo, 1234) if rank == 0 else None
     D.setup_engine(eng, sd, dev)          # pack on rank 0, ONE RCCL broadcast, bind everywhere
 
+    # BASELINE.json configs[3]: distinct feature maps per rank and frame, ONE candidate stack shared by every rank -- rank 0 makes
+    # it, one broadcast (RCCL) hands it to the others, like the weights
     feat_np, cand_np = synth.make_inputs(B, a.size, seed=99 + 1000 * rank, cand_batch=1)
     feat = torch.from_numpy(feat_np).to(dev)
-    cand = torch.from_numpy(cand_np).to(dev)
+    if rank != 0:
+        cand_np = None
+    cand = D.broadcast_tensor(None if cand_np is None else torch.from_numpy(cand_np), (1, 12, a.size, a.size), torch.float32, dev)
     out = torch.empty((B, 3, a.size, a.size), device=dev)
 
     def barrier():
@@ -211,6 +259,8 @@ def main():
         tmin, tmed, threads = torch_oracle.time_cpu(sd_t, x, topo.nres, topo.num_downs, repeats=n_timed)
         cpu_baseline = {"value": round(1.0 / tmin, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                         "median_value": round(1.0 / tmed, 3),
+                        "kind_note": "port = oracle/torch_oracle.py: the reference's own torch op sequence, asserted bit-identical to the reference "
+                                     "modules by oracle/make_golden.py (the Python reference cannot travel to the GPU box)",
                         "sample": "%s generator, batch 1, %dx%d fp32, 1 warm-up + %d timed frames of "
                                   "oracle/torch_oracle.py (torch %s CPU/oneDNN, %d threads)"
                                   % (a.variant, a.size, a.size, n_timed, torch.__version__, threads)}
@@ -280,6 +330,8 @@ def main():
         extra["edge_map_rasteriser"] = {"us_per_frame_batch8": round(e0.elapsed_time(e1) * 1e3 / 160, 2),
                                         "hbm_frac_of_8TBs": round(8 * a.size * a.size * 4 / (e0.elapsed_time(e1) * 1e-3 / 20) / 8e12, 4),
                                         "note": "lspraster_edge_maps: 88 thick edges per frame -> fp32 [8,1,512,512]; parity unpinned vs cv2 (bit-exact to oracle/raster_oracle.c)"}
+        extra["torch_rocm_baseline"] = torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a)
+        extra["config2_normal_b8_bf16"] = config2_extra(dev, a)
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
@@ -306,6 +358,89 @@ def main():
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a):
+    """The as-shipped-on-this-hardware comparator: the same generator through PyTorch-ROCm / MIOpen
+    on the same MI355X, same weights and inputs, fp32, batch 1 and batch 8 (candidates expanded like the reference's cat would
+    need).  Baseline leg: oracle/torch_oracle.py is the reference's module sequence restated op for op (asserted bit-identical
+    to the reference classes on CPU by oracle/make_golden.py), here simply moved to cuda:0.  cudnn.benchmark = True is what the
+    reference sets (models/base_model.py:46-47)."""
+    from oracle import torch_oracle
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    out = {"kind": "port", "device": torch.cuda.get_device_name(dev), "torch": torch.__version__,
+           "note": "oracle/torch_oracle.py (the reference's op sequence, bit-identical to its modules on CPU) on cuda:0: ATen -> MIOpen, fp32, eager, cudnn.benchmark=True"}
+    try:
+        sd_d = {k: v.to(dev) for k, v in torch_oracle.to_torch(sd).items()}
+        for b in (1, 8):
+            f = torch.from_numpy(synth_inputs(b, a.size)[0]).to(dev)
+            x = torch.cat([f, torch.from_numpy(cand_np).to(dev).expand(b, -1, -1, -1)], 1).contiguous()
+            for _ in range(3):
+                y = torch_oracle.generator_forward(sd_d, x, topo.nres, topo.num_downs)
+            torch.cuda.synchronize()
+            n = 10 if b == 1 else 4
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                y = torch_oracle.generator_forward(sd_d, x, topo.nres, topo.num_downs)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            out["batch%d" % b] = {"frames_per_s": round(b / (ms * 1e-3), 2), "ms_per_step": round(ms, 3),
+                                  "tflops": round(topo.flops_per_frame() * b / (ms * 1e-3) / 1e12, 2)}
+            del y
+    except Exception as ex:      # a MIOpen failure must not take the headline line with it
+        out["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+    torch.backends.cudnn.benchmark = prev
+    torch.cuda.empty_cache()
+    return out
+
+
+def synth_inputs(b, size):
+    from livespeechportraits_amd import synth
+    return synth.make_inputs(b, size, seed=99, cand_batch=1)
+
+
+def config2_extra(dev, a):
+    """BASELINE.json configs[2] inside the default run: Obama1 ('normal'), batch 8, 512x512, bf16 storage / fp32 accumulate.  Frames/s
+    with the same timing protocol as the headline, the whole-forward fraction of the dense bf16 MFMA peak, and every frame's
+    distance from the fp32 oracle (the reference has no bf16 path: a declared tolerance, NOT a parity result)."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.topology import build_topology
+    topo = build_topology("normal", size=a.size)
+    sd = synth.make_state_dict(topo, 1234)
+    eng = Engine("normal", size=a.size, max_batch=8, dtype="bf16")
+    eng.load_state_dict(sd)
+    eng.bind(eng.pack(), dev)
+    feat_np, cand_np = synth.make_inputs(8, a.size, seed=99, cand_batch=1)
+    feat, cand = torch.from_numpy(feat_np).to(dev), torch.from_numpy(cand_np).to(dev)
+    out = torch.empty((8, 3, a.size, a.size), device=dev)
+    for _ in range(5):
+        eng.forward(feat, cand, out)
+    torch.cuda.synchronize()
+    n = max(10, a.steps // 2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        eng.forward(feat, cand, out)
+    e1.record(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    r = {"frames_per_s": round(8 * n / dt, 1), "ms_per_step": round(1e3 * dt / n, 4), "steps": n, "dtype": "bf16",
+         "whole_forward_frac_of_dense_bf16_peak": round(topo.flops_per_frame() * 8 / (e0.elapsed_time(e1) * 1e-3 / n) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+         "workload": "normal generator (Obama1), batch 8, %dx%d, bf16 storage / fp32 accumulate, candidates shared" % (a.size, a.size)}
+    if not a.no_cpu_baseline:
+        from oracle import torch_oracle
+        sd_t = torch_oracle.to_torch(sd)
+        x = torch.cat([torch.from_numpy(feat_np), torch.from_numpy(cand_np).expand(8, -1, -1, -1)], 1)
+        ref = torch_oracle.generator_forward(sd_t, x, topo.nres, topo.num_downs)
+        d = (out.cpu() - ref).abs().flatten(1)
+        r["vs_fp32_oracle"] = {"max_abs_per_frame": [round(float(v), 6) for v in d.max(1).values],
+                               "mean_abs_per_frame": [round(float(v), 6) for v in d.mean(1)],
+                               "note": "parity-unpinned by construction (the reference has only fp16 autocast); tests/test_gpu_plans.py declares 1e-2 max / 2.5e-3 mean per frame for this variant"}
+    eng.close()
+    return r
 
 
 def headpose_extra(dev, cpu_threads):

@@ -64,6 +64,20 @@ def broadcast_blob(blob: Optional[torch.Tensor], nbytes: int, device: torch.devi
     return buf
 
 
+def broadcast_tensor(t: Optional[torch.Tensor], shape, dtype: torch.dtype, device: torch.device, src: int = 0) -> torch.Tensor:
+    """Every rank returns a ``shape`` / ``dtype`` tensor on ``device`` holding rank ``src``'s ``t`` (the one candidate stack all
+    ranks render with: BASELINE.json configs[3]).  One collective, start-up only; runs through the backend whenever a group exists."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    buf = torch.empty(tuple(shape), dtype=dtype, device=device)
+    if rank == src:
+        if t is None or tuple(t.shape) != tuple(shape):
+            raise ValueError("source rank must supply the tensor to broadcast")
+        buf.copy_(t)
+    if dist.is_initialized():
+        dist.broadcast(buf, src=src)
+    return buf
+
+
 def setup_engine(engine, state_dict, device: torch.device, src: int = 0) -> None:
     """Pack on ``src`` (the only rank that needs the state dict), broadcast, bind everywhere."""
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -81,7 +95,9 @@ def render_sharded(engine, feature_maps: torch.Tensor, cand_image: torch.Tensor,
     """``feature_maps`` [T,1,H,W] is the GLOBAL frame list (same on every rank, on this
     rank's device); each rank renders frames shard_range(T, rank, world) in chunks of
     ``chunk`` (default engine.max_batch).  Returns the local frames, or all T frames on
-    every rank when ``gather`` (one all_gather of T/world x 3 x H x W floats)."""
+    every rank when ``gather``: one all_gather_into_tensor of ceil(T/world) x 3 x H x W floats per rank (shorter shards are padded
+    for the collective and the padding dropped afterwards, so T need not divide the world size).  The collective runs whenever a
+    process group exists, world size 1 included -- that is how the RCCL path is exercised on a 1-GPU box."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     total = feature_maps.shape[0]
@@ -90,10 +106,18 @@ def render_sharded(engine, feature_maps: torch.Tensor, cand_image: torch.Tensor,
     outs = [engine.forward(feature_maps[i:min(i + chunk, hi)].contiguous(), cand_image)
             for i in range(lo, hi, chunk)]
     local = torch.cat(outs) if outs else feature_maps.new_empty((0, engine.output_nc) + tuple(feature_maps.shape[2:]))
-    if not gather or world == 1:
+    if not gather or not dist.is_initialized():
         return local
-    if total % world:
-        raise ValueError("gather needs the frame count to divide the world size")
-    full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, local)
-    return full
+    per = (total + world - 1) // world                       # the longest shard
+    if per == 0:
+        return local
+    send = local
+    if local.shape[0] != per:
+        send = local.new_zeros((per,) + tuple(local.shape[1:]))
+        send[:local.shape[0]] = local
+    full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, send.contiguous())
+    if world * per == total:
+        return full
+    spans = [shard_range(total, r, world) for r in range(world)]
+    return torch.cat([full[r * per:r * per + (hi - lo)] for r, (lo, hi) in enumerate(spans)])

@@ -70,6 +70,13 @@ def _worker(rank, world, port, tmp):
     assert local.shape[0] == hi - lo and torch.equal(local[:, 0, 0, 0], 2.0 * torch.arange(lo, hi, dtype=torch.float32))
     full = D.render_sharded(Fake(), frames, None, gather=True)
     assert torch.equal(full[:, 0, 0, 0], 2.0 * torch.arange(8, dtype=torch.float32))
+    # a frame count that does not divide the world size: shards of 4 and 3 frames, padded for the collective, padding dropped
+    frames7 = frames[:7].contiguous()
+    full7 = D.render_sharded(Fake(), frames7, None, gather=True)
+    assert full7.shape[0] == 7 and torch.equal(full7[:, 0, 0, 0], 2.0 * torch.arange(7, dtype=torch.float32))
+    # one shared tensor from rank 0 (the candidate stack of BASELINE.json configs[3])
+    t = D.broadcast_tensor(torch.full((2, 3), 5.0) if rank == 0 else None, (2, 3), torch.float32, torch.device("cpu"))
+    assert torch.equal(t, torch.full((2, 3), 5.0))
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, "ok%d" % rank), "w").write("1")
@@ -79,3 +86,21 @@ def test_two_rank_broadcast_and_sharding(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def test_bench_launcher_refuses_to_run_without_devices():
+    """bench.py --gpus N with no launcher environment becomes the launcher; with no ROCm device it must exit non-zero with a
+    message and print no JSON line (never a silent world-size-1 record)."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "no ROCm device" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # a launcher that disagrees with --gpus is an error too
+    env.update(RANK="0", WORLD_SIZE="3", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", LSP_DIST_BACKEND="gloo")
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert q.returncode != 0 and not [ln for ln in q.stdout.splitlines() if ln.startswith("{")]

@@ -418,7 +418,7 @@ def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LSP_DIST_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                                       "--variant", "normal", "--no-cpu-baseline", "--no-extra"],
+                                       "--variant", "normal", "--no-cpu-baseline"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-600:] for o in outs]
@@ -427,3 +427,31 @@ def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2
     assert d["value"] > 0 and abs(d["value"] - 2 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-2 * d["value"]     # whole-job frames / max-rank time
+    c3 = d["extra"]["config3_batch8_per_gpu"]          # BASELINE.json configs[3]'s shape: 8 frames per rank, shared candidates
+    assert c3["ranks_in_group"] == 2 and c3["global_batch"] == 16 and c3["frames_per_s"] > 0 and c3["backend"] == "gloo"
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher and no RANK / WORLD_SIZE in the environment must start two ranks itself
+    (VERDICT r2 #1: it used to run world = 1 with a warning).  gloo because both ranks share the box's one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LSP_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--variant", "normal", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-800:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_in_group"] == 2 and d["config"]["global_batch"] == 2
+    assert d["extra"]["config3_batch8_per_gpu"]["ranks_in_group"] == 2
+    # without the gloo override, asking for more ranks than devices is an error, never a silent 1-GPU record
+    import torch
+    env.pop("LSP_DIST_BACKEND")
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=300)
+    assert q.returncode != 0 and "device(s) visible" in q.stderr and not [ln for ln in q.stdout.splitlines() if ln.startswith("{")]

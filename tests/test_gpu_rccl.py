@@ -37,8 +37,10 @@ intact = bool(torch.equal(buf.cpu(), blob))
 eng.bind(buf)                                       # used in place, no copy
 out = eng.forward(torch.from_numpy(feat).to(dev), torch.from_numpy(cand).to(dev)).cpu().numpy()
 err = float(np.abs(out - arrays["out"]).max())
-# the all-gather of render_sharded(gather=True) through the same backend
-g = D.render_sharded(eng, torch.from_numpy(feat).to(dev), torch.from_numpy(cand).to(dev), gather=True)
+# the all-gather of render_sharded(gather=True) through the same backend: with a process group up the collective runs at world
+# size 1 too (all_gather_into_tensor on RCCL), and the shared candidate stack goes through broadcast_tensor
+cand_d = D.broadcast_tensor(torch.from_numpy(cand), cand.shape, torch.float32, dev)
+g = D.render_sharded(eng, torch.from_numpy(feat).to(dev), cand_d, gather=True)
 libs = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
 print(json.dumps({"intact": intact, "bytes": int(buf.numel()), "err": err, "gather_equal": bool(np.array_equal(g.cpu().numpy(), out)),
                   "rccl_mapped": sorted(set(libs))[:1]}))
