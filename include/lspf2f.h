@@ -210,7 +210,12 @@ int lspf2f_subset_timed(lspf2f_handle *h, const float *feat_dev, const float *ca
  *   16 x 16 / 32 x 16 = the full-K single-launch kernel of the 16x16 / 8x8 levels (fp32, stride 1, extents 2..16,
  *   c0 in {128, 256, 512}, c1 in {0, c0}, cout % 128 == 0; no scratch).  With k_group == -1 the full-K kernel takes w_packed in
  *   its own tile-blocked layout, [cout/16][source][tap][4 waves][g][64 lanes][4] with lane (li, kq) of block (nt, T, w, g) holding
- *   channels 4 * (kq * 4G + w * G + g) .. + 3 (G = c0 / 64) of output row 16 nt + li -- the copy the packer adds for those layers. */
+ *   channels 4 * (kq * 4G + w * G + g) .. + 3 (G = c0 / 64) of output row 16 nt + li -- the copy the packer adds for those layers.
+ *   4001 / 4002 (with k_group == -1) = the Winograd F(2x2,3x3) kernel with 1 / 2 blocks of 32 output channels per wave (fp32, one source,
+ *   stride 1, hs % 16 == 0, c0 % 8 == 0, cout % 32 == 0 / % 64 == 0): w_packed holds G g G^T in the fragment order
+ *   [cout/32][xi-row 4][c0/8][j 4][64 lanes][4] (lane l: output channel 32 nblock + (l & 31), input channels 8 s + 4 (l >> 5) .. + 3, the copy
+ *   the packer adds for those layers); split_k = K slices (1..8, 0 = 1) combined inside the launch -- the scratch then holds the slabs
+ *   followed by one arrival counter per (tile-block, channel group), which must be ZERO on entry and is left zero. */
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride,
                                     int upsample, int tile_m, int tile_n, int split_k, int k_group, int dtype);
 int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, const float *scale,

@@ -188,12 +188,14 @@ hipError_t launch_bandconv(const BandConvParams &p_in, hipStream_t s)
         {bandconv512<8, 1, false, false>, bandconv512<8, 1, false, true>, bandconv512<8, 1, true, false>, bandconv512<8, 1, true, true>},
         {bandconv512<4, 1, false, false>, bandconv512<4, 1, false, true>, bandconv512<4, 1, true, false>, bandconv512<4, 1, true, true>},
         {bandconv512<2, 1, false, false>, bandconv512<2, 1, false, true>, bandconv512<2, 1, true, false>, bandconv512<2, 1, true, true>}};
-    static unsigned long long attr_mask = 0;
-    if (attr_needed_on_this_device(attr_mask))
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
         for (int k = 0; k < 16; ++k) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[k >> 2][k & 3]), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
         }
+        attr_done_on_this_device(attr_mask);
+    }
     const int lvl = p.W == 16 ? 0 : p.W == 8 ? 1 : p.W == 4 ? 2 : 3;
     hipLaunchKernelGGL(kern[lvl][(p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();

@@ -292,11 +292,12 @@ static hipError_t launch_first_conv_mfma(const FirstConvParams &p, hipStream_t s
     const int Ho = p.H / 2, Wo = p.W / 2;
     const long tiles = (long)p.B * ((Wo + 63) / 64) * ((Ho + 1) / 2);
     const size_t smem = (size_t)(13 * 5 * 132 + 118 * NH * 32) * sizeof(float);
-    static unsigned long long attr_mask = 0;
+    static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&first_conv_mfma<T, NH>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
     }
     hipLaunchKernelGGL((first_conv_mfma<T, NH>), dim3((unsigned)tiles), dim3(256), smem, s, p);
     return hipGetLastError();

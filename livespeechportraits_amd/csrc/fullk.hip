@@ -263,11 +263,12 @@ bool fullk_supported(const FullKParams &p, int pb)
 template <int PB, int G, int NCH, bool WT>
 static hipError_t launch_fullk_w(const FullKParams &p, size_t smem, hipStream_t s)
 {
-    static unsigned long long attr_mask = 0;
+    static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_fullk<PB, G, NCH, WT>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
     }
     hipLaunchKernelGGL((conv3x3_fullk<PB, G, NCH, WT>), dim3(p.ntm * p.ntn), dim3(256), smem, s, p);
     return hipGetLastError();

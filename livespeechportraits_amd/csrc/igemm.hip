@@ -586,11 +586,12 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
     constexpr size_t smem_patch = (size_t)WGM * WGN * 32 * 36 * sizeof(float);   // epilogue transpose patches
     size_t smem = p.ktiles_per_split > G ? smem_max : smem_one;
     if (smem < smem_patch) smem = smem_patch;
-    static unsigned long long attr_mask = 0;   // raise the dynamic-LDS cap once per instantiation and device
+    static AttrMask attr_mask;   // raise the dynamic-LDS cap once per instantiation and device
     if (smem_max > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3<T, BM, BN, WGM, WGN, G, UP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
         if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
     }
     IgemmParams q = p;
     q.ntm = ntm; q.ntn = ntn; q.gx = ntm * ntn * npar; q.gy = p.splits;

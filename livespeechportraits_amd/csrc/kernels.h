@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <atomic>
 
 namespace lspf2f {
 
@@ -66,15 +67,25 @@ struct IgemmParams {
                                 // 4 no barrier, 8 no buffer flip, 16 no epilogue, 32 no K loop
 };
 
-// Kernel attributes (dynamic-LDS cap) are per device: `mask` has one bit per HIP device that already has the attribute of
-// one kernel instantiation.  Returns true when the current device still needs it (and marks it).
-inline bool attr_needed_on_this_device(unsigned long long &mask)
+// Kernel attributes (dynamic-LDS cap) are per device: an AttrMask has one bit per HIP device that already has the attribute of one
+// kernel instantiation.  attr_needed_on_this_device() only LOOKS; the caller marks the device with attr_done_on_this_device() after
+// hipFuncSetAttribute has succeeded, so a failed call is retried by the next launch, and a second host thread either sees the bit
+// (the attribute is set) or sets the same attribute again (idempotent) -- it can never launch ahead of it.
+struct AttrMask { std::atomic<unsigned long long> bits{0}; };
+inline int attr_device_bit()
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    if (mask >> dev & 1ull) return false;
-    mask |= 1ull << dev;
-    return true;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev <= 63) ? dev : -1;
+}
+inline bool attr_needed_on_this_device(const AttrMask &mask)
+{
+    const int dev = attr_device_bit();
+    return dev < 0 || !(mask.bits.load(std::memory_order_acquire) >> dev & 1ull);
+}
+inline void attr_done_on_this_device(AttrMask &mask)
+{
+    const int dev = attr_device_bit();
+    if (dev >= 0) mask.bits.fetch_or(1ull << dev, std::memory_order_release);
 }
 
 struct TileConfig { int bm, bn; };
@@ -87,6 +98,27 @@ bool igemm_tile_supported(int bm, int bn);
 bool igemm_group_supported(int bm, int bn, int g, bool up);
 hipError_t launch_igemm(const IgemmParams &p, int bm, int bn, int g, hipStream_t s);
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s);
+
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 conv (wino.hip): fp32, one source, H % 8 == 0, W % 16 == 0, C % 8 == 0,
+// N % (32 * nb) == 0 with nb = 32-channel blocks per wave (1 | 2).  A workgroup owns 4 x 8 Winograd tiles (8 x 16 output pixels) x 32 nb
+// channels; K (the input channels) may be split 2..8 ways, combined inside the launch by the last-arriving workgroup of a tile.
+struct WinoParams {
+    const float *src;             // NHWC [B][H][W][C]
+    const float *u;               // G g G^T in the fragment order of pack_wino_weights()
+    const float *scale, *shift;   // [N] folded BatchNorm, or nullptr
+    const float *residual;        // NHWC [B][H][W][N] or nullptr
+    float *out;                   // NHWC [B][H][W][N]
+    float *partial;               // splits > 1: fp32 slabs [splits][B*H*W][N]
+    unsigned *tile_cnt;           // splits > 1: one arrival counter per (tile-block, channel group), zero between launches
+    int B, H, W, C, N, relu, splits;
+    // filled by launch_wino
+    int steps_per_split, ntb, nng, tby, tbx, nmajor, xcd;
+    size_t slab_bytes;
+    FastDiv div_plane, div_fast, div_tbf, div_tbx;
+};
+bool wino_supported(const WinoParams &p, int nb);
+hipError_t launch_wino(const WinoParams &p, int nb, hipStream_t s);
+void pack_wino_weights(const float *oihw, int cin, int cout, float *out);   // host: OIHW [cout][cin][3][3] -> [cout/32][4][cin/8][4][64][4]
 
 // Tiny-M single-source conv (M <= 16 output pixels, whole input <= 64 KB): one launch, no split-K.
 struct SmallMParams {

@@ -62,6 +62,30 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
     *group_out = group;
 }
 
+int wino_choice(int batch, int ho, int cin, int cout, int *splits_out)
+{
+    // A workgroup = 32 Winograd tiles (8 x 16 output pixels) x 32 nb channels over the whole K (or a slice).  Two channel blocks per wave halve
+    // the fragment reads per MFMA but cost half the workgroups: used when that still leaves two workgroups per CU.  Below ~1.5 workgroups
+    // per CU the input channels are split (combined inside the launch), keeping >= 4 eight-channel steps per slice.
+    const long ntb = (long)batch * (ho / 8) * (ho / 16);
+    int nb = (cout % 64 == 0 && ntb * (cout / 64) >= 512) ? 2 : 1;
+    const long wgs = ntb * (cout / (32 * nb));
+    const int steps = cin / 8;
+    int splits = 1;
+    if (wgs < 384) {
+        splits = (int)((512 + wgs - 1) / wgs);
+        splits = std::min(splits, std::min(8, std::max(1, steps / 4)));
+        const int per = (steps + splits - 1) / splits;
+        splits = (steps + per - 1) / per;                  // every slice non-empty
+    }
+    WinoParams q{};
+    q.B = batch; q.H = ho; q.W = ho; q.C = cin; q.N = cout; q.splits = 1;
+    if (!wino_supported(q, nb)) return 0;
+    if (splits > 1 && wgs > (long)Plan::kTileCounters) return 0;
+    *splits_out = splits;
+    return nb;
+}
+
 static void level_channels(int depth, int ngf, int input_nc, int output_nc, int *cin, int *inner, int *cout)
 {
     // networks.py:557-570: innermost and the num_downs-5 middle blocks are ngf*8 -> ngf*8, then
@@ -242,6 +266,12 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wfk_off = (int64_t)off;
             off += (size_t)l.cout * 9 * l.cin * sizeof(float);
         }
+        if (l.kind == kIgemm && wino_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+            // 16/9 of the 9-tap bytes; the 9-tap copy stays (plans of other batch sizes, LSP_HIP_WINO=0)
+            off = align_up(off, 256);
+            l.wwg_off = (int64_t)off;
+            off += (size_t)16 * l.cout * l.cin * sizeof(float);
+        }
         if (l.kind == kIgemm && rowup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wru_off = (int64_t)off;
@@ -351,6 +381,9 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             const int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
             if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
+            int wsplits = 1;
+            const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
+            if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
             const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho, l.c0) : 0;
             if (rowconv) { bm = (l.c0 == 64 ? 64 : 32) * rowconv; bn = l.c0; splits = 1; group = 1; }
             int rowup = p.use_rowup && l.wru_off >= 0 ? rowup_rows(batch, l.hs, l.hs) : 0;
@@ -379,7 +412,8 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             }
             if (tiled) {
                 const long tiles = (long)(l.up4 ? 4 : 1) * ((M + bm - 1) / std::max(bm, 1)) * ((l.cout + bn - 1) / std::max(bn, 1));
-                (*tiled)[li].fused_splitk = p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
+                (*tiled)[li].wino = wino;
+                (*tiled)[li].fused_splitk = wino ? splits > 1 : p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
                                             (size_t)splits * Mout * l.cout * sizeof(float) < (size_t)0x7fffffff;
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
                 (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv; (*tiled)[li].rowup = rowup;
@@ -480,6 +514,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
                     for (int t = 0; t < 9; ++t)
                         dst[((size_t)co * 9 + t) * cin + ci] = W[((size_t)co * cin + ci) * 9 + t];
             if (l.wfk_off >= 0) pack_fullk_weights(dst, l.c0, l.c1 ? 2 : 1, cout, reinterpret_cast<float *>(base + l.wfk_off));
+            if (l.wwg_off >= 0) pack_wino_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwg_off));
         } else if (l.kind == kFirstConv) {
             // [ci][tap][co]  -- broadcast rows for the direct first-layer kernel
             for (int co = 0; co < cout; ++co)

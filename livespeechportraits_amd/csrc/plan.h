@@ -47,6 +47,7 @@ struct LayerDesc {
     int64_t wrc_off = -1;    // bf16 plans, 64 -> 64 stride-1 layers: a copy of the weights in the fragment order of the weights-stationary kernel (rowconv.hip)
     int64_t wru_off = -1;    // bf16 plans, sub-pixel up-conv over two 128-channel sources -> 64 channels (L1.up): weights in the fragment order of rowup256
     int64_t wrl_off = -1;    // bf16 plans, last conv over two 64-channel sources: the GEMM-form weights in the fragment order of rowlast128 (rowconv.hip)
+    int64_t wwg_off = -1;    // fp32 plans, stride-1 single-source convs at >= 32x32: G g G^T in the fragment order of the Winograd kernel (wino.hip)
     int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
     int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
@@ -57,6 +58,7 @@ struct LayerDesc {
     bool bandconv = false;  // executed by the activation-stationary kernel of the 16x16 / 8x8 levels (bandconv.hip, bf16 plans)
     int rowup = 0;         // > 0: executed by rowup256 (rowconv.hip) with this many low-res rows per strip
     int rowconv = 0;       // > 0: executed by the weights-stationary 64 -> 64 bf16 kernel (rowconv.hip) with this many output rows per strip
+    int wino = 0;          // > 0: executed by the Winograd F(2x2,3x3) kernel (wino.hip) with this many 32-channel blocks per wave (1 | 2); `splits` = its K splits
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
 };
 
@@ -81,6 +83,7 @@ struct Plan {
                                                // A-B-A-B); LSP_HIP_BANDCONV_MIN_FRAMES lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
+    bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
     size_t elt() const { return dtype == 1 ? 2 : 4; }
     int ktile_channels() const { return dtype == 1 ? 64 : 32; }   // a K-tile is 128 B of channels
@@ -167,6 +170,16 @@ inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int
     }
     return 0;
 }
+// Winograd kernel eligibility, batch-independent part (which layers get the G g G^T copy at pack time); the per-batch choice asks
+// wino_supported() itself (kernels.h) through wino_choice() in plan.cpp
+static const int kWinoMinExtent = 32;
+inline bool wino_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
+{
+    return dtype == 0 && stride == 1 && !up && !up4 && !inorm && c1 == 0 && hs == ho && ho >= kWinoMinExtent && ho % 16 == 0 &&
+           c0 % 8 == 0 && cout % 32 == 0;
+}
+// per batch: 32-channel blocks per wave (0 = keep the implicit GEMM) and K splits
+int wino_choice(int batch, int ho, int cin, int cout, int *splits);
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 
 }  // namespace lspf2f

@@ -666,10 +666,11 @@ hipError_t launch_rowlast(const RowLastParams &p_in, hipStream_t s)
     p.div_sx = FastDiv::make((unsigned)p.nsx);
     p.div_sy = FastDiv::make((unsigned)p.nsy);
     const size_t smem = (size_t)RL_NR * 2 * RL_PITCH;
-    static unsigned long long attr_mask = 0;
+    static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
     }
     hipLaunchKernelGGL(rowlast128, dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
@@ -874,11 +875,12 @@ hipError_t launch_rowup(const RowUpParams &p_in, hipStream_t s)
     p.div_sx = FastDiv::make((unsigned)p.nsx);
     p.div_sy = FastDiv::make((unsigned)p.nsy);
     const size_t smem = (size_t)RU_NR * 2 * RU_PITCH + 4 * (size_t)RC_PATCH;
-    static unsigned long long attr_mask = 0;
+    static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowup256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowup256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
     }
     if (p.relu) hipLaunchKernelGGL(rowup256<true>, dim3(p.nblocks), dim3(256), smem, s, p);
     else hipLaunchKernelGGL(rowup256<false>, dim3(p.nblocks), dim3(256), smem, s, p);
@@ -929,14 +931,16 @@ hipError_t launch_rowconv(const RowConvParams &p_in, hipStream_t s)
     typedef void (*kern_t)(const RowConvParams);
     static const kern_t kern[8] = {rowconv64<false, false>, rowconv64<false, true>, rowconv64<true, false>, rowconv64<true, true>,
                                    rowconv128<false, false>, rowconv128<false, true>, rowconv128<true, false>, rowconv128<true, true>};
-    static unsigned long long attr_mask = 0;
-    if (attr_needed_on_this_device(attr_mask))
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
         for (int k = 0; k < 8; ++k) {
             const size_t need = k < 4 ? 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH)
                                       : (size_t)RD_NR * RD_PITCH + 4 * ((size_t)RD_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH);
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[k]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
             if (e != hipSuccess) return e;
         }
+        attr_done_on_this_device(attr_mask);
+    }
     hipLaunchKernelGGL(kern[(wide ? 4 : 0) + (p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
 }

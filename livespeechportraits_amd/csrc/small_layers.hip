@@ -136,7 +136,7 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     const size_t act_bytes = ((size_t)p.B * p.Hs * p.Ws + 1) * p.Cin * 4;
     const size_t red_bytes = (size_t)16 * NC * 264 * 4;
     const size_t smem = 160 * 4 + (act_bytes > red_bytes ? act_bytes : red_bytes);
-    static unsigned long long attr_mask = 0;
+    static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
@@ -144,6 +144,7 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
         if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
     }
     if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
     else hipLaunchKernelGGL((conv3x3_smallm<float, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);

@@ -1,0 +1,372 @@
+// gfx950 (MI355X / CDNA4): stride-1 3x3 convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores -- 16 GEMMs of
+// [tiles x Cin] . [Cin x Cout] (one per position xi of the 4x4 transformed tile) instead of one GEMM with K = 9 Cin: 16 multiplies per
+// 4 outputs instead of 36, i.e. 4/9 of the matrix FLOPs of the implicit GEMM (igemm.hip).  fp32 in, fp32 accumulate, BatchNorm-folded
+// scale / shift, residual add and ReLU in the epilogue like every other conv of this library.  See DESIGN.md section 4.8.
+//
+// Reference semantics: the 3x3 / stride 1 / pad 1 / bias-free Conv2d calls of ResidualBlock, models/networks.py:650-675 (:663, :666),
+// followed by BatchNorm2d in eval mode, the residual add and ReLU (:670-675).
+//
+//   Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// Workgroup = 4 x 8 Winograd tiles (8 x 16 output pixels of one frame) x 32*NB output channels, 4 waves.  Wave i owns row i of the
+// transformed tile (xi = 4i .. 4i+3): it needs rows (ra, rb) of the raw 4x4 patch only, computes its four V values in registers straight
+// from the raw patch in LDS (8 ds_read_b128 + 32 adds per 8 channels: the transformed input never exists in memory), and keeps 4 x NB
+// accumulators of 32 tiles x 32 channels (v_mfma_f32_32x32x2_f32).  The weights arrive pre-transformed (U = G g G^T, host packer, double)
+// in the order the MFMA wants them: one 1-KB LDS-DMA piece = the B fragment of 4 MFMAs; a wave copies exactly the fragments it alone uses.
+// Per 8 input channels a wave issues 16 NB MFMAs for 8 + 4 NB fragment reads.  The four waves meet once, in the epilogue: the column half of
+// the output transform in registers, the row half across waves through an LDS patch.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace lspf2f {
+
+static constexpr unsigned kOOBw = 0x80000000u;   // voffset beyond any num_records: the LDS-DMA lands zeros (image border, unused chunks)
+
+static constexpr int kRawPieces = 6;                       // 360 chunks of 16 B (10 x 18 pixels x 2 channel quads) in 6 pieces of 64
+static constexpr int kRawStage = kRawPieces * 1024;        // bytes per ring slot
+
+__host__ __device__ constexpr int wino_u_stage(int nb) { return 4 * 4 * nb * 1024; }              // 4 waves x (4 j x nb) pieces
+__host__ __device__ constexpr int wino_raw_base(int nb) { return 2 * wino_u_stage(nb); }
+__host__ __device__ constexpr int wino_dump(int nb) { return wino_raw_base(nb) + 2 * kRawStage; }
+__host__ __device__ constexpr int wino_lds_bytes(int nb)
+{
+    const int loop = wino_dump(nb) + 1024;
+    const int patch = 4 * 2 * nb * 32 * 36 * 4;             // epilogue: [wave][b][nb][32 tiles][36]
+    return loop > patch ? loop : patch;
+}
+
+// two LDS-DMA pieces with unrelated LDS destinations, one descriptor and scalar offset (the raw patch: pieces w and w + 4, or the dump slot)
+__device__ __forceinline__ void dma16_two(unsigned lds_a, unsigned lds_b, unsigned va, unsigned vb, i32x4 srd, int soff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %3, %5, %6 offen lds\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_a), "s"(lds_b), "v"(va), "v"(vb), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// The K loop of one wave.  ROW = its row i of B^T d B: t = d[ra] (+|-) d[rb] per patch column, then the column transform.
+//   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3
+template <int NB, int ROW>
+__device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][NB], const char *smem_c, unsigned lds0, int wave, int lane,
+                                          unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, unsigned soff_nb,
+                                          int ks_begin, int ks_end)
+{
+    constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
+    constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB), DUMP = wino_dump(NB);
+    // fragment-read addresses: lane (tile r = l & 31 -> ty = r >> 3, tx = r & 7; channel quad q = l >> 5) reads patch pixel
+    // (2 ty + dy, 2 tx + dx); chunk = ((pary * 2 + parx) * 2 + q) * 45 + hy * 9 + hx with (py, px) = (2 hy + pary, 2 hx + parx)
+    const int r = lane & 31, q = lane >> 5, ty = r >> 3, tx = r & 7;
+    unsigned araw[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int dy = k == 0 ? RA : RB;
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int chunk = (((dy & 1) * 2 + (dx & 1)) * 2 + q) * 45 + (ty + (dy >> 1)) * 9 + tx + (dx >> 1);
+            araw[k][dx] = (unsigned)(RAWB + chunk * 16);
+        }
+    }
+    const unsigned au = (unsigned)(wave * (4 * NB * 1024) + lane * 16);     // this wave's fragments inside a U ring slot
+    // the wave's four j fragments of one channel block: consecutive 1-KB pieces in memory and in LDS (dma16_group advances M0; the per-piece
+    // voffsets are registers rather than instruction offsets, which the LDS-DMA form would also add to the LDS address)
+    const unsigned vu[4] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + 1024), (unsigned)(lane * 16 + 2048), (unsigned)(lane * 16 + 3072)};
+    const unsigned lds_u = lds0 + (unsigned)(wave * (4 * NB * 1024));
+    const unsigned lds_r0 = lds0 + (unsigned)(RAWB + wave * 1024);
+    const unsigned lds_r1 = wave < 2 ? lds_r0 + 4096u : lds0 + (unsigned)DUMP;   // pieces 4, 5 exist for waves 0, 1 only; the others feed the dump slot
+
+    auto fetch = [&](int ks, int slot) {
+        dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            dma16_group<4, 1024>(lds_u + (unsigned)(slot * USTAGE + nb * 4096), vu, srd_u, (int)(soff_u0 + (unsigned)nb * soff_nb + (unsigned)ks * 4096u));
+    };
+
+    const int nsteps = ks_end - ks_begin;
+    if (nsteps <= 0) return;
+    fetch(ks_begin, 0);
+    dma_wait<0>();
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        const char *rawp = smem_c + cur * kRawStage;
+        const char *up = smem_c + cur * USTAGE + au;
+        // raw rows of this step and the first weight fragment: issued straight behind the barrier, their latency rides under the DMA issue below
+        float4 d[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
+        float4 u[2];
+        u[0] = *reinterpret_cast<const float4 *>(up);
+        if (t + 1 < nsteps) fetch(ks_begin + t + 1, cur ^ 1);       // the other slot was released by the barrier that ended step t - 1
+        float4 tt[4], v[4];
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            if constexpr (ROW == 0 || ROW == 3) tt[dx] = f4sub(d[0][dx], d[1][dx]);
+            else if constexpr (ROW == 1) tt[dx] = f4add(d[0][dx], d[1][dx]);
+            else tt[dx] = f4sub(d[1][dx], d[0][dx]);
+        }
+        v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+#pragma unroll
+        for (int f = 0; f < 4 * NB; ++f) {                           // fragment f = nb * 4 + j, the order the pieces sit in LDS
+            const int nb = f >> 2, j = f & 3;
+            if (f + 1 < 4 * NB) u[(f + 1) & 1] = *reinterpret_cast<const float4 *>(up + (f + 1) * 1024);
+            const float4 uu = u[f & 1];
+            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, uu.x, acc[j][nb], 0, 0, 0);
+            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, uu.y, acc[j][nb], 0, 0, 0);
+            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, uu.z, acc[j][nb], 0, 0, 0);
+            acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, uu.w, acc[j][nb], 0, 0, 0);
+        }
+        dma_wait<0>();             // step t + 1 has landed (this wave's pieces; the barrier covers the other waves')
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
+    const char *smem_c = reinterpret_cast<const char *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // one scalar-load round trip for the whole argument block (see igemm.hip)
+    asm volatile("" :: "s"(p.src), "s"(p.u), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.partial), "s"(p.tile_cnt));
+    asm volatile("" :: "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C), "s"(p.N), "s"(p.relu), "s"(p.splits), "s"(p.steps_per_split), "s"(p.ntb), "s"(p.nng),
+                       "s"(p.tbx), "s"(p.nmajor), "s"(p.xcd), "s"(p.div_plane.m), "s"(p.div_plane.s1), "s"(p.div_plane.s2), "s"(p.div_fast.m),
+                       "s"(p.div_fast.s1), "s"(p.div_fast.s2), "s"(p.div_tbf.m), "s"(p.div_tbf.s1), "s"(p.div_tbf.s2), "s"(p.div_tbx.m), "s"(p.div_tbx.s1),
+                       "s"(p.div_tbx.s2));
+
+    // block -> (split z, tile-block tb, channel group ng).  XCD-aware like the igemm: the dispatcher deals blocks round-robin over the 8 XCDs,
+    // so logical ids are handed out in 8 contiguous chunks; inside a split plane either the channel groups of a tile-block are adjacent
+    // (activation-heavy layers) or the tile-blocks of a channel group (weight-heavy layers: an XCD's L2 then holds a slice of U).
+    unsigned lin = blockIdx.x;
+    if (p.xcd) {
+        const unsigned total = gridDim.x, qq = total >> 3, rr = total & 7, x = lin & 7;
+        lin = x * qq + (x < rr ? x : rr) + (lin >> 3);
+    }
+    const int z = (int)p.div_plane.div(lin);
+    const unsigned rem = lin - (unsigned)z * (unsigned)(p.ntb * p.nng);
+    int tb, ng;
+    if (p.nmajor) { ng = (int)p.div_fast.div(rem); tb = (int)rem - ng * p.ntb; }
+    else { tb = (int)p.div_fast.div(rem); ng = (int)rem - tb * p.nng; }
+    const int b = (int)p.div_tbf.div((unsigned)tb);               // frame; tile-blocks per frame = tby * tbx
+    const int tbi = tb - b * (p.tby * p.tbx);
+    const int by = (int)p.div_tbx.div((unsigned)tbi), bx = tbi - by * p.tbx;
+    const int Y0 = by * 8, X0 = bx * 16;
+    const int n0 = ng * 32 * NB;
+    const int S = p.C >> 3;                                      // 8-channel K-steps
+    const int ks_begin = z * p.steps_per_split;
+    int ks_end = ks_begin + p.steps_per_split;
+    if (ks_end > S) ks_end = S;
+
+    // raw-patch DMA: this wave's two pieces; lane -> chunk -> (patch pixel, channel quad) -> byte offset in the NHWC source or out of range
+    unsigned vraw[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int ci = (wave + 4 * k) * 64 + lane;
+        const int par = ci / 90, rem2 = ci - par * 90, qd = rem2 / 45, r2 = rem2 - qd * 45, hy = r2 / 9, hx = r2 - hy * 9;
+        const int y = Y0 - 1 + 2 * hy + (par >> 1), x = X0 - 1 + 2 * hx + (par & 1);
+        const bool ok = ci < 360 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        vraw[k] = ok ? ((unsigned)((b * p.H + y) * p.W + x) * (unsigned)p.C + (unsigned)(qd * 4)) * 4u : kOOBw;
+    }
+    const i32x4 srd_src = make_srd(p.src, (unsigned)(p.B * p.H * p.W) * (unsigned)p.C * 4u);
+    const i32x4 srd_u = make_srd(p.u, 16u * (unsigned)p.C * (unsigned)p.N * 4u);
+    // U fragments: [n-block][xi-row][k-step][j][64 lanes][4]
+    const unsigned soff_nb = 4u * (unsigned)S * 4096u;                               // one n-block further
+    const unsigned soff_u0 = (unsigned)((n0 >> 5) * 4 + wave) * (unsigned)S * 4096u;
+
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
+
+    switch (wave) {
+    case 0: wino_loop<NB, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
+    case 1: wino_loop<NB, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
+    case 2: wino_loop<NB, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
+    default: wino_loop<NB, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
+    }
+    // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
+
+    // ---- output transform.  Column half in registers: Z[i][0] = M0 + M1 + M2, Z[i][1] = M1 - M2 - M3 (this wave's row i); row half across the
+    // four waves through LDS: Y[0][b] = Z0 + Z1 + Z2, Y[1][b] = Z1 - Z2 - Z3.  C/D layout of the 32x32 MFMA: col = lane & 31,
+    // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5); the patch is [wave][b][nb][32 rows][36] so that a reader owns 4 consecutive channels of a tile.
+    constexpr int EP = 36;
+    {
+        const int ccol = lane & 31, crow = 4 * (lane >> 5);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float *pz0 = smem + ((wave * 2 + 0) * NB + nb) * (32 * EP);
+            float *pz1 = smem + ((wave * 2 + 1) * NB + nb) * (32 * EP);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + crow;
+                pz0[row * EP + ccol] = (acc[0][nb][e] + acc[1][nb][e]) + acc[2][nb][e];
+                pz1[row * EP + ccol] = (acc[1][nb][e] - acc[2][nb][e]) - acc[3][nb][e];
+            }
+        }
+    }
+    __syncthreads();
+    const int trow = tid >> 3, cq = (tid & 7) * 4;                 // this thread's tile (ty = trow >> 3, tx = trow & 7) and channel quad
+    const int oy = Y0 + 2 * (trow >> 3), ox = X0 + 2 * (trow & 7);
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.splits > 1 ? (int)p.slab_bytes : 0, 0x00020000);
+    const size_t npix = (size_t)p.B * p.H * p.W;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + nb * 32 + cq;
+        float4 zz[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+                zz[i][bb] = *reinterpret_cast<const float4 *>(smem + ((i * 2 + bb) * NB + nb) * (32 * EP) + trow * EP + cq);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.splits == 1 && p.scale) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + n);
+            sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                float4 v = a == 0 ? f4add(f4add(zz[0][bb], zz[1][bb]), zz[2][bb]) : f4sub(f4sub(zz[1][bb], zz[2][bb]), zz[3][bb]);
+                const size_t pix = ((size_t)b * p.H + (size_t)(oy + a)) * p.W + (size_t)(ox + bb);
+                const size_t e = pix * p.N + n;
+                if (p.splits > 1) {
+                    // partial sums of this K slice; published write-through to whichever workgroup arrives last at the tile
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab_rsrc, (unsigned)(((size_t)z * npix * p.N + e) * 4), 0, 16);
+                } else {
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (p.residual) {
+                        const float4 rv = *reinterpret_cast<const float4 *>(p.residual + e);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4 *>(p.out + e) = v;
+                }
+            }
+    }
+    if (p.splits == 1) return;
+
+    // ---- split-K combine inside the launch (the igemm's protocol): write-through slabs above -> every wave drains its stores -> barrier -> one
+    // relaxed agent-scope ticket per tile; the last arriver sums the slabs in z order (bit-reproducible) with loads that bypass its L1 and runs
+    // the epilogue.  The counter is reset by the last arriver (zeroed once per workspace binding by the host).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned *flag = reinterpret_cast<unsigned *>(smem);
+    const unsigned tile = (unsigned)(tb * p.nng + ng);
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag[0] != (unsigned)p.splits - 1u) return;
+    if (tid == 0) __hip_atomic_store(p.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + nb * 32 + cq;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) {
+            sc = *reinterpret_cast<const float4 *>(p.scale + n);
+            sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const size_t pix = ((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1));
+            const size_t e = pix * p.N + n;
+            float4 tsl[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < p.splits)
+                    tsl[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, (unsigned)(((size_t)s * npix * p.N + e) * 4), 0, 16));
+            float4 v = tsl[0];
+#pragma unroll
+            for (int s = 1; s < 8; ++s)
+                if (s < p.splits) { v.x += tsl[s].x; v.y += tsl[s].y; v.z += tsl[s].z; v.w += tsl[s].w; }
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (p.residual) {
+                const float4 rv = *reinterpret_cast<const float4 *>(p.residual + e);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(p.out + e) = v;
+        }
+    }
+}
+
+bool wino_supported(const WinoParams &p, int nb)
+{
+    if (nb != 1 && nb != 2) return false;
+    if (p.B < 1 || p.H % 8 || p.W % 16 || p.C % 8 || p.C < 8 || p.N % (32 * nb)) return false;
+    const size_t lim = 0x7fffffffull;                      // 32-bit buffer offsets with the top bit reserved as the out-of-range marker
+    if ((size_t)p.B * p.H * p.W * p.C * 4 > lim || (size_t)16 * p.C * p.N * 4 > lim) return false;
+    if (p.splits < 1 || p.splits > 8) return false;
+    if (p.splits > 1 && (!p.partial || !p.tile_cnt || (size_t)p.splits * p.B * p.H * p.W * p.N * 4 > lim)) return false;
+    return true;
+}
+
+template <int NB>
+static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
+{
+    constexpr int smem = wino_lds_bytes(NB);
+    static AttrMask attr_mask;
+    if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    hipLaunchKernelGGL(wino3x3<NB>, dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
+{
+    if (!wino_supported(p_in, nb)) return hipErrorInvalidValue;
+    WinoParams p = p_in;
+    const int S = p.C / 8;
+    p.steps_per_split = (S + p.splits - 1) / p.splits;
+    if ((p.splits - 1) * p.steps_per_split >= S) return hipErrorInvalidValue;       // an empty split would publish garbage-free zeros but wastes a slab: planner bug
+    p.tby = p.H / 8; p.tbx = p.W / 16;
+    p.ntb = p.B * p.tby * p.tbx;
+    p.nng = p.N / (32 * nb);
+    if (p.splits > 1) p.slab_bytes = (size_t)p.splits * p.B * p.H * p.W * p.N * 4;
+    // weight-heavy layers: an XCD keeps a slice of U in its L2 (channel groups slowest); activation-heavy: a band of tile-blocks
+    const size_t act = (size_t)p.B * p.H * p.W * p.C * 4, wgt = (size_t)16 * p.C * p.N * 4;
+    p.nmajor = wgt > act ? 1 : 0;
+    p.xcd = 1;
+    p.div_plane = FastDiv::make((unsigned)(p.ntb * p.nng));
+    p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
+    p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));
+    p.div_tbx = FastDiv::make((unsigned)p.tbx);
+    return nb == 2 ? launch_wino_t<2>(p, s) : launch_wino_t<1>(p, s);
+}
+
+// Host: OIHW [N][C][3][3] -> U = G g G^T (double, rounded once) in the MFMA fragment order [n-block N/32][xi-row 4][k-step C/8][j 4][lane 64][4]:
+// lane l holds output channel 32 nblock + (l & 31), input channels 8 s + 4 (l >> 5) + 0..3 -- one 1-KB piece = the B operand of 4 MFMAs.
+void pack_wino_weights(const float *oihw, int cin, int cout, float *out)
+{
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const int S = cin / 8;
+    for (int n = 0; n < cout; ++n)
+        for (int c = 0; c < cin; ++c) {
+            const float *g = oihw + ((size_t)n * cin + c) * 9;
+            double tmp[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int b = 0; b < 3; ++b) tmp[i][b] = G[i][0] * (double)g[b] + G[i][1] * (double)g[3 + b] + G[i][2] * (double)g[6 + b];
+            const int nblk = n >> 5, s = c >> 3, lane = (n & 31) + 32 * ((c & 7) >> 2), t = c & 3;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const double u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                    out[(((((size_t)nblk * 4 + i) * S + s) * 4 + j) * 64 + lane) * 4 + t] = (float)u;
+                }
+        }
+}
+
+}  // namespace lspf2f

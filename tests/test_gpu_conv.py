@@ -496,3 +496,101 @@ def test_conv3x3_upconv_row_kernel_bf16(cfg, gpu_device):
     ref = (F.relu(ref) if relu else ref).float()
     tol = (ref.abs() * 2.0 ** -8 + 1e-3)
     assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
+
+
+# ---- Winograd F(2x2, 3x3) kernel (csrc/wino.hip): the stride-1 residual convs of the >= 32x32 levels in fp32 plans ----------------
+def pack_wino(w):
+    """OIHW -> G g G^T in the kernel's fragment order; the numpy statement of the layout (tools/wino_model.py), not the library's packer"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wino_model
+    return torch.from_numpy(wino_model.pack_u(w.numpy()))
+
+
+def run_wino(dev, x, w, scale, shift, res, relu, nb, splits):
+    from livespeechportraits_amd import _native as N
+    lib = N.load()
+    b, c, h, _ = x.shape
+    cout = w.shape[0]
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    d0, wp = nhwc(x), pack_wino(w).to(dev)
+    dsc = scale.to(dev) if scale is not None else None
+    dsh = shift.to(dev) if shift is not None else None
+    dres = nhwc(res) if res is not None else None
+    out = torch.full((b, h, h, cout), float("nan"), device=dev)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, h, h, c, 0, cout, 1, 0, 4000 + nb, 0, splits, -1, 0)
+    scratch = torch.zeros(max(sb, 4), dtype=torch.uint8, device=dev)      # slabs + arrival counters (zero on entry, left zero by the kernel)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    N.check(lib.lspf2f_conv3x3(p(d0), None, p(wp), p(dsc), p(dsh), p(dres), p(out), b, h, h, c, 0, cout, 1, 0, int(relu), 4000 + nb, 0, splits, -1, 0,
+                               p(scratch), scratch.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return out.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+WINO_CASES = [
+    # b, c, cout, h, nb, splits, epilogue (scale/shift + residual + relu)
+    (1, 32, 32, 32, 1, 1, False),
+    (1, 32, 64, 32, 2, 1, True),
+    (2, 64, 64, 32, 2, 1, True),
+    (3, 40, 96, 48, 1, 1, True),          # 48 = 3 tile-block columns, channel counts that are no power of two
+    (1, 64, 64, 64, 1, 2, True),
+    (1, 128, 64, 32, 2, 4, True),
+    (2, 256, 32, 16, 1, 8, True),         # 16x16 frames: one tile-block column, halo on every side
+    (1, 104, 32, 32, 1, 3, False),        # 13 K-steps in 3 slices of 5, 5, 3
+    (1, 64, 64, 256, 2, 1, True),         # the four shapes of the `large` plan at batch 1
+    (1, 128, 128, 128, 1, 1, True),
+    (1, 256, 256, 64, 1, 2, True),
+    (1, 512, 512, 32, 1, 4, True),
+]
+
+
+@pytest.mark.parametrize("cfg", WINO_CASES, ids=lambda c: "b%d_c%d_o%d_h%d_nb%d_s%d%s" % (c[:6] + ("_ep" if c[6] else "",)))
+def test_conv3x3_winograd(cfg, gpu_device):
+    """wino3x3 against the fp64 convolution.  Winograd trades multiplies for additions on the inputs, so its fp32 rounding error is a few
+    times the direct form's; the bound is relative to the layer's output range and the direct kernel's error on the same problem is printed
+    beside it.  Whole-network parity (the goldens, <= 5e-5) runs through this kernel too."""
+    b, c, cout, h, nb, splits, ep = cfg
+    g = torch.Generator().manual_seed(1000 + c + cout + h)
+    x = torch.randn(b, c, h, h, generator=g)
+    w = torch.randn(cout, c, 3, 3, generator=g) / (3.0 * c ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5 if ep else None
+    shift = torch.randn(cout, generator=g) * 0.1 if ep else None
+    res = torch.randn(b, cout, h, h, generator=g) if ep else None
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    if ep:
+        ref = torch.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    got = run_wino(gpu_device, x, w, scale, shift, res, ep, nb, splits)
+    assert torch.isfinite(got).all(), "kernel left unwritten (NaN) outputs"
+    err = (got.double() - ref).abs().max().item()
+    direct = None
+    if c % 32 == 0 and h <= 64:
+        direct = (run_conv(gpu_device, x, None, w, scale, shift, res, 1, False, ep).double() - ref).abs().max().item()
+    print("\nwino %s: max-abs %.2e (output range %.2f); implicit GEMM on the same problem: %s" % (
+        cfg, err, ref.abs().max().item(), "%.2e" % direct if direct is not None else "-"))
+    assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
+    if splits > 1:       # the in-launch combine sums the slices in a fixed order, whichever workgroup arrives last
+        again = run_wino(gpu_device, x, w, scale, shift, res, ep, nb, splits)
+        assert torch.equal(got, again)
+
+
+def test_conv3x3_winograd_impulse_layout(gpu_device):
+    """One-hot input and one-hot tap land on exactly one output value, for taps and pixels on tile and tile-block seams."""
+    c, h = 16, 32
+    for (ci, y, x_, co, ky, kx) in [(5, 7, 15, 11, 0, 2), (13, 8, 16, 40, 2, 0), (0, 0, 0, 63, 1, 1), (9, 31, 31, 32, 0, 0)]:
+        x = torch.zeros(1, c, h, h)
+        x[0, ci, y, x_] = 2.0
+        w = torch.zeros(64, c, 3, 3)
+        w[co, ci, ky, kx] = 3.0           # out[co][oy][ox] += 3 * in[ci][oy + ky - 1][ox + kx - 1]
+        exp = F.conv2d(x, w, None, 1, 1)
+        got = run_wino(gpu_device, x, w, None, None, None, False, 2, 1)
+        assert torch.equal(got, exp), (ci, y, x_, co, ky, kx)
+
+
+def test_conv3x3_winograd_rejects_unsupported_shapes(gpu_device):
+    from livespeechportraits_amd import _native as N
+    w = rnd(32, 32, 3, 3)
+    with pytest.raises(N.Lspf2fError):
+        run_wino(gpu_device, rnd(1, 32, 24, 24), w, None, None, None, False, 1, 1)       # 24 % 16 != 0
+    with pytest.raises(N.Lspf2fError):
+        run_wino(gpu_device, rnd(1, 32, 32, 32), w, None, None, None, False, 2, 1)       # cout 32 needs nb = 1

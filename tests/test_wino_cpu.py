@@ -1,0 +1,97 @@
+"""CPU checks of the Winograd F(2x2,3x3) path (csrc/wino.hip): the lane-level data-flow model against a direct convolution, the library's
+host packer against the model's statement of the fragment order, and which layers of a plan take the kernel.  No GPU: the kernel's
+own parity tests are tests/test_gpu_conv.py::test_conv3x3_winograd* and every network-level golden test (the plans route through it)."""
+import os
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import wino_model as WM   # noqa: E402
+
+
+def test_data_flow_model_equals_direct_convolution():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 8, 32, 16))
+    w = rng.standard_normal((64, 16, 3, 3)).astype(np.float32)
+    sc, sh = rng.standard_normal(64), rng.standard_normal(64)
+    res = rng.standard_normal((2, 8, 32, 64))
+    got = WM.conv_model(x, WM.pack_u(w), 64, sc, sh, res, relu=True)
+    ref = np.maximum(WM.conv_direct(x, w) * sc + sh + res, 0)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()       # U is rounded to fp32 once; everything else is float64 here
+
+
+def test_transform_matrices_are_the_published_f2x2_3x3():
+    """Y = A^T [(G g G^T) . (B^T d B)] A reproduces a 3x3 correlation on a 4x4 patch exactly (Lavin & Gray 2015, F(2x2, 3x3))."""
+    rng = np.random.default_rng(0)
+    d, g = rng.standard_normal((4, 4)), rng.standard_normal((3, 3))
+    y = WM.AT @ ((WM.G @ g @ WM.G.T) * (WM.BT @ d @ WM.BT.T)) @ WM.AT.T
+    ref = np.array([[(d[a:a + 3, b:b + 3] * g).sum() for b in range(2)] for a in range(2)])
+    assert np.abs(y - ref).max() < 1e-12
+
+
+def test_host_packer_writes_the_fragment_order_the_kernel_reads():
+    """Plan::pack -> pack_wino_weights: the G g G^T copy of every Winograd layer sits behind the 9-tap copy in the blob and equals the
+    numpy statement of the layout (tools/wino_model.pack_u); run through the data-flow model it convolves correctly."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    topo, sd = synth.synthetic("normal", ngf=32, num_downs=5, size=64)
+    e = Engine("normal", ngf=32, num_downs=5, size=64, max_batch=2)
+    e.load_state_dict(sd)
+    blob = e.pack().numpy()
+    checked = 0
+    for l in e.layers(1):
+        if not l["kernel"].startswith("wino3x3"):
+            continue
+        cin, cout = l["cin"], l["cout"]
+        nine = cout * cin * 9 * 4
+        off = (l["w_offset"] + nine + 255) // 256 * 256
+        got = blob[off: off + cout * cin * 16 * 4].view(np.float32)
+        key = [k for k in sd if k.endswith(".weight") and sd[k].shape == (cout, cin, 3, 3)]
+        # identify the layer's weight through the 9-tap copy the igemm would read: [co][tap][ci]
+        rows = blob[l["w_offset"]: l["w_offset"] + nine].view(np.float32).reshape(cout, 9, cin)
+        w = np.ascontiguousarray(rows.transpose(0, 2, 1).reshape(cout, cin, 3, 3))
+        assert any(np.array_equal(w, sd[k]) for k in key)
+        exp = WM.pack_u(w)
+        assert got.shape == exp.shape and np.allclose(got, exp, rtol=3e-7, atol=1e-9)
+        assert (got == exp).mean() > 0.99                      # double rounding of G g G^T may differ in the last bit, rarely
+        if checked == 0:
+            rng = np.random.default_rng(1)
+            x = rng.standard_normal((1, 8, 16, cin))
+            ref = WM.conv_direct(x, w)
+            assert np.abs(WM.conv_model(x, got, cout) - ref).max() <= 1e-5 * np.abs(ref).max()
+        checked += 1
+    assert checked >= 2
+    e.close()
+
+
+def test_planner_routes_the_stride1_convs_of_the_large_levels_through_the_winograd_kernel():
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("large", max_batch=8)
+    for batch in (1, 8):
+        ls = e.layers(batch)
+        wino = [l for l in ls if l["kernel"].startswith("wino3x3")]
+        # the 32 ResidualBlock convs at 256x256 .. 32x32 (networks.py:650-675): 8 per level, 64 / 128 / 256 / 512 channels
+        assert len(wino) == 32 and all(l["stride"] == 1 and not l["upsample"] and l["cin"] == l["cout"] and l["h_out"] >= 32 for l in wino)
+        assert sorted({(l["cin"], l["h_out"]) for l in wino}) == [(64, 256), (128, 128), (256, 64), (512, 32)]
+        assert all(l["exec_flops_per_frame"] * 9 == l["flops_per_frame"] * 4 for l in wino)
+        for l in wino:
+            groups = l["cout"] // l["tile_n"]
+            wgs = batch * (l["h_out"] // 8) * (l["h_out"] // 16) * groups * l["split_k"]
+            assert wgs >= 384, (l["name"], wgs)               # the chip has 256 CUs
+            assert l["cin"] // 8 // l["split_k"] >= 4
+        if batch == 8:
+            assert all(l["split_k"] == 1 for l in wino)
+    assert not any(l["kernel"].startswith("wino3x3") for l in Engine("large", dtype="bf16").layers(1))
+    assert not any(l["kernel"].startswith("wino3x3") for l in Engine("large", norm="instance").layers(1))
+    e.close()
+
+
+def test_winograd_can_be_switched_off_per_handle(monkeypatch):
+    from livespeechportraits_amd.engine import Engine
+    monkeypatch.setenv("LSP_HIP_WINO", "0")
+    e = Engine("normal")
+    assert not any(l["kernel"].startswith("wino3x3") for l in e.layers(1))
+    e.close()

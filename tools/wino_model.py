@@ -1,0 +1,125 @@
+"""Lane-level numpy model of csrc/wino.hip (Winograd F(2x2,3x3) stride-1 conv, fp32) -- test infrastructure.
+
+It replays, index for index, what the kernel does with its data: the LDS-DMA chunk map of the raw input patch, the per-wave
+fragment reads, the input transform of ξ-row `wave`, the k pairing of v_mfma_f32_32x32x2_f32, the accumulator layout, the
+epilogue patch and the output scatter.  tests/test_wino_cpu.py runs it on the weights packed by the library's own host packer
+(lspf2f_pack_wino_weights) and compares with a float64 direct convolution: a wrong index anywhere shows up on the CPU, before
+any GPU time is spent.  Arithmetic is float64 here (this file checks the data flow, not rounding).
+
+Geometry (must match wino.hip):
+  tile-block   = 4 x 8 Winograd tiles = 8 x 16 output pixels; raw patch 10 x 18 pixels
+  MFMA row r   = tile (ty = r >> 3, tx = r & 7); lane l: row l & 31, k-quad q = l >> 5
+  K-step       = 8 channels: lane quad q holds channels 8s + 4q .. +3, MFMA t (0..3) contracts channels {8s + t, 8s + 4 + t}
+  raw chunk ci = ((pary*2 + parx)*2 + q)*45 + hy*9 + hx  <->  patch pixel (2hy + pary, 2hx + parx), channel quad q
+  U fragments  = [n-block][xi-row i][k-step s][j][lane][4]: lane l -> n = 32*nblock + (l & 31), channels 8s + 4(l >> 5) + 0..3
+"""
+import numpy as np
+
+BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+
+ROWS = {0: (0, 2, 1.0, -1.0), 1: (1, 2, 1.0, 1.0), 2: (1, 2, -1.0, 1.0), 3: (1, 3, 1.0, -1.0)}   # xi-row i: t = sa*d[ra] + sb*d[rb]
+
+
+def pack_u(w_oihw):
+    """numpy restatement of pack_wino_weights(): OIHW [N][C][3][3] -> fragment order (float64 in, float32 out)."""
+    n_out, c_in = w_oihw.shape[:2]
+    u = np.einsum("ia,ncab,jb->ijcn", G, w_oihw.astype(np.float64), G)          # [4][4][C][N]
+    out = np.zeros((n_out // 32, 4, c_in // 8, 4, 64, 4), np.float32)
+    lane = np.arange(64)
+    for t in range(4):
+        ch = 4 * (lane >> 5) + t                                                # channel within the k-step
+        for s in range(c_in // 8):
+            for nb in range(n_out // 32):
+                out[nb, :, s, :, :, t] = u[:, :, 8 * s + ch, 32 * nb + (lane & 31)]
+    return out.reshape(-1)
+
+
+def chunk_decode(ci):
+    par, rem = divmod(ci, 90)
+    q, r2 = divmod(rem, 45)
+    hy, hx = divmod(r2, 9)
+    return par >> 1, par & 1, q, hy, hx
+
+
+def chunk_index(py, px, q):
+    return (((py & 1) * 2 + (px & 1)) * 2 + q) * 45 + (py >> 1) * 9 + (px >> 1)
+
+
+def conv_model(x_nhwc, u_packed, n_out, scale=None, shift=None, residual=None, relu=False):
+    B, H, W, C = x_nhwc.shape
+    assert H % 8 == 0 and W % 16 == 0 and C % 8 == 0 and n_out % 32 == 0
+    U = u_packed.reshape(n_out // 32, 4, C // 8, 4, 64, 4).astype(np.float64)
+    out = np.zeros((B, H, W, n_out))
+    lane = np.arange(64)
+    r, q = lane & 31, lane >> 5
+    ty, tx = r >> 3, r & 7
+    for b in range(B):
+        for by in range(H // 8):
+            for bx in range(W // 16):
+                Y0, X0 = 8 * by, 16 * bx
+                for nblk in range(n_out // 32):
+                    acc = np.zeros((4, 4, 32, 32))                                  # [i][j][row (tile)][col (n)]
+                    for s in range(C // 8):
+                        # ---- LDS-DMA of the raw patch: 6 pieces of 64 chunks x 4 floats
+                        lds = np.zeros((384, 4))
+                        for ci in range(360):
+                            pary, parx, qq, hy, hx = chunk_decode(ci)
+                            y, x = Y0 - 1 + 2 * hy + pary, X0 - 1 + 2 * hx + parx
+                            if 0 <= y < H and 0 <= x < W:
+                                lds[ci] = x_nhwc[b, y, x, 8 * s + 4 * qq: 8 * s + 4 * qq + 4]
+                        for i in range(4):                                          # wave = xi-row
+                            ra, rb, sa, sb = ROWS[i]
+                            d = np.zeros((2, 4, 64, 4))
+                            for k, dy in enumerate((ra, rb)):
+                                for dx in range(4):
+                                    d[k, dx] = lds[chunk_index(2 * ty + dy, 2 * tx + dx, q)]
+                            t = sa * d[0] + sb * d[1]                               # [4 cols][lane][4 ch]
+                            v = [t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]]
+                            for j in range(4):
+                                ufrag = U[nblk, i, s, j]                            # [lane][4]
+                                for tt in range(4):
+                                    a_op, b_op = v[j][:, tt], ufrag[:, tt]          # one value per lane
+                                    # v_mfma_f32_32x32x2_f32: D[row][col] += sum_k A[row][k] * B[k][col], lane -> (row | col = l & 31, k = l >> 5)
+                                    A = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+                                    A[r, q] = a_op; Bm[q, r] = b_op
+                                    acc[i, j] += A @ Bm
+                    # ---- epilogue: in-wave column transform, cross-wave row transform through the LDS patch
+                    z = np.zeros((4, 2, 32, 32))
+                    for i in range(4):
+                        z[i, 0] = acc[i, 0] + acc[i, 1] + acc[i, 2]
+                        z[i, 1] = acc[i, 1] - acc[i, 2] - acc[i, 3]
+                    for row in range(32):                                           # thread (row = tile, channel quad)
+                        tty, ttx = row >> 3, row & 7
+                        for bcol in range(2):
+                            y0v = z[0, bcol, row] + z[1, bcol, row] + z[2, bcol, row]
+                            y1v = z[1, bcol, row] - z[2, bcol, row] - z[3, bcol, row]
+                            out[b, Y0 + 2 * tty, X0 + 2 * ttx + bcol, 32 * nblk: 32 * nblk + 32] = y0v
+                            out[b, Y0 + 2 * tty + 1, X0 + 2 * ttx + bcol, 32 * nblk: 32 * nblk + 32] = y1v
+    if scale is not None:
+        out = out * scale + shift
+    if residual is not None:
+        out = out + residual
+    if relu:
+        out = np.maximum(out, 0)
+    return out
+
+
+def conv_direct(x_nhwc, w_oihw):
+    B, H, W, C = x_nhwc.shape
+    xp = np.zeros((B, H + 2, W + 2, C)); xp[:, 1:-1, 1:-1] = x_nhwc
+    out = np.zeros((B, H, W, w_oihw.shape[0]))
+    for ky in range(3):
+        for kx in range(3):
+            out += np.einsum("bhwc,nc->bhwn", xp[:, ky:ky + H, kx:kx + W], w_oihw[:, :, ky, kx].astype(np.float64))
+    return out
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 8, 32, 16))
+    w = rng.standard_normal((64, 16, 3, 3)).astype(np.float32)
+    got = conv_model(x, pack_u(w), 64)
+    ref = conv_direct(x, w)
+    print("max abs diff", np.abs(got - ref).max(), "of", np.abs(ref).max())
