@@ -684,7 +684,8 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     const int ktc = dtype == 1 ? 64 : 32;
     if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
-    if ((c0 % ktc) || (c1 % ktc) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1))
+    const bool wino_tile = (tile_m == 4001 || tile_m == 4002) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
+    if (!wino_tile && ((c0 % ktc) || (c1 % ktc) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1)))
         return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (fp32) / 64 (bf16)");
     if (cout % 4) return fail(LSPF2F_ERR_UNSUPPORTED, "cout must be a multiple of 4");
     if (stride != 1 && stride != 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "stride must be 1 or 2");
@@ -732,6 +733,13 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                 q.partial = static_cast<float *>(scratch);
                 q.tile_cnt = reinterpret_cast<unsigned *>(static_cast<char *>(scratch) + slab);   // must be zero on entry; every launch leaves it zero
             }
+#ifdef LSPF2F_WINO_STAMPS
+            {   // stamps live behind slabs and counters when the caller's scratch has room for them
+                const size_t used = (slab + ncnt * sizeof(unsigned) + 255) / 256 * 256;
+                const size_t blocks = ncnt * (size_t)sp;
+                if (scratch && scratch_bytes >= used + blocks * 4 * 8 * 8) q.stamps = reinterpret_cast<unsigned long long *>(static_cast<char *>(scratch) + used);
+            }
+#endif
             if (dtype != 0 || c1 != 0 || stride != 1 || upsample != 0 || hs != ws || !wino_supported(q, tile_m - 4000))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the Winograd kernel does not support this shape");
             e = launch_wino(q, tile_m - 4000, static_cast<hipStream_t>(hip_stream));

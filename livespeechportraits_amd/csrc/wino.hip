@@ -17,8 +17,21 @@
 // the output transform in registers, the row half across waves through an LDS patch.
 #include "device_common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace lspf2f {
+
+// phase timestamps (tools/wino_stamps.py; builds with -DLSPF2F_WINO_STAMPS only): s_memtime values kept in registers, written once at the end
+#ifdef LSPF2F_WINO_STAMPS
+#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WSTAMP_DECL unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define WSTAMP_FLUSH do { if (p.stamps && lane == 0) { unsigned long long *q_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8; \
+    for (int i_ = 0; i_ < 8; ++i_) q_[i_] = stamp_t[i_]; } } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#define WSTAMP_DECL do {} while (0)
+#define WSTAMP_FLUSH do {} while (0)
+#endif
 
 static constexpr unsigned kOOBw = 0x80000000u;   // voffset beyond any num_records: the LDS-DMA lands zeros (image border, unused chunks)
 
@@ -53,7 +66,7 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 template <int NB, int ROW>
 __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][NB], const char *smem_c, unsigned lds0, int wave, int lane,
                                           unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, unsigned soff_nb,
-                                          int ks_begin, int ks_end)
+                                          int ks_begin, int ks_end, unsigned long long *first_landed)
 {
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
     constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB), DUMP = wino_dump(NB);
@@ -90,6 +103,9 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
     fetch(ks_begin, 0);
     dma_wait<0>();
     __syncthreads();
+#ifdef LSPF2F_WINO_STAMPS
+    *first_landed = __builtin_amdgcn_s_memtime();
+#endif
     int cur = 0;
     for (int t = 0; t < nsteps; ++t) {
         const char *rawp = smem_c + cur * kRawStage;
@@ -136,6 +152,8 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
     const char *smem_c = reinterpret_cast<const char *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WSTAMP_DECL;
+    WSTAMP(0);
     // one scalar-load round trip for the whole argument block (see igemm.hip)
     asm volatile("" :: "s"(p.src), "s"(p.u), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.partial), "s"(p.tile_cnt));
     asm volatile("" :: "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C), "s"(p.N), "s"(p.relu), "s"(p.splits), "s"(p.steps_per_split), "s"(p.ntb), "s"(p.nng),
@@ -182,6 +200,35 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
     const unsigned soff_nb = 4u * (unsigned)S * 4096u;                               // one n-block further
     const unsigned soff_u0 = (unsigned)((n0 >> 5) * 4 + wave) * (unsigned)S * 4096u;
 
+    // Epilogue operands requested BEFORE the K loop (the igemm's trick): folded-BN scale / shift of this thread's channel quads and its residual
+    // pixels.  In the epilogue they would be dependent global round trips with the matrix pipe idle; here they ride under the first fetch.  They
+    // are older than every LDS-DMA piece and loads return in order, so the loop's waits are unaffected.
+    const int trow = tid >> 3, cq = (tid & 7) * 4;                 // this thread's tile (ty = trow >> 3, tx = trow & 7) and channel quad
+    const int oy = Y0 + 2 * (trow >> 3), ox = X0 + 2 * (trow & 7);
+    const bool pre = p.splits == 1 && !p.nopre;
+    float4 scv[NB], shv[NB], rpre[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + nb * 32 + cq;
+        scv[nb] = make_float4(1.f, 1.f, 1.f, 1.f); shv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pre && p.scale) {
+            scv[nb] = *reinterpret_cast<const float4 *>(p.scale + n);
+            shv[nb] = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            rpre[nb][ab] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pre && p.residual)
+                rpre[nb][ab] = *reinterpret_cast<const float4 *>(p.residual + (((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1))) * p.N + n);
+        }
+    }
+    WSTAMP(1);
+#ifdef LSPF2F_WINO_STAMPS
+    unsigned long long *fl = &stamp_t[2];
+#else
+    unsigned long long *fl = nullptr;
+#endif
+
     f32x16 acc[4][NB];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -191,12 +238,13 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
     switch (wave) {
-    case 0: wino_loop<NB, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
-    case 1: wino_loop<NB, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
-    case 2: wino_loop<NB, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
-    default: wino_loop<NB, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end); break;
+    case 0: wino_loop<NB, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 1: wino_loop<NB, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 2: wino_loop<NB, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    default: wino_loop<NB, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
+    WSTAMP(3);
 
     // ---- output transform.  Column half in registers: Z[i][0] = M0 + M1 + M2, Z[i][1] = M1 - M2 - M3 (this wave's row i); row half across the
     // four waves through LDS: Y[0][b] = Z0 + Z1 + Z2, Y[1][b] = Z1 - Z2 - Z3.  C/D layout of the 32x32 MFMA: col = lane & 31,
@@ -217,8 +265,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
         }
     }
     __syncthreads();
-    const int trow = tid >> 3, cq = (tid & 7) * 4;                 // this thread's tile (ty = trow >> 3, tx = trow & 7) and channel quad
-    const int oy = Y0 + 2 * (trow >> 3), ox = X0 + 2 * (trow & 7);
+    WSTAMP(4);
     const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.splits > 1 ? (int)p.slab_bytes : 0, 0x00020000);
     const size_t npix = (size_t)p.B * p.H * p.W;
 #pragma unroll
@@ -230,8 +277,8 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
                 zz[i][bb] = *reinterpret_cast<const float4 *>(smem + ((i * 2 + bb) * NB + nb) * (32 * EP) + trow * EP + cq);
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.splits == 1 && p.scale) {
+        float4 sc = scv[nb], sh = shv[nb];
+        if (!pre && p.splits == 1 && p.scale) {               // LSP_HIP_WINO_PRE=0 (A-B runs): the operands are fetched here instead
             sc = *reinterpret_cast<const float4 *>(p.scale + n);
             sh = *reinterpret_cast<const float4 *>(p.shift + n);
         }
@@ -247,16 +294,16 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab_rsrc, (unsigned)(((size_t)z * npix * p.N + e) * 4), 0, 16);
                 } else {
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                    if (p.residual) {
-                        const float4 rv = *reinterpret_cast<const float4 *>(p.residual + e);
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                    }
+                    float4 rv = rpre[nb][a * 2 + bb];                 // zeros when the layer has no residual
+                    if (!pre && p.residual) rv = *reinterpret_cast<const float4 *>(p.residual + e);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     *reinterpret_cast<float4 *>(p.out + e) = v;
                 }
             }
     }
-    if (p.splits == 1) return;
+    WSTAMP(5);
+    if (p.splits == 1) { WSTAMP_FLUSH; return; }
 
     // ---- split-K combine inside the launch (the igemm's protocol): write-through slabs above -> every wave drains its stores -> barrier -> one
     // relaxed agent-scope ticket per tile; the last arriver sums the slabs in z order (bit-reproducible) with loads that bypass its L1 and runs
@@ -267,7 +314,8 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
     const unsigned tile = (unsigned)(tb * p.nng + ng);
     if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (flag[0] != (unsigned)p.splits - 1u) return;
+    WSTAMP(6);
+    if (flag[0] != (unsigned)p.splits - 1u) { WSTAMP_FLUSH; return; }
     if (tid == 0) __hip_atomic_store(p.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -299,6 +347,8 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
             *reinterpret_cast<float4 *>(p.out + e) = v;
         }
     }
+    WSTAMP(7);
+    WSTAMP_FLUSH;
 }
 
 bool wino_supported(const WinoParams &p, int nb)
@@ -341,6 +391,12 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     const size_t act = (size_t)p.B * p.H * p.W * p.C * 4, wgt = (size_t)16 * p.C * p.N * 4;
     p.nmajor = wgt > act ? 1 : 0;
     p.xcd = 1;
+    static const int pre_env = std::getenv("LSP_HIP_WINO_PRE") ? std::atoi(std::getenv("LSP_HIP_WINO_PRE")) : 1;    // tools only (A-B runs)
+    static const int xcd_env = std::getenv("LSP_HIP_WINO_XCD") ? std::atoi(std::getenv("LSP_HIP_WINO_XCD")) : -1;   // 0 dispatch order, 1 tile-block-major, 2 channel-group-major
+    p.nopre = pre_env ? 0 : 1;
+    if (xcd_env == 0) p.xcd = 0;
+    if (xcd_env == 1) p.nmajor = 0;
+    if (xcd_env == 2) p.nmajor = 1;
     p.div_plane = FastDiv::make((unsigned)(p.ntb * p.nng));
     p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
     p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));

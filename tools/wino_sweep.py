@@ -45,7 +45,7 @@ def main():
             sc, sh = torch.ones(c, device=dev), torch.zeros(c, device=dev)
             res = torch.randn(b, h, h, c, device=dev)
             out = torch.empty(b, h, h, c, device=dev)
-            gf = 2 * c * c * 9 * h * h * b / 1e9
+            gf = 2 * c * c * 9 * h * h * b / 1e6            # MFLOP, so that gf / us = TFLOP/s
             sb = lib.lspf2f_conv3x3_scratch_bytes(b, h, h, c, 0, c, 1, 0, 0, 0, 0, 0, 0)
             scr = torch.zeros(max(sb, 4), dtype=torch.uint8, device=dev)
             t = timed(lambda: N.check(lib.lspf2f_conv3x3(p(x), None, p(w9), p(sc), p(sh), p(res), p(out), b, h, h, c, 0, c, 1, 0, 1, 0, 0, 0, 0, 0, p(scr), scr.numel(), st)))
