@@ -68,6 +68,9 @@ int wino_choice(int batch, int ho, int cin, int cout, int *splits_out)
     // the fragment reads per MFMA but cost half the workgroups: used when that still leaves two workgroups per CU.  Below ~1.5 workgroups
     // per CU the input channels are split (combined inside the launch), keeping >= 4 eight-channel steps per slice.
     const long ntb = (long)batch * (ho / 8) * (ho / 16);
+    // 16x16 frames (2 tile-blocks each): measured 18.9 us against 17.4 us for the full-K kernel at 1 frame, 48.9 against 89.4 us for
+    // igemm + split-K at 8 frames (tools/wino_sweep.py); the full-K kernel covers <= 2 frames, Winograd takes over from 4
+    if (ho < 32 && ntb * (cout / 32) < 128) return 0;
     int nb = (cout % 64 == 0 && ntb * (cout / 64) >= 512) ? 2 : 1;
     const long wgs = ntb * (cout / (32 * nb));
     const int steps = cin / 8;

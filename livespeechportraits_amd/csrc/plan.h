@@ -172,7 +172,7 @@ inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int
 }
 // Winograd kernel eligibility, batch-independent part (which layers get the G g G^T copy at pack time); the per-batch choice asks
 // wino_supported() itself (kernels.h) through wino_choice() in plan.cpp
-static const int kWinoMinExtent = 32;
+static const int kWinoMinExtent = 16;     // 16x16 only from 4 frames up (wino_choice): below that the full-K kernel is as fast
 inline bool wino_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
 {
     return dtype == 0 && stride == 1 && !up && !up4 && !inorm && c1 == 0 && hs == ho && ho >= kWinoMinExtent && ho % 16 == 0 &&

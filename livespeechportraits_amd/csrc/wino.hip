@@ -38,12 +38,14 @@ static constexpr unsigned kOOBw = 0x80000000u;   // voffset beyond any num_recor
 static constexpr int kRawPieces = 6;                       // 360 chunks of 16 B (10 x 18 pixels x 2 channel quads) in 6 pieces of 64
 static constexpr int kRawStage = kRawPieces * 1024;        // bytes per ring slot
 
+// LDS: [ns ring slots of U fragments][ns ring slots of raw patch][1 KB dump]; ns = ring depth (2, or 3 with one channel block per wave:
+// its K-step is 1024 cycles of MFMA per wave, less than a loaded L2 round trip, so the copy of step t + 2 is in flight while step t multiplies)
 __host__ __device__ constexpr int wino_u_stage(int nb) { return 4 * 4 * nb * 1024; }              // 4 waves x (4 j x nb) pieces
-__host__ __device__ constexpr int wino_raw_base(int nb) { return 2 * wino_u_stage(nb); }
-__host__ __device__ constexpr int wino_dump(int nb) { return wino_raw_base(nb) + 2 * kRawStage; }
-__host__ __device__ constexpr int wino_lds_bytes(int nb)
+__host__ __device__ constexpr int wino_raw_base(int nb, int ns) { return ns * wino_u_stage(nb); }
+__host__ __device__ constexpr int wino_dump(int nb, int ns) { return wino_raw_base(nb, ns) + ns * kRawStage; }
+__host__ __device__ constexpr int wino_lds_bytes(int nb, int ns)
 {
-    const int loop = wino_dump(nb) + 1024;
+    const int loop = wino_dump(nb, ns) + 1024;
     const int patch = 4 * 2 * nb * 32 * 36 * 4;             // epilogue: [wave][b][nb][32 tiles][36]
     return loop > patch ? loop : patch;
 }
@@ -63,13 +65,14 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 
 // The K loop of one wave.  ROW = its row i of B^T d B: t = d[ra] (+|-) d[rb] per patch column, then the column transform.
 //   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3
-template <int NB, int ROW>
+template <int NB, int NS, int ROW>
 __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][NB], const char *smem_c, unsigned lds0, int wave, int lane,
                                           unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, unsigned soff_nb,
                                           int ks_begin, int ks_end, unsigned long long *first_landed)
 {
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
-    constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB), DUMP = wino_dump(NB);
+    constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB, NS), DUMP = wino_dump(NB, NS);
+    constexpr int PIECES = 2 + 4 * NB;                                      // LDS-DMA instructions this wave issues per step
     // fragment-read addresses: lane (tile r = l & 31 -> ty = r >> 3, tx = r & 7; channel quad q = l >> 5) reads patch pixel
     // (2 ty + dy, 2 tx + dx); chunk = ((pary * 2 + parx) * 2 + q) * 45 + hy * 9 + hx with (py, px) = (2 hy + pary, 2 hx + parx)
     const int r = lane & 31, q = lane >> 5, ty = r >> 3, tx = r & 7;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
     const int nsteps = ks_end - ks_begin;
     if (nsteps <= 0) return;
     fetch(ks_begin, 0);
-    dma_wait<0>();
+    if (NS > 2 && nsteps > 1) { fetch(ks_begin + 1, 1); dma_wait<PIECES>(); } else dma_wait<0>();
     __syncthreads();
 #ifdef LSPF2F_WINO_STAMPS
     *first_landed = __builtin_amdgcn_s_memtime();
@@ -118,7 +121,11 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
             for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
         float4 u[2];
         u[0] = *reinterpret_cast<const float4 *>(up);
-        if (t + 1 < nsteps) fetch(ks_begin + t + 1, cur ^ 1);       // the other slot was released by the barrier that ended step t - 1
+        // ring slot (cur + NS - 1) % NS was last read in step t - 1; every wave has passed the barrier that ended it
+        const int ahead = t + NS - 1;
+        const bool issue = ahead < nsteps;
+        int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
+        if (issue) fetch(ks_begin + ahead, slot);
         float4 tt[4], v[4];
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
@@ -137,14 +144,15 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
             acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, uu.z, acc[j][nb], 0, 0, 0);
             acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, uu.w, acc[j][nb], 0, 0, 0);
         }
-        dma_wait<0>();             // step t + 1 has landed (this wave's pieces; the barrier covers the other waves')
+        // step t + 1 must have landed (this wave's pieces; the barrier covers the other waves'): everything but the pieces issued in THIS iteration
+        if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
         __syncthreads();
-        cur ^= 1;
+        if (++cur == NS) cur = 0;
     }
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams p)
+template <int NB, int NS>
+__global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef __attribute__((address_space(3))) float lds_float;
@@ -238,10 +246,10 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
     switch (wave) {
-    case 0: wino_loop<NB, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    case 1: wino_loop<NB, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    case 2: wino_loop<NB, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    default: wino_loop<NB, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 0: wino_loop<NB, NS, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 1: wino_loop<NB, NS, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 2: wino_loop<NB, NS, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    default: wino_loop<NB, NS, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
     WSTAMP(3);
@@ -310,6 +318,24 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
     // the epilogue.  The counter is reset by the last arriver (zeroed once per workspace binding by the host).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // the combine's operands are requested by every slice BEFORE its ticket, so that for the slice that turns out to be last they are in flight
+    // during the ticket's round trip instead of behind it (the others drop them)
+    float4 sc2[NB], sh2[NB], rv2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + nb * 32 + cq;
+        sc2[nb] = make_float4(1.f, 1.f, 1.f, 1.f); sh2[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) {
+            sc2[nb] = *reinterpret_cast<const float4 *>(p.scale + n);
+            sh2[nb] = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            rv2[nb][ab] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.residual)
+                rv2[nb][ab] = *reinterpret_cast<const float4 *>(p.residual + (((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1))) * p.N + n);
+        }
+    }
     unsigned *flag = reinterpret_cast<unsigned *>(smem);
     const unsigned tile = (unsigned)(tb * p.nng + ng);
     if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -320,29 +346,28 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void wino3x3(const WinoParams
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + nb * 32 + cq;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) {
-            sc = *reinterpret_cast<const float4 *>(p.scale + n);
-            sh = *reinterpret_cast<const float4 *>(p.shift + n);
+        const float4 sc = sc2[nb], sh = sh2[nb];
+        float4 tsl[4][8];
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {                       // all slab loads of this channel quad in flight at once
+            const size_t pix = ((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1));
+            const size_t e = pix * p.N + n;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl)
+                if (sl < p.splits)
+                    tsl[ab][sl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, (unsigned)(((size_t)sl * npix * p.N + e) * 4), 0, 16));
         }
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) {
             const size_t pix = ((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1));
             const size_t e = pix * p.N + n;
-            float4 tsl[8];
+            float4 v = tsl[ab][0];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s < p.splits)
-                    tsl[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, (unsigned)(((size_t)s * npix * p.N + e) * 4), 0, 16));
-            float4 v = tsl[0];
-#pragma unroll
-            for (int s = 1; s < 8; ++s)
-                if (s < p.splits) { v.x += tsl[s].x; v.y += tsl[s].y; v.z += tsl[s].z; v.w += tsl[s].w; }
+            for (int sl = 1; sl < 8; ++sl)
+                if (sl < p.splits) { v.x += tsl[ab][sl].x; v.y += tsl[ab][sl].y; v.z += tsl[ab][sl].z; v.w += tsl[ab][sl].w; }
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            if (p.residual) {
-                const float4 rv = *reinterpret_cast<const float4 *>(p.residual + e);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
+            const float4 rv = rv2[nb][ab];
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4 *>(p.out + e) = v;
         }
@@ -362,17 +387,17 @@ bool wino_supported(const WinoParams &p, int nb)
     return true;
 }
 
-template <int NB>
+template <int NB, int NS>
 static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
 {
-    constexpr int smem = wino_lds_bytes(NB);
+    constexpr int smem = wino_lds_bytes(NB, NS);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL(wino3x3<NB>, dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wino3x3<NB, NS>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
@@ -401,7 +426,9 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
     p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));
     p.div_tbx = FastDiv::make((unsigned)p.tbx);
-    return nb == 2 ? launch_wino_t<2>(p, s) : launch_wino_t<1>(p, s);
+    static const int stages_env = std::getenv("LSP_HIP_WINO_STAGES") ? std::atoi(std::getenv("LSP_HIP_WINO_STAGES")) : 3;      // tools only (A-B runs)
+    if (nb == 2) return launch_wino_t<2, 2>(p, s);
+    return stages_env == 2 ? launch_wino_t<1, 2>(p, s) : launch_wino_t<1, 3>(p, s);
 }
 
 // Host: OIHW [N][C][3][3] -> U = G g G^T (double, rounded once) in the MFMA fragment order [n-block N/32][xi-row 4][k-step C/8][j 4][lane 64][4]:

@@ -23,8 +23,9 @@ def main():
     res = torch.randn(b, h, h, c, device=dev)
     out = torch.empty(b, h, h, c, device=dev)
     blocks = b * (h // 8) * (h // 16) * (c // (32 * nb)) * sp
-    sb = lib.lspf2f_conv3x3_scratch_bytes(b, h, h, c, 0, c, 1, 0, 4000 + nb, 0, sp, -1, 0)
-    used = (sb + 255) // 256 * 256
+    slab = sp * b * h * h * c * 4 if sp > 1 else 0
+    ncnt = b * (h // 8) * (h // 16) * (c // (32 * nb))
+    used = (slab + ncnt * 4 + 255) // 256 * 256            # where the library puts the stamps: behind slabs and arrival counters
     scr = torch.zeros(used + blocks * 4 * 8 * 8, dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
