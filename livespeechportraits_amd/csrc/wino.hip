@@ -65,7 +65,7 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 
 // The K loop of one wave.  ROW = its row i of B^T d B: t = d[ra] (+|-) d[rb] per patch column, then the column transform.
 //   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3
-template <int NB, int NS, int ROW>
+template <int NB, int NS, bool IL, int ROW>
 __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][NB], const char *smem_c, unsigned lds0, int wave, int lane,
                                           unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, unsigned soff_nb,
                                           int ks_begin, int ks_end, unsigned long long *first_landed)
@@ -94,8 +94,16 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
     const unsigned lds_r0 = lds0 + (unsigned)(RAWB + wave * 1024);
     const unsigned lds_r1 = wave < 2 ? lds_r0 + 4096u : lds0 + (unsigned)DUMP;   // pieces 4, 5 exist for waves 0, 1 only; the others feed the dump slot
 
-    auto fetch = [&](int ks, int slot) {
+    auto fetch_raw = [&](int ks, int slot) {
         dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
+    };
+    // two of the wave's U pieces: half h (0 | 1) of channel block nb
+    auto fetch_u2 = [&](int ks, int slot, int nb, int h) {
+        const unsigned vv[2] = {vu[2 * h], vu[2 * h + 1]};
+        dma16_group<2, 1024>(lds_u + (unsigned)(slot * USTAGE + nb * 4096 + h * 2048), vv, srd_u, (int)(soff_u0 + (unsigned)nb * soff_nb + (unsigned)ks * 4096u));
+    };
+    auto fetch = [&](int ks, int slot) {
+        fetch_raw(ks, slot);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
             dma16_group<4, 1024>(lds_u + (unsigned)(slot * USTAGE + nb * 4096), vu, srd_u, (int)(soff_u0 + (unsigned)nb * soff_nb + (unsigned)ks * 4096u));
@@ -125,7 +133,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
         const int ahead = t + NS - 1;
         const bool issue = ahead < nsteps;
         int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
-        if (issue) fetch(ks_begin + ahead, slot);
+        if (!IL && issue) fetch(ks_begin + ahead, slot);
         float4 tt[4], v[4];
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
@@ -143,6 +151,12 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
             acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, uu.y, acc[j][nb], 0, 0, 0);
             acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, uu.z, acc[j][nb], 0, 0, 0);
             acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, uu.w, acc[j][nb], 0, 0, 0);
+            // IL: the copies of step t + NS - 1 go out in small groups BETWEEN this step's MFMA groups (each group of 4 MFMAs keeps the matrix pipe busy for
+            // 256 cycles, a group of two pieces takes ~150 to issue), instead of as one ~600-cycle block ahead of them with the pipe idle
+            if (IL && issue) {
+                if (f == 0) fetch_raw(ks_begin + ahead, slot);
+                if (f >= 1 && f <= 2 * NB) fetch_u2(ks_begin + ahead, slot, (f - 1) >> 1, (f - 1) & 1);
+            }
         }
         // step t + 1 must have landed (this wave's pieces; the barrier covers the other waves'): everything but the pieces issued in THIS iteration
         if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
@@ -151,7 +165,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
     }
 }
 
-template <int NB, int NS>
+template <int NB, int NS, bool IL>
 __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -246,10 +260,10 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
     switch (wave) {
-    case 0: wino_loop<NB, NS, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    case 1: wino_loop<NB, NS, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    case 2: wino_loop<NB, NS, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    default: wino_loop<NB, NS, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 0: wino_loop<NB, NS, IL, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 1: wino_loop<NB, NS, IL, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 2: wino_loop<NB, NS, IL, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    default: wino_loop<NB, NS, IL, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
     WSTAMP(3);
@@ -387,17 +401,17 @@ bool wino_supported(const WinoParams &p, int nb)
     return true;
 }
 
-template <int NB, int NS>
+template <int NB, int NS, bool IL>
 static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
 {
     constexpr int smem = wino_lds_bytes(NB, NS);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL((wino3x3<NB, NS>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wino3x3<NB, NS, IL>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
@@ -426,9 +440,11 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
     p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));
     p.div_tbx = FastDiv::make((unsigned)p.tbx);
-    static const int stages_env = std::getenv("LSP_HIP_WINO_STAGES") ? std::atoi(std::getenv("LSP_HIP_WINO_STAGES")) : 3;      // tools only (A-B runs)
-    if (nb == 2) return launch_wino_t<2, 2>(p, s);
-    return stages_env == 2 ? launch_wino_t<1, 2>(p, s) : launch_wino_t<1, 3>(p, s);
+    // tools only (A-B runs): LSP_HIP_WINO_IL=0 issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them
+    static const int il_env = std::getenv("LSP_HIP_WINO_IL") ? std::atoi(std::getenv("LSP_HIP_WINO_IL")) : 1;
+    if (nb == 2) return il_env ? launch_wino_t<2, 2, true>(p, s) : launch_wino_t<2, 2, false>(p, s);
+    if (il_env == 2) return launch_wino_t<1, 2, true>(p, s);
+    return il_env ? launch_wino_t<1, 3, true>(p, s) : launch_wino_t<1, 2, false>(p, s);
 }
 
 // Host: OIHW [N][C][3][3] -> U = G g G^T (double, rounded once) in the MFMA fragment order [n-block N/32][xi-row 4][k-step C/8][j 4][lane 64][4]:
