@@ -77,8 +77,8 @@ def main():
     ap.add_argument("--variant", default="large", choices=["large", "normal"])
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = the parity configuration (default); bf16 = BASELINE.json configs[2] storage path")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="f32 = the parity configuration (default); bf16 = BASELINE.json configs[2] storage path; f16 = the reference's opt.fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--layers", default=None, help="write the per-layer timing table to this file")
@@ -343,7 +343,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "%s generator (%s), batch %d per GPU, %dx%d, %s, synthetic weights+inputs"
                                % (a.variant, "May" if a.variant == "large" else "Obama1", B, a.size, a.size,
-                                  "fp32" if a.dtype == "f32" else "bf16 storage / fp32 accumulate (parity-unpinned: tolerance declared in tests)"),
+                                  {"f32": "fp32", "bf16": "bf16 storage / fp32 accumulate (parity-unpinned: tolerance declared in tests)",
+                                   "f16": "fp16 storage / fp32 accumulate (the reference's opt.fp16; pinned on the autocast oracle in tests)"}[a.dtype]),
                    "global_batch": world * B, "parallelism": "dp%d (frames sharded, one RCCL weight broadcast)" % world,
                    "gflop_per_frame": round(topo.flops_per_frame() / 1e9, 2)},
         "roofline": roofline, "cpu_baseline": cpu_baseline,

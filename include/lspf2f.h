@@ -50,9 +50,13 @@ typedef enum lspf2f_variant {
 
 typedef enum lspf2f_dtype {
     LSPF2F_DTYPE_F32 = 0,       /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity configuration */
-    LSPF2F_DTYPE_BF16 = 1       /* bf16 activations + conv weights in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate and
+    LSPF2F_DTYPE_BF16 = 1,      /* bf16 activations + conv weights in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate and
                                    epilogue; API tensors stay fp32.  The reference has no bf16 path (only fp16 autocast,
                                    feature2face_G.py:28-30): compared against the fp32 oracle with a declared tolerance */
+    LSPF2F_DTYPE_F16 = 2        /* fp16 (IEEE binary16) activations + conv weights in HBM, v_mfma_f32_32x32x16_f16, fp32 accumulate
+                                   and epilogue; API tensors stay fp32.  Replaces the reference's opt.fp16 branch -- torch.cuda.amp.autocast
+                                   around netG (models/feature2face_G.py:28-30, feature2face_model.py:232-236) -- and is pinned on it:
+                                   the oracle under torch.autocast(float16) is the comparison (tests/test_gpu_plans.py) */
 } lspf2f_dtype;
 
 /* flags for lspf2f_config.flags */

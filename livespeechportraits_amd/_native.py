@@ -21,7 +21,7 @@ ERR_NAMES = {
     -5: "STATE", -6: "HIP", -7: "NO_DEVICE",
 }
 VARIANT_IDS = {"normal": 0, "large": 1}
-DTYPE_IDS = {"f32": 0, "bf16": 1}
+DTYPE_IDS = {"f32": 0, "bf16": 1, "f16": 2}
 FLAG_KEEP_INTERMEDIATES = 1
 FLAG_INSTANCE_NORM = 4
 NORM_IDS = {"batch": 0, "instance": 1}

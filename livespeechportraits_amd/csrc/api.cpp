@@ -85,7 +85,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
 {
     if (!cfg || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (cfg->abi_version != LSPF2F_ABI_VERSION) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "ABI version mismatch");
-    if (cfg->dtype != LSPF2F_DTYPE_F32 && cfg->dtype != LSPF2F_DTYPE_BF16) return fail(LSPF2F_ERR_UNSUPPORTED, "unknown dtype");
+    if (cfg->dtype != LSPF2F_DTYPE_F32 && cfg->dtype != LSPF2F_DTYPE_BF16 && cfg->dtype != LSPF2F_DTYPE_F16) return fail(LSPF2F_ERR_UNSUPPORTED, "unknown dtype");
     if (cfg->height != cfg->width) return fail(LSPF2F_ERR_UNSUPPORTED, "frames must be square (loadSize x loadSize)");
     if (cfg->max_batch < 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "max_batch must be >= 1");
     lspf2f_handle *h = new (std::nothrow) lspf2f_handle();
@@ -653,7 +653,7 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride, int upsample,
                                     int tile_m, int tile_n, int split_k, int k_group, int dtype)
 {
-    const int ktc = dtype == 1 ? 64 : 32;
+    const int ktc = dtype ? 64 : 32;
     if ((tile_m == 4001 || tile_m == 4002) && k_group == -1) {      // Winograd kernel: slabs + one arrival counter per (tile-block, channel group)
         const int sp = split_k > 0 ? split_k : 1;
         if (sp == 1) return 0;
@@ -680,13 +680,13 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                    int c1, int cout, int stride, int upsample, int relu, int tile_m, int tile_n, int split_k,
                    int k_group, int dtype, void *scratch, size_t scratch_bytes, void *hip_stream)
 {
-    if (dtype != 0 && dtype != 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "dtype must be 0 (fp32) or 1 (bf16)");
-    const int ktc = dtype == 1 ? 64 : 32;
+    if (dtype < 0 || dtype > 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+    const int ktc = dtype ? 64 : 32;
     if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
     const bool wino_tile = (tile_m == 4001 || tile_m == 4002) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
     if (!wino_tile && ((c0 % ktc) || (c1 % ktc) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1)))
-        return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (fp32) / 64 (bf16)");
+        return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (fp32) / 64 (bf16, fp16)");
     if (cout % 4) return fail(LSPF2F_ERR_UNSUPPORTED, "cout must be a multiple of 4");
     if (stride != 1 && stride != 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "stride must be 1 or 2");
     if (upsample && stride != 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "upsample requires stride 1");

@@ -31,7 +31,32 @@ template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t *p)
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
+// fp16 storage (dtype 2: the reference's opt.fp16 / autocast configuration, models/feature2face_G.py:28-30): IEEE binary16, round-to-nearest-even
+// on store, fp32 accumulate and epilogue like the bf16 path.  _Float16 is a distinct type from bf16_t, which is what the templates dispatch on.
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <> __device__ __forceinline__ float4 load4<f16_t>(const f16_t *p)
+{
+    const f32x4v f = __builtin_convertvector(__builtin_bit_cast(f16x4, *reinterpret_cast<const uint2 *>(p)), f32x4v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
 template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t *p, float4 v)
+{
+    const f32x4v f = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<uint2 *>(p) = __builtin_bit_cast(uint2, __builtin_convertvector(f, f16x4));
+}
+// one element, whatever the storage type
+template <typename T> __device__ __forceinline__ float ld1(const T *p);
+template <> __device__ __forceinline__ float ld1<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t *p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ld1<f16_t>(const f16_t *p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st1(T *p, float v);
+template <> __device__ __forceinline__ void st1<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t *p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void st1<f16_t>(f16_t *p, float v) { *p = (f16_t)v; }
 template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v)
 {

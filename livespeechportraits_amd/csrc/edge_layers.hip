@@ -280,8 +280,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FirstConvParams p)
             float v = acc[h][r] + bias;
             if (p.relu) v = fmaxf(v, 0.f);
             const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * p.Cout + n;
-            if constexpr (sizeof(T) == 4) static_cast<float *>(p.out)[o] = v;
-            else static_cast<bf16_t *>(p.out)[o] = f2bf(v);
+            st1(static_cast<T *>(p.out) + o, v);
         }
     }
 }
@@ -311,7 +310,8 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
         long blocks = (npix / ppw + 3) / 4;                  // one pixel group per wave ...
         if (blocks > 4096) blocks = 4096;                    // ... up to 16 blocks per CU, then grid-stride
         if (blocks < 1) blocks = 1;
-        if (p.dtype == 1) hipLaunchKernelGGL((first_conv_feat<bf16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.dtype == 2) hipLaunchKernelGGL((first_conv_feat<f16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else if (p.dtype == 1) hipLaunchKernelGGL((first_conv_feat<bf16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((first_conv_feat<float, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         return hipGetLastError();
     }
@@ -319,16 +319,19 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
     // of 32 up to 128; bf16 output only for the layer itself (the candidate cache is fp32)
     const bool cache_pass = p.relu == 0 && p.base == nullptr && p.ci_begin > 0;
     if (!p.base && !p.force_direct && p.feat_nc + p.cand_nc == 13 && (p.Cout == 32 || p.Cout == 64 || p.Cout == 128)) {
-        const bool bf = p.dtype == 1 && !cache_pass;
+        const int st = cache_pass ? 0 : p.dtype;            // storage type of what this pass writes
         switch (p.Cout / 32) {
-        case 1: return bf ? launch_first_conv_mfma<bf16_t, 1>(p, s) : launch_first_conv_mfma<float, 1>(p, s);
-        case 2: return bf ? launch_first_conv_mfma<bf16_t, 2>(p, s) : launch_first_conv_mfma<float, 2>(p, s);
-        default: return bf ? launch_first_conv_mfma<bf16_t, 4>(p, s) : launch_first_conv_mfma<float, 4>(p, s);
+        case 1: return st == 2 ? launch_first_conv_mfma<f16_t, 1>(p, s) : st == 1 ? launch_first_conv_mfma<bf16_t, 1>(p, s) : launch_first_conv_mfma<float, 1>(p, s);
+        case 2: return st == 2 ? launch_first_conv_mfma<f16_t, 2>(p, s) : st == 1 ? launch_first_conv_mfma<bf16_t, 2>(p, s) : launch_first_conv_mfma<float, 2>(p, s);
+        default: return st == 2 ? launch_first_conv_mfma<f16_t, 4>(p, s) : st == 1 ? launch_first_conv_mfma<bf16_t, 4>(p, s) : launch_first_conv_mfma<float, 4>(p, s);
         }
     }
     const long total = (long)p.B * (p.H / 2) * (p.W / 2);
     const int K = (p.ci_end - p.ci_begin) * 9;
-    if (p.dtype == 1 && p.out != nullptr && !(p.relu == 0 && p.base == nullptr && p.ci_begin > 0))
+    if (p.dtype == 2 && p.out != nullptr && !(p.relu == 0 && p.base == nullptr && p.ci_begin > 0))
+        hipLaunchKernelGGL(first_conv<f16_t>, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
+                           (size_t)K * 32 * sizeof(float), s, p);
+    else if (p.dtype == 1 && p.out != nullptr && !(p.relu == 0 && p.base == nullptr && p.ci_begin > 0))
         hipLaunchKernelGGL(first_conv<bf16_t>, dim3((unsigned)((total + 255) / 256), p.Cout / 32), dim3(256),
                            (size_t)K * 32 * sizeof(float), s, p);
     else   // fp32 activations, or the candidate-share pass (its cache is always fp32)
@@ -689,6 +692,15 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
 
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
+    if (p.dtype == 2) {
+        switch (p.Cout) {
+        case 1: return launch_last_conv_co<f16_t, 1>(p, s);
+        case 2: return launch_last_conv_co<f16_t, 2>(p, s);
+        case 3: return launch_last_conv_co<f16_t, 3>(p, s);
+        case 4: return launch_last_conv_co<f16_t, 4>(p, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (p.dtype == 1) {
         switch (p.Cout) {
         case 1: return launch_last_conv_co<bf16_t, 1>(p, s);

@@ -304,6 +304,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].y, fb[set][j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].z, fb[set][j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i].w, fb[set][j].w, acc[i][j], 0, 0, 0);
+                } else if constexpr (__is_same(T, f16_t)) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][i]), __builtin_bit_cast(f16x8, fb[set][j]),
+                                                                       acc[i][j], 0, 0, 0);
                 } else {
                     // the 16-B slot is 8 consecutive bf16 channels = this lane's K = 8*(lane>>5) .. +7 operand
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]),
@@ -655,7 +658,7 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
     p.div_rw = FastDiv::make((unsigned)(p.up4 ? p.Ws : p.Wo));
     // 2 GiB per tensor: buffer-load offsets are 32-bit with the top bit reserved as the OOB marker
     const size_t lim = 0x7fffffffull;
-    const size_t eb = p.dtype == 1 ? 2 : 4;
+    const size_t eb = p.dtype ? 2 : 4;
     if ((size_t)p.B * p.Hs * p.Ws * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * eb > lim) return hipErrorInvalidValue;
     if ((p.C0 * eb) % 128 || (p.C1 * eb) % 128) return hipErrorInvalidValue;   // a K-tile is 128 B of channels
     {   // XCD chunking: partition the larger operand across the 8 L2s (LSP_HIP_XCD=0/1/2 overrides, tools only)
@@ -669,6 +672,7 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
         if (rule == 1 && p.splits > 1 && p.dtype == 0) rule = 0;
         p.xcd = forced >= 0 ? forced : rule;
     }
+    if (p.dtype == 2) return launch_igemm_typed<f16_t>(p, bm, bn, g, s);
     return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
 }
 
@@ -688,6 +692,7 @@ static hipError_t launch_splitk_reduce_t(const IgemmParams &p, hipStream_t s)
 
 hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
 {
+    if (p.dtype == 2) return launch_splitk_reduce_t<f16_t>(p, s);
     return p.dtype == 1 ? launch_splitk_reduce_t<bf16_t>(p, s) : launch_splitk_reduce_t<float>(p, s);
 }
 

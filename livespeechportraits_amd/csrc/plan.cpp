@@ -12,6 +12,21 @@ static const double kBnEps = 1e-5;   // nn.BatchNorm2d default (networks.py neve
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// fp32 -> 16-bit storage, round to nearest even: bf16 (dtype 1) or IEEE binary16 (dtype 2)
+static uint16_t narrow16(float f, int dtype)
+{
+    if (dtype == 2) {
+        const _Float16 h = (_Float16)f;
+        uint16_t u;
+        std::memcpy(&u, &h, 2);
+        return u;
+    }
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
 void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *bm_out, int *bn_out, int *splits_out, int *group_out)
 {
     // par = independent GEMM slices per launch (4 output parities in sub-pixel up-conv form)
@@ -36,7 +51,7 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
         const long t64 = (long)par * ((M + 63) / 64) * ((N + 63) / 64);
         long tiles = t64;
         if (!up9 && N >= 128 && t128 >= want) { bn = 128; tiles = t128; }
-        if (dtype == 1 && !up9) {
+        if (dtype != 0 && !up9) {
             // bf16: an MFMA step is 16x shorter, so the per-K-tile overhead (DMA issue, barrier) dominates
             // and the biggest tile that still gives every CU a workgroup wins by 10-35 %
             // (profiles/r01_tune_conv_bf16_b8.txt): 128 rows x (128 | 64) columns
@@ -224,8 +239,8 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
     if (norm_ != 0 && norm_ != 1) return "norm must be 0 (BatchNorm2d, eval) or 1 (InstanceNorm2d)";
     if (norm_ == 1 && dtype_ != 0) return "the InstanceNorm variant is fp32 only";
     norm = norm_;
-    if (dtype_ != 0 && dtype_ != 1) return "dtype must be 0 (fp32) or 1 (bf16)";
-    if (dtype_ == 1 && ngf_ % 64 != 0) return "bf16 needs ngf % 64 == 0 (a K-tile is 64 bf16 channels)";
+    if (dtype_ < 0 || dtype_ > 2) return "dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)";
+    if (dtype_ != 0 && ngf_ % 64 != 0) return "16-bit storage needs ngf % 64 == 0 (a K-tile is 64 channels)";
     dtype = dtype_;
     if (variant_ != 0 && variant_ != 1)
         return "variant must be 0 (normal) or 1 (large); the 'small' U-Net (networks.py:680-769) is not supported";
@@ -257,7 +272,7 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
         }
-        if (last_as_gemm(l) && l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
+        if (dtype == 1 && last_as_gemm(l) && l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
             off = align_up(off, 256);
             l.wrl_off = (int64_t)off;
             off += (size_t)9 * 4 * 64 * 8 * elt();
@@ -465,7 +480,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
     for (const auto &l : layers) {
         const float *W = get(l.wkey).data.data();           // OIHW
         // igemm-family weights are stored in the plan's dtype; staged in fp32 then narrowed (RNE) if bf16
-        const bool narrow = dtype == 1 && layer_weights_typed(l);
+        const bool narrow = dtype != 0 && layer_weights_typed(l);
         const size_t wcount = (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9);
         std::vector<float> stage_buf;
         float *dst = reinterpret_cast<float *>(base + l.w_off);
@@ -500,12 +515,8 @@ std::string Plan::pack(void *blob, size_t bytes) const
                         for (int a = 0; a < 2; ++a)
                             for (int b = 0; b < 2; ++b) {
                                 const int tap = ((par >> 1) + a) * 3 + (par & 1) + b;
-                                for (int ci = 0; ci < cin; ++ci) {
-                                    uint32_t u;
-                                    std::memcpy(&u, &dst[(((size_t)par * cout + co) * 4 + a * 2 + b) * cin + ci], 4);
-                                    u += 0x7fffu + ((u >> 16) & 1u);
-                                    g[(((size_t)par * cout + co) * 9 + tap) * cin + ci] = (uint16_t)(u >> 16);
-                                }
+                                for (int ci = 0; ci < cin; ++ci)
+                                    g[(((size_t)par * cout + co) * 9 + tap) * cin + ci] = narrow16(dst[(((size_t)par * cout + co) * 4 + a * 2 + b) * cin + ci], dtype);
                             }
                 if (l.wrl_off >= 0)     // (the blob is zero-filled, so the untouched taps of g are zeros)
                     pack_rowlast_weights(g, reinterpret_cast<uint16_t *>(base + l.wrl_off), 4 * cout);
@@ -527,12 +538,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
         }
         if (narrow) {
             uint16_t *d16 = reinterpret_cast<uint16_t *>(base + l.w_off);
-            for (size_t i = 0; i < wcount; ++i) {
-                uint32_t u;
-                std::memcpy(&u, &stage_buf[i], 4);
-                u += 0x7fffu + ((u >> 16) & 1u);             // round to nearest even
-                d16[i] = (uint16_t)(u >> 16);
-            }
+            for (size_t i = 0; i < wcount; ++i) d16[i] = narrow16(stage_buf[i], dtype);    // round to nearest even
         }
         if (l.wru_off >= 0)
             pack_rowup_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wru_off));

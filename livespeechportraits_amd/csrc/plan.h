@@ -73,7 +73,8 @@ struct ParamDesc {         // an expected state-dict entry
 struct Plan {
     int variant = 1, nres = 2, input_nc = 13, feat_nc = 1, output_nc = 3, ngf = 64, num_downs = 8, size = 512;
     bool keep_intermediates = false;
-    int dtype = 0;             // 0: fp32 activations + weights; 1: bf16 storage (fp32 accumulate), first/last-layer weights fp32
+    int dtype = 0;             // 0: fp32 activations + weights; 1: bf16 storage (fp32 accumulate), first/last-layer weights fp32; 2: fp16 storage, likewise
+                               // (the reference's opt.fp16 / autocast configuration; runs on the generic kernels, the bf16-only row / band kernels stay off)
     int norm = 0;              // 0: BatchNorm2d in eval mode (folded, the shipped checkpoints); 1: InstanceNorm2d (norm_layer argument
                                // of the reference constructors, networks.py:555 / :459): conv biases on, statistics at run time, fp32 only
     bool use_bandconv = true;  // bf16 plans: LSP_HIP_BANDCONV=0 at create puts the 16x16 / 8x8 layers back on the implicit GEMM (A-B runs)
@@ -85,11 +86,11 @@ struct Plan {
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
-    size_t elt() const { return dtype == 1 ? 2 : 4; }
-    int ktile_channels() const { return dtype == 1 ? 64 : 32; }   // a K-tile is 128 B of channels
+    size_t elt() const { return dtype ? 2 : 4; }
+    int ktile_channels() const { return dtype ? 64 : 32; }   // a K-tile is 128 B of channels
     bool layer_weights_typed(const LayerDesc &l) const { return l.kind == kIgemm; }   // else fp32
     // bf16: the last conv runs as an implicit GEMM on the low-res source (N = 4 parities x cout) + a pixel-shuffle/tanh pass
-    bool last_as_gemm(const LayerDesc &l) const { return dtype == 1 && l.kind == kLastConv && l.cin % 64 == 0; }
+    bool last_as_gemm(const LayerDesc &l) const { return dtype != 0 && l.kind == kLastConv && l.cin % 64 == 0; }
     std::vector<LayerDesc> layers;
     std::vector<TensorDesc> tensors;
     std::vector<ParamDesc> params;

@@ -113,12 +113,10 @@ __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
             float v = sum;
             if (p.scale) v = v * p.scale[n] + p.shift[n];
             if (p.residual) {
-                if constexpr (sizeof(T) == 4) v += static_cast<const float *>(p.residual)[(size_t)m * p.Cout + n];
-                else v += bf2f(static_cast<const bf16_t *>(p.residual)[(size_t)m * p.Cout + n]);
+                v += ld1(static_cast<const T *>(p.residual) + (size_t)m * p.Cout + n);
             }
             if (p.relu) v = fmaxf(v, 0.f);
-            if constexpr (sizeof(T) == 4) static_cast<float *>(p.out)[(size_t)m * p.Cout + n] = v;
-            else static_cast<bf16_t *>(p.out)[(size_t)m * p.Cout + n] = f2bf(v);
+            st1(static_cast<T *>(p.out) + (size_t)m * p.Cout + n, v);
         }
     }
 }
@@ -143,10 +141,14 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<f16_t, NC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
+    if (p.dtype == 2) hipLaunchKernelGGL((conv3x3_smallm<f16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
+    else if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
     else hipLaunchKernelGGL((conv3x3_smallm<float, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
     return hipGetLastError();
 }

@@ -27,7 +27,7 @@ class Engine:
             raise ValueError("opt.size must be 'normal' or 'large' for the HIP renderer "
                              "(got %r; the 'small' U-Net is not on the shipped path)" % (variant,))
         if dtype not in N.DTYPE_IDS:
-            raise ValueError("dtype must be 'f32' or 'bf16'")
+            raise ValueError("dtype must be 'f32', 'bf16' or 'f16'")
         if norm not in N.NORM_IDS:
             raise ValueError("norm must be 'batch' (BatchNorm2d, the shipped checkpoints) or 'instance' (norm_layer=nn.InstanceNorm2d)")
         self.dtype, self.norm = dtype, norm
@@ -269,7 +269,7 @@ class Engine:
         for l in self.layers(batch):
             if l["name"] == name and l["out_offset"] >= 0:
                 n = batch * l["h_out"] * l["h_out"] * l["cout"]
-                tdt, eb = (torch.bfloat16, 2) if self.dtype == "bf16" else (torch.float32, 4)
+                tdt, eb = {"bf16": (torch.bfloat16, 2), "f16": (torch.float16, 2)}.get(self.dtype, (torch.float32, 4))
                 raw = self._ws[l["out_offset"]: l["out_offset"] + eb * n]
                 return raw.view(tdt).view(batch, l["h_out"], l["h_out"], l["cout"])
         raise KeyError(name)

@@ -84,8 +84,9 @@ class Feature2FaceGenerator(nn.Module):
     """Feature2FaceGenerator_{normal,large}: parameters here, arithmetic in liblspf2f."""
 
     def __init__(self, variant: str, input_nc: int = 13, output_nc: int = 3, num_downs: int = 8,
-                 ngf: int = 64, feat_nc: int = 1, norm_layer=nn.BatchNorm2d):
+                 ngf: int = 64, feat_nc: int = 1, norm_layer=nn.BatchNorm2d, dtype: str = "f32"):
         super().__init__()
+        self.dtype = dtype                       # storage type of activations / conv weights: 'f32', or 'f16' for the reference's opt.fp16
         self.variant, self.input_nc, self.output_nc = variant, input_nc, output_nc
         self.num_downs, self.ngf, self.feat_nc = num_downs, ngf, feat_nc
         self.norm = _norm_kind(norm_layer)
@@ -108,7 +109,7 @@ class Feature2FaceGenerator(nn.Module):
             same_size = e is not None and e.size == size
             mb = max(batch, e.max_batch) if same_size else batch
             e = Engine(self.variant, self.input_nc, self.feat_nc, self.output_nc, self.ngf,
-                       self.num_downs, size, mb, norm=self.norm)
+                       self.num_downs, size, mb, norm=self.norm, dtype=self.dtype)
             # The packed layout depends on the frame size (an up-conv switches to the 16-tap sub-pixel form once it writes
             # >= 32x32, plan.cpp), not on the batch: the blob is reused only when just max_batch grew.
             if same_size and not self._dirty and self._blob is not None and self._blob.device == device \
@@ -138,7 +139,9 @@ class Feature2FaceGenerator(nn.Module):
                 "the feature2face HIP renderer needs ROCm tensors (got %s); there is no CPU fallback -- "
                 "the reference's own CPU path is models/networks.py run under PyTorch" % feat.device)
         e = self._engine_for(feat.shape[-1], feat.shape[0], feat.device)
-        return e.forward(feat.float(), cand.float() if cand is not None else None)
+        out = e.forward(feat.float(), cand.float() if cand is not None else None)
+        # under autocast the reference's generator returns a float16 tensor (tanh of a half tensor, feature2face_G.py:28-30)
+        return out.half() if self.dtype == "f16" else out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x = cat([feature_map, cand_image], 1) as the reference's G receives it."""

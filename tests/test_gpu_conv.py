@@ -21,7 +21,7 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     b, c0, hs, ws = x0.shape
     c1 = x1.shape[1] if x1 is not None else 0
     cout = w.shape[0]
-    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    tdt = {1: torch.bfloat16, 2: torch.float16}.get(dtype, torch.float32)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev).to(tdt)
     d0 = nhwc(x0)
     d1 = nhwc(x1) if x1 is not None else None
@@ -369,6 +369,42 @@ def test_conv3x3_bf16_storage(cfg, gpu_device):
         ref = ref_conv(x0, x1, wq, scale, shift, r, stride, bool(up), True)
     assert torch.isfinite(got).all()
     tol = (ref.abs() * 2.0 ** -8 + 1e-3)
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("cfg", BF16_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_s%d_up%d_res%d_t%dx%d_k%d_g%d" % (
+    c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8][0], c[8][1], c[9], c[10]))
+def test_conv3x3_fp16_storage(cfg, gpu_device):
+    """fp16 (IEEE binary16) activations / weights in HBM, fp32 accumulate + epilogue: the storage path behind the reference's opt.fp16
+    (models/feature2face_G.py:28-30).  Reference = the same conv on the fp16-ROUNDED operands in fp64; the kernel may differ by one
+    fp16 ulp of the result (2^-11 relative) plus the fp32 accumulation-order noise."""
+    b, c0, c1, cout, hs, stride, up, res, tile, split, g = cfg
+    h16 = lambda t: t.half().float() if t is not None else None
+    x0 = h16(rnd(b, c0, hs, hs, seed=41))
+    x1 = h16(rnd(b, c1, hs, hs, seed=42)) if c1 else None
+    w = rnd(cout, c0 + c1, 3, 3, seed=43) * 0.05
+    scale, shift = rnd(cout, seed=44) * 0.5 + 1.0, rnd(cout, seed=45) * 0.1
+    ho = 2 * hs if up else (hs + stride - 1) // stride
+    r = h16(rnd(b, cout, ho, ho, seed=46)) if res else None
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, up, True, tile, split, g, dtype=2)
+    wq = h16(pack_subpixel(w)) if up == 2 else h16(w)
+    if up == 2:
+        x = x0 if x1 is None else torch.cat([x0, x1], 1)
+        xp = F.pad(x.double(), (1, 1, 1, 1))
+        ref = torch.zeros(b, cout, 2 * hs, 2 * hs, dtype=torch.float64)
+        for py in (0, 1):
+            for px in (0, 1):
+                acc = 0
+                for a in (0, 1):
+                    for bb in (0, 1):
+                        patch = xp[:, :, a + py: a + py + hs, bb + px: bb + px + hs]
+                        acc = acc + torch.einsum("bchw,oc->bohw", patch, wq[py * 2 + px, :, a, bb, :].double())
+                ref[:, :, py::2, px::2] = acc
+        ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).float()
+    else:
+        ref = ref_conv(x0, x1, wq, scale, shift, r, stride, bool(up), True)
+    assert torch.isfinite(got).all()
+    tol = (ref.abs() * 2.0 ** -11 + 2e-4)
     assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
 
 

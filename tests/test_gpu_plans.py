@@ -79,6 +79,70 @@ def test_bf16_batch8_full_size_every_frame(variant, gpu_device, oracle_b8):
     assert (per.max(1) <= tol_max).all() and (per.mean(1) <= tol_mean).all()
 
 
+@pytest.mark.parametrize("variant", ["normal", "large"])
+def test_fp16_batch8_against_the_autocast_oracle(variant, gpu_device, oracle_b8):
+    """opt.fp16 (models/feature2face_G.py:28-30, feature2face_model.py:232-236): the reference wraps netG in torch.cuda.amp.autocast.  The
+    pin is the oracle's own op sequence under torch.autocast(float16) on this device (ATen -> MIOpen half convs): its distance from the fp32
+    oracle is the error the reference accepts when a user sets fp16, and the HIP fp16 path (fp16 storage, fp32 accumulate and epilogue, one
+    rounding per layer instead of one per op) must stay inside it -- every frame, max and mean -- and close to the autocast output itself."""
+    from livespeechportraits_amd.engine import Engine
+    from oracle import torch_oracle
+    topo, sd, feat, cand, ref32 = oracle_b8(variant)
+    sd_d = {k: v.to(gpu_device) for k, v in torch_oracle.to_torch(sd).items()}
+    x = torch.cat([torch.from_numpy(feat), torch.from_numpy(cand).expand(8, -1, -1, -1)], 1).to(gpu_device)
+    with torch.autocast("cuda", dtype=torch.float16):
+        ref16 = torch.cat([torch_oracle.generator_forward(sd_d, x[i:i + 1], topo.nres, topo.num_downs) for i in range(8)])
+    assert ref16.dtype == torch.float16            # what the reference's inference() returns under opt.fp16
+    ref16 = ref16.float().cpu().numpy()
+    e = Engine(variant, size=512, max_batch=8, dtype="f16")
+    e.load_state_dict(sd)
+    e.bind(e.pack(), gpu_device)
+    out = e.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
+    d_ref = np.abs(ref16 - ref32).reshape(8, -1)           # autocast oracle vs fp32 oracle
+    d_got = np.abs(out - ref32).reshape(8, -1)             # HIP fp16 path vs fp32 oracle
+    d_16 = np.abs(out - ref16).reshape(8, -1)              # HIP fp16 path vs autocast oracle
+    fmt = lambda a: " ".join("%.1e" % v for v in a)
+    print("\n%s fp16 batch 8, per frame:\n  autocast oracle vs fp32 oracle  max %s | mean %s\n  HIP fp16 vs fp32 oracle         max %s | mean %s\n"
+          "  HIP fp16 vs autocast oracle     max %s | mean %s" % (variant, fmt(d_ref.max(1)), fmt(d_ref.mean(1)), fmt(d_got.max(1)), fmt(d_got.mean(1)),
+                                                                 fmt(d_16.max(1)), fmt(d_16.mean(1))))
+    assert (d_got.max(1) <= 1.25 * d_ref.max(1) + 1e-4).all() and (d_got.mean(1) <= 1.25 * d_ref.mean(1) + 1e-5).all()
+    assert (d_16.max(1) <= 2.0 * d_ref.max(1) + 1e-4).all() and (d_16.mean(1) <= 2.0 * d_ref.mean(1) + 1e-5).all()
+    e.close()
+
+
+def test_opt_fp16_selects_the_fp16_path_and_returns_half(gpu_device, tmp_path):
+    """create_model(opt) with fp16=1: no warning-and-fp32 any more -- the generator runs its fp16 plan and inference() returns a float16
+    tensor, the dtype the reference's autocast branch returns (feature2face_model.py:232-236)."""
+    import argparse
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.models import create_model
+    from livespeechportraits_amd.topology import build_topology
+    from oracle import torch_oracle
+    topo = build_topology("normal", size=256)
+    sd = synth.make_state_dict(topo, 1234)
+    ckpt = str(tmp_path / "g.pkl")
+    torch.save({"module." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, ckpt)
+    outs = {}
+    feat, cand = synth.make_inputs(2, 256, seed=7, cand_batch=1)
+    for fp16 in (0, 1):
+        opt = argparse.Namespace(model="feature2face", gpu_ids=[0], isTrain=False, size="normal", ngf=64, n_downsample_G=8, fp16=fp16,
+                                 checkpoints_dir=str(tmp_path), name="t", load_epoch=ckpt, verbose=False)
+        m = create_model(opt)
+        m.setup(opt)
+        m.eval()
+        g = m._g().netG
+        assert g.dtype == ("f16" if fp16 else "f32")
+        y = m.inference(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device))
+        assert y.dtype == (torch.float16 if fp16 else torch.float32) and tuple(y.shape) == (2, 3, 256, 256)
+        assert g._engine.dtype == ("f16" if fp16 else "f32")
+        outs[fp16] = y.float().cpu().numpy()
+    ref = torch_oracle.inference(torch_oracle.to_torch(sd), torch.from_numpy(feat), torch.from_numpy(cand).expand(2, -1, -1, -1), 1, 8).numpy()
+    assert np.abs(outs[0] - ref).max() <= TIGHT
+    d = np.abs(outs[1] - ref)
+    print("\nopt.fp16 = 1 at 256x256: max-abs %.2e mean-abs %.2e vs the fp32 oracle" % (d.max(), d.mean()))
+    assert 1e-6 < d.max() <= 2e-3          # really the fp16 plan (not bit-equal to fp32), and in fp16's error class
+
+
 def test_frame_size_switch_on_a_live_model_repacks(gpu_device):
     """the packed layout depends on the frame size (up-convs change form at 32x32), so a model that
     renders 512 -> 256 -> 512 must re-pack, not reuse the blob.  Checked against the live oracle at both sizes."""

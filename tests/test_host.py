@@ -352,3 +352,33 @@ def test_bf16_plans_route_the_edge_layers_of_the_256_level_to_row_kernels(monkey
     rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(4, 2, 32, 4, 16, 2, 8)        # [par][nb][ch][tap][kc][hi][e]
     frag = blob[l["w_offset"] + nbytes: l["w_offset"] + 2 * nbytes].view(np.uint16).reshape(2, 4, 4, 16, 2, 32, 8)
     assert np.array_equal(frag, rows.transpose(1, 0, 3, 4, 5, 2, 6))
+
+
+def test_fp16_plan_runs_on_the_generic_kernels_and_packs_rne_half():
+    """dtype 'f16' (the reference's opt.fp16): 16-bit K-tiles like bf16, but none of the bf16-only kernels, no Winograd (fp32 only); conv weights
+    are narrowed to IEEE half with round-to-nearest-even by the host packer."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    topo, sd = synth.synthetic("normal", ngf=64, num_downs=5, size=64)
+    e = Engine("normal", ngf=64, num_downs=5, size=64, max_batch=8, dtype="f16")
+    for b in (1, 8):
+        fams = {l["kernel"].split(" ")[0].split("+")[0] for l in e.layers(b)}
+        assert fams <= {"first_conv", "igemm3x3", "conv3x3_smallm", "last_conv"}, fams
+    last = e.layers(1)[-1]
+    assert last["kernel"] == "last_conv (igemm3x3 + pixel_shuffle_tanh)"
+    e.load_state_dict(sd)
+    blob = e.pack().numpy()
+    checked = 0
+    for l, c in zip(e.layers(1), topo.convs):
+        if not l["kernel"].startswith(("igemm3x3", "conv3x3_smallm")) or (l["upsample"] and l["h_out"] >= 32):
+            continue
+        w = sd[c.weight_key]
+        exp = w.transpose(0, 2, 3, 1).astype(np.float16).reshape(-1)               # numpy casts with round-to-nearest-even
+        got = blob[l["w_offset"]: l["w_offset"] + 2 * exp.size].view(np.float16)
+        if l["weight_bytes"] == 2 * exp.size:
+            assert np.array_equal(got, exp), l["name"]
+            checked += 1
+    assert checked >= 5
+    assert Engine("normal", dtype="f16").packed_bytes() < Engine("normal").packed_bytes()
+    with pytest.raises(Exception):
+        Engine("normal", ngf=32, num_downs=5, size=64, dtype="f16")                  # a 16-bit K-tile is 64 channels
