@@ -109,6 +109,20 @@ class HeadposeEngine:
             N.check_a2h(self.lib.lspa2h_generate(*args))
         return out
 
+    def generate_checked(self, audio, pre, noise, expq, sigma_scale: float, frame_future: int, retries: int = 2) -> torch.Tensor:
+        """generate() + the status word, synchronously.  The pipeline's workgroups hand activations to each other through polled mailboxes;
+        every poll is bounded, so a workgroup that could not get onto the chip (another stream holding the CUs for the whole time-out) turns
+        into a status code, never a hang.  The results of such a call are invalid: wait for the device to drain and run it again -- the
+        draws are inputs (``noise`` / ``expq``), so the retry computes exactly the same poses -- and only raise if it keeps happening."""
+        code = 0
+        for attempt in range(retries + 1):
+            out = self.generate(audio, pre, noise, expq, sigma_scale, frame_future)
+            code = self.status(audio.device)
+            if code == 0:
+                return out
+            torch.cuda.synchronize(audio.device)          # whatever occupied the CUs finishes; the next attempt starts on a quiet device
+        raise RuntimeError("head-pose kernel: inter-workgroup hand-off 0x%x timed out %d times in a row" % (code, retries + 1))
+
     def generate_timed(self, audio, pre, noise, expq, sigma_scale, frame_future) -> Tuple[torch.Tensor, float, float]:
         out, args = self._args(audio, pre, noise, expq, sigma_scale, frame_future)
         pre_ms, loop_ms = ctypes.c_float(), ctypes.c_float()

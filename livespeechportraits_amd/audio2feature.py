@@ -55,7 +55,7 @@ class Audio2Feature(nn.Module):
         x = audio_features.float().contiguous().reshape(-1, ndim * 2)          # pairs of APC frames -> one video frame
         pk = self._pack(audio_features.device, x.shape[0])
         x = pk["d3"](pk["d0"](x))
-        x = pk["lstm"].forward(x)
+        x = pk["lstm"].forward_checked(x)        # status word checked; a lost hand-off is retried on a drained device (rnn_engine.py)
         x = pk["f6"](pk["f3"](pk["f0"](x)))
         return x.reshape(bs, item_len // 2, -1)
 

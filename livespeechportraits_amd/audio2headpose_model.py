@@ -69,10 +69,7 @@ class Audio2HeadposeModel(BaseModel):
         eng = net.engine(dev, audio.shape[0])
         a = torch.from_numpy(audio).to(dev)
         pre = torch.from_numpy(np.asarray(pre_headpose, dtype=np.float32).reshape(-1)).to(dev)
-        out = eng.generate(a, pre, noise, expq, float(sigma_scale), int(frame_future))
-        code = eng.status(dev)
-        if code:
-            raise RuntimeError("head-pose kernel: inter-workgroup hand-off 0x%x timed out" % code)
+        out = eng.generate_checked(a, pre, noise, expq, float(sigma_scale), int(frame_future))     # status checked, retried on a lost hand-off
         return out.cpu().numpy().astype(np.float64)       # the reference fills an np.zeros (float64) array, :149
 
     def _generate_lstm(self, net, audio, sigma_scale):

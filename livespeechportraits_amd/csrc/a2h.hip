@@ -547,7 +547,7 @@ struct lspa2h_handle {
     float *ws = nullptr;
     size_t ws_bytes = 0;
     bool packed = false;
-    bool attr_done = false, pipe_attr_done = false, boxes_clean = false;
+    bool attr_done = false, pipe_attr_done = false, pipe_fits = false, boxes_clean = false;
     unsigned epoch = 0;
     int last_rows = 0;
     size_t xbox_bytes() const { return (size_t)(layers + 1) * (size_t)(field - 1 + cfg.max_audio_frames) * RC * 8; }
@@ -861,11 +861,17 @@ static int generate_impl(lspa2h_handle *h, const float *audio_dev, int n_audio, 
         const size_t lds_pipe = (size_t)(RC * 3 + SC + 2 * MAX_OUT + 16 + (size_t)maxd * RC) * sizeof(float) + 8 * NT * 16;
         if (!h->pipe_attr_done) {
             // not the full 160 KB: __syncthreads_and keeps a word of static LDS
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&a2h_pipe),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&a2h_pipe),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
             if (e != hipSuccess) return hipfail(e, "hipFuncSetAttribute(a2h_pipe)");
+            // the L + 1 working blocks poll each other: they must all fit the device at once (checked once per handle)
+            bool ok = false;
+            e = lspgemm::fits_resident(reinterpret_cast<const void *>(&a2h_pipe), NT, lds_pipe, L + 1, &ok);
+            if (e != hipSuccess) return hipfail(e, "occupancy query (a2h_pipe)");
+            h->pipe_fits = ok;
             h->pipe_attr_done = true;
         }
+        if (!h->pipe_fits) goto single_workgroup;            // a device too small for the pipeline: the one-workgroup kernel needs no co-residency
         // Blocks are dealt round-robin over the 8 XCDs (observed, not contractual): using every 8th block puts the
         // whole chain behind one L2.  Measured 45.4 vs 51.0 us per frame; results do not depend on it.
         static const int spread = std::getenv("LSP_A2H_SPREAD") ? std::atoi(std::getenv("LSP_A2H_SPREAD")) : 0;   // tools: 1 = consecutive blocks
@@ -874,6 +880,7 @@ static int generate_impl(lspa2h_handle *h, const float *audio_dev, int n_audio, 
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LSPA2H_OK : hipfail(e, "a2h_pipe launch");
     }
+single_workgroup:
     const size_t lds = (size_t)(RC * 3 + SC + 2 * MAX_OUT + 16 + (size_t)h->qrows * RC) * sizeof(float);
     if (!h->attr_done) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&a2h_stream),

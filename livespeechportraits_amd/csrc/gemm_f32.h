@@ -6,6 +6,24 @@
 
 namespace lspgemm {
 
+// Hand-off kernels (a2h_pipe, rnn_wave, rnn_layer: the workgroups of ONE launch poll each other's mailboxes) only make progress when all
+// their working blocks are resident at once.  A launch-time check against the occupancy query is what hipLaunchCooperativeKernel buys
+// (MI355X_MICROARCH.md, coop-launch row: +15-19 us per launch and the same residency as a plain launch), so it is done here once per kernel
+// instead: working blocks <= resident capacity of the device, with one block per CU of margin where several fit (the API answer can be one
+// block per CU high at some SGPR counts).  What a concurrent stream may occupy at run time is covered by the bounded polls + status word
+// and the callers' retry (livespeechportraits_amd/a2h_engine.py, rnn_engine.py).
+inline hipError_t fits_resident(const void *kernel, int threads, size_t dyn_lds, int working_blocks, bool *ok)
+{
+    int dev = 0, per_cu = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn_lds);
+    if (e != hipSuccess) return e;
+    const long cap = (long)(per_cu > 1 ? per_cu - 1 : per_cu) * cus;
+    *ok = cap >= working_blocks;
+    return hipSuccess;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmParams {

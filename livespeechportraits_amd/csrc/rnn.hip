@@ -292,7 +292,7 @@ struct lsprnn_handle {
     size_t blob_floats = 0;
     const float *blob = nullptr;
     float *ws = nullptr;
-    bool boxes_clean = false;
+    bool boxes_clean = false, wave_fit_checked = false, layer_fit_checked = false;
     unsigned epoch = 0;
     void add(const std::string &k, size_t n) { Slot s; s.key = k; s.numel = n; index[k] = (int)tensors.size(); tensors.push_back(std::move(s)); }
     const std::vector<float> &T(const std::string &k) const { return tensors[index.at(k)].data; }
@@ -482,10 +482,15 @@ int lsprnn_forward(lsprnn_handle *h, const float *x_dev, int T, float *out_dev, 
         const int nwg = L * h->Gw;
         p.stride = nwg <= 32 ? 8 : (nwg <= 64 ? 4 : (nwg <= 128 ? 2 : 1));
         const dim3 grid(L * h->Gw * p.stride), block(NT);
-        if (GT == 3 && h->Pw == 32) hipLaunchKernelGGL((rnn_wave<3, 32, 16>), grid, block, 0, s, p);
-        else if (GT == 3) hipLaunchKernelGGL((rnn_wave<3, 16, 16>), grid, block, 0, s, p);
-        else if (h->Pw == 32) hipLaunchKernelGGL((rnn_wave<4, 32, 16>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((rnn_wave<4, 16, 16>), grid, block, 0, s, p);
+        void (*kern)(WaveParams) = GT == 3 ? (h->Pw == 32 ? rnn_wave<3, 32, 16> : rnn_wave<3, 16, 16>) : (h->Pw == 32 ? rnn_wave<4, 32, 16> : rnn_wave<4, 16, 16>);
+        if (!h->wave_fit_checked) {      // the L * Gw working blocks poll each other: they must all be resident at once (gemm_f32.h)
+            bool ok = false;
+            e = lspgemm::fits_resident(reinterpret_cast<const void *>(kern), NT, 0, nwg, &ok);
+            if (e != hipSuccess) return hipfail(e, "occupancy query (rnn_wave)");
+            if (!ok) return fail(LSPRNN_ERR_UNSUPPORTED, "rnn_wave: the stack's workgroups do not fit this device at once");
+            h->wave_fit_checked = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, 0, s, p);
         e = hipGetLastError();
         return e == hipSuccess ? LSPRNN_OK : hipfail(e, "rnn_wave launch");
     }
@@ -503,10 +508,15 @@ int lsprnn_forward(lsprnn_handle *h, const float *x_dev, int T, float *out_dev, 
         p.T = T; p.H = H;
         p.stride = 8;           // every 8th block: the whole all-gather sits behind one XCD's L2 (speed only, see csrc/a2h.hip)
         const dim3 grid(h->G * p.stride), block(NT);
-        if (GT == 3 && h->P == 16) hipLaunchKernelGGL((rnn_layer<3, 16>), grid, block, 0, s, p);
-        else if (GT == 3) hipLaunchKernelGGL((rnn_layer<3, 8>), grid, block, 0, s, p);
-        else if (h->P == 16) hipLaunchKernelGGL((rnn_layer<4, 16>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((rnn_layer<4, 8>), grid, block, 0, s, p);
+        void (*kern)(LayerParams) = GT == 3 ? (h->P == 16 ? rnn_layer<3, 16> : rnn_layer<3, 8>) : (h->P == 16 ? rnn_layer<4, 16> : rnn_layer<4, 8>);
+        if (!h->layer_fit_checked) {
+            bool ok = false;
+            e = lspgemm::fits_resident(reinterpret_cast<const void *>(kern), NT, 0, h->G, &ok);
+            if (e != hipSuccess) return hipfail(e, "occupancy query (rnn_layer)");
+            if (!ok) return fail(LSPRNN_ERR_UNSUPPORTED, "rnn_layer: the layer's workgroups do not fit this device at once");
+            h->layer_fit_checked = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, 0, s, p);
         e = hipGetLastError();
         if (e != hipSuccess) return hipfail(e, "rnn_layer launch");
         in = hseq;

@@ -80,6 +80,18 @@ class RecurrentEngine:
             N.check_rnn(self.lib.lsprnn_forward(self.h, ctypes.c_void_p(x.data_ptr()), x.shape[0], ctypes.c_void_p(out.data_ptr()), _stream(x.device)))
         return out
 
+    def forward_checked(self, x: torch.Tensor, retries: int = 2) -> torch.Tensor:
+        """forward() + the status word, synchronously; a lost inter-workgroup hand-off (bounded polls: another stream held the CUs) is retried
+        after the device has drained -- the recurrence is deterministic, the retry computes the same numbers -- and raised if it persists."""
+        code = 0
+        for attempt in range(retries + 1):
+            out = self.forward(x)
+            code = self.status()
+            if code == 0:
+                return out
+            torch.cuda.synchronize(x.device)
+        raise RuntimeError("recurrent kernel: inter-workgroup hand-off timed out %d times in a row (status %d)" % (retries + 1, code))
+
     def status(self) -> int:
         code = ctypes.c_uint32()
         dev = self.blob.device

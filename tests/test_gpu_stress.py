@@ -75,3 +75,59 @@ def test_recurrent_stacks_under_load_are_bit_stable():
             assert e.status() == 0, "%s hand-off timed out under load (rep %d)" % (cell, rep)
             assert np.array_equal(out.cpu().numpy(), quiet), "%s repetition %d differs from the quiet run" % (cell, rep)
     torch.cuda.synchronize()
+
+
+def test_checked_calls_retry_a_lost_handoff_and_return_the_same_numbers(monkeypatch):
+    """generate_checked / forward_checked (what the model classes call): a time-out reported by the status word -- simulated here on the
+    first attempt, it needs a saturated device for tens of milliseconds to happen for real -- makes them drain the device and run the call
+    again; the retry is bit-identical because the kernels are deterministic and the random draws are inputs.  A persistent time-out raises."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.a2h_engine import HeadposeEngine
+    from livespeechportraits_amd.rnn_engine import RecurrentEngine
+    dev = torch.device("cuda:0")
+    cfg, ff, nframe = dict(synth.A2H_DEFAULTS), 15, 60
+    e = HeadposeEngine(max_audio_frames=nframe + ff)
+    e.load_state_dict(synth.make_a2h_state_dict(cfg))
+    e.bind(dev)
+    audio, pre = synth.make_a2h_inputs(nframe + ff, cfg)
+    au, pr = torch.from_numpy(audio).to(dev), torch.from_numpy(pre).to(dev)
+    noise = torch.from_numpy(synth.symmetric(nframe * 12, 1.0, 5).reshape(nframe, 12)).to(dev)
+    quiet = e.generate_checked(au, pr, noise, None, 0.3, ff).cpu().numpy()
+    real_status = e.status
+    calls = {"n": 0}
+
+    def flaky(device=None):
+        calls["n"] += 1
+        code = real_status(device)
+        return 0x77 if calls["n"] == 1 else code
+    monkeypatch.setattr(e, "status", flaky)
+    again = e.generate_checked(au, pr, noise, None, 0.3, ff).cpu().numpy()
+    assert calls["n"] == 2 and np.array_equal(again, quiet)
+    monkeypatch.setattr(e, "status", lambda device=None: 0x77)
+    with pytest.raises(RuntimeError, match="timed out 3 times"):
+        e.generate_checked(au, pr, noise, None, 0.3, ff)
+
+    g = RecurrentEngine("GRU", 3, 80, 512, max_steps=256)
+    g.load_state_dict(_gru_sd(synth))
+    g.bind(dev)
+    x = torch.from_numpy(synth.make_mel(200)).to(dev)
+    q = g.forward_checked(x).cpu().numpy()
+    rs = g.status
+    n = {"n": 0}
+
+    def flaky2():
+        n["n"] += 1
+        c = rs()
+        return 5 if n["n"] == 1 else c
+    monkeypatch.setattr(g, "status", flaky2)
+    assert np.array_equal(g.forward_checked(x).cpu().numpy(), q) and n["n"] == 2
+
+
+def _gru_sd(synth):
+    """the APC encoder's three single-layer GRUs as one 3-layer stack's tensors (the mapping livespeechportraits_amd/apc.py uses)"""
+    sd = synth.make_apc_state_dict()
+    out = {}
+    for k, v in sd.items():             # rnns.<i>.weight_ih_l0 -> weight_ih_l<i>
+        i = int(k.split(".")[1])
+        out[k.split(".")[2].replace("_l0", "_l%d" % i)] = v
+    return out

@@ -80,9 +80,12 @@ def test_matches_reference_golden(case, gpu_device):
     from oracle import torch_oracle
     sd64 = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in sd.items() if v.dtype == np.float32}
     x64 = torch.cat([f.cpu(), c.cpu().expand(meta["batch"], -1, -1, -1)], 1).double()
-    if meta["size"] <= 192:
-        ref64 = torch_oracle.generator_forward(sd64, x64, topo.nres, topo.num_downs).float().numpy()
-        print("   reference fp32 vs float64 evaluation: %.2e; ours vs float64: %.2e" % (np.abs(ref - ref64).max(), np.abs(out.cpu().numpy() - ref64).max()))
+    # GPU vs float64 and reference vs float64, at every size (a few seconds of float64 on the host at 512x512): the HIP path may be no
+    # further from exact arithmetic than the reference module itself is -- the claim the self-distance bound below only implies
+    ref64 = torch_oracle.generator_forward(sd64, x64, topo.nres, topo.num_downs).float().numpy()
+    r64, g64 = np.abs(ref - ref64), np.abs(out.cpu().numpy() - ref64)
+    print("   reference fp32 vs float64 evaluation: max %.2e mean %.2e; ours vs float64: max %.2e mean %.2e" % (r64.max(), r64.mean(), g64.max(), g64.mean()))
+    assert g64.max() <= 1.2 * r64.max() + 1e-5 and g64.mean() <= 1.2 * r64.mean() + 1e-6
     self_d = meta["reference_self_distance"]
     print("   the reference vs itself (oneDNN off): max %.2e mean %.2e" % (self_d["onednn_off_max"], self_d["onednn_off_mean"]))
     assert err.max() <= 1.5 * self_d["onednn_off_max"] and err.mean() <= 1.5 * self_d["onednn_off_mean"]

@@ -106,3 +106,24 @@ def test_clip_length_of_the_demo_and_device_entry_point(gpu_device):
     want = mel_oracle.compute_mel_one_sequence(audio[:16000 * 2])               # first 2 s through the oracle
     assert np.abs(m[:want.shape[0] - 2].cpu().numpy() - want[:-2]).max() <= 2e-4
     assert torch.equal(m, mel.compute_mel(torch.from_numpy(audio).to(gpu_device)))
+
+
+def test_filterbank_matches_real_librosa():
+    """The pin on real librosa: exists the moment oracle/make_golden_melfb.py has run where librosa is importable.  Then the oracle's Slaney
+    construction and the library's host copy are held to librosa.filters.mel itself (float32 round-off), which removes "unpinned" from the
+    filterbank of the mel front-end."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "melfb_librosa.npz")
+    if not os.path.exists(path):
+        pytest.xfail("unpinned: tests/golden/melfb_librosa.npz does not exist -- librosa is absent from this image; "
+                     "`python oracle/make_golden_melfb.py` writes it wherever librosa is importable")
+    from livespeechportraits_amd import _native as N
+    from oracle import mel_oracle
+    fb = np.load(path)["fb"]
+    assert fb.shape == (80, 257)
+    assert np.abs(mel_oracle.slaney_mel_filterbank() - fb).max() <= 1e-6
+    lib = N.load()
+    n = lib.lspmel_basis_floats()
+    blob = np.empty(n, np.float32)
+    assert lib.lspmel_make_basis(blob.ctypes.data, n) == 0
+    assert np.abs(blob[514 * 268:].reshape(80, 260)[:, :257] - fb).max() <= 1e-6

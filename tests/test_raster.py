@@ -7,6 +7,7 @@ PARITY UNPINNED against cv2 (OpenCV is absent from the build image): what is che
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -177,3 +178,40 @@ def test_render_loop_from_landmarks(gpu_device, tmp_path):
     maps = [torch.from_numpy(R.get_data_test_mode(f[0], f[1], pad, topo.size)) for f in frames]        # the host route, via the oracle
     want = render_frames(model, maps, c, batch=2)
     assert len(got) == 5 and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+# ---- the pin on real OpenCV: exists the moment oracle/make_golden_raster.py has run where cv2 is importable ------------------------
+def _cv2_fixture():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster_cv2.npz")
+    if not os.path.exists(path):
+        pytest.xfail("unpinned: tests/golden/raster_cv2.npz does not exist -- OpenCV is absent from this image; "
+                     "`python oracle/make_golden_raster.py` writes it wherever cv2 is importable")
+    meta = json.load(open(path[:-4] + ".json"))
+    z = np.load(path)
+    return meta, {c[0]: np.unpackbits(z[c[0] + "_bits"])[:int(np.prod(z[c[0] + "_shape"]))].reshape(z[c[0] + "_shape"]).astype(np.uint8) * 255
+                  for c in meta["cases"]}
+
+
+def test_oracle_matches_real_opencv():
+    """oracle/raster_oracle.c == cv2.line on the fixture's landmark sets, bit for bit (removes "parity unpinned" from the rasteriser)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    meta, imgs = _cv2_fixture()
+    import make_golden_raster as G
+    from oracle import raster_oracle as R
+    for name, size, n, seed in meta["cases"]:
+        lm, sh = G.landmark_sets(size, n, seed)
+        for k in range(n):
+            assert np.array_equal(R.get_feature_image(lm[k], (size, size), sh[k], None), imgs[name][k]), (name, k)
+
+
+@pytest.mark.gpu
+def test_kernel_matches_real_opencv(gpu_device):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    meta, imgs = _cv2_fixture()
+    import make_golden_raster as G
+    from livespeechportraits_amd.feature_map import FeatureMapRasteriser
+    for name, size, n, seed in meta["cases"]:
+        lm, sh = G.landmark_sets(size, n, seed)
+        got = FeatureMapRasteriser(size, 18, gpu_device).rasterise(lm, sh, as_uint8=True).cpu().numpy()
+        assert np.array_equal(got, imgs[name]), name
