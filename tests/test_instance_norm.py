@@ -80,12 +80,19 @@ def test_matches_reference_golden(case, gpu_device):
     from oracle import torch_oracle
     sd64 = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in sd.items() if v.dtype == np.float32}
     x64 = torch.cat([f.cpu(), c.cpu().expand(meta["batch"], -1, -1, -1)], 1).double()
-    # GPU vs float64 and reference vs float64, at every size (a few seconds of float64 on the host at 512x512): the HIP path may be no
-    # further from exact arithmetic than the reference module itself is -- the claim the self-distance bound below only implies
+    # GPU vs float64 and reference vs float64, at every size (a few seconds of float64 on the host at 512x512).  "The reference" is not one
+    # number here: the fixture records the distance from float64 of three fp32 evaluations of the SAME reference module under the same torch
+    # (default oneDNN kernels = the golden, ATen's native convolutions, oneDNN channels_last) -- on in_large_512 they range from 8.7e-4 to
+    # 2.1e-3 max-abs, because InstanceNorm amplifies whichever fp32 rounding the high-resolution levels made (running the <= 64x64 levels in
+    # float64 changes none of them: oracle/make_golden_in.py).  The HIP path must be no further from exact arithmetic than the
+    # widest of the reference's own evaluations, max and mean.
     ref64 = torch_oracle.generator_forward(sd64, x64, topo.nres, topo.num_downs).float().numpy()
     r64, g64 = np.abs(ref - ref64), np.abs(out.cpu().numpy() - ref64)
-    print("   reference fp32 vs float64 evaluation: max %.2e mean %.2e; ours vs float64: max %.2e mean %.2e" % (r64.max(), r64.mean(), g64.max(), g64.mean()))
-    assert g64.max() <= 1.2 * r64.max() + 1e-5 and g64.mean() <= 1.2 * r64.mean() + 1e-6
+    evals = meta["reference_self_distance"]["fp32_evaluations_vs_float64"]
+    print("   vs the float64 evaluation -- reference (golden) max %.2e mean %.2e; its other fp32 evaluations %s; ours: max %.2e mean %.2e" % (
+        r64.max(), r64.mean(), {k: "%.2e / %.2e" % tuple(v) for k, v in evals.items() if k != "onednn"}, g64.max(), g64.mean()))
+    assert abs(r64.max() - evals["onednn"][0]) <= 1e-6                       # the fixture's own number, recomputed
+    assert g64.max() <= 1.2 * max(v[0] for v in evals.values()) and g64.mean() <= 1.2 * max(v[1] for v in evals.values())
     self_d = meta["reference_self_distance"]
     print("   the reference vs itself (oneDNN off): max %.2e mean %.2e" % (self_d["onednn_off_max"], self_d["onednn_off_mean"]))
     assert err.max() <= 1.5 * self_d["onednn_off_max"] and err.mean() <= 1.5 * self_d["onednn_off_mean"]
