@@ -177,7 +177,7 @@ def main():
     # workspace) are captured into their own graph and replayed between two hipEvents on the launch stream (lspf2f_subset_timed):
     # no host gaps, kernel boundaries included, the same launches the timed region replays.  The classes partition the forward, their
     # times add up to <= the timed step, and each class's average launch duration is what the committed rocprofv3 summary
-    # (profiles/r02_kernel_stats_*.txt) shows for that kernel name.
+    # (profiles/r03_kernel_stats_*.txt) shows for that kernel name.
     layers = eng.layers(B)
     eng.forward(feat, cand, out)
 
@@ -226,22 +226,29 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC passes (offline: rocprofv3 --pmc cannot run inside this process);
     # only quoted for the workload it was measured on
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_%s_b%d_%s.json" % (a.variant, B, a.dtype))
+    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_%s_b%d_%s.json" % (a.variant, B, a.dtype))
+    family = "wino3x3" if dom["kernel"].startswith("wino3x3") else dom["kernel"].split("<")[0]
     if a.size == 512 and os.path.exists(pmc_path):
         pj = json.load(open(pmc_path))
-        fam = pj["per_forward_bytes"].get("igemm3x3")
+        fam = pj["per_forward_bytes"].get(family)
         if fam:
-            traffic = int(fam["fetch_x2"] + fam["write"])
-            traffic_src = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE of the igemm3x3 launches of one forward, rocprofv3 --pmc, separate passes)" % os.path.basename(pmc_path)
+            # the PMC families are per kernel NAME (all template instances together); scaled to the dominant class by its share of the family's
+            # algorithmic bytes when the family has more than one class in this plan
+            fam_bytes = sum(r["bytes"] for r in table if r["kernel"].startswith(family))
+            share = dom["bytes"] / fam_bytes if fam_bytes else 1.0
+            traffic = int((fam["fetch_x2"] + fam["write"]) * share)
+            traffic_src = ("profiles/%s (FETCH_SIZE x2 + WRITE_SIZE of the %s launches of one forward, rocprofv3 --pmc, separate passes; x %.2f = this class's share "
+                           "of the family's algorithmic bytes)" % (os.path.basename(pmc_path), family, share))
 
     roofline = {
         "bound": "mfma",
-        "kernel": "%s: the %d launches per forward of the dominant kernel (all conv layers it executes; split-K reduce launches are their own row)" % (dom["kernel"], dom["launches"]),
+        "kernel": "%s: the %d launches per forward of the dominant kernel class (all conv layers it executes; split-K reduce launches are their own row)" % (dom["kernel"], dom["launches"]),
         "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac_mfma"],
         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": dom["bytes"],
         "flops_per_launch_set": dom["flops"], "ms_per_launch_set": dom["ms"], "us_per_launch": dom["us_per_launch"],
         "executed": {"tflops": round(dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12, 2), "frac": round(dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12 / peak, 4),
-                     "note": "MFMA FLOPs actually issued: the sub-pixel up-convs need 4/9 of the algorithmic count"},
+                     "note": "MFMA FLOPs actually issued: Winograd F(2x2,3x3) layers and sub-pixel up-convs issue 4/9 of the algorithmic count, so an "
+                             "algorithmic fraction above 1 is arithmetic saved, not utilisation; `executed.frac` is the matrix-pipe utilisation"},
         "method": "launches of one kernel class replayed from their own hipGraph between two hipEvents on the launch stream (lspf2f_subset_timed); "
                   "agrees with the rocprofv3 --kernel-trace --stats averages committed under profiles/",
         "per_class": table, "sum_of_classes_ms": round(class_ms, 4),

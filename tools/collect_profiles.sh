@@ -4,7 +4,7 @@
 # Output under gpurun_out/<tag>/; tools/summarise_profiles.sh turns it into the tracked files under profiles/.
 set -u
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02_profiles}
+TAG=${1:-r03_profiles}
 CONFIGS=${2:-"large_b1_f32 large_b8_f32 normal_b8_bf16"}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"

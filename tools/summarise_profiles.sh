@@ -1,8 +1,9 @@
 #!/bin/bash
-# Build container: gpurun_out/<tag>/ (tools/collect_profiles.sh) -> tracked summaries under profiles/ named r02_*.
+# Build container: gpurun_out/<tag>/ (tools/collect_profiles.sh) -> tracked summaries under profiles/ named <round>_*.   tools/summarise_profiles.sh [tag] [round]
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-r02_profiles}
+TAG=${1:-r03_profiles}
+R=${2:-r03}
 IN=gpurun_out/$TAG
 for cfg in large_b1_f32 large_b8_f32 normal_b8_bf16; do
   [ -f "$IN/bench_$cfg.json" ] || continue
@@ -14,9 +15,9 @@ c = sqlite3.connect(sys.argv[1]).cursor()
 print(c.execute("select count(*) from kernels where name like '%first_conv%'").fetchone()[0])
 PY
 )
-  python tools/rocprof_summary.py "$db" > profiles/r02_kernel_stats_$cfg.txt
-  cp "$IN/classes_$cfg.txt" profiles/r02_kernel_classes_$cfg.txt
-  cp "$IN/bench_$cfg.json" profiles/r02_bench_$cfg.json
+  python tools/rocprof_summary.py "$db" > profiles/${R}_kernel_stats_$cfg.txt
+  cp "$IN/classes_$cfg.txt" profiles/${R}_kernel_classes_$cfg.txt
+  cp "$IN/bench_$cfg.json" profiles/${R}_bench_$cfg.json
   # PMC runs: bench.py --steps 2 --warmup 1 = 3 replays + 1 eager forward + 10 class replays + 1 warm-up each; normalise by the first_conv count
   nf=$(python - "$IN/pmc_$cfg/pmc_fetch" <<'PY'
 import csv, glob, sys
@@ -26,6 +27,6 @@ for p in glob.glob(sys.argv[1] + "/**/pmc_counter_collection.csv", recursive=Tru
 print(max(n, 1))
 PY
 )
-  python tools/pmc_summary.py "$IN/pmc_$cfg" --forwards "$nf" --json profiles/r02_pmc_$cfg.json --label "bench.py $cfg" > profiles/r02_pmc_$cfg.txt
+  python tools/pmc_summary.py "$IN/pmc_$cfg" --forwards "$nf" --json profiles/${R}_pmc_$cfg.json --label "bench.py $cfg" > profiles/${R}_pmc_$cfg.txt
 done
-ls profiles/ | grep r02
+ls profiles/ | grep ${R}
