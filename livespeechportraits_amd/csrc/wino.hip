@@ -124,14 +124,26 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
         // raw rows of this step and the first weight fragment: issued straight behind the barrier, their latency rides under the DMA issue below
         float4 d[2][4];
 #pragma unroll
+#ifndef WINO_ABL_NOHEAD
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
+#endif
         float4 u[2];
         u[0] = *reinterpret_cast<const float4 *>(up);
+#ifdef WINO_ABL_NOHEAD       // ablation (tools/wino_ablate_job.sh): no raw reads / transform -- whatever the registers hold is multiplied
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) asm volatile("" : "+v"(d[k][dx].x), "+v"(d[k][dx].y), "+v"(d[k][dx].z), "+v"(d[k][dx].w));
+#endif
         // ring slot (cur + NS - 1) % NS was last read in step t - 1; every wave has passed the barrier that ended it
         const int ahead = t + NS - 1;
+#ifdef WINO_ABL_NODMA
+        const bool issue = false;
+#else
         const bool issue = ahead < nsteps;
+#endif
         int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
         if (!IL && issue) fetch(ks_begin + ahead, slot);
         float4 tt[4], v[4];
@@ -160,7 +172,9 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
         }
         // step t + 1 must have landed (this wave's pieces; the barrier covers the other waves'): everything but the pieces issued in THIS iteration
         if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
+#ifndef WINO_ABL_NOBARRIER
         __syncthreads();
+#endif
         if (++cur == NS) cur = 0;
     }
 }
