@@ -123,8 +123,8 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
         const char *up = smem_c + cur * USTAGE + au;
         // raw rows of this step and the first weight fragment: issued straight behind the barrier, their latency rides under the DMA issue below
         float4 d[2][4];
-#pragma unroll
 #ifndef WINO_ABL_NOHEAD
+#pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
