@@ -1,0 +1,9 @@
+#!/bin/bash
+# round-3 GPU session 8: ping-pong form of the Winograd kernel (LSP_HIP_WINO_PP=0/1)
+cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r3s8; mkdir -p $OUT
+timeout 300 python -m pytest tests/test_gpu_conv.py -k winograd -q > $OUT/wino_tests.log 2>&1; echo "wino tests rc=$?"; tail -3 $OUT/wino_tests.log
+timeout 300 python -m pytest tests/test_gpu_network.py tests/test_gpu_plans.py -q -x > $OUT/net_tests.log 2>&1; echo "network tests rc=$?"; tail -3 $OUT/net_tests.log
+timeout 300 tools/ab_switch.sh LSP_HIP_WINO_PP large 1 f32 0
+timeout 300 tools/ab_switch.sh LSP_HIP_WINO_PP large 8 f32 0
+timeout 300 tools/ab_switch.sh LSP_HIP_WINO_PP normal 1 f32 0
+timeout 400 bash tools/wino_stamps_job.sh 2>&1 | grep -v XCD | tail -70
