@@ -118,7 +118,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
         // the same only by chance (measured: a K-step of 2700 cycles against 2048 of MFMA issue per SIMD, tools/wino_ablate_job.sh).
         // Barrier count: 1 + 2 nsteps + 1, the same for both halves (half 1 idles one phase at the start, half 0 one at the end).
         if (nsteps > 0) fetch(ks_begin, 0);
-        dma_wait<0>();
+        if (NS > 2 && nsteps > 1) { fetch(ks_begin + 1, 1); dma_wait<PIECES>(); } else dma_wait<0>();
         __syncthreads();
 #ifdef LSPF2F_WINO_STAMPS
         *first_landed = __builtin_amdgcn_s_memtime();
@@ -135,7 +135,13 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
                 for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
             float4 u[2];
             u[0] = *reinterpret_cast<const float4 *>(up);
-            if (t + 1 < nsteps) fetch(ks_begin + t + 1, cur ^ 1);      // that slot was last read in the MFMA phase of step t - 1, two barriers ago
+            // the copies of step t + NS - 1 go into the slot of step t - 1 (raw read in its HEAD phase, fragments in its MFMA phase: both at least
+            // one barrier ago).  IL: issued between this step's MFMA groups (a back-to-back block of 6-10 pieces takes longer to issue than the
+            // partner's MFMA phase lasts -- measured 1740 cycles per phase against 1024 of MFMA); else as one block here
+            const int ahead = t + NS - 1;
+            const bool issue = ahead < nsteps;
+            int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
+            if (!IL && issue) fetch(ks_begin + ahead, slot);
             float4 tt[4], v[4];
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
@@ -157,10 +163,14 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
                 acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, uu.y, acc[j][nb], 0, 0, 0);
                 acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, uu.z, acc[j][nb], 0, 0, 0);
                 acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, uu.w, acc[j][nb], 0, 0, 0);
+                if (IL && issue) {
+                    if (f == 0) fetch_raw(ks_begin + ahead, slot);
+                    if (f >= 1 && f <= 2 * NB) fetch_u2(ks_begin + ahead, slot, (f - 1) >> 1, (f - 1) & 1);
+                }
             }
-            dma_wait<0>();             // step t + 1 has landed (this wave's pieces; the barrier covers the other waves')
+            if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();     // step t + 1 has landed (this wave's pieces; the barrier covers the others')
             __syncthreads();
-            cur ^= 1;
+            if (++cur == NS) cur = 0;
         }
         if (half == 0) __syncthreads();
         return;
@@ -520,8 +530,10 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     // LSP_HIP_WINO_PP (tools only): 1 = ping-pong form (512-thread workgroups, two work items each) whenever a split plane holds an even number of
     // work items, 0 = never
     static const int pp_env = std::getenv("LSP_HIP_WINO_PP") ? std::atoi(std::getenv("LSP_HIP_WINO_PP")) : 1;
-    if (pp_env && (p.ntb * p.nng) % 2 == 0)
-        return nb == 2 ? launch_wino_t<2, 2, false, true>(p, s) : launch_wino_t<1, 2, false, true>(p, s);
+    if (pp_env && (p.ntb * p.nng) % 2 == 0) {
+        if (pp_env == 2) return nb == 2 ? launch_wino_t<2, 2, false, true>(p, s) : launch_wino_t<1, 2, false, true>(p, s);    // copies issued in the HEAD phase
+        return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);                        // copies between the MFMA groups
+    }
     if (nb == 2) return il_env ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<2, 2, false, false>(p, s);
     if (il_env == 2) return launch_wino_t<1, 2, true, false>(p, s);
     return il_env ? launch_wino_t<1, 3, true, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
