@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r3s9; mkdir -p $OUT
+timeout 300 python -m pytest tests/test_gpu_conv.py -k winograd -q > $OUT/wino_tests.log 2>&1; echo "wino tests rc=$?"; tail -3 $OUT/wino_tests.log
+timeout 300 tools/ab_switch.sh LSP_HIP_WINO_PP large 1 f32 0
+timeout 300 tools/ab_switch.sh LSP_HIP_WINO_PP large 8 f32 0
+timeout 400 bash tools/wino_stamps_job.sh 2>&1 | grep -E "workgroups|K loop:"
