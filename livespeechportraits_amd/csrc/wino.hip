@@ -25,7 +25,7 @@ namespace lspf2f {
 #ifdef LSPF2F_WINO_STAMPS
 #define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define WSTAMP_DECL unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define WSTAMP_FLUSH do { if (p.stamps && lane == 0) { unsigned long long *q_ = p.stamps + ((size_t)stamp_item * 4 + wave) * 8; \
+#define WSTAMP_FLUSH do { if (p.stamps && lane == 0) { unsigned long long *q_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8; \
     for (int i_ = 0; i_ < 8; ++i_) q_[i_] = stamp_t[i_]; } } while (0)
 #else
 #define WSTAMP(i) do {} while (0)
@@ -65,10 +65,10 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 
 // The K loop of one wave.  ROW = its row i of B^T d B: t = d[ra] (+|-) d[rb] per patch column, then the column transform.
 //   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3
-template <int NB, int NS, bool IL, bool PP, int ROW>
+template <int NB, int NS, bool IL, int ROW>
 __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][NB], const char *smem_c, unsigned lds0, int wave, int lane,
                                           unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, unsigned soff_nb,
-                                          int ks_begin, int ks_end, unsigned long long *first_landed, int half)
+                                          int ks_begin, int ks_end, unsigned long long *first_landed)
 {
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
     constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB, NS), DUMP = wino_dump(NB, NS);
@@ -110,71 +110,6 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
     };
 
     const int nsteps = ks_end - ks_begin;
-    if constexpr (PP) {
-        // Ping-pong form (512-thread workgroups: two independent halves of four waves, one wave of each half per SIMD).  A K-step of a half is
-        // two phases separated by workgroup barriers -- HEAD: read the raw rows, transform, issue the copies of the next step; MFMA: the
-        // 16 NB matrix instructions with their fragment reads, then the wait for the next step's copies -- and the halves run one phase apart,
-        // so on every SIMD one wave multiplies while its partner reads, adds and issues copies.  Two independent 256-thread workgroups per CU do
-        // the same only by chance (measured: a K-step of 2700 cycles against 2048 of MFMA issue per SIMD, tools/wino_ablate_job.sh).
-        // Barrier count: 1 + 2 nsteps + 1, the same for both halves (half 1 idles one phase at the start, half 0 one at the end).
-        if (nsteps > 0) fetch(ks_begin, 0);
-        if (NS > 2 && nsteps > 1) { fetch(ks_begin + 1, 1); dma_wait<PIECES>(); } else dma_wait<0>();
-        __syncthreads();
-#ifdef LSPF2F_WINO_STAMPS
-        *first_landed = __builtin_amdgcn_s_memtime();
-#endif
-        if (half == 1) __syncthreads();
-        int cur = 0;
-        for (int t = 0; t < nsteps; ++t) {
-            const char *rawp = smem_c + cur * kRawStage;
-            const char *up = smem_c + cur * USTAGE + au;
-            float4 d[2][4];
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
-            float4 u[2];
-            u[0] = *reinterpret_cast<const float4 *>(up);
-            // the copies of step t + NS - 1 go into the slot of step t - 1 (raw read in its HEAD phase, fragments in its MFMA phase: both at least
-            // one barrier ago).  IL: issued between this step's MFMA groups (a back-to-back block of 6-10 pieces takes longer to issue than the
-            // partner's MFMA phase lasts -- measured 1740 cycles per phase against 1024 of MFMA); else as one block here
-            const int ahead = t + NS - 1;
-            const bool issue = ahead < nsteps;
-            int slot = cur + NS - 1; if (slot >= NS) slot -= NS;
-            if (!IL && issue) fetch(ks_begin + ahead, slot);
-            float4 tt[4], v[4];
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                if constexpr (ROW == 0 || ROW == 3) tt[dx] = f4sub(d[0][dx], d[1][dx]);
-                else if constexpr (ROW == 1) tt[dx] = f4add(d[0][dx], d[1][dx]);
-                else tt[dx] = f4sub(d[1][dx], d[0][dx]);
-            }
-            v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
-            // keep the transform on this side of the barrier: it is this phase's work
-            asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z), "+v"(v[1].w));
-            asm volatile("" : "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
-            __syncthreads();
-#pragma unroll
-            for (int f = 0; f < 4 * NB; ++f) {
-                const int nb = f >> 2, j = f & 3;
-                if (f + 1 < 4 * NB) u[(f + 1) & 1] = *reinterpret_cast<const float4 *>(up + (f + 1) * 1024);
-                const float4 uu = u[f & 1];
-                acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, uu.x, acc[j][nb], 0, 0, 0);
-                acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, uu.y, acc[j][nb], 0, 0, 0);
-                acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, uu.z, acc[j][nb], 0, 0, 0);
-                acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, uu.w, acc[j][nb], 0, 0, 0);
-                if (IL && issue) {
-                    if (f == 0) fetch_raw(ks_begin + ahead, slot);
-                    if (f >= 1 && f <= 2 * NB) fetch_u2(ks_begin + ahead, slot, (f - 1) >> 1, (f - 1) & 1);
-                }
-            }
-            if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();     // step t + 1 has landed (this wave's pieces; the barrier covers the others')
-            __syncthreads();
-            if (++cur == NS) cur = 0;
-        }
-        if (half == 0) __syncthreads();
-        return;
-    }
     if (nsteps <= 0) return;
     fetch(ks_begin, 0);
     if (NS > 2 && nsteps > 1) { fetch(ks_begin + 1, 1); dma_wait<PIECES>(); } else dma_wait<0>();
@@ -244,22 +179,17 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
     }
 }
 
-template <int NB, int NS, bool IL, bool PP>
-__global__ __launch_bounds__(PP ? 512 : 256, PP || NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
+template <int NB, int NS, bool IL>
+__global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem_wg[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef __attribute__((address_space(3))) float lds_float;
-    // PP: the workgroup is two independent halves (waves 0-3, 4-7), each with its own work item, LDS region and epilogue; `tid`, `wave` and
-    // `smem` below are the half's own
-    const int half = PP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
-    float *smem = smem_wg + half * (wino_lds_bytes(NB, NS) / 4);
-    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem_wg + (unsigned)(half * wino_lds_bytes(NB, NS));
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
     const char *smem_c = reinterpret_cast<const char *>(smem);
-    const int tid = threadIdx.x & 255, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     WSTAMP_DECL;
     WSTAMP(0);
-    const unsigned stamp_item = PP ? 2 * blockIdx.x + (unsigned)half : blockIdx.x; (void)stamp_item;
     // one scalar-load round trip for the whole argument block (see igemm.hip)
     asm volatile("" :: "s"(p.src), "s"(p.u), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.partial), "s"(p.tile_cnt));
     asm volatile("" :: "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C), "s"(p.N), "s"(p.relu), "s"(p.splits), "s"(p.steps_per_split), "s"(p.ntb), "s"(p.nng),
@@ -275,7 +205,6 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP || NB == 2 || NS == 3 ? 2 : 3) v
         const unsigned total = gridDim.x, qq = total >> 3, rr = total & 7, x = lin & 7;
         lin = x * qq + (x < rr ? x : rr) + (lin >> 3);
     }
-    if (PP) lin = 2 * lin + (unsigned)half;          // items 2k, 2k + 1: neighbours in the logical order, same K slice (the launcher checks the plane is even)
     const int z = (int)p.div_plane.div(lin);
     const unsigned rem = lin - (unsigned)z * (unsigned)(p.ntb * p.nng);
     int tb, ng;
@@ -345,10 +274,10 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP || NB == 2 || NS == 3 ? 2 : 3) v
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
     switch (wave) {
-    case 0: wino_loop<NB, NS, IL, PP, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl, half); break;
-    case 1: wino_loop<NB, NS, IL, PP, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl, half); break;
-    case 2: wino_loop<NB, NS, IL, PP, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl, half); break;
-    default: wino_loop<NB, NS, IL, PP, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl, half); break;
+    case 0: wino_loop<NB, NS, IL, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 1: wino_loop<NB, NS, IL, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 2: wino_loop<NB, NS, IL, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    default: wino_loop<NB, NS, IL, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
     WSTAMP(3);
@@ -486,17 +415,17 @@ bool wino_supported(const WinoParams &p, int nb)
     return true;
 }
 
-template <int NB, int NS, bool IL, bool PP>
+template <int NB, int NS, bool IL>
 static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
 {
-    constexpr int smem = (PP ? 2 : 1) * wino_lds_bytes(NB, NS);
+    constexpr int smem = wino_lds_bytes(NB, NS);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL((wino3x3<NB, NS, IL, PP>), dim3((unsigned)(q.ntb * q.nng * q.splits) / (PP ? 2 : 1)), dim3(PP ? 512 : 256), smem, s, q);
+    hipLaunchKernelGGL((wino3x3<NB, NS, IL>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
@@ -527,16 +456,9 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     p.div_tbx = FastDiv::make((unsigned)p.tbx);
     // tools only (A-B runs): LSP_HIP_WINO_IL=0 issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them
     static const int il_env = std::getenv("LSP_HIP_WINO_IL") ? std::atoi(std::getenv("LSP_HIP_WINO_IL")) : 1;
-    // LSP_HIP_WINO_PP (tools only): 1 = ping-pong form (512-thread workgroups, two work items each) whenever a split plane holds an even number of
-    // work items, 0 = never
-    static const int pp_env = std::getenv("LSP_HIP_WINO_PP") ? std::atoi(std::getenv("LSP_HIP_WINO_PP")) : 1;
-    if (pp_env && (p.ntb * p.nng) % 2 == 0) {
-        if (pp_env == 2) return nb == 2 ? launch_wino_t<2, 2, false, true>(p, s) : launch_wino_t<1, 2, false, true>(p, s);    // copies issued in the HEAD phase
-        return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);                        // copies between the MFMA groups
-    }
-    if (nb == 2) return il_env ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<2, 2, false, false>(p, s);
-    if (il_env == 2) return launch_wino_t<1, 2, true, false>(p, s);
-    return il_env ? launch_wino_t<1, 3, true, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
+    if (nb == 2) return il_env ? launch_wino_t<2, 2, true>(p, s) : launch_wino_t<2, 2, false>(p, s);
+    if (il_env == 2) return launch_wino_t<1, 2, true>(p, s);
+    return il_env ? launch_wino_t<1, 3, true>(p, s) : launch_wino_t<1, 2, false>(p, s);
 }
 
 // Host: OIHW [N][C][3][3] -> U = G g G^T (double, rounded once) in the MFMA fragment order [n-block N/32][xi-row 4][k-step C/8][j 4][lane 64][4]:
