@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: the bench line of every configuration quoted in README.md / DESIGN.md, one JSON file each under gpurun_out/<tag>/.
-R=$GRAFT_REPO_ROOT; TAG=${1:-r02_bench_all}; OUT=$R/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$R"
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03_bench_all}; OUT=$R/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$R"
 python bench.py > "$OUT/default.json" 2> "$OUT/default.err"
 for cfg in "large 8 f32" "normal 1 f32" "normal 8 f32" "normal 8 bf16" "large 8 bf16" "large 1 bf16" "normal 1 bf16"; do
   set -- $cfg
