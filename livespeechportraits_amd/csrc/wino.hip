@@ -155,6 +155,30 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
             else tt[dx] = f4sub(d[1][dx], d[0][dx]);
         }
         v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+        if (p.rot) {
+            // consecutive MFMAs on DIFFERENT accumulators: the four j of a channel block rotate, so no instruction waits for its predecessor's result
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float4 uj[4];
+                uj[0] = nb == 0 ? u[0] : *reinterpret_cast<const float4 *>(up + (nb * 4) * 1024);
+#pragma unroll
+                for (int j = 1; j < 4; ++j) uj[j] = *reinterpret_cast<const float4 *>(up + (nb * 4 + j) * 1024);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = c == 0 ? v[j].x : c == 1 ? v[j].y : c == 2 ? v[j].z : v[j].w;
+                        const float b = c == 0 ? uj[j].x : c == 1 ? uj[j].y : c == 2 ? uj[j].z : uj[j].w;
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j][nb], 0, 0, 0);
+                    }
+                    const int f = nb * 4 + c;
+                    if (IL && issue) {
+                        if (f == 0) fetch_raw(ks_begin + ahead, slot);
+                        if (f >= 1 && f <= 2 * NB) fetch_u2(ks_begin + ahead, slot, (f - 1) >> 1, (f - 1) & 1);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int f = 0; f < 4 * NB; ++f) {                           // fragment f = nb * 4 + j, the order the pieces sit in LDS
             const int nb = f >> 2, j = f & 3;
@@ -170,6 +194,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
                 if (f == 0) fetch_raw(ks_begin + ahead, slot);
                 if (f >= 1 && f <= 2 * NB) fetch_u2(ks_begin + ahead, slot, (f - 1) >> 1, (f - 1) & 1);
             }
+        }
         }
         // step t + 1 must have landed (this wave's pieces; the barrier covers the other waves'): everything but the pieces issued in THIS iteration
         if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
@@ -576,9 +601,11 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     // tools only (A-B runs): LSP_HIP_WINO_IL=0 issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them
     static const int il_env = std::getenv("LSP_HIP_WINO_IL") ? std::atoi(std::getenv("LSP_HIP_WINO_IL")) : 1;
     // LSP_HIP_WINO_SP=0 (tools only): the transform of a step at its head instead of inside the previous step's MFMA stream
+    static const int rot_env = std::getenv("LSP_HIP_WINO_ROT") ? std::atoi(std::getenv("LSP_HIP_WINO_ROT")) : 0;
+    p.rot = rot_env;
     static const int sp_env = std::getenv("LSP_HIP_WINO_SP") ? std::atoi(std::getenv("LSP_HIP_WINO_SP")) : 1;
     if (nb == 2) return il_env ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<2, 2, false, false>(p, s);
-    if (sp_env) return launch_wino_t<1, 3, true, true>(p, s);
+    if (sp_env && !rot_env) return launch_wino_t<1, 3, true, true>(p, s);
     if (il_env == 2) return launch_wino_t<1, 2, true, false>(p, s);
     return il_env ? launch_wino_t<1, 3, true, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
 }
