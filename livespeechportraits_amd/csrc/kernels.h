@@ -112,7 +112,7 @@ struct WinoParams {
     unsigned *tile_cnt;           // splits > 1: one arrival counter per (tile-block, channel group), zero between launches
     int B, H, W, C, N, relu, splits;
     // filled by launch_wino
-    int steps_per_split, ntb, nng, tby, tbx, nmajor, xcd, nopre, rot;
+    int steps_per_split, ntb, nng, tby, tbx, nmajor, xcd, nopre;
     size_t slab_bytes;
     FastDiv div_plane, div_fast, div_tbf, div_tbx;
     unsigned long long *stamps;   // -DLSPF2F_WINO_STAMPS builds: [blocks][4 waves][8] cycle counters (tools/wino_stamps.py)

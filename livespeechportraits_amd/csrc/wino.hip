@@ -66,7 +66,7 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 
 // The K loop of one wave.  ROW = its row i of B^T d B: t = d[ra] (+|-) d[rb] per patch column, then the column transform.
 //   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3
-template <int NB, int NS, bool IL, int ROW>
+template <int NB, int NS, bool IL, bool ROT, int ROW>
 __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][NB], const char *smem_c, unsigned lds0, int wave, int lane,
                                           unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, unsigned soff_nb,
                                           int ks_begin, int ks_end, unsigned long long *first_landed)
@@ -155,7 +155,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
             else tt[dx] = f4sub(d[1][dx], d[0][dx]);
         }
         v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
-        if (p.rot) {
+        if constexpr (ROT) {
             // consecutive MFMAs on DIFFERENT accumulators: the four j of a channel block rotate, so no instruction waits for its predecessor's result
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -313,7 +313,7 @@ __device__ __forceinline__ void wino_loop_sp(const WinoParams &p, f32x16 (&acc)[
     }
 }
 
-template <int NB, int NS, bool IL, bool SP>
+template <int NB, int NS, bool IL, bool SP, bool ROT>
 __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -417,10 +417,10 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
         }
     } else {
         switch (wave) {
-        case 0: wino_loop<NB, NS, IL, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-        case 1: wino_loop<NB, NS, IL, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-        case 2: wino_loop<NB, NS, IL, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-        default: wino_loop<NB, NS, IL, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+        case 0: wino_loop<NB, NS, IL, ROT, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+        case 1: wino_loop<NB, NS, IL, ROT, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+        case 2: wino_loop<NB, NS, IL, ROT, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+        default: wino_loop<NB, NS, IL, ROT, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
         }
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
@@ -559,17 +559,17 @@ bool wino_supported(const WinoParams &p, int nb)
     return true;
 }
 
-template <int NB, int NS, bool IL, bool SP>
+template <int NB, int NS, bool IL, bool SP, bool ROT = false>
 static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
 {
     constexpr int smem = wino_lds_bytes(NB, NS, SP ? NS + 1 : 0);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, SP, ROT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL((wino3x3<NB, NS, IL, SP>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wino3x3<NB, NS, IL, SP, ROT>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
@@ -601,11 +601,11 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     // tools only (A-B runs): LSP_HIP_WINO_IL=0 issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them
     static const int il_env = std::getenv("LSP_HIP_WINO_IL") ? std::atoi(std::getenv("LSP_HIP_WINO_IL")) : 1;
     // LSP_HIP_WINO_SP=0 (tools only): the transform of a step at its head instead of inside the previous step's MFMA stream
-    static const int rot_env = std::getenv("LSP_HIP_WINO_ROT") ? std::atoi(std::getenv("LSP_HIP_WINO_ROT")) : 0;
-    p.rot = rot_env;
+    static const int rot_env = std::getenv("LSP_HIP_WINO_ROT") ? std::atoi(std::getenv("LSP_HIP_WINO_ROT")) : 0;   // tools only: rotated accumulator order
+    if (rot_env) return nb == 2 ? launch_wino_t<2, 2, true, false, true>(p, s) : launch_wino_t<1, 3, true, false, true>(p, s);
     static const int sp_env = std::getenv("LSP_HIP_WINO_SP") ? std::atoi(std::getenv("LSP_HIP_WINO_SP")) : 1;
     if (nb == 2) return il_env ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<2, 2, false, false>(p, s);
-    if (sp_env && !rot_env) return launch_wino_t<1, 3, true, true>(p, s);
+    if (sp_env) return launch_wino_t<1, 3, true, true>(p, s);
     if (il_env == 2) return launch_wino_t<1, 2, true, false>(p, s);
     return il_env ? launch_wino_t<1, 3, true, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
 }
