@@ -41,12 +41,11 @@ static constexpr int kRawStage = kRawPieces * 1024;        // bytes per ring slo
 // LDS: [ns ring slots of U fragments][ns ring slots of raw patch][1 KB dump]; ns = ring depth (2, or 3 with one channel block per wave:
 // its K-step is 1024 cycles of MFMA per wave, less than a loaded L2 round trip, so the copy of step t + 2 is in flight while step t multiplies)
 __host__ __device__ constexpr int wino_u_stage(int nb) { return 4 * 4 * nb * 1024; }              // 4 waves x (4 j x nb) pieces
-// (SP form: the raw ring is one slot deeper than the fragment ring, nr = ns + 1)
 __host__ __device__ constexpr int wino_raw_base(int nb, int ns) { return ns * wino_u_stage(nb); }
-__host__ __device__ constexpr int wino_dump(int nb, int ns, int nr = 0) { return wino_raw_base(nb, ns) + (nr ? nr : ns) * kRawStage; }
-__host__ __device__ constexpr int wino_lds_bytes(int nb, int ns, int nr = 0)
+__host__ __device__ constexpr int wino_dump(int nb, int ns) { return wino_raw_base(nb, ns) + ns * kRawStage; }
+__host__ __device__ constexpr int wino_lds_bytes(int nb, int ns)
 {
-    const int loop = wino_dump(nb, ns, nr) + 1024;
+    const int loop = wino_dump(nb, ns) + 1024;
     const int patch = 4 * 2 * nb * 32 * 36 * 4;             // epilogue: [wave][b][nb][32 tiles][36]
     return loop > patch ? loop : patch;
 }
@@ -206,114 +205,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
 }
 
 
-// SP form of the K loop (one channel block per wave): the transform of step t + 1 -- 8 fragment reads of the raw patch, 32 adds -- is issued inside
-// the MFMA stream of step t instead of between a barrier and the first MFMA, where nothing of this wave can cover it (ablation, DESIGN.md 4.8: 2.7 us
-// of a 28-us layer).  The raw patch of step t + 1 must then be visible one barrier earlier, so the raw ring runs one step further ahead than the
-// fragment ring: in step t the wave issues raw(t + 3) and U(t + 2); both rings keep one full step between issue and the wait that covers them, and
-// "everything but this step's pieces has landed" is still one counted vmcnt.
-template <int ROW>
-__device__ __forceinline__ void wino_loop_sp(const WinoParams &p, f32x16 (&acc)[4][1], const char *smem_c, unsigned lds0, int wave, int lane,
-                                             unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0,
-                                             int ks_begin, int ks_end, unsigned long long *first_landed)
-{
-    constexpr int NS = 3, NR = 4;
-    constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
-    constexpr int USTAGE = wino_u_stage(1), RAWB = wino_raw_base(1, NS), DUMP = wino_dump(1, NS, NR);
-    const int r = lane & 31, q = lane >> 5, ty = r >> 3, tx = r & 7;
-    unsigned araw[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int dy = k == 0 ? RA : RB;
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-            const int chunk = (((dy & 1) * 2 + (dx & 1)) * 2 + q) * 45 + (ty + (dy >> 1)) * 9 + tx + (dx >> 1);
-            araw[k][dx] = (unsigned)(RAWB + chunk * 16);
-        }
-    }
-    const unsigned au = (unsigned)(wave * 4096 + lane * 16);
-    const unsigned vu[4] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + 1024), (unsigned)(lane * 16 + 2048), (unsigned)(lane * 16 + 3072)};
-    const unsigned lds_u = lds0 + (unsigned)(wave * 4096);
-    const unsigned lds_r0 = lds0 + (unsigned)(RAWB + wave * 1024);
-    const unsigned lds_r1 = wave < 2 ? lds_r0 + 4096u : lds0 + (unsigned)DUMP;
-    auto fetch_raw = [&](int ks, int slot) {
-        dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
-    };
-    auto fetch_u2 = [&](int ks, int slot, int h) {
-        const unsigned vv[2] = {vu[2 * h], vu[2 * h + 1]};
-        dma16_group<2, 1024>(lds_u + (unsigned)(slot * USTAGE + h * 2048), vv, srd_u, (int)(soff_u0 + (unsigned)ks * 4096u));
-    };
-    auto read_raw = [&](float4 (&d)[2][4], int rslot) {
-        const char *rawp = smem_c + rslot * kRawStage;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
-    };
-    auto transform = [&](const float4 (&d)[2][4], float4 (&v)[4]) {
-        float4 tt[4];
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-            if constexpr (ROW == 0 || ROW == 3) tt[dx] = f4sub(d[0][dx], d[1][dx]);
-            else if constexpr (ROW == 1) tt[dx] = f4add(d[0][dx], d[1][dx]);
-            else tt[dx] = f4sub(d[1][dx], d[0][dx]);
-        }
-        v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
-    };
-
-    const int nsteps = ks_end - ks_begin;
-    if (nsteps <= 0) return;
-    // steps 0..2 of the raw ring and 0..1 of the fragment ring before the loop
-    fetch_raw(ks_begin, 0); fetch_u2(ks_begin, 0, 0); fetch_u2(ks_begin, 0, 1);
-    if (nsteps > 1) { fetch_raw(ks_begin + 1, 1); fetch_u2(ks_begin + 1, 1, 0); fetch_u2(ks_begin + 1, 1, 1); }
-    if (nsteps > 2) fetch_raw(ks_begin + 2, 2);
-    dma_wait<0>();
-    __syncthreads();
-#ifdef LSPF2F_WINO_STAMPS
-    *first_landed = __builtin_amdgcn_s_memtime();
-#endif
-    float4 v[4];
-    {
-        float4 d0[2][4];
-        read_raw(d0, 0);
-        transform(d0, v);
-    }
-    int ucur = 0, rnext = 1;            // fragment slot of step t; raw slot of step t + 1
-    for (int t = 0; t < nsteps; ++t) {
-        const char *up = smem_c + ucur * USTAGE + au;
-        float4 u[2];
-        u[0] = *reinterpret_cast<const float4 *>(up);
-        const bool more = t + 1 < nsteps;
-        float4 d[2][4], vn[4];
-        if (more) read_raw(d, rnext);                      // step t + 1's rows: visible since the barrier that ended step t - 1
-        const bool iu = t + 2 < nsteps, ir = t + 3 < nsteps;
-        int uslot = ucur + 2; if (uslot >= NS) uslot -= NS;          // held U(t - 1): read in step t - 1
-        int rslot = rnext + 2; if (rslot >= NR) rslot -= NR;          // held raw(t - 1): read in step t - 2
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            if (f + 1 < 4) u[(f + 1) & 1] = *reinterpret_cast<const float4 *>(up + (f + 1) * 1024);
-            const float4 uu = u[f & 1];
-            acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[f].x, uu.x, acc[f][0], 0, 0, 0);
-            acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[f].y, uu.y, acc[f][0], 0, 0, 0);
-            acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[f].z, uu.z, acc[f][0], 0, 0, 0);
-            acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[f].w, uu.w, acc[f][0], 0, 0, 0);
-            if (f == 0 && ir) fetch_raw(ks_begin + t + 3, rslot);
-            if (f == 1 && iu) fetch_u2(ks_begin + t + 2, uslot, 0);
-            if (f == 2 && iu) fetch_u2(ks_begin + t + 2, uslot, 1);
-            if (f == 1 && more) transform(d, vn);          // between the MFMA groups: the matrix pipe works on f = 1's four instructions meanwhile
-        }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = vn[j];
-        }
-        // raw(t + 2) and U(t + 1) -- issued in step t - 1 -- must have landed: everything but THIS step's pieces
-        if (ir) dma_wait<6>(); else if (iu) dma_wait<4>(); else dma_wait<0>();
-        __syncthreads();
-        if (++ucur == NS) ucur = 0;
-        if (++rnext == NR) rnext = 0;
-    }
-}
-
-template <int NB, int NS, bool IL, bool SP, bool ROT>
+template <int NB, int NS, bool IL, bool ROT>
 __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -407,21 +299,11 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
-    if constexpr (SP) {
-        static_assert(NB == 1 && NS == 3, "the SP form is written for one channel block per wave");
-        switch (wave) {
-        case 0: wino_loop_sp<0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
-        case 1: wino_loop_sp<1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
-        case 2: wino_loop_sp<2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
-        default: wino_loop_sp<3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
-        }
-    } else {
-        switch (wave) {
-        case 0: wino_loop<NB, NS, IL, ROT, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-        case 1: wino_loop<NB, NS, IL, ROT, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-        case 2: wino_loop<NB, NS, IL, ROT, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-        default: wino_loop<NB, NS, IL, ROT, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-        }
+    switch (wave) {
+    case 0: wino_loop<NB, NS, IL, ROT, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 1: wino_loop<NB, NS, IL, ROT, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    case 2: wino_loop<NB, NS, IL, ROT, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    default: wino_loop<NB, NS, IL, ROT, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
     WSTAMP(3);
@@ -559,17 +441,17 @@ bool wino_supported(const WinoParams &p, int nb)
     return true;
 }
 
-template <int NB, int NS, bool IL, bool SP, bool ROT = false>
+template <int NB, int NS, bool IL, bool ROT>
 static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
 {
-    constexpr int smem = wino_lds_bytes(NB, NS, SP ? NS + 1 : 0);
+    constexpr int smem = wino_lds_bytes(NB, NS);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, SP, ROT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, ROT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL((wino3x3<NB, NS, IL, SP, ROT>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wino3x3<NB, NS, IL, ROT>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
@@ -598,16 +480,13 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
     p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));
     p.div_tbx = FastDiv::make((unsigned)p.tbx);
-    // tools only (A-B runs): LSP_HIP_WINO_IL=0 issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them
+    // tools only (A-B runs): LSP_HIP_WINO_IL=0 issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them;
+    // LSP_HIP_WINO_ROT=0 runs the four MFMAs of an accumulator back to back instead of rotating over the four accumulators of a channel block
     static const int il_env = std::getenv("LSP_HIP_WINO_IL") ? std::atoi(std::getenv("LSP_HIP_WINO_IL")) : 1;
-    // LSP_HIP_WINO_SP=0 (tools only): the transform of a step at its head instead of inside the previous step's MFMA stream
-    static const int rot_env = std::getenv("LSP_HIP_WINO_ROT") ? std::atoi(std::getenv("LSP_HIP_WINO_ROT")) : 0;   // tools only: rotated accumulator order
-    if (rot_env) return nb == 2 ? launch_wino_t<2, 2, true, false, true>(p, s) : launch_wino_t<1, 3, true, false, true>(p, s);
-    static const int sp_env = std::getenv("LSP_HIP_WINO_SP") ? std::atoi(std::getenv("LSP_HIP_WINO_SP")) : 1;
-    if (nb == 2) return il_env ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<2, 2, false, false>(p, s);
-    if (sp_env) return launch_wino_t<1, 3, true, true>(p, s);
-    if (il_env == 2) return launch_wino_t<1, 2, true, false>(p, s);
-    return il_env ? launch_wino_t<1, 3, true, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
+    static const int rot_env = std::getenv("LSP_HIP_WINO_ROT") ? std::atoi(std::getenv("LSP_HIP_WINO_ROT")) : 1;
+    if (!il_env) return nb == 2 ? launch_wino_t<2, 2, false, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
+    if (!rot_env) return nb == 2 ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<1, 3, true, false>(p, s);
+    return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);
 }
 
 // Host: OIHW [N][C][3][3] -> U = G g G^T (double, rounded once) in the MFMA fragment order [n-block N/32][xi-row 4][k-step C/8][j 4][lane 64][4]:

@@ -98,3 +98,31 @@ def test_winograd_can_be_switched_off_per_handle(monkeypatch):
     e = Engine("normal")
     assert not any(l["kernel"].startswith("wino3x3") for l in e.layers(1))
     e.close()
+
+
+def test_winograd_kernel_instances_do_not_spill(tmp_path):
+    """Every wino3x3 instantiation sits at 164-256 registers per lane; one more live value and hipcc spills to scratch, which costs 30 % of the
+    forward without failing any parity test (it happened once: a runtime switch between two loop bodies).  Cross-compile the file and read
+    the compiler's own resource report: no scratch, and the occupancy the LDS budget is planned for."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "livespeechportraits_amd", "csrc", "wino.hip")
+    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage",
+                        "-c", src, "-o", str(tmp_path / "w.o")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", p.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "wino3x3" not in name:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        nb = int(re.search(r"wino3x3ILi(\d)E", name).group(1))
+        assert scratch == 0, (name, scratch)
+        assert occ >= 2, (name, occ)          # two workgroups per CU share every SIMD (nb = 2: 79 KB of LDS each; nb = 1: up to three)
+        assert nb in (1, 2)
+    assert seen >= 4
