@@ -117,14 +117,6 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
 #ifdef LSPF2F_WINO_STAMPS
     *first_landed = __builtin_amdgcn_s_memtime();
 #endif
-    // UPRE (rotated order, one channel block per wave): the step's four weight fragments are this wave's own copies, so they can be read as soon
-    // as its own vmcnt wait has passed -- BEFORE the barrier that publishes the raw patch -- and their latency hides behind the barrier
-    constexpr bool UPRE = ROT && NB == 1;
-    float4 un[4];
-    if constexpr (UPRE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) un[j] = *reinterpret_cast<const float4 *>(smem_c + au + j * 1024);
-    }
     int cur = 0;
     for (int t = 0; t < nsteps; ++t) {
         const char *rawp = smem_c + cur * kRawStage;
@@ -138,7 +130,7 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
             for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
 #endif
         float4 u[2];
-        if constexpr (!UPRE) u[0] = *reinterpret_cast<const float4 *>(up);
+        u[0] = *reinterpret_cast<const float4 *>(up);
 #ifdef WINO_ABL_NOHEAD       // ablation (tools/wino_ablate_job.sh): no raw reads / transform -- whatever the registers hold is multiplied
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -167,14 +159,9 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 float4 uj[4];
-                if constexpr (UPRE) {
+                uj[0] = nb == 0 ? u[0] : *reinterpret_cast<const float4 *>(up + (nb * 4) * 1024);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) uj[j] = un[j];
-                } else {
-                    uj[0] = nb == 0 ? u[0] : *reinterpret_cast<const float4 *>(up + (nb * 4) * 1024);
-#pragma unroll
-                    for (int j = 1; j < 4; ++j) uj[j] = *reinterpret_cast<const float4 *>(up + (nb * 4 + j) * 1024);
-                }
+                for (int j = 1; j < 4; ++j) uj[j] = *reinterpret_cast<const float4 *>(up + (nb * 4 + j) * 1024);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -210,14 +197,6 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
         }
         // step t + 1 must have landed (this wave's pieces; the barrier covers the other waves'): everything but the pieces issued in THIS iteration
         if (NS > 2 && issue) dma_wait<PIECES>(); else dma_wait<0>();
-        if constexpr (UPRE) {
-            if (t + 1 < nsteps) {
-                int nx = cur + 1; if (nx == NS) nx = 0;
-                const char *upn = smem_c + nx * USTAGE + au;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) un[j] = *reinterpret_cast<const float4 *>(upn + j * 1024);
-            }
-        }
 #ifndef WINO_ABL_NOBARRIER
         __syncthreads();
 #endif
