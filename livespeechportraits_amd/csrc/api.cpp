@@ -309,7 +309,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             RowLastParams q{};
             q.src0 = tptr(l.src0); q.src1 = tptr(l.src1); q.w = h->blob + l.wrl_off;
             q.out = reinterpret_cast<float *>(h->ws + P.partial_offset);
-            q.B = batch; q.H = l.hs; q.W = l.hs; q.R = rowlast_rows(batch, l.hs, l.hs);
+            q.B = batch; q.H = l.hs; q.W = l.hs; q.R = rowlast_rows(batch, l.hs, l.hs); q.dtype = P.dtype;
             e = launch_rowlast(q, s);
             if (e == hipSuccess) {
                 ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0};
@@ -364,19 +364,19 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         RowUpParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wru_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.out = tptr(l.out);
-        p.B = batch; p.H = l.hs; p.W = l.hs; p.R = l.rowup; p.relu = l.relu;
+        p.B = batch; p.H = l.hs; p.W = l.hs; p.R = l.rowup; p.relu = l.relu; p.dtype = P.dtype;
         e = launch_rowup(p, s);
     } else if (l.bandconv) {
         BandConvParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.wbc_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.residual = tptr(l.res); p.out = tptr(l.out);
-        p.B = batch; p.W = l.ho; p.Cout = l.cout; p.relu = l.relu;
+        p.B = batch; p.W = l.ho; p.Cout = l.cout; p.relu = l.relu; p.dtype = P.dtype;
         e = launch_bandconv(p, s);
     } else if (l.rowconv) {
         RowConvParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.wrc_off); p.wfrag = 1; p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.residual = tptr(l.res); p.out = tptr(l.out);
-        p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.c0; p.R = l.rowconv; p.relu = l.relu;
+        p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.c0; p.R = l.rowconv; p.relu = l.relu; p.dtype = P.dtype;
         e = launch_rowconv(p, s);
     } else if (l.fullk) {
         FullKParams p{};
@@ -713,7 +713,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
         if (tile_m > 3000 && tile_n == 64 && k_group == -1) {     // 3000 + R: the sub-pixel up-conv row kernel, weights in its fragment order
             RowUpParams q{};
             q.src0 = src0; q.src1 = src1; q.w = w_packed; q.scale = scale; q.shift = shift; q.out = out;
-            q.B = batch; q.H = hs; q.W = ws; q.R = tile_m - 3000; q.relu = relu;
+            q.B = batch; q.H = hs; q.W = ws; q.R = tile_m - 3000; q.relu = relu; q.dtype = dtype;
             if (!rowup_layer(hs, c0, c1, cout, upsample == 2, dtype, false) || residual || hs != ws || !rowup_supported(q) || (q.R & 1))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 up-conv row kernel does not support this shape");
             e = launch_rowup(q, static_cast<hipStream_t>(hip_stream));
@@ -749,7 +749,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
         if (tile_m == 2000 && k_group == -1) {     // the activation-stationary bf16 kernel of the 16x16 / 8x8 levels; weights in its fragment order
             BandConvParams q{};
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
-            q.B = batch; q.W = hs; q.Cout = cout; q.relu = relu;
+            q.B = batch; q.W = hs; q.Cout = cout; q.relu = relu; q.dtype = dtype;
             if (!bandconv_layer(hs, c0, c1, cout, stride, upsample == 1, upsample == 2, dtype, false) || hs != ws || !bandconv_supported(q))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 band kernel does not support this shape");
             e = launch_bandconv(q, static_cast<hipStream_t>(hip_stream));
@@ -759,7 +759,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
         if (tile_m > 1000 && (tile_n == 64 || tile_n == 128)) {   // 1000 + R: the weights-stationary bf16 kernel (tile_n channels in and out) with R output rows per strip
             RowConvParams q{};
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
-            q.B = batch; q.H = hs; q.W = ws; q.C = tile_n; q.R = tile_m - 1000; q.relu = relu;
+            q.B = batch; q.H = hs; q.W = ws; q.C = tile_n; q.R = tile_m - 1000; q.relu = relu; q.dtype = dtype;
             q.wfrag = k_group == -1 ? 1 : 0;     // -1: w_packed is already in the row kernel's fragment order
             if (!rowconv_layer(hs, c0, c1, cout, stride, upsample == 1, upsample == 2, dtype, false) || c0 != tile_n || hs != ws || !rowconv_supported(q))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 row kernel does not support this shape");

@@ -26,7 +26,7 @@ constexpr int BC_PATCH = 32 * 144;        // per wave and pixel block: 32 px x (
 }  // namespace
 
 // W = frame width (= height) of the level: 16 | 8.  PXB = pixel blocks of 32 per workgroup: a tile is TR = 32*PXB / W whole rows.
-template <int W, int PXB, bool RES, bool RELU>
+template <bool F16, int W, int PXB, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
 {
     constexpr bool MULTI = W * W < 32 * PXB;          // 4x4 / 2x2 levels: a tile is FR whole frames (2 / 8), each with its own halo
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
         for (int pb = 0; pb < PXB; ++pb) {
             const unsigned bp = bp0[pb] + (unsigned)(ky * BW + kx);
             const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const char *>(smem) + bp * 1024u + ((chunk ^ (bp & 7u)) << 4));
-            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[pb], 0, 0, 0);
+            acc[pb] = mfma32_16b<F16>(a, bv, acc[pb]);
         }
     }
 
@@ -141,11 +141,11 @@ __global__ __launch_bounds__(256) void bandconv512(const BandConvParams p)
         if (b >= p.B) continue;                        // a tile of whole frames past the batch
         const size_t e = ((size_t)(b * W + y0 + tr) * W + tc) * (size_t)p.Cout + n;
         if (RES) {
-            const float4 rv = load4(static_cast<const bf16_t *>(p.residual) + e);
+            const float4 rv = load4(static_cast<const typename St16<F16>::type *>(p.residual) + e);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
         if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        store4(static_cast<bf16_t *>(p.out) + e, v);
+        store4(static_cast<typename St16<F16>::type *>(p.out) + e, v);
     }
 }
 
@@ -183,21 +183,25 @@ hipError_t launch_bandconv(const BandConvParams &p_in, hipStream_t s)
     const size_t red = (size_t)4 * pxb * BC_PATCH;
     const size_t smem = pass_bytes > red ? pass_bytes : red;
     typedef void (*kern_t)(const BandConvParams);
-    static const kern_t kern[4][4] = {
-        {bandconv512<16, 2, false, false>, bandconv512<16, 2, false, true>, bandconv512<16, 2, true, false>, bandconv512<16, 2, true, true>},
-        {bandconv512<8, 1, false, false>, bandconv512<8, 1, false, true>, bandconv512<8, 1, true, false>, bandconv512<8, 1, true, true>},
-        {bandconv512<4, 1, false, false>, bandconv512<4, 1, false, true>, bandconv512<4, 1, true, false>, bandconv512<4, 1, true, true>},
-        {bandconv512<2, 1, false, false>, bandconv512<2, 1, false, true>, bandconv512<2, 1, true, false>, bandconv512<2, 1, true, true>}};
+    static const kern_t kern[8][4] = {
+        {bandconv512<false, 16, 2, false, false>, bandconv512<false, 16, 2, false, true>, bandconv512<false, 16, 2, true, false>, bandconv512<false, 16, 2, true, true>},
+        {bandconv512<false, 8, 1, false, false>, bandconv512<false, 8, 1, false, true>, bandconv512<false, 8, 1, true, false>, bandconv512<false, 8, 1, true, true>},
+        {bandconv512<false, 4, 1, false, false>, bandconv512<false, 4, 1, false, true>, bandconv512<false, 4, 1, true, false>, bandconv512<false, 4, 1, true, true>},
+        {bandconv512<false, 2, 1, false, false>, bandconv512<false, 2, 1, false, true>, bandconv512<false, 2, 1, true, false>, bandconv512<false, 2, 1, true, true>},
+        {bandconv512<true, 16, 2, false, false>, bandconv512<true, 16, 2, false, true>, bandconv512<true, 16, 2, true, false>, bandconv512<true, 16, 2, true, true>},
+        {bandconv512<true, 8, 1, false, false>, bandconv512<true, 8, 1, false, true>, bandconv512<true, 8, 1, true, false>, bandconv512<true, 8, 1, true, true>},
+        {bandconv512<true, 4, 1, false, false>, bandconv512<true, 4, 1, false, true>, bandconv512<true, 4, 1, true, false>, bandconv512<true, 4, 1, true, true>},
+        {bandconv512<true, 2, 1, false, false>, bandconv512<true, 2, 1, false, true>, bandconv512<true, 2, 1, true, false>, bandconv512<true, 2, 1, true, true>}};
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 32; ++k) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[k >> 2][k & 3]), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
         }
         attr_done_on_this_device(attr_mask);
     }
     const int lvl = p.W == 16 ? 0 : p.W == 8 ? 1 : p.W == 4 ? 2 : 3;
-    hipLaunchKernelGGL(kern[lvl][(p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(kern[(p.dtype == 2 ? 4 : 0) + lvl][(p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 

@@ -48,6 +48,35 @@ template <> __device__ __forceinline__ void store4<f16_t>(f16_t *p, float4 v)
     const f32x4v f = {v.x, v.y, v.z, v.w};
     *reinterpret_cast<uint2 *>(p) = __builtin_bit_cast(uint2, __builtin_convertvector(f, f16x4));
 }
+// 16-bit storage kernels written once for both types (F16 = IEEE half, else bf16): registers carry the 16-byte operand as bf16x8 whatever it holds
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <bool F16> __device__ __forceinline__ f32x16 mfma32_16b(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ f32x4acc mfma16_16b(bf16x8 a, bf16x8 b, f32x4acc c)
+{
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <bool F16> __device__ __forceinline__ unsigned pack16x2(float lo, float hi)       // two floats -> one register of two 16-bit values, RNE
+{
+    if constexpr (F16) { const v2f v = {lo, hi}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2)); }
+    else return pack_bf16x2(lo, hi);
+}
+template <bool F16> __device__ __forceinline__ float lo16(unsigned w)
+{
+    if constexpr (F16) return (float)__builtin_bit_cast(f16x2, w).x; else return __uint_as_float(w << 16);
+}
+template <bool F16> __device__ __forceinline__ float hi16(unsigned w)
+{
+    if constexpr (F16) return (float)__builtin_bit_cast(f16x2, w).y; else return __uint_as_float(w & 0xffff0000u);
+}
+template <bool F16> struct St16 { typedef bf16_t type; };
+template <> struct St16<true> { typedef f16_t type; };
+
 // one element, whatever the storage type
 template <typename T> __device__ __forceinline__ float ld1(const T *p);
 template <> __device__ __forceinline__ float ld1<float>(const float *p) { return *p; }

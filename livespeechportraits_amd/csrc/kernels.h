@@ -164,6 +164,7 @@ struct RowConvParams {
     int R;                        // output rows per workgroup strip (rowconv_rows())
     int relu;
     int wfrag;                    // weights in the fragment order of pack_rowconv_weights() (the shipped path) instead of [64][9][64]
+    int dtype;                    // 1 = bf16 (default when 0), 2 = fp16: the 16-bit storage type of src / w / residual / out
     int nsx, nsy, nblocks;        // filled by launch_rowconv
     FastDiv div_sx, div_sy;
 };
@@ -180,6 +181,7 @@ struct BandConvParams {
     const void *residual;         // NHWC bf16 or nullptr
     void *out;                    // NHWC bf16 [B][W][W][Cout]
     int B, W, Cout, relu;
+    int dtype;                    // 1 = bf16 (default when 0), 2 = fp16
     int ntiles, nblocks;          // filled by launch_bandconv
     FastDiv div_tiles;
 };
@@ -194,6 +196,7 @@ struct RowLastParams {
     const void *w;                // bf16, fragment order of pack_rowlast_weights()
     float *out;                   // fp32 [B][H][W][12]
     int B, H, W, R;
+    int dtype;                    // 1 = bf16 (default when 0), 2 = fp16
     int nsx, nsy, nblocks;        // filled by launch_rowlast
     FastDiv div_sx, div_sy;
 };
@@ -210,6 +213,7 @@ struct RowUpParams {
     const float *scale, *shift;   // [64] or nullptr
     void *out;                    // NHWC bf16 [B][2H][2W][64]
     int B, H, W, R, relu;         // R = low-res rows per strip, even
+    int dtype;                    // 1 = bf16 (default when 0), 2 = fp16
     int nsx, nsy, nblocks;        // filled by launch_rowup
     FastDiv div_sx, div_sy;
 };

@@ -272,7 +272,7 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
         }
-        if (dtype == 1 && last_as_gemm(l) && l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
+        if (last_as_gemm(l) && l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
             off = align_up(off, 256);
             l.wrl_off = (int64_t)off;
             off += (size_t)9 * 4 * 64 * 8 * elt();

@@ -135,18 +135,18 @@ inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes)
 // as many out, stride 1, no upsample, BatchNorm (folded) plans
 inline bool rowconv_layer(int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
 {
-    if (dtype != 1 || c1 != 0 || cout != c0 || stride != 1 || up || up4 || inorm) return false;
+    if (dtype == 0 || c1 != 0 || cout != c0 || stride != 1 || up || up4 || inorm) return false;      // 16-bit storage: bf16 (1) or fp16 (2)
     return (c0 == 64 && ho % 64 == 0) || (c0 == 128 && ho % 32 == 0);
 }
 // row kernel of the sub-pixel up-conv (mirrors rowup_supported() in rowconv.hip)
 inline bool rowup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm)
 {
-    return dtype == 1 && up4 && c0 == 128 && c1 == 128 && cout == 64 && !inorm && hs % 32 == 0;
+    return dtype != 0 && up4 && c0 == 128 && c1 == 128 && cout == 64 && !inorm && hs % 32 == 0;
 }
 // activation-stationary kernel eligibility (mirrors bandconv_supported() in bandconv.hip)
 inline bool bandconv_layer(int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
 {
-    return dtype == 1 && c0 == 512 && c1 == 0 && cout % 32 == 0 && stride == 1 && !up && !up4 && !inorm && (ho == 16 || ho == 8 || ho == 4 || ho == 2);
+    return dtype != 0 && c0 == 512 && c1 == 0 && cout % 32 == 0 && stride == 1 && !up && !up4 && !inorm && (ho == 16 || ho == 8 || ho == 4 || ho == 2);
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0
 // which layers get the tile-blocked weight copy at pack time (independent of the batch: the blob layout must not depend on it)

@@ -67,7 +67,7 @@ template <int N> __device__ __forceinline__ void vm_wait()
 }
 }  // namespace
 
-template <bool RES, bool RELU>
+template <bool F16, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void rowconv64(const RowConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void rowconv64(const RowConvParams p)
             const u32x4 rv = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(smem) + resbase + pass * 1024 + lane * 16);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                v[2 * t] += __uint_as_float(rv[t] << 16);
-                v[2 * t + 1] += __uint_as_float(rv[t] & 0xffff0000u);
+                v[2 * t] += lo16<F16>(rv[t]);
+                v[2 * t + 1] += hi16<F16>(rv[t]);
             }
         }
         // ReLU on the rounded pair: a bf16 is negative iff it is negative as a 16-bit integer, and rounding keeps sign and zero, so
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void rowconv64(const RowConvParams p)
         unsigned o0[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            unsigned w = pack_bf16x2(v[2 * t], v[2 * t + 1]);
+            unsigned w = pack16x2<F16>(v[2 * t], v[2 * t + 1]);
             if (RELU) w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0}));
             o0[t] = w;
         }
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256) void rowconv64(const RowConvParams p)
         for (int f = 0; f < 12; ++f) {
             if (f + 2 < 12) bfr[(f + 2) % 3] = frag(i, f + 2);
             const int kx = f >> 2, kc = f & 3;
-            ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[6 + kx][kc], bfr[f % 3], ao, 0, 0, 0);
-            am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[3 + kx][kc], bfr[f % 3], am, 0, 0, 0);
-            an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0 + kx][kc], bfr[f % 3], f == 0 ? zero16 : an, 0, 0, 0);   // output row i starts here: C = 0
+            ao = mfma32_16b<F16>(wf[6 + kx][kc], bfr[f % 3], ao);
+            am = mfma32_16b<F16>(wf[3 + kx][kc], bfr[f % 3], am);
+            an = mfma32_16b<F16>(wf[0 + kx][kc], bfr[f % 3], f == 0 ? zero16 : an);   // output row i starts here: C = 0
             if (f == 1) finish(i - 3, 0);
             if (f == 5) finish(i - 3, 1);
             if (f == 8) {
@@ -307,7 +307,7 @@ constexpr int RD_OPS = RD_IN + RD_RP + RD_ST;
 static_assert((RD_PF - 1) * RD_OPS < 64, "vmcnt is a 6-bit counter");
 }  // namespace
 
-template <bool RES, bool RELU>
+template <bool F16, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void rowconv128(const RowConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -441,14 +441,14 @@ __global__ __launch_bounds__(256) void rowconv128(const RowConvParams p)
             const u32x4 rv = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(smem) + resbase + pass * 1024 + lane * 16);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                v[2 * t] += __uint_as_float(rv[t] << 16);
-                v[2 * t + 1] += __uint_as_float(rv[t] & 0xffff0000u);
+                v[2 * t] += lo16<F16>(rv[t]);
+                v[2 * t + 1] += hi16<F16>(rv[t]);
             }
         }
         unsigned o0[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            unsigned w = pack_bf16x2(v[2 * t], v[2 * t + 1]);
+            unsigned w = pack16x2<F16>(v[2 * t], v[2 * t + 1]);
             if (RELU) w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), (i16x2){0, 0}));
             o0[t] = w;
         }
@@ -469,9 +469,9 @@ __global__ __launch_bounds__(256) void rowconv128(const RowConvParams p)
         for (int f = 0; f < 24; ++f) {
             if (f + 2 < 24) bfr[(f + 2) % 3] = frag(i, f + 2);
             const int kx = f >> 3, kc = f & 7;
-            ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[6 + kx][kc], bfr[f % 3], ao, 0, 0, 0);
-            am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[3 + kx][kc], bfr[f % 3], am, 0, 0, 0);
-            an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0 + kx][kc], bfr[f % 3], f == 0 ? zero16 : an, 0, 0, 0);
+            ao = mfma32_16b<F16>(wf[6 + kx][kc], bfr[f % 3], ao);
+            am = mfma32_16b<F16>(wf[3 + kx][kc], bfr[f % 3], am);
+            an = mfma32_16b<F16>(wf[0 + kx][kc], bfr[f % 3], f == 0 ? zero16 : an);
             if (f == 3) finish(i - 3, 0);
             if (f == 11) finish(i - 3, 1);
         }
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void rowconv128(const RowConvParams p)
 // the strip's 64 pixels each.  The two concatenated 64-channel sources keep their own rings of 128-B pixel records (an LDS-DMA piece has one
 // buffer descriptor), swizzled like the igemm's K-tiles; one barrier per row step.  Output: fp32 [B][H][W][12] for pixel_shuffle_tanh.
 namespace {
-typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef f32x4acc f32x4v;
 constexpr int RL_TW = 64;                 // low-res pixels per strip row
 constexpr int RL_PITCH = 12288;           // bytes per ring row and source: 96 records of 128 B = 3 passes of the workgroup (66 are real)
 constexpr int RL_NR = 5;
@@ -510,6 +510,7 @@ constexpr int RL_OPS = 3 + 3 + 1;         // vector-memory operations per step a
 static_assert((RL_PF - 1) * RL_OPS < 64, "vmcnt is a 6-bit counter");
 }  // namespace
 
+template <bool F16>
 __global__ __launch_bounds__(256) void rowlast128(const RowLastParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -610,9 +611,9 @@ __global__ __launch_bounds__(256) void rowlast128(const RowLastParams p)
         for (int f = 0; f < 12; ++f) {
             const int kx = f >> 2, kc = f & 3;
             const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(row + boff[kx][kc]);
-            ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[6 + kx][kc], bv, ao, 0, 0, 0);
-            am = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[3 + kx][kc], bv, am, 0, 0, 0);
-            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0 + kx][kc], bv, f == 0 ? zero4 : an, 0, 0, 0);
+            ao = mfma16_16b<F16>(wf[6 + kx][kc], bv, ao);
+            am = mfma16_16b<F16>(wf[3 + kx][kc], bv, am);
+            an = mfma16_16b<F16>(wf[0 + kx][kc], bv, f == 0 ? zero4 : an);
         }
         // output row j = i - 2 is complete.  D layout: lane = pixel l15, register r = output n = 4*g4 + r: 12 floats per pixel, lanes g4 < 3
         const int j = i - 2;
@@ -668,11 +669,13 @@ hipError_t launch_rowlast(const RowLastParams &p_in, hipStream_t s)
     const size_t smem = (size_t)RL_NR * 2 * RL_PITCH;
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL(rowlast128, dim3(p.nblocks), dim3(256), smem, s, p);
+    if (p.dtype == 2) hipLaunchKernelGGL(rowlast128<true>, dim3(p.nblocks), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(rowlast128<false>, dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 
@@ -691,7 +694,7 @@ constexpr int RU_OPS = 6 + 2;             // vector-memory operations per step a
 static_assert((RU_PF - 1) * RU_OPS < 64, "vmcnt is a 6-bit counter");
 }  // namespace
 
-template <bool RELU>
+template <bool F16, bool RELU>
 __global__ __launch_bounds__(256) void rowup256(const RowUpParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(256) void rowup256(const RowUpParams p)
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int t = 0; t < 8; ++t) { v[t] = v[t] * sc[t] + sh[t]; if (RELU) v[t] = fmaxf(v[t], 0.f); }
-        const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        const u32x4 o = {pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3]), pack16x2<F16>(v[4], v[5]), pack16x2<F16>(v[6], v[7])};
         const unsigned off = live ? (unsigned)(((2 * (y0 + j) + py) * (2 * p.W) + 2 * (x0 + pxl) + px) * 128 + nb * 64 + (lane & 3) * 16) : kOOB;
         __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
     };
@@ -816,8 +819,8 @@ __global__ __launch_bounds__(256) void rowup256(const RowUpParams p)
         for (int f = 0; f < 32; ++f) {
             const int bb = f >> 4, kc = f & 15;
             const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(row + (kc >> 3) * RU_PITCH + rb[bb] + (((unsigned)((kc & 7) * 2 + hi) ^ rs[bb]) << 4));
-            ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 + bb][kc], bv, ao, 0, 0, 0);                       // tap row a = 1: output row i - py - 1
-            an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0 + bb][kc], bv, f == 0 ? zero16 : an, 0, 0, 0);     // tap row a = 0: output row i - py
+            ao = mfma32_16b<F16>(wf[2 + bb][kc], bv, ao);                       // tap row a = 1: output row i - py - 1
+            an = mfma32_16b<F16>(wf[0 + bb][kc], bv, f == 0 ? zero16 : an);     // tap row a = 0: output row i - py
             if (f == 3) finish(i - py - 2, 0);
             if (f == 13) finish(i - py - 2, 1);
         }
@@ -877,13 +880,20 @@ hipError_t launch_rowup(const RowUpParams &p_in, hipStream_t s)
     const size_t smem = (size_t)RU_NR * 2 * RU_PITCH + 4 * (size_t)RC_PATCH;
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowup256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowup256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipSuccess;
+        const void *ks[4] = {reinterpret_cast<const void *>(&rowup256<false, true>), reinterpret_cast<const void *>(&rowup256<false, false>),
+                             reinterpret_cast<const void *>(&rowup256<true, true>), reinterpret_cast<const void *>(&rowup256<true, false>)};
+        for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipFuncSetAttribute(ks[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    if (p.relu) hipLaunchKernelGGL(rowup256<true>, dim3(p.nblocks), dim3(256), smem, s, p);
-    else hipLaunchKernelGGL(rowup256<false>, dim3(p.nblocks), dim3(256), smem, s, p);
+    if (p.dtype == 2) {
+        if (p.relu) hipLaunchKernelGGL((rowup256<true, true>), dim3(p.nblocks), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((rowup256<true, false>), dim3(p.nblocks), dim3(256), smem, s, p);
+    } else {
+        if (p.relu) hipLaunchKernelGGL((rowup256<false, true>), dim3(p.nblocks), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((rowup256<false, false>), dim3(p.nblocks), dim3(256), smem, s, p);
+    }
     return hipGetLastError();
 }
 
@@ -929,19 +939,21 @@ hipError_t launch_rowconv(const RowConvParams &p_in, hipStream_t s)
     const size_t smem = wide ? (size_t)RD_NR * RD_PITCH + 4 * ((size_t)RD_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH)
                              : 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH);
     typedef void (*kern_t)(const RowConvParams);
-    static const kern_t kern[8] = {rowconv64<false, false>, rowconv64<false, true>, rowconv64<true, false>, rowconv64<true, true>,
-                                   rowconv128<false, false>, rowconv128<false, true>, rowconv128<true, false>, rowconv128<true, true>};
+    static const kern_t kern[16] = {rowconv64<false, false, false>, rowconv64<false, false, true>, rowconv64<false, true, false>, rowconv64<false, true, true>,
+                                    rowconv128<false, false, false>, rowconv128<false, false, true>, rowconv128<false, true, false>, rowconv128<false, true, true>,
+                                    rowconv64<true, false, false>, rowconv64<true, false, true>, rowconv64<true, true, false>, rowconv64<true, true, true>,
+                                    rowconv128<true, false, false>, rowconv128<true, false, true>, rowconv128<true, true, false>, rowconv128<true, true, true>};
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        for (int k = 0; k < 8; ++k) {
-            const size_t need = k < 4 ? 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH)
+        for (int k = 0; k < 16; ++k) {
+            const size_t need = (k & 7) < 4 ? 4 * ((size_t)RC_NR * RC_ROWB + (size_t)RC_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH)
                                       : (size_t)RD_NR * RD_PITCH + 4 * ((size_t)RD_RES_NR * RC_RES_SLOT + (size_t)RC_PATCH);
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[k]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
             if (e != hipSuccess) return e;
         }
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL(kern[(wide ? 4 : 0) + (p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
+    hipLaunchKernelGGL(kern[(p.dtype == 2 ? 8 : 0) + (wide ? 4 : 0) + (p.residual ? 2 : 0) + (p.relu ? 1 : 0)], dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 

@@ -26,11 +26,11 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
     d0 = nhwc(x0)
     d1 = nhwc(x1) if x1 is not None else None
     if k_group == -1 and tile[0] > 3000:
-        wp = pack_rowup(w).to(dev)                            # the up-conv row kernel's fragment order (bf16)
+        wp = pack_rowup(w).to(dev).to(tdt)                    # the up-conv row kernel's fragment order (bf16 | fp16)
     elif k_group == -1 and tile[0] == 2000:
-        wp = pack_bandconv(w).to(dev)                         # the band kernel's fragment order (bf16)
+        wp = pack_bandconv(w).to(dev).to(tdt)                 # the band kernel's fragment order
     elif k_group == -1 and tile[0] > 1000:
-        wp = pack_rowconv(w).to(dev)                          # the row kernel's MFMA-fragment order (bf16)
+        wp = pack_rowconv(w).to(dev).to(tdt)                  # the row kernel's MFMA-fragment order
     elif k_group == -1:
         wp = pack_fullk(w, c0, 2 if c1 else 1).to(dev)       # the full-K kernel's tile-blocked layout
     elif up == 2:
@@ -73,14 +73,14 @@ def pack_rowconv(w):
     nb*32 + (lane & 31), k = kc*16 + 8*(lane >> 5) .. +7 (Plan::pack does the same on the host, pack_rowconv_weights)"""
     c = w.shape[0]
     rows = w.permute(0, 2, 3, 1).reshape(c // 32, 32, 9, c // 16, 2, 8)      # [nb][ch][tap][kc][hi][e]
-    return rows.permute(0, 2, 3, 4, 1, 5).contiguous().to(torch.bfloat16)   # [nb][tap][kc][hi][ch][e]: lane = hi*32 + ch
+    return rows.permute(0, 2, 3, 4, 1, 5).contiguous()                       # [nb][tap][kc][hi][ch][e]: lane = hi*32 + ch (fp32; run_conv narrows)
 
 
 def pack_rowup(w):
     """OIHW [64][256][3][3] -> the sub-pixel form [par][co][a][b][ci] -> bf16 [nb 2][par 4][tap 4][kc 16][lane 64][8]
     (pack_rowup_weights on the host)"""
     sub = pack_subpixel(w).reshape(4, 2, 32, 4, 16, 2, 8)                       # [par][nb][ch][tap][kc][hi][e]
-    return sub.permute(1, 0, 3, 4, 5, 2, 6).contiguous().to(torch.bfloat16)     # [nb][par][tap][kc][hi][ch][e]
+    return sub.permute(1, 0, 3, 4, 5, 2, 6).contiguous()                         # [nb][par][tap][kc][hi][ch][e]
 
 
 def pack_bandconv(w):
@@ -88,7 +88,7 @@ def pack_bandconv(w):
     k = input channel q*128 + kc*16 + 8*(lane >> 5) .. +7 of the tap (pack_bandconv_weights on the host)"""
     cout = w.shape[0]
     rows = w.permute(0, 2, 3, 1).reshape(cout // 32, 32, 9, 4, 8, 2, 8)        # [cs][ch][tap][q][kc][hi][e]
-    return rows.permute(0, 3, 2, 4, 5, 1, 6).contiguous().to(torch.bfloat16)    # [cs][q][tap][kc][hi][ch][e]
+    return rows.permute(0, 3, 2, 4, 5, 1, 6).contiguous()                        # [cs][q][tap][kc][hi][ch][e]
 
 
 def pack_subpixel(w):
@@ -630,3 +630,51 @@ def test_conv3x3_winograd_rejects_unsupported_shapes(gpu_device):
         run_wino(gpu_device, rnd(1, 32, 24, 24), w, None, None, None, False, 1, 1)       # 24 % 16 != 0
     with pytest.raises(N.Lspf2fError):
         run_wino(gpu_device, rnd(1, 32, 32, 32), w, None, None, None, False, 2, 1)       # cout 32 needs nb = 1
+
+
+# ---- the 16-bit row / band kernels in fp16 storage (round 3: the same kernels, templated on the storage type, serve opt.fp16 plans) ----
+F16_SPECIAL = [
+    # kind, args
+    ("rows", (64, 1, 64, 16, True, True)),
+    ("rows", (128, 2, 64, 7, False, True)),
+    ("band", (2, 16, 512, True, True)),
+    ("band", (3, 8, 96, True, False)),
+    ("rowup", (2, 32, 8)),
+]
+
+
+@pytest.mark.parametrize("kind,cfg", F16_SPECIAL, ids=lambda v: v if isinstance(v, str) else "_".join(str(int(x)) for x in v))
+def test_16bit_kernels_in_fp16_storage(kind, cfg, gpu_device):
+    """rowconv64 / rowconv128 / bandconv512 / rowup256 with IEEE-half operands (v_mfma_f32_32x32x16_f16): against the fp64 conv of the
+    fp16-rounded operands within one fp16 ulp, and (row kernels: same MFMA, same accumulation order) bit-equal to the implicit GEMM."""
+    h16 = lambda t: t.half().float() if t is not None else None
+    if kind == "rows":
+        c, b, h, rows, res, relu = cfg
+        x0 = h16(rnd(b, c, h, h, seed=71))
+        w = rnd(c, c, 3, 3, seed=72) * 0.05
+        scale, shift = rnd(c, seed=73) * 0.5 + 1.0, rnd(c, seed=74) * 0.1
+        r = h16(rnd(b, c, h, h, seed=75)) if res else None
+        got = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (1000 + rows, c), 0, -1, dtype=2)
+        ref = ref_conv(x0, None, h16(w), scale, shift, r, 1, False, relu)
+        other = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (64, 64), 1, 1, dtype=2)
+        assert torch.equal(got, other)
+    elif kind == "band":
+        b, h, cout, res, relu = cfg
+        x0 = h16(rnd(b, 512, h, h, seed=81))
+        w = rnd(cout, 512, 3, 3, seed=82) * 0.02
+        scale, shift = rnd(cout, seed=83) * 0.5 + 1.0, rnd(cout, seed=84) * 0.1
+        r = h16(rnd(b, cout, h, h, seed=85)) if res else None
+        got = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (2000, 0), 0, -1, dtype=2)
+        ref = ref_conv(x0, None, h16(w), scale, shift, r, 1, False, relu)
+    else:
+        b, hs, rows = cfg
+        x0, x1 = h16(rnd(b, 128, hs, hs, seed=91)), h16(rnd(b, 128, hs, hs, seed=92))
+        w = rnd(64, 256, 3, 3, seed=93) * 0.03
+        scale, shift = rnd(64, seed=94) * 0.5 + 1.0, rnd(64, seed=95) * 0.1
+        got = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, True, (3000 + rows, 64), 0, -1, dtype=2)
+        other = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, True, (128, 64), 1, 1, dtype=2)     # the igemm's sub-pixel path
+        assert torch.equal(got, other)
+        ref = other
+    assert torch.isfinite(got).all()
+    tol = (ref.abs() * 2.0 ** -11 + 3e-4)
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
