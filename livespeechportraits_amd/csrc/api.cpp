@@ -102,6 +102,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_ROWUP")) h->plan.use_rowup = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_ROWLAST")) h->plan.use_rowlast = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_WINO")) h->plan.use_wino = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_WINOUP")) h->plan.use_winoup = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
@@ -209,6 +210,8 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
     case kFirstConv: return "first_conv";
     case kLastConv: return l.wgemm_off >= 0 ? (l.wrl_off >= 0 && P.use_rowlast ? "last_conv (rowlast128 + pixel_shuffle_tanh)" : "last_conv (igemm3x3 + pixel_shuffle_tanh)") : "last_conv";
     default:
+        if (l.winoup) return l.winoup == 2 ? (l.splits > 1 ? "winoup3x3<2> (split-K combined in the launch)" : "winoup3x3<2>")
+                                           : (l.splits > 1 ? "winoup3x3<1> (split-K combined in the launch)" : "winoup3x3<1>");
         if (l.wino) return l.wino == 2 ? (l.splits > 1 ? "wino3x3<2> (split-K combined in the launch)" : "wino3x3<2>")
                                        : (l.splits > 1 ? "wino3x3<1> (split-K combined in the launch)" : "wino3x3<1>");
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
@@ -236,6 +239,10 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     const bool sub = l.up4 || l.kind == kLastConv;   // sub-pixel form: 16/9 weight bytes, 4/9 FLOPs
     o->weight_bytes = (int64_t)l.cout * l.cin * (sub ? 16 : 9) * (int64_t)(h->plan.layer_weights_typed(l) ? h->plan.elt() : 4);
     o->exec_flops_per_frame = sub ? o->flops_per_frame * 4 / 9 : o->flops_per_frame;
+    if (l.winoup) {     // up-conv Winograd form: 9 multiplies per 2x2 outputs instead of 36 (16 in the sub-pixel form); 9 transformed taps per (co, ci)
+        o->exec_flops_per_frame = o->flops_per_frame / 4;
+        o->weight_bytes = (int64_t)l.cout * l.cin * 9 * 4;
+    }
     if (l.wino) {       // Winograd F(2x2, 3x3): 16 multiplies per 2x2 outputs instead of 36; the weights it reads are the 4x4 transformed ones
         o->exec_flops_per_frame = o->flops_per_frame * 4 / 9;
         o->weight_bytes = (int64_t)l.cout * l.cin * 16 * 4;
@@ -350,6 +357,16 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             e = launch_in_small(q, s);
         }
+    } else if (l.winoup) {
+        WinoUpParams p{};
+        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.u = bptr(l.wwu_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.out = tptr(l.out);
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.N = l.cout; p.relu = l.relu; p.splits = l.splits;
+        if (l.splits > 1) {
+            p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
+            p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
+        }
+        if (h->timing_part & 1) e = launch_winoup(p, l.winoup, s);
     } else if (l.wino) {
         WinoParams p{};
         p.src = tptr(l.src0); p.u = bptr(l.wwg_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
@@ -654,6 +671,11 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
                                     int tile_m, int tile_n, int split_k, int k_group, int dtype)
 {
     const int ktc = dtype ? 64 : 32;
+    if ((tile_m == 5001 || tile_m == 5002) && k_group == -1) {      // up-conv Winograd kernel: slabs at OUTPUT resolution + arrival counters
+        const int sp = split_k > 0 ? split_k : 1;
+        if (sp == 1) return 0;
+        return (size_t)sp * batch * 4 * hs * hs * cout * sizeof(float) + (size_t)batch * (hs / 4) * (hs / 8) * (cout / (32 * (tile_m - 5000))) * sizeof(unsigned);
+    }
     if ((tile_m == 4001 || tile_m == 4002) && k_group == -1) {      // Winograd kernel: slabs + one arrival counter per (tile-block, channel group)
         const int sp = split_k > 0 ? split_k : 1;
         if (sp == 1) return 0;
@@ -684,7 +706,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     const int ktc = dtype ? 64 : 32;
     if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
-    const bool wino_tile = (tile_m == 4001 || tile_m == 4002) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
+    const bool wino_tile = (tile_m == 4001 || tile_m == 4002 || tile_m == 5001 || tile_m == 5002) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
     if (!wino_tile && ((c0 % ktc) || (c1 % ktc) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1)))
         return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (fp32) / 64 (bf16, fp16)");
     if (cout % 4) return fail(LSPF2F_ERR_UNSUPPORTED, "cout must be a multiple of 4");
@@ -718,6 +740,25 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 up-conv row kernel does not support this shape");
             e = launch_rowup(q, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (rowup) launch");
+            return LSPF2F_OK;
+        }
+        if ((tile_m == 5001 || tile_m == 5002) && k_group == -1) {   // 5000 + nb: the up-conv Winograd kernel, w_packed in its fragment order; split_k = K splits
+            const int sp = split_k > 0 ? split_k : 1, nbk = tile_m - 5000;
+            const size_t slab = sp > 1 ? (size_t)sp * batch * 4 * hs * ws * cout * sizeof(float) : 0;
+            WinoUpParams q{};
+            q.src0 = static_cast<const float *>(src0); q.src1 = c1 ? static_cast<const float *>(src1) : nullptr; q.u = static_cast<const float *>(w_packed);
+            q.scale = scale; q.shift = shift; q.out = static_cast<float *>(out);
+            q.B = batch; q.Hs = hs; q.Ws = ws; q.C0 = c0; q.C1 = c1; q.N = cout; q.relu = relu; q.splits = sp;
+            if (sp > 1) {
+                const size_t ncnt = (size_t)batch * (hs / 4) * (ws / 8) * (cout / (32 * nbk));
+                if (!scratch || scratch_bytes < slab + ncnt * sizeof(unsigned)) return fail(LSPF2F_ERR_STATE, "split-K scratch missing or too small");
+                q.partial = static_cast<float *>(scratch);
+                q.tile_cnt = reinterpret_cast<unsigned *>(static_cast<char *>(scratch) + slab);   // must be zero on entry; every launch leaves it zero
+            }
+            if (dtype != 0 || stride != 1 || !upsample || residual || hs != ws || !winoup_supported(q, nbk))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "the up-conv Winograd kernel does not support this shape");
+            e = launch_winoup(q, nbk, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (winoup) launch");
             return LSPF2F_OK;
         }
         if ((tile_m == 4001 || tile_m == 4002) && k_group == -1) {   // 4000 + nb: the Winograd kernel, w_packed in its fragment order; split_k = K splits (0: 1)

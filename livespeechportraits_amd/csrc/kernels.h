@@ -121,6 +121,26 @@ bool wino_supported(const WinoParams &p, int nb);
 hipError_t launch_wino(const WinoParams &p, int nb, hipStream_t s);
 void pack_wino_weights(const float *oihw, int cin, int cout, float *out);   // host: OIHW [cout][cin][3][3] -> [cout/32][4][cin/8][4][64][4]
 
+// Upsample(x2, nearest) + conv3x3 over the concat of two equally wide sources (or one) as a 9-multiply Winograd form (winoup.hip): fp32,
+// Hs % 4 == 0, Ws % 8 == 0, C0 % 8 == 0, C1 in {0, C0}, N % (32 * nb) == 0.  A workgroup (3 waves) owns 4 x 8 source pixels (8 x 16 output pixels) x
+// 32 nb channels; K may be split 2..8 ways, combined inside the launch.
+struct WinoUpParams {
+    const float *src0, *src1;     // NHWC [B][Hs][Ws][C0|C1]; src1 == nullptr when C1 == 0
+    const float *u;               // fragment order of pack_winoup_weights()
+    const float *scale, *shift;   // [N] folded BatchNorm, or nullptr
+    float *out;                   // NHWC [B][2Hs][2Ws][N]
+    float *partial;               // splits > 1: fp32 slabs [splits][B*4*Hs*Ws][N]
+    unsigned *tile_cnt;           // splits > 1: arrival counters, zero between launches
+    int B, Hs, Ws, C0, C1, N, relu, splits;
+    // filled by launch_winoup
+    int steps_per_split, ntb, nng, tby, tbx, nmajor;
+    size_t slab_bytes;
+    FastDiv div_plane, div_fast, div_tbf, div_tbx;
+};
+bool winoup_supported(const WinoUpParams &p, int nb);
+hipError_t launch_winoup(const WinoUpParams &p, int nb, hipStream_t s);
+void pack_winoup_weights(const float *oihw, int cin, int cout, float *out);   // host: OIHW -> [cout/32][3][cin/8][3][64][4]
+
 // Tiny-M single-source conv (M <= 16 output pixels, whole input <= 64 KB): one launch, no split-K.
 struct SmallMParams {
     const void *src;             // NHWC [B][Hs][Ws][Cin]            (fp32 or bf16, see dtype)

@@ -104,6 +104,26 @@ int wino_choice(int batch, int ho, int cin, int cout, int *splits_out)
     return nb;
 }
 
+int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out)
+{
+    // a workgroup = 32 source pixels (8 x 16 output pixels) x 32 nb channels; two channel blocks per wave whenever the layer is wide enough (a K-step
+    // is then 24 MFMAs per wave instead of 12), and K splits -- >= 8 eight-channel steps each -- until there are ~2 workgroups per CU
+    const long ntb = (long)batch * (hs / 4) * (hs / 8);
+    const int nb = cout % 64 == 0 ? 2 : 1;
+    const long wgs = ntb * (cout / (32 * nb));
+    const int steps = cin / 8;
+    int splits = 1;
+    if (wgs < 384) {
+        splits = (int)((512 + wgs - 1) / wgs);
+        splits = std::min(splits, std::min(8, std::max(1, steps / 8)));
+        const int per = (steps + splits - 1) / splits;
+        splits = (steps + per - 1) / per;
+    }
+    if (splits > 1 && wgs > (long)Plan::kTileCounters) return 0;
+    *splits_out = splits;
+    return nb;
+}
+
 static void level_channels(int depth, int ngf, int input_nc, int output_nc, int *cin, int *inner, int *cout)
 {
     // networks.py:557-570: innermost and the num_downs-5 middle blocks are ngf*8 -> ngf*8, then
@@ -290,6 +310,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wwg_off = (int64_t)off;
             off += (size_t)16 * l.cout * l.cin * sizeof(float);
         }
+        if (l.kind == kIgemm && winoup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
+            off = align_up(off, 256);
+            l.wwu_off = (int64_t)off;
+            off += (size_t)9 * l.cout * l.cin * sizeof(float);
+        }
         if (l.kind == kIgemm && rowup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wru_off = (int64_t)off;
@@ -402,6 +427,9 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             int wsplits = 1;
             const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
             if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
+            int usplits = 1;
+            const int winoup = (p.use_wino && p.use_winoup && l.wwu_off >= 0) ? winoup_choice(batch, l.hs, l.cin, l.cout, &usplits) : 0;
+            if (winoup) { bm = 32; bn = 32 * winoup; splits = usplits; group = 1; }
             const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho, l.c0) : 0;
             if (rowconv) { bm = (l.c0 == 64 ? 64 : 32) * rowconv; bn = l.c0; splits = 1; group = 1; }
             int rowup = p.use_rowup && l.wru_off >= 0 ? rowup_rows(batch, l.hs, l.hs) : 0;
@@ -431,7 +459,8 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             if (tiled) {
                 const long tiles = (long)(l.up4 ? 4 : 1) * ((M + bm - 1) / std::max(bm, 1)) * ((l.cout + bn - 1) / std::max(bn, 1));
                 (*tiled)[li].wino = wino;
-                (*tiled)[li].fused_splitk = wino ? splits > 1 : p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
+                (*tiled)[li].winoup = winoup;
+                (*tiled)[li].fused_splitk = (wino || winoup) ? splits > 1 : p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
                                             (size_t)splits * Mout * l.cout * sizeof(float) < (size_t)0x7fffffff;
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
                 (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv; (*tiled)[li].rowup = rowup;
@@ -506,6 +535,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
                                     dst[(((size_t)(py * 2 + px) * cout + co) * 4 + a * 2 + b) * cin + ci] = (float)acc;
                                 }
                         }
+            if (l.wwu_off >= 0) pack_winoup_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwu_off));
             if (last_as_gemm(l)) {
                 // the same pre-summed taps as one 3x3 conv on the LOW-res source: output channel par*cout + co, tap
                 // (a, b) of parity (py, px) sits at low-res offset (py - 1 + a, px - 1 + b); the other taps are zero

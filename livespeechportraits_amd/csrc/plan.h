@@ -48,6 +48,7 @@ struct LayerDesc {
     int64_t wru_off = -1;    // bf16 plans, sub-pixel up-conv over two 128-channel sources -> 64 channels (L1.up): weights in the fragment order of rowup256
     int64_t wrl_off = -1;    // bf16 plans, last conv over two 64-channel sources: the GEMM-form weights in the fragment order of rowlast128 (rowconv.hip)
     int64_t wwg_off = -1;    // fp32 plans, stride-1 single-source convs at >= 32x32: G g G^T in the fragment order of the Winograd kernel (wino.hip)
+    int64_t wwu_off = -1;    // fp32 plans, sub-pixel up-convs over two equally wide sources: the 9 transformed taps in the fragment order of winoup.hip
     int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
     int bm = 0, bn = 0, splits = 1, group = 1;   // group = K-tiles per pipeline step
@@ -59,6 +60,7 @@ struct LayerDesc {
     int rowup = 0;         // > 0: executed by rowup256 (rowconv.hip) with this many low-res rows per strip
     int rowconv = 0;       // > 0: executed by the weights-stationary 64 -> 64 bf16 kernel (rowconv.hip) with this many output rows per strip
     int wino = 0;          // > 0: executed by the Winograd F(2x2,3x3) kernel (wino.hip) with this many 32-channel blocks per wave (1 | 2); `splits` = its K splits
+    int winoup = 0;        // > 0: executed by the up-conv Winograd kernel (winoup.hip) with this many 32-channel blocks per wave; `splits` = its K splits
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
 };
 
@@ -85,6 +87,7 @@ struct Plan {
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
+    bool use_winoup = true;    // fp32 plans: sub-pixel up-convs on the up-conv Winograd kernel (LSP_HIP_WINOUP=0 at create: the implicit GEMM, A-B runs)
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
     size_t elt() const { return dtype ? 2 : 4; }
     int ktile_channels() const { return dtype ? 64 : 32; }   // a K-tile is 128 B of channels
@@ -181,6 +184,12 @@ inline bool wino_layer(int hs, int ho, int c0, int c1, int cout, int stride, boo
 }
 // per batch: 32-channel blocks per wave (0 = keep the implicit GEMM) and K splits
 int wino_choice(int batch, int ho, int cin, int cout, int *splits);
+// the up-conv form (winoup.hip): sub-pixel up-convs of fp32 BatchNorm plans whose two sources are equally wide
+inline bool winoup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm)
+{
+    return dtype == 0 && up4 && !inorm && (c1 == c0 || c1 == 0) && c0 % 8 == 0 && cout % 32 == 0 && hs % 8 == 0;
+}
+int winoup_choice(int batch, int hs, int cin, int cout, int *splits);
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 
 }  // namespace lspf2f

@@ -17,6 +17,7 @@
 // the output transform in registers, the row half across waves through an LDS patch.
 #include "device_common.h"
 #include "kernels.h"
+#include "wino_common.h"
 #include <cstdlib>
 
 namespace lspf2f {
@@ -49,19 +50,6 @@ __host__ __device__ constexpr int wino_lds_bytes(int nb, int ns)
     const int patch = 4 * 2 * nb * 32 * 36 * 4;             // epilogue: [wave][b][nb][32 tiles][36]
     return loop > patch ? loop : patch;
 }
-
-// two LDS-DMA pieces with unrelated LDS destinations, one descriptor and scalar offset (the raw patch: pieces w and w + 4, or the dump slot)
-__device__ __forceinline__ void dma16_two(unsigned lds_a, unsigned lds_b, unsigned va, unsigned vb, i32x4 srd, int soff)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "buffer_load_dwordx4 %3, %5, %6 offen lds\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "buffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_a), "s"(lds_b), "v"(va), "v"(vb), "s"(srd), "s"(soff) : "memory");
-}
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 // The K loop of one wave.  ROW = its row i of B^T d B: t = d[ra] (+|-) d[rb] per patch column, then the column transform.
 //   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3

@@ -678,3 +678,84 @@ def test_16bit_kernels_in_fp16_storage(kind, cfg, gpu_device):
     assert torch.isfinite(got).all()
     tol = (ref.abs() * 2.0 ** -11 + 3e-4)
     assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
+
+
+# ---- up-conv Winograd form (csrc/winoup.hip): Upsample x2 + conv3x3 over two equally wide sources, 9 multiplies per 2x2 outputs ------------
+def run_winoup(dev, x0, x1, w, scale, shift, relu, nb, splits):
+    import os
+    import sys
+    from livespeechportraits_amd import _native as N
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wino_model
+    lib = N.load()
+    b, c0, hs, _ = x0.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout = w.shape[0]
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    d0, d1 = nhwc(x0), nhwc(x1) if x1 is not None else None
+    wp = torch.from_numpy(wino_model.pack_u_up(w.numpy())).to(dev)            # the numpy statement of the layout, not the library's packer
+    dsc = scale.to(dev) if scale is not None else None
+    dsh = shift.to(dev) if shift is not None else None
+    out = torch.full((b, 2 * hs, 2 * hs, cout), float("nan"), device=dev)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, 1, 5000 + nb, 0, splits, -1, 0)
+    scratch = torch.zeros(max(sb, 4), dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(wp), p(dsc), p(dsh), None, p(out), b, hs, hs, c0, c1, cout, 1, 1, int(relu), 5000 + nb, 0, splits, -1, 0,
+                               p(scratch), scratch.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return out.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+WINOUP_CASES = [
+    # b, c0, c1, cout, hs, nb, splits, epilogue
+    (1, 16, 16, 32, 8, 1, 1, False),
+    (2, 32, 32, 64, 16, 2, 1, True),
+    (1, 24, 0, 32, 8, 1, 1, True),           # one source
+    (3, 40, 40, 96, 12, 1, 2, True),         # extents and channel counts that are no power of two; 10 K-steps in 2 slices
+    (1, 64, 64, 64, 16, 2, 4, True),
+    (1, 128, 128, 64, 128, 2, 1, True),      # the four shapes of the `large` plan at batch 1
+    (1, 256, 256, 128, 64, 2, 2, True),
+    (1, 512, 512, 256, 32, 2, 4, True),
+    (1, 512, 512, 512, 16, 2, 8, True),
+]
+
+
+@pytest.mark.parametrize("cfg", WINOUP_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_nb%d_s%d%s" % (c[:7] + ("_ep" if c[7] else "",)))
+def test_conv3x3_winograd_upconv(cfg, gpu_device):
+    """winoup3x3 against the fp64 reference (nearest x2 upsample, 3x3 conv over the channel concat, folded BN, ReLU), the sub-pixel implicit GEMM on
+    the same problem printed beside it."""
+    b, c0, c1, cout, hs, nb, splits, ep = cfg
+    g = torch.Generator().manual_seed(2000 + c0 + cout + hs)
+    x0 = torch.randn(b, c0, hs, hs, generator=g)
+    x1 = torch.randn(b, c1, hs, hs, generator=g) if c1 else None
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / (3.0 * (c0 + c1) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5 if ep else None
+    shift = torch.randn(cout, generator=g) * 0.1 if ep else None
+    ref = ref_conv(x0, x1, w, scale, shift, None, 1, True, ep).double()
+    ref = F.conv2d(F.interpolate((x0 if x1 is None else torch.cat([x0, x1], 1)).double(), scale_factor=2, mode="nearest"), w.double(), None, 1, 1)
+    if ep:
+        ref = torch.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    got = run_winoup(gpu_device, x0, x1, w, scale, shift, ep, nb, splits)
+    assert torch.isfinite(got).all(), "kernel left unwritten (NaN) outputs"
+    err = (got.double() - ref).abs().max().item()
+    direct = None
+    if (c0 % 32 == 0 and c1 % 32 == 0) and hs <= 32:
+        direct = (run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, ep).double() - ref).abs().max().item()
+    print("\nwinoup %s: max-abs %.2e (output range %.2f); sub-pixel implicit GEMM on the same problem: %s" % (
+        cfg, err, ref.abs().max().item(), "%.2e" % direct if direct is not None else "-"))
+    assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
+    if splits > 1:
+        assert torch.equal(got, run_winoup(gpu_device, x0, x1, w, scale, shift, ep, nb, splits))
+
+
+def test_conv3x3_winograd_upconv_impulse_layout(gpu_device):
+    """One-hot source pixel and one-hot tap: exactly the outputs of the upsampled convolution, on tile-block seams and borders."""
+    c, hs = 8, 16
+    for (ci, y, x_, co, ky, kx) in [(2, 3, 7, 5, 0, 2), (9, 4, 8, 31, 2, 0), (0, 0, 0, 0, 1, 1), (15, 15, 15, 17, 0, 0)]:
+        x0, x1 = torch.zeros(1, c, hs, hs), torch.zeros(1, c, hs, hs)
+        (x0 if ci < c else x1)[0, ci % c, y, x_] = 2.0
+        w = torch.zeros(32, 2 * c, 3, 3)
+        w[co, ci, ky, kx] = 3.0
+        exp = F.conv2d(F.interpolate(torch.cat([x0, x1], 1), scale_factor=2, mode="nearest"), w, None, 1, 1)
+        got = run_winoup(gpu_device, x0, x1, w, None, None, False, 1, 1)
+        assert torch.equal(got, exp), (ci, y, x_, co, ky, kx)

@@ -116,7 +116,7 @@ def test_pack_weights_matches_numpy_restatement():
         n = c.cin * c.cout
         if l["kernel"] == "first_conv":
             exp = w.transpose(1, 2, 3, 0).reshape(-1)                # [ci][ky][kx][co]
-        elif l["weight_bytes"] == 16 * n * 4 and not l["kernel"].startswith("wino3x3"):   # sub-pixel up-conv (incl. the last layer); the Winograd
+        elif (l["weight_bytes"] == 16 * n * 4 and not l["kernel"].startswith("wino3x3")) or l["kernel"].startswith("winoup3x3"):   # sub-pixel up-conv (incl. the last layer, and the up-convs that run on winoup3x3: their sub-pixel copy stays at w_offset); the Winograd
             # layers also read 16 values per (co, ci) but keep the 9-tap copy at w_offset (their G g G^T copy: tests/test_wino_cpu.py)
             seen_sub = True
             grp = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}

@@ -108,21 +108,73 @@ def test_winograd_kernel_instances_do_not_spill(tmp_path):
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = os.path.join(ROOT, "livespeechportraits_amd", "csrc", "wino.hip")
-    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage",
-                        "-c", src, "-o", str(tmp_path / "w.o")], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
-    blocks = re.split(r"remark: Function Name: ", p.stderr)[1:]
+    report = ""
+    for f in ("wino.hip", "winoup.hip"):
+        src = os.path.join(ROOT, "livespeechportraits_amd", "csrc", f)
+        p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage",
+                            "-c", src, "-o", str(tmp_path / "w.o")], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        report += p.stderr
+    blocks = re.split(r"remark: Function Name: ", report)[1:]
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        if "wino3x3" not in name:
+        if "wino3x3" not in name and "winoup3x3" not in name:
             continue
         seen += 1
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
-        nb = int(re.search(r"wino3x3ILi(\d)E", name).group(1))
+        nb = int(re.search(r"wino(?:up)?3x3ILi(\d)E", name).group(1))
         assert scratch == 0, (name, scratch)
         assert occ >= 2, (name, occ)          # two workgroups per CU share every SIMD (nb = 2: 79 KB of LDS each; nb = 1: up to three)
         assert nb in (1, 2)
-    assert seen >= 4
+    assert seen >= 6
+
+
+# ---- the up-conv form (csrc/winoup.hip): Upsample(x2, nearest) + Conv3x3 with 9 multiplies per 2x2 outputs ------------------------------
+def test_upconv_form_is_exact_and_its_data_flow_model_convolves():
+    """Row 2 of B^T d B vanishes on an upsampled patch (rows a, b, b, c): 9 of the 16 transformed positions carry everything."""
+    rng = np.random.default_rng(5)
+    s, g = rng.standard_normal((3, 3)), rng.standard_normal((3, 3))
+    m = [0, 1, 1, 2]
+    d = np.array([[s[m[a]][m[b]] for b in range(4)] for a in range(4)])           # the upsampled 4x4 patch under an even-aligned output tile
+    v = WM.BT @ d @ WM.BT.T
+    assert np.abs(v[2]).max() == 0 and np.abs(v[:, 2]).max() == 0
+    x0, x1 = rng.standard_normal((2, 4, 16, 8)), rng.standard_normal((2, 4, 16, 8))
+    w = rng.standard_normal((64, 16, 3, 3)).astype(np.float32)
+    ref = WM.upconv_direct(x0, x1, w)
+    assert np.abs(WM.upconv_model(x0, x1, WM.pack_u_up(w), 64) - ref).max() <= 1e-5 * np.abs(ref).max()
+    w1 = rng.standard_normal((32, 8, 3, 3)).astype(np.float32)                     # one source
+    ref1 = WM.upconv_direct(x0, None, w1)
+    assert np.abs(WM.upconv_model(x0, None, WM.pack_u_up(w1), 32) - ref1).max() <= 1e-5 * np.abs(ref1).max()
+
+
+def test_upconv_packer_and_planner():
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    topo, sd = synth.synthetic("normal", ngf=32, num_downs=5, size=128)
+    e = Engine("normal", ngf=32, num_downs=5, size=128, max_batch=2)
+    e.load_state_dict(sd)
+    blob = e.pack().numpy()
+    checked = 0
+    for l, c in zip(e.layers(1), topo.convs):
+        if not l["kernel"].startswith("winoup3x3"):
+            continue
+        cin, cout = l["cin"], l["cout"]
+        w = sd[c.weight_key]
+        exp = WM.pack_u_up(w)
+        off = (l["w_offset"] + cout * cin * 16 * 4 + 255) // 256 * 256              # behind the sub-pixel copy
+        got = blob[off: off + exp.size * 4].view(np.float32)
+        assert np.allclose(got, exp, rtol=3e-7, atol=1e-9) and (got == exp).mean() > 0.99, l["name"]
+        assert l["exec_flops_per_frame"] * 4 == l["flops_per_frame"] and l["weight_bytes"] == 9 * cin * cout * 4
+        checked += 1
+    assert checked >= 1
+    big = Engine("large", max_batch=8)
+    for batch in (1, 8):
+        ups = [l for l in big.layers(batch) if l["kernel"].startswith("winoup3x3")]
+        assert [l["name"] for l in ups] == ["L4.up", "L3.up", "L2.up", "L1.up"]        # the sub-pixel up-convs (>= 32x32 outputs); L5-L7.up stay 9-tap
+        for l in ups:
+            wgs = batch * (l["h_in"] // 4) * (l["h_in"] // 8) * (l["cout"] // l["tile_n"]) * l["split_k"]
+            assert wgs >= 384 and l["cin"] // 8 // l["split_k"] >= 8
+    assert not any(l["kernel"].startswith("winoup3x3") for l in Engine("large", dtype="bf16").layers(1))
+    e.close(); big.close()

@@ -106,6 +106,90 @@ def conv_model(x_nhwc, u_packed, n_out, scale=None, shift=None, residual=None, r
     return out
 
 
+# ---- Upsample(x2, nearest) + Conv3x3 as a 9-multiply Winograd form (csrc/winoup.hip) -------------------------------------------------
+# The 4x4 patch of the UPSAMPLED image under an (even-aligned) 2x2 output tile has rows (a, b, b, c) = source rows (y-1, y, y+1): row 2 of
+# B^T d B vanishes and rows 0, 1, 3 are a - b, 2b, b - c -- so a tile is one SOURCE pixel with its 3x3 neighbourhood, and only the 9 positions
+# (i, j) in {0, 1, 3}^2 of the transformed tile are multiplied.  The factors 2 are folded into the weights.
+UP_IDX = (0, 1, 3)
+UP_SCALE = {0: 1.0, 1: 2.0, 3: 1.0}
+
+
+def pack_u_up(w_oihw):
+    """numpy restatement of pack_winoup_weights(): OIHW [N][C][3][3] -> [N/32][xi-row 3][C/8][j 3][64 lanes][4], U' = c_i c_j (G g G^T)[i][j]"""
+    n_out, c_in = w_oihw.shape[:2]
+    u = np.einsum("ia,ncab,jb->ijcn", G, w_oihw.astype(np.float64), G)
+    out = np.zeros((n_out // 32, 3, c_in // 8, 3, 64, 4), np.float32)
+    lane = np.arange(64)
+    for wi, i in enumerate(UP_IDX):
+        for wj, j in enumerate(UP_IDX):
+            for t in range(4):
+                ch = 4 * (lane >> 5) + t
+                for s in range(c_in // 8):
+                    for nb in range(n_out // 32):
+                        out[nb, wi, s, wj, :, t] = UP_SCALE[i] * UP_SCALE[j] * u[i, j, 8 * s + ch, 32 * nb + (lane & 31)]
+    return out.reshape(-1)
+
+
+def upconv_model(x0, x1, u_packed, n_out):
+    """lane-level model of winoup3x3: x0 / x1 NHWC sources (x1 may be None), output [B][2H][2W][n_out]"""
+    B, H, W, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    C = C0 + C1
+    assert H % 4 == 0 and W % 8 == 0 and C0 % 8 == 0 and C1 % 8 == 0 and n_out % 32 == 0
+    U = u_packed.reshape(n_out // 32, 3, C // 8, 3, 64, 4).astype(np.float64)
+    out = np.zeros((B, 2 * H, 2 * W, n_out))
+    lane = np.arange(64)
+    r, q = lane & 31, lane >> 5
+    ty, tx = r >> 3, r & 7
+    for b in range(B):
+        for by in range(H // 4):
+            for bx in range(W // 8):
+                Y0, X0 = 4 * by, 8 * bx
+                for nblk in range(n_out // 32):
+                    acc = np.zeros((3, 3, 32, 32))
+                    for s in range(C // 8):
+                        src, c0 = (x0, 8 * s) if 8 * s < C0 else (x1, 8 * s - C0)
+                        lds = np.zeros((128, 4))                                    # chunk = (q*6 + py)*10 + px
+                        for ci in range(120):
+                            qq, rem = divmod(ci, 60)
+                            py, px = divmod(rem, 10)
+                            y, x = Y0 - 1 + py, X0 - 1 + px
+                            if 0 <= y < H and 0 <= x < W:
+                                lds[ci] = src[b, y, x, c0 + 4 * qq: c0 + 4 * qq + 4]
+                        rd = lambda dy, dx: lds[(q * 6 + ty + dy) * 10 + tx + dx]
+                        for w in range(3):                                          # wave = xi-row index UP_IDX[w]
+                            if w == 0:
+                                T = [rd(0, dx) - rd(1, dx) for dx in range(3)]
+                            elif w == 1:
+                                T = [rd(1, dx) for dx in range(3)]
+                            else:
+                                T = [rd(1, dx) - rd(2, dx) for dx in range(3)]
+                            v = [T[0] - T[1], T[1], T[1] - T[2]]
+                            for j in range(3):
+                                ufrag = U[nblk, w, s, j]
+                                for tt in range(4):
+                                    A = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+                                    A[r, q] = v[j][:, tt]; Bm[q, r] = ufrag[:, tt]
+                                    acc[w, j] += A @ Bm
+                    z = np.zeros((3, 2, 32, 32))
+                    for w in range(3):
+                        z[w, 0] = acc[w, 0] + acc[w, 1]
+                        z[w, 1] = acc[w, 1] - acc[w, 2]
+                    for row in range(32):
+                        tty, ttx = row >> 3, row & 7
+                        for bcol in range(2):
+                            oy, ox = 2 * (Y0 + tty), 2 * (X0 + ttx) + bcol
+                            out[b, oy, ox, 32 * nblk: 32 * nblk + 32] = z[0, bcol, row] + z[1, bcol, row]
+                            out[b, oy + 1, ox, 32 * nblk: 32 * nblk + 32] = z[1, bcol, row] - z[2, bcol, row]
+    return out
+
+
+def upconv_direct(x0, x1, w_oihw):
+    x = x0 if x1 is None else np.concatenate([x0, x1], 3)
+    up = x.repeat(2, axis=1).repeat(2, axis=2)
+    return conv_direct(up, w_oihw)
+
+
 def conv_direct(x_nhwc, w_oihw):
     B, H, W, C = x_nhwc.shape
     xp = np.zeros((B, H + 2, W + 2, C)); xp[:, 1:-1, 1:-1] = x_nhwc
@@ -123,3 +207,6 @@ if __name__ == "__main__":
     got = conv_model(x, pack_u(w), 64)
     ref = conv_direct(x, w)
     print("max abs diff", np.abs(got - ref).max(), "of", np.abs(ref).max())
+    x0, x1 = rng.standard_normal((1, 4, 16, 8)), rng.standard_normal((1, 4, 16, 8))
+    w2 = rng.standard_normal((32, 16, 3, 3)).astype(np.float32)
+    print("up-conv max abs diff", np.abs(upconv_model(x0, x1, pack_u_up(w2), 32) - upconv_direct(x0, x1, w2)).max())
