@@ -103,6 +103,8 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_ROWLAST")) h->plan.use_rowlast = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_WINO")) h->plan.use_wino = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_WINOUP")) h->plan.use_winoup = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_WINOUP_NB")) h->plan.winoup_nb = std::atoi(env);
+    if (const char *env = std::getenv("LSP_HIP_WINOUP_TARGET")) h->plan.winoup_target = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;

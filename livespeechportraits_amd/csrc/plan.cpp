@@ -104,17 +104,17 @@ int wino_choice(int batch, int ho, int cin, int cout, int *splits_out)
     return nb;
 }
 
-int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out)
+int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out, int force_nb, int target)
 {
     // a workgroup = 32 source pixels (8 x 16 output pixels) x 32 nb channels; two channel blocks per wave whenever the layer is wide enough (a K-step
     // is then 24 MFMAs per wave instead of 12), and K splits -- >= 8 eight-channel steps each -- until there are ~2 workgroups per CU
     const long ntb = (long)batch * (hs / 4) * (hs / 8);
-    const int nb = cout % 64 == 0 ? 2 : 1;
+    const int nb = force_nb ? force_nb : (cout % 64 == 0 ? 2 : 1);
     const long wgs = ntb * (cout / (32 * nb));
     const int steps = cin / 8;
     int splits = 1;
-    if (wgs < 384) {
-        splits = (int)((512 + wgs - 1) / wgs);
+    if (wgs < target * 3 / 4) {
+        splits = (int)((target + wgs - 1) / wgs);
         splits = std::min(splits, std::min(8, std::max(1, steps / 8)));
         const int per = (steps + splits - 1) / splits;
         splits = (steps + per - 1) / per;
@@ -428,7 +428,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
             if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
             int usplits = 1;
-            const int winoup = (p.use_wino && p.use_winoup && l.wwu_off >= 0) ? winoup_choice(batch, l.hs, l.cin, l.cout, &usplits) : 0;
+            const int winoup = (p.use_wino && p.use_winoup && l.wwu_off >= 0) ? winoup_choice(batch, l.hs, l.cin, l.cout, &usplits, p.winoup_nb, p.winoup_target) : 0;
             if (winoup) { bm = 32; bn = 32 * winoup; splits = usplits; group = 1; }
             const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho, l.c0) : 0;
             if (rowconv) { bm = (l.c0 == 64 ? 64 : 32) * rowconv; bn = l.c0; splits = 1; group = 1; }

@@ -711,7 +711,7 @@ WINOUP_CASES = [
     (1, 16, 16, 32, 8, 1, 1, False),
     (2, 32, 32, 64, 16, 2, 1, True),
     (1, 24, 0, 32, 8, 1, 1, True),           # one source
-    (3, 40, 40, 96, 12, 1, 2, True),         # extents and channel counts that are no power of two; 10 K-steps in 2 slices
+    (3, 40, 40, 96, 24, 1, 2, True),         # extents and channel counts that are no power of two; 10 K-steps in 2 slices
     (1, 64, 64, 64, 16, 2, 4, True),
     (1, 128, 128, 64, 128, 2, 1, True),      # the four shapes of the `large` plan at batch 1
     (1, 256, 256, 128, 64, 2, 2, True),
