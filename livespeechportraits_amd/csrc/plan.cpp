@@ -106,10 +106,12 @@ int wino_choice(int batch, int ho, int cin, int cout, int *splits_out)
 
 int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out, int force_nb, int target)
 {
-    // a workgroup = 32 source pixels (8 x 16 output pixels) x 32 nb channels; two channel blocks per wave whenever the layer is wide enough (a K-step
-    // is then 24 MFMAs per wave instead of 12), and K splits -- >= 8 eight-channel steps each -- until there are ~2 workgroups per CU
+    // a workgroup = 32 source pixels (8 x 16 output pixels) x 32 nb channels, THREE waves: two such workgroups leave a CU's four SIMDs with 2, 2, 1, 1
+    // waves, four give every SIMD three.  So: one channel block per wave (115 registers, 28 KB of LDS: five fit) and K splits -- >= 8 eight-channel
+    // steps each -- until there are ~4 workgroups per CU.  Measured, `large` fp32 (A-B-A-B, one session): nb 1 / 1024 workgroups 610.6 frames/s,
+    // nb 1 / 512 605.6, nb 2 / 512 602.5, nb 2 / 1024 580.8, nb 1 / 1536 602.0, nb 1 / 2048 599.8; batch 8: nb 1 967.4, nb 2 945.8
     const long ntb = (long)batch * (hs / 4) * (hs / 8);
-    const int nb = force_nb ? force_nb : (cout % 64 == 0 ? 2 : 1);
+    const int nb = force_nb ? force_nb : 1;
     const long wgs = ntb * (cout / (32 * nb));
     const int steps = cin / 8;
     int splits = 1;

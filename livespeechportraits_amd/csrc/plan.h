@@ -87,7 +87,7 @@ struct Plan {
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
-    int winoup_nb = 0, winoup_target = 512;   // tools (LSP_HIP_WINOUP_NB / _TARGET at create): force the channel blocks per wave / the workgroup count aimed at
+    int winoup_nb = 0, winoup_target = 1024;   // tools (LSP_HIP_WINOUP_NB / _TARGET at create): force the channel blocks per wave / the workgroup count aimed at
     bool use_winoup = true;    // fp32 plans: sub-pixel up-convs on the up-conv Winograd kernel (LSP_HIP_WINOUP=0 at create: the implicit GEMM, A-B runs)
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
     size_t elt() const { return dtype ? 2 : 4; }
@@ -190,7 +190,7 @@ inline bool winoup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, 
 {
     return dtype == 0 && up4 && !inorm && (c1 == c0 || c1 == 0) && c0 % 8 == 0 && cout % 32 == 0 && hs % 8 == 0;
 }
-int winoup_choice(int batch, int hs, int cin, int cout, int *splits, int force_nb = 0, int target = 512);
+int winoup_choice(int batch, int hs, int cin, int cout, int *splits, int force_nb = 0, int target = 1024);
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 
 }  // namespace lspf2f
