@@ -230,8 +230,12 @@ def main():
     family = "wino3x3" if dom["kernel"].startswith("wino3x3") else dom["kernel"].split("<")[0]
     if a.size == 512 and os.path.exists(pmc_path):
         pj = json.load(open(pmc_path))
+        exact = pj["per_forward_bytes"].get(dom["kernel"])          # per template instance where the summary has it (wino3x3<1> / <2>)
         fam = pj["per_forward_bytes"].get(family)
-        if fam:
+        if exact and (exact["fetch_x2"] + exact["write"]) > 0:
+            traffic = int(exact["fetch_x2"] + exact["write"])
+            traffic_src = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE of the %s launches of one forward, rocprofv3 --pmc, separate passes)" % (os.path.basename(pmc_path), dom["kernel"])
+        elif fam:
             # the PMC families are per kernel NAME (all template instances together); scaled to the dominant class by its share of the family's
             # algorithmic bytes when the family has more than one class in this plan
             fam_bytes = sum(r["bytes"] for r in table if r["kernel"].startswith(family))

@@ -1,6 +1,6 @@
 // gfx950 (MI355X / CDNA4): Upsample(x2, nearest) + Conv3x3 (+ folded BatchNorm, ReLU) over the never-materialised concat of two sources, as a
 // Winograd form with 9 multiplies per 2x2 output tile -- against 16 in the sub-pixel form of igemm.hip and 36 in the literal one.
-// fp32 in, fp32 accumulate.  See DESIGN.md section 4.10.
+// fp32 in, fp32 accumulate.  See DESIGN.md section 4.9.
 //
 // Reference semantics: the up side of a skip block, models/networks.py:610-611 / :617-618 / :626-627 (nn.Upsample(scale_factor=2, 'nearest') -> Conv2d
 // 3x3 pad 1 over cat([x, model(x)], 1), :646) followed by BatchNorm2d (eval) and ReLU (:619-620, :628-629).

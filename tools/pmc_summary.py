@@ -45,8 +45,8 @@ def main():
     print("# total per forward: fetch %.1f MB (x2 %.1f MB), write %.1f MB" % (tot_f, 2 * tot_f, tot_w))
     if a.json:
         import json
-        fam = {"conv_family": ("igemm3x3", "wino3x3", "splitk_reduce", "conv3x3_smallm", "conv3x3_fullk", "rowconv", "rowup", "bandconv"), "igemm3x3": ("igemm3x3",),
-               "wino3x3": ("wino3x3",), "rowconv": ("rowconv", "rowup"), "bandconv": ("bandconv",),
+        fam = {"conv_family": ("igemm3x3", "wino3x3", "winoup3x3", "splitk_reduce", "conv3x3_smallm", "conv3x3_fullk", "rowconv", "rowup", "bandconv"), "igemm3x3": ("igemm3x3",),
+               "wino3x3": ("wino3x3",), "wino3x3<1>": ("wino3x3<1,",), "wino3x3<2>": ("wino3x3<2,",), "winoup3x3": ("winoup3x3",), "rowconv": ("rowconv", "rowup"), "bandconv": ("bandconv",),
                "splitk_reduce": ("splitk_reduce",), "conv3x3_fullk": ("conv3x3_fullk",), "conv3x3_smallm": ("conv3x3_smallm",),
                "first_conv": ("first_conv",), "last_conv": ("last_conv", "pixel_shuffle", "rowlast")}
         out = {}
