@@ -48,9 +48,10 @@ struct lspf2f_handle {
     bool packed = false;
     bool use_graph = true;
     bool last_direct = false;     // bf16 plans: direct last-conv kernel instead of the GEMM form (LSP_HIP_LASTCONV_DIRECT, read at create)
+    bool prefetch = true;         // LSP_HIP_PREFETCH=0 (read at create): weight-streaming layers do not request the next launch's weights
     bool fuse_splitk = true;      // LSP_HIP_FUSED_SPLITK=0 (read at create): always combine split-K slabs with a separate launch
     bool counters_clean = false;  // the arrival counters at the head of the workspace were zeroed since it was bound
-    bool first_direct = false;    // LSP_HIP_FIRSTCONV_DIRECT (read at create): vector-ALU first conv instead of the matrix-core kernel
+    int first_direct = 0;         // LSP_HIP_FIRSTCONV_DIRECT (read at create): 1 = vector-ALU first conv; LSP_HIP_FIRSTCONV_REGSTAGE: 2 = register-staged matrix-core kernel
     int timing_part = 3;          // lspf2f_subset_timed: 1 = main kernels only, 2 = split-K reduce only, 3 = everything (always 3 on the hot path)
     int last_route = 0;           // forced direct last-conv kernel (LSP_HIP_LASTCONV_{STRIP,ROWS,GENERIC}, read at create; tests only)
     const void *cand_cached = nullptr;   // candidate stack whose first-conv contribution sits in the workspace cache
@@ -111,10 +112,11 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     // environment switches are read HERE, once per handle, never on the launch path
     if (const char *env = std::getenv("LSP_HIP_GRAPH")) h->use_graph = h->use_graph && std::strcmp(env, "0") != 0;
     h->last_direct = std::getenv("LSP_HIP_LASTCONV_DIRECT") != nullptr;
-    h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") != nullptr;
+    h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") ? 1 : std::getenv("LSP_HIP_FIRSTCONV_REGSTAGE") ? 2 : 0;
     if (const char *env = std::getenv("LSP_HIP_FUSED_SPLITK")) h->fuse_splitk = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_PREFETCH")) h->prefetch = std::strcmp(env, "0") != 0;
     h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
-                  : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : 0;
+                  : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : std::getenv("LSP_HIP_LASTCONV_VALU") ? 5 : 0;
     *out = h;
     return LSPF2F_OK;
 }
@@ -293,7 +295,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         // two slots at the head of the workspace: [0] lspf2f_set_candidates' per-person cache, [1] the per-forward share of a
         // broadcast stack -- separate, so a broadcast forward never overwrites what the cache holds
         float *cache = reinterpret_cast<float *>(cand != nullptr ? h->ws + P.cand_cache_bytes() : h->ws);
-        p.force_direct = h->first_direct ? 1 : 0;
+        p.force_direct = h->first_direct;
         // a candidate stack shared by a batch (cand_batch == 1, batch > 1): its 12-channel share is computed once (matrix-core kernel,
         // channel range) and every frame adds its feature-map channel in a streaming pass -- measured 77 us vs 150 us at batch 8 for
         // running the full 13-channel layer per frame
@@ -352,6 +354,15 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.Cin = l.cin; p.Cout = l.cout;
         p.stride = l.stride; p.up = l.up; p.relu = l.inorm ? 0 : l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
+        if (h->prefetch && P.dtype == 0 && !l.inorm) {
+            // the next launch, if it is another weight-streaming layer: its weights are requested from inside this one
+            const size_t li = (size_t)(&l - P.layers.data());
+            if (li + 1 < P.layers.size()) {
+                const LayerDesc &n = P.layers[li + 1];
+                const int64_t off = n.smallm ? n.w_off : n.fullk ? n.wfk_off : -1;
+                if (off >= 0 && n.kind == kIgemm) { p.pf = h->blob + off; p.pf_bytes = (unsigned)((size_t)n.cout * 9 * n.cin * sizeof(float)); }
+            }
+        }
         e = launch_smallm(p, s);
         if (e == hipSuccess && l.inorm) {          // raw conv output (+ bias) -> statistics + normalisation (+ residual, ReLU) in one launch
             InstNormParams q{};
@@ -580,7 +591,7 @@ int lspf2f_set_candidates(lspf2f_handle *h, const float *cand_dev, void *hip_str
     c.out = reinterpret_cast<float *>(h->ws);
     c.B = 1; c.H = l.hs; c.W = l.hs; c.feat_nc = P.feat_nc; c.cand_nc = P.input_nc - P.feat_nc; c.cand_batch = 1;
     c.Cout = l.cout; c.ci_begin = P.feat_nc; c.ci_end = P.input_nc; c.base = nullptr; c.relu = 0;
-    c.force_direct = h->first_direct ? 1 : 0;
+    c.force_direct = h->first_direct;
     const hipError_t e = launch_first_conv(c, static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return hipfail(e, "lspf2f_set_candidates launch");
     h->cand_cached = cand_dev;

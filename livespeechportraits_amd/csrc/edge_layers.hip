@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace lspf2f {
 
@@ -285,6 +286,162 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FirstConvParams p)
     }
 }
 
+
+// The same layer with both operands staged by LDS-DMA (the shape feature2face_G.py builds: 1 feature-map channel + 12 candidate channels,
+// W % 128 == 0, H % 4 == 0, Cout = 32 NH).  The kernel above spends ~1550 vector instructions per thread on staging (address arithmetic, 59
+// loads into registers, 59 LDS writes) before its first MFMA; here a thread issues 17 copies and nothing passes through registers:
+//   * the window is kept in 16-byte columns, x = 2 ox0 - 4 .. 2 ox0 + 127 (33 float4 per line: every global read is aligned, the left pad of
+//     the first tile column and the rows above / below the image are out-of-range copies, which land as zeros), as two runs of whole 1-KB
+//     pieces -- feature-map lines (5 x 33 slots in 3 pieces), candidate lines (60 x 33 slots in 31 pieces) -- because a piece has ONE
+//     descriptor and the two tensors are separate allocations;
+//   * the weights [117][N] are 30 pieces of the blob as it lies; rows outside [ci_begin, ci_end) and the pad row 117 are out-of-range lanes;
+//   * piece P = 4 j + wave, so the window lands in channel order and the K loop starts on channels 0..3 while 4..8 and 9..12 are still in
+//     flight (three counted waits + barriers instead of one);
+//   * epilogue addresses are one base pointer + compile-time offsets.
+template <typename T, int NH>
+__global__ __launch_bounds__(256) void first_conv_dma(const FirstConvParams p)
+{
+    constexpr int CIN = 13, KS = (CIN * 9 + 1) / 2;          // 59 K steps of 2
+    constexpr int LW = 132;                                   // floats per window line (33 float4)
+    constexpr int N = NH * 32;
+    constexpr int WPIECES = (118 * N * 4 + 1023) / 1024;      // weight pieces (30 at N = 64)
+    constexpr int WJ = (WPIECES + 3) / 4;                     // per wave
+    constexpr int FPIECES = 3, CPIECES = 31, XJ = 9;          // window pieces: 3 + 31 = 34 -> 9 per wave (the last two are dummies)
+    constexpr int WIN0 = WPIECES * 1024;                      // LDS byte offset of the window
+    constexpr int DUMP = WIN0 + (FPIECES + CPIECES) * 1024;   // 1 KB: where the dummy pieces of waves that have fewer real ones go
+    constexpr int CAND0 = FPIECES * 256;                      // float offset of the candidate lines inside the window
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)sm;
+    const float *wl = sm;                                     // [118][N]
+    const float *win = sm + WIN0 / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const int tiles_x = Wo / 64, tiles_y = Ho / 2;
+    int t = blockIdx.x;
+    const int b = t / (tiles_x * tiles_y);
+    t -= b * tiles_x * tiles_y;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * 2, ox0 = tx * 64;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- weights
+    {
+        const i32x4 srd = make_srd(p.w, (unsigned)(117 * N * 4));
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int P = 4 * j + wave;
+            const int slot = 64 * P + lane, k = (slot * 4) / N, ci = k / 9;
+            const bool ok = P < WPIECES && k < CIN * 9 && ci >= p.ci_begin && ci < p.ci_end;
+            const unsigned voff[1] = {ok ? (unsigned)slot * 16u : OOB};
+            dma16_group<1, 0>(lds0 + (unsigned)(P < WPIECES ? P * 1024 : DUMP), voff, srd, 0);
+        }
+    }
+    // ---- window
+    {
+        const size_t plane = (size_t)p.H * p.W;
+        const i32x4 srd_f = make_srd(p.feat + (size_t)b * p.feat_nc * plane, (unsigned)(plane * 4));
+        const i32x4 srd_c = make_srd(p.cand ? p.cand + (size_t)(p.cand_batch == 1 ? 0 : b) * p.cand_nc * plane : p.feat, (unsigned)(p.cand ? 12 * plane * 4 : 0));
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int P = 4 * j + wave;
+            const bool isf = P < FPIECES;                                        // wave-uniform
+            const int s = isf ? 64 * P + lane : 64 * (P - FPIECES) + lane;
+            const int q = s / 33, c4 = s - q * 33;
+            const int cl = isf ? 0 : q / 5, r = isf ? q : q - cl * 5;            // channel inside its tensor, window row
+            const int ci = isf ? 0 : 1 + cl;
+            const int iy = 2 * oy0 - 1 + r, x0 = 2 * ox0 - 4 + 4 * c4;
+            const bool ok = P < FPIECES + CPIECES && s < (isf ? 5 * 33 : 60 * 33) && ci >= p.ci_begin && ci < p.ci_end &&
+                            (unsigned)iy < (unsigned)p.H && x0 >= 0;
+            const unsigned voff[1] = {ok ? (unsigned)(((cl * p.H + iy) * p.W + x0) * 4) : OOB};
+            const unsigned dst = lds0 + (unsigned)(P < FPIECES + CPIECES ? WIN0 + P * 1024 : DUMP);
+            if (isf) dma16_group<1, 0>(dst, voff, srd_f, 0);
+            else dma16_group<1, 0>(dst, voff, srd_c, 0);
+        }
+    }
+
+    // wave -> 32 pixels: output row oy0 + (wave >> 1), columns ox0 + 32 (wave & 1) + m
+    const int m = lane & 31, kp = lane >> 5;
+    const int orow = wave >> 1, ocol = 32 * (wave & 1) + m;
+    const float *abase = win + (2 * orow) * LW + 2 * ocol + 3;       // + line(ci, ky) * LW + kx; column 3 of the window is x = 2 ox0 - 1
+    f32x16 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+    auto a_off = [&](int s2) {
+        auto off = [](int k) { const int ci = k / 9, tap = k % 9; return (ci == 0 ? 0 : CAND0 + (ci - 1) * 5 * LW) + (tap / 3) * LW + tap % 3; };
+        const int k0 = 2 * s2, k1 = 2 * s2 + 1;
+        const int o0 = off(k0), o1 = k1 < CIN * 9 ? off(k1) : 0;   // k = 117: the weight row is zero
+        return kp ? o1 : o0;
+    };
+    // K steps [S0, S1): operands of step s + 1 are read before the MFMAs of step s are issued, inside the range only (what lies past it may
+    // not have landed yet)
+    auto ksteps = [&](auto s0c, auto s1c) {
+        constexpr int S0 = decltype(s0c)::value, S1 = decltype(s1c)::value;
+        float a_cur = abase[a_off(S0)], a_nxt = 0.f;
+        float b_cur[NH], b_nxt[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { b_cur[h] = wl[(2 * S0 + kp) * N + h * 32 + m]; b_nxt[h] = 0.f; }
+#pragma unroll
+        for (int s2 = S0; s2 < S1; ++s2) {
+            if (s2 + 1 < S1) {
+                a_nxt = abase[a_off(s2 + 1)];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) b_nxt[h] = wl[(2 * (s2 + 1) + kp) * N + h * 32 + m];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[h], acc[h], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) b_cur[h] = b_nxt[h];
+        }
+    };
+    // window pieces of a wave land in issue order: j <= 2 covers channels 0..3 (slots < 12 * 64), j <= 5 channels 0..8, j <= 8 everything
+    dma_wait<6>();
+    __syncthreads();
+    ksteps(std::integral_constant<int, 0>{}, std::integral_constant<int, 18>{});       // k < 36
+    dma_wait<3>();
+    __syncthreads();
+    ksteps(std::integral_constant<int, 18>{}, std::integral_constant<int, 40>{});      // k < 80 (k = 80 is the last tap of channel 8: next range)
+    dma_wait<0>();
+    __syncthreads();
+    ksteps(std::integral_constant<int, 40>{}, std::integral_constant<int, KS>{});
+
+    // epilogue: C/D layout row (pixel) = (r & 3) + 8 (r >> 2) + 4 kp, col (channel) = m
+    const int oy = oy0 + orow;
+    T *ob = static_cast<T *>(p.out) + (((size_t)b * Ho + oy) * Wo + ox0 + 32 * (wave & 1) + 4 * kp) * N + m;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float bias = p.bias ? p.bias[h * 32 + m] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[h][r] + bias;
+            if (p.relu) v = fmaxf(v, 0.f);
+            st1(ob + ((r & 3) + 8 * (r >> 2)) * N + h * 32, v);
+        }
+    }
+}
+
+template <typename T, int NH>
+static hipError_t launch_first_conv_dma(const FirstConvParams &p, hipStream_t s)
+{
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const long tiles = (long)p.B * (Wo / 64) * (Ho / 2);
+    const size_t smem = (size_t)((118 * NH * 32 * 4 + 1023) / 1024 + 34 + 1) * 1024;
+    static AttrMask attr_mask;
+    if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&first_conv_dma<T, NH>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    hipLaunchKernelGGL((first_conv_dma<T, NH>), dim3((unsigned)tiles), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
 template <typename T, int NH>
 static hipError_t launch_first_conv_mfma(const FirstConvParams &p, hipStream_t s)
 {
@@ -318,8 +475,14 @@ hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
     // matrix-core form: no partial sums to start from, 13 input channels (the only count feature2face_G.py builds), Cout a multiple
     // of 32 up to 128; bf16 output only for the layer itself (the candidate cache is fp32)
     const bool cache_pass = p.relu == 0 && p.base == nullptr && p.ci_begin > 0;
-    if (!p.base && !p.force_direct && p.feat_nc + p.cand_nc == 13 && (p.Cout == 32 || p.Cout == 64 || p.Cout == 128)) {
+    if (!p.base && p.force_direct != 1 && p.feat_nc + p.cand_nc == 13 && (p.Cout == 32 || p.Cout == 64 || p.Cout == 128)) {
         const int st = cache_pass ? 0 : p.dtype;            // storage type of what this pass writes
+        // both operands by LDS-DMA for the shape the reference builds (force_direct == 2: the register-staged kernel, A-B runs)
+        if (p.force_direct != 2 && p.feat_nc == 1 && p.cand_nc == 12 && p.W % 128 == 0 && p.H % 4 == 0 && p.Cout <= 64 &&
+            (size_t)12 * p.H * p.W * 4 < 0x80000000ull) {
+            if (p.Cout == 32) return st == 2 ? launch_first_conv_dma<f16_t, 1>(p, s) : st == 1 ? launch_first_conv_dma<bf16_t, 1>(p, s) : launch_first_conv_dma<float, 1>(p, s);
+            return st == 2 ? launch_first_conv_dma<f16_t, 2>(p, s) : st == 1 ? launch_first_conv_dma<bf16_t, 2>(p, s) : launch_first_conv_dma<float, 2>(p, s);
+        }
         switch (p.Cout / 32) {
         case 1: return st == 2 ? launch_first_conv_mfma<f16_t, 1>(p, s) : st == 1 ? launch_first_conv_mfma<bf16_t, 1>(p, s) : launch_first_conv_mfma<float, 1>(p, s);
         case 2: return st == 2 ? launch_first_conv_mfma<f16_t, 2>(p, s) : st == 1 ? launch_first_conv_mfma<bf16_t, 2>(p, s) : launch_first_conv_mfma<float, 2>(p, s);
@@ -658,6 +821,238 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Last layer on the matrix cores (fp32 plans, C0 == C1 == 64, Cout <= 4).  The vector-ALU kernels above re-read the 96 pre-summed weight
+// vectors from LDS for every source pixel (the LDS pipe, not the ALU, bounds them: 185 us at batch 8, 36 us at batch 1).  Here the weights are a
+// matrix operand.  v_mfma_f32_4x4x1_16b_f32 is 16 independent 4x4x1 products per instruction: block = (pixel group g of 4 neighbouring source
+// pixels, output parity) -- rows = the group's 4 pixels, columns = the 3 output channels (+1 idle), K = one (tap, input channel) of that
+// parity's 2x2 neighbourhood -- so a wave instruction advances 16 source pixels x 4 parities by one K step and only 1/4 of the columns idle,
+// against 13/16 (N = 3 of 16) for the 16x16 shapes.  4 taps x 128 channels = 512 K steps per 16 pixels, 8 cycles each: 55 us of matrix time at
+// batch 8, 7 us at batch 1, next to 42 / 5 us of HBM time for the 268 / 33.5 MB read once.
+//   * workgroup = 8 x 32 source pixels; its 10 x 34 pixel halo tile is staged by LDS-DMA 32 channels at a time (4 stages: source 0 | 1, lower |
+//     upper half), 128 B per pixel, two buffers.  Image borders are out-of-range copies (zeros).  A pixel's eight 16-byte quads are stored at slot
+//     q ^ ((p >> 1) & 7) (p = pixel index in the tile, 40 per row): an A read is 16 lanes x 16 B of 16 DIFFERENT pixels at the same quad, and with
+//     the swizzle and the row pitch of 40 (= 8 mod 16) every ds_read_b128 lane group lands on 16 distinct bank slots (tools/lastconv_model.py
+//     checks all of them).  The swizzle is applied on the global side of the copy, where it permutes 16-byte pieces inside one 128-byte run.
+//   * wave = 2 x 32 pixels = 4 MFMA tiles of 16; one B read (the weights of (parity, channel), broadcast over the 4 groups) serves the 4 tiles:
+//     5 ds_read_b128 per 16 MFMAs.  Weights sit in LDS as [parity * 4 + channel][tap][128] with a row pitch of 516 floats (16 rows -> 16 bank slots).
+//   * the accumulators (4 registers per tile: the group's 4 pixels) go through LDS once more so that the NCHW fp32 rows and the HWC uint8 rows
+//     leave as full 16-byte / 4-byte coalesced stores; tanh and tensor2im as in the other kernels.
+__global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, int ntiles)
+{
+    constexpr int WP = 40;                                    // staged pixels per tile row (34 used)
+    constexpr int LWB = 16 * 516 * 4;                         // weight bytes in LDS
+    constexpr int STG = 10 * WP * 128;                        // one stage buffer
+    constexpr int OTB = LWB + 2 * STG;                        // output tile [4][16][68] floats
+    constexpr int DUMP = OTB + 4 * 16 * 68 * 4;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)sm;
+    const char *smc = reinterpret_cast<const char *>(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = p.Ws >> 5, tiles_y = p.Hs >> 3;
+    const size_t frame = (size_t)p.Hs * p.Ws * 64;
+    const int H = 2 * p.Hs, W = 2 * p.Ws;
+
+    // ---- weights, once per workgroup: row (parity, n) = 512 floats = two 1-KB pieces; rows n >= Cout are out of range (zeros)
+    {
+        const i32x4 srd = make_srd(p.w, (unsigned)(4 * p.Cout * 512 * 4));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int Wp = 4 * j + wave, row = Wp >> 1, par = row >> 2, n = row & 3;
+            const unsigned voff[1] = {n < p.Cout ? (unsigned)((((par * p.Cout + n) * 512) + (Wp & 1) * 256 + lane * 4) * 4) : OOB};
+            dma16_group<1, 0>(lds0 + (unsigned)(row * 2064 + (Wp & 1) * 1024), voff, srd, 0);
+        }
+    }
+    // ---- stage copies of one tile: piece I = 8 consecutive tile pixels (row I / 5, columns 8 (I % 5) ..) x 8 slots; lane -> (pixel, slot), global
+    // quad = slot ^ swizzle.  The copy side runs two stages ahead of the arithmetic and may already be in the workgroup's next tile.
+    unsigned vst[13];
+    i32x4 srd0, srd1;
+    auto tile_origin = [&](int tile, int &b, int &y0, int &x0) {
+        b = tile / (tiles_x * tiles_y);
+        const int r = tile - b * tiles_x * tiles_y;
+        const int ty = r / tiles_x;
+        y0 = ty * 8; x0 = (r - ty * tiles_x) * 32;
+    };
+    auto plan_copies = [&](int tile) {
+        int b, y0, x0;
+        tile_origin(tile, b, y0, x0);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            const int I = 4 * j + wave;
+            const int row = I / 5, cc = 8 * (I - row * 5) + (lane >> 3);
+            const int pp = row * WP + cc, q = (lane & 7) ^ ((pp >> 1) & 7);
+            const int y = y0 - 1 + row, x = x0 - 1 + cc;
+            const bool ok = I < 50 && cc < 34 && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+            vst[j] = ok ? (unsigned)(((y * p.Ws + x) * 64 + 4 * q) * 4) : OOB;
+        }
+        srd0 = make_srd(static_cast<const float *>(p.src0) + (size_t)b * frame, (unsigned)(frame * 4));
+        srd1 = make_srd(static_cast<const float *>(p.src1) + (size_t)b * frame, (unsigned)(frame * 4));
+    };
+    auto issue = [&](int st, int buf) {
+        const unsigned dst = lds0 + (unsigned)(LWB + buf * STG + wave * 1024);
+        const int soff = (st & 1) * 128;
+        const unsigned v0[4] = {vst[0], vst[1], vst[2], vst[3]}, v1[4] = {vst[4], vst[5], vst[6], vst[7]}, v2[4] = {vst[8], vst[9], vst[10], vst[11]};
+        const unsigned v3[1] = {vst[12]};
+        const unsigned last = wave < 2 ? dst + 48 * 1024 : lds0 + (unsigned)DUMP;      // pieces 48, 49 exist; 50, 51 go to the dump slot
+        if (st < 2) {
+            dma16_group<4, 4096>(dst, v0, srd0, soff); dma16_group<4, 4096>(dst + 16384, v1, srd0, soff); dma16_group<4, 4096>(dst + 32768, v2, srd0, soff);
+            dma16_group<1, 0>(last, v3, srd0, soff);
+        } else {
+            dma16_group<4, 4096>(dst, v0, srd1, soff); dma16_group<4, 4096>(dst + 16384, v1, srd1, soff); dma16_group<4, 4096>(dst + 32768, v2, srd1, soff);
+            dma16_group<1, 0>(last, v3, srd1, soff);
+        }
+    };
+
+    // ---- operand addresses.  lane = (g, parity, i): as A the i-th pixel of group g, as B / D output channel n = i
+    const int g = lane >> 4, par = (lane >> 2) & 3, mi = lane & 3;
+    const int py = par >> 1, px = par & 1;
+    unsigned abase[4][4], aswz[4][4];                        // [tile][tap]: byte offset of the pixel inside a stage buffer, its slot swizzle (<< 4)
+#pragma unroll
+    for (int tau = 0; tau < 4; ++tau)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int R = 2 * wave + (tau >> 1), Cb = 16 * (tau & 1);
+            const int pp = (R + (t >> 1) + py) * WP + Cb + 4 * g + mi + (t & 1) + px;
+            abase[tau][t] = (unsigned)(pp * 128);
+            aswz[tau][t] = (unsigned)(((pp >> 1) & 7) << 4);
+        }
+    const unsigned brow = (unsigned)((par * 4 + mi) * 2064);
+    f32x4acc acc[4];
+#pragma unroll
+    for (int tau = 0; tau < 4; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int st, int buf) {
+        const char *sb = smc + LWB + buf * STG;
+        const char *wb = smc + brow + (unsigned)(((st >> 1) * 64 + (st & 1) * 32) * 4);
+        float4 a_cur[4], a_nxt[4], b_cur, b_nxt;
+        auto fetch = [&](int it, float4 (&a)[4], float4 &bv) {
+            const int t = it >> 3, q = it & 7;
+            bv = *reinterpret_cast<const float4 *>(wb + t * 512 + q * 16);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) a[tau] = *reinterpret_cast<const float4 *>(sb + abase[tau][t] + (aswz[tau][t] ^ (unsigned)(q << 4)));
+        };
+        fetch(0, a_cur, b_cur);
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            if (it + 1 < 32) fetch(it + 1, a_nxt, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].x, b_cur.x, acc[tau], 0, 0, 0);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].y, b_cur.y, acc[tau], 0, 0, 0);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].z, b_cur.z, acc[tau], 0, 0, 0);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].w, b_cur.w, acc[tau], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) a_cur[tau] = a_nxt[tau];
+            b_cur = b_nxt;
+        }
+    };
+
+    // ---- steps n = (tile, stage): copy of step n + 2 goes out when step n's buffer is free.  A wave's copies land in issue order: weights (8), then
+    // 13 per step, so "at most 13 in flight" = step n has landed.
+    float *ot = sm + OTB / 4;
+    const int nmine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // tiles blockIdx.x, + gridDim.x, ...
+    const int nsteps = 4 * nmine;
+    int itile = blockIdx.x;                                   // the copy side's tile
+    plan_copies(itile);
+    issue(0, 0);
+    issue(1, 1);
+    int ist = 2;                                              // next stage the copy side issues
+    int ctile = blockIdx.x;
+    for (int n = 0; n < nsteps; ++n) {
+        const int st = n & 3, buf = n & 1;
+        if (n + 1 < nsteps) dma_wait<13>(); else dma_wait<0>();
+        __syncthreads();
+        compute(st, buf);
+        if (st == 3 && mi < p.Cout) {
+            // acc[tile][r] = output (row 2 R + py, column 2 (Cb + 4 g + r) + px) of channel mi -> LDS tile [n][16][68]
+            const float bias = p.bias ? p.bias[mi] : 0.f;
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) {
+                const int Y = 2 * (2 * wave + (tau >> 1)) + py, Xb = 2 * (16 * (tau & 1) + 4 * g) + px;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = acc[tau][r] + bias;
+                    ot[(mi * 16 + Y) * 68 + Xb + 2 * r] = p.apply_tanh ? tanhf(pre) : pre;
+                }
+            }
+        }
+        if (st == 3) {
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                                      // this step's buffer is free; the output tile is complete
+        if (st == 3) {
+            // coalesced rows: NCHW fp32 (16 B per lane) and / or HWC uint8 = tensor2im (4 B per lane)
+            int b, y0, x0;
+            tile_origin(ctile, b, y0, x0);
+            if (p.out)
+                for (int i = tid; i < p.Cout * 256; i += 256) {
+                    const int nn = i >> 8, Y = (i >> 4) & 15, x4 = i & 15;
+                    *reinterpret_cast<float4 *>(p.out + (((size_t)b * p.Cout + nn) * H + 2 * y0 + Y) * W + 2 * x0 + 4 * x4) =
+                        *reinterpret_cast<const float4 *>(ot + (nn * 16 + Y) * 68 + 4 * x4);
+                }
+            if (p.out_u8) {
+                const int wpr = 16 * p.Cout;                 // 4-byte words per tile row (64 pixels x Cout bytes)
+                for (int i = tid; i < 16 * wpr; i += 256) {
+                    const int Y = i / wpr, wd = i - Y * wpr;
+                    unsigned pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * wd + e, X = k / p.Cout, nn = k - X * p.Cout;
+                        pk |= (unsigned)to_u8(ot[(nn * 16 + Y) * 68 + X]) << (8 * e);
+                    }
+                    *reinterpret_cast<unsigned *>(p.out_u8 + (((size_t)b * H + 2 * y0 + Y) * W + 2 * x0) * p.Cout + 4 * wd) = pk;
+                }
+            }
+            ctile += gridDim.x;
+        }
+        if (n + 2 < nsteps) {
+            if (ist == 4) { ist = 0; itile += gridDim.x; plan_copies(itile); }
+            issue(ist, buf);
+            ++ist;
+        }
+    }
+}
+
+static bool last_conv_mfma_ok(const LastConvParams &p)
+{
+    return p.dtype == 0 && p.C0 == 64 && p.C1 == 64 && p.Cout >= 1 && p.Cout <= 4 && p.Hs % 8 == 0 && p.Ws % 32 == 0 &&
+           (size_t)p.Hs * p.Ws * 256 < 0x80000000ull;
+}
+
+static hipError_t launch_last_conv_mfma(const LastConvParams &p, hipStream_t s)
+{
+    const size_t smem = 16 * 516 * 4 + 2 * (10 * 40 * 128) + 4 * 16 * 68 * 4 + 1024;
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&last_conv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    // one workgroup per CU (150 KB of LDS), each walks tiles blockIdx.x, + grid, ...: the weights are staged once per workgroup and a tile's first
+    // copies fly under the previous tile's arithmetic
+    const long tiles = (long)p.B * (p.Hs / 8) * (p.Ws / 32);
+    static int cu_count[64];                                  // per device, filled on first use (racing fills write the same value)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cu_count[dev] == 0) {
+            int n = 0;
+            cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        cus = cu_count[dev];
+    }
+    const long grid = tiles < cus ? tiles : cus;
+    hipLaunchKernelGGL(last_conv_mfma, dim3((unsigned)grid), dim3(256), smem, s, p, (int)tiles);
+    return hipGetLastError();
+}
+
 template <typename T, int CO>
 static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
 {
@@ -692,6 +1087,10 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
 
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
+    // route 0 (by shape) and 4: the matrix-core kernel where it applies; 5: the vector-ALU kernels by size (A-B runs)
+    if ((p.route == 0 || p.route == 4) && last_conv_mfma_ok(p)) return launch_last_conv_mfma(p, s);
+    if (p.route == 4) return hipErrorInvalidValue;
+    if (p.route == 5) { LastConvParams q = p; q.route = 0; return launch_last_conv(q, s); }
     if (p.dtype == 2) {
         switch (p.Cout) {
         case 1: return launch_last_conv_co<f16_t, 1>(p, s);

@@ -151,6 +151,11 @@ struct SmallMParams {
     int dtype;                   // 0 = fp32, 1 = bf16
     int B, Hs, Ws, Ho, Wo, Cin, Cout;
     int stride, up, relu, M;
+    // optional: bytes [0, pf_bytes) at pf are the weights the NEXT launch of the forward streams (another weight-streaming layer).  A fifth wave
+    // per workgroup pulls this workgroup's 1/gridDim share of them towards the chip while the other four work (small_layers.hip).
+    const void *pf;
+    unsigned pf_bytes;
+    unsigned pf_dump;            // filled by launch_smallm: LDS byte offset of the dump slot
 };
 bool smallm_supported(const SmallMParams &p);
 hipError_t launch_smallm(const SmallMParams &p, hipStream_t s);
@@ -254,7 +259,7 @@ struct FirstConvParams {
     const float *base;      // optional pre-activation partial sums [1][H/2][W/2][Cout] to start from
     int relu;
     const float *bias;      // [Cout] conv bias (InstanceNorm plans: use_bias, networks.py:590) or nullptr; final pass only
-    int force_direct;       // tests / A-B runs: the vector-ALU kernel instead of the matrix-core one
+    int force_direct;       // tests / A-B runs: 1 = the vector-ALU kernel, 2 = the register-staged matrix-core kernel (0 = by shape)
 };
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
 
@@ -267,7 +272,7 @@ struct LastConvParams {
     int B, Hs, Ws, C0, C1, Cout;
     int apply_tanh;
     unsigned char *out_u8;     // optional HWC uint8 frame [B][2Hs][2Ws][Cout] = tensor2im(out); out may then be nullptr
-    int route;                 // 0 = kernel chosen by size; 1 strip, 2 rows, 3 generic (forced per handle, tests only)
+    int route;                 // 0 = kernel chosen by shape; 1 strip, 2 rows, 3 generic, 4 matrix-core, 5 vector-ALU by size (forced per handle: tests, A-B runs)
     const float *bias;         // [Cout] conv bias added before tanh (InstanceNorm plans) or nullptr
 };
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);

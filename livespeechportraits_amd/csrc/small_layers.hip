@@ -12,8 +12,14 @@ namespace lspf2f {
 // all 256 CUs stream weight rows (issued first, one latency), the whole input tensor (<= 64 KB)
 // is staged in LDS, each thread multiplies its K-slice for all pixels on the VALU, and the block
 // reduces through LDS in a fixed order.  Same packed weights [Cout][tap][Cin] as the igemm.
-template <typename T, int NC>
-__global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
+//
+// PF: the layers this kernel runs are a chain (14 launches in `large`), each waiting ~2 us for 9.4 MB of weights nobody has asked for yet.
+// With PF the workgroup carries a fifth wave that does nothing but request this workgroup's share of the NEXT launch's weights (LDS-DMA into
+// a 1-KB dump slot: no registers, its own vmcnt, so none of the four working waves ever waits for it), so that the next launch finds them on
+// the chip -- in this XCD's L2 when the next launch maps the same rows to the same workgroup index (smallm -> smallm: block b owns rows
+// 2b, 2b+1 in both), in the memory-side cache otherwise.  The wave takes part in the barriers and leaves once its requests have landed.
+template <typename T, int NC, bool PF>
+__global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMParams p)
 {
     constexpr int MM = 16;                                 // max output pixels (batch folded in)
     constexpr int NJ = 5;                                  // K/4 <= 5*256 float4 per weight row (Cin <= 512... 568)
@@ -28,6 +34,20 @@ __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
     asm volatile("" :: "s"(p.src), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.Hs), "s"(p.Ws), "s"(p.Ho),
                        "s"(p.Wo), "s"(p.Cin), "s"(p.Cout), "s"(p.stride), "s"(p.up), "s"(p.relu), "s"(p.M));
     const int C4 = p.Cin >> 2, K4 = 9 * C4;
+    if (PF && tid >= 256) {
+        typedef __attribute__((address_space(3))) float lds_float;
+        const unsigned dump = (unsigned)(unsigned long long)(lds_float *)sm + p.pf_dump;
+        const i32x4 srd = make_srd(p.pf, p.pf_bytes);
+        const unsigned share = (p.pf_bytes / gridDim.x + 1023u) & ~1023u;       // whole 1-KB pieces; the tail past pf_bytes reads as zeros
+        const unsigned lane_off = (unsigned)(tid - 256) * 16u;
+        // the whole offset rides in the vector operand: that is the one the descriptor's range check sees
+        for (unsigned o = 0; o < share; o += 1024u) dma16(dump, blockIdx.x * share + o + lane_off, srd, 0);
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the dump slot belongs to this workgroup until the copies have landed
+        return;
+    }
 
     // 1. weights of this workgroup's channels: issue first
     float4 wv[NC][NJ];
@@ -40,9 +60,17 @@ __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
                 ? load4(static_cast<const T *>(p.w) + (size_t)(n0 + nc) * 9 * p.Cin + (size_t)k4 * 4)
                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    // 2. input tensor -> LDS, (m, tap) -> source pixel table
+    // 2. input tensor -> LDS, (m, tap) -> source pixel table.  The epilogue's operands (folded BatchNorm, residual) of the threads that will write
+    //    an output are requested here as well: asked for at the end they were a dependent L2 round trip per launch
     const int npix = p.B * p.Hs * p.Ws;
     const int nin4 = npix * C4;
+    const int eo = tid >> 3, em = eo / NC, en = n0 + eo % NC;
+    const bool ewrite = tid < MM * NC * 8 && (tid & 7) == 0 && em < p.M && en < p.Cout;
+    float e_sc = 1.f, e_sh = 0.f, e_res = 0.f;
+    if (ewrite) {
+        if (p.scale) { e_sc = p.scale[en]; e_sh = p.shift[en]; }
+        if (p.residual) e_res = ld1(static_cast<const T *>(p.residual) + (size_t)em * p.Cout + en);
+    }
     for (int i = tid; i < nin4; i += 256)
         reinterpret_cast<float4 *>(act)[i] = load4(static_cast<const T *>(p.src) + (size_t)i * 4);   // LDS copy is fp32
     for (int i = tid; i < C4; i += 256) reinterpret_cast<float4 *>(act)[nin4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -108,15 +136,10 @@ __global__ __launch_bounds__(256) void conv3x3_smallm(const SmallMParams p)
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
         sum += __shfl_xor(sum, 4);
-        const int m = o / NC, n = n0 + o % NC;
-        if (part == 0 && m < p.M && n < p.Cout) {
-            float v = sum;
-            if (p.scale) v = v * p.scale[n] + p.shift[n];
-            if (p.residual) {
-                v += ld1(static_cast<const T *>(p.residual) + (size_t)m * p.Cout + n);
-            }
+        if (part == 0 && ewrite) {
+            float v = sum * e_sc + e_sh + e_res;             // scale 1 / shift 0 / residual 0 where the layer has none: the same roundings as before
             if (p.relu) v = fmaxf(v, 0.f);
-            st1(static_cast<T *>(p.out) + (size_t)m * p.Cout + n, v);
+            st1(static_cast<T *>(p.out) + (size_t)em * p.Cout + en, v);
         }
     }
 }
@@ -133,23 +156,27 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     constexpr int NC = 2;
     const size_t act_bytes = ((size_t)p.B * p.Hs * p.Ws + 1) * p.Cin * 4;
     const size_t red_bytes = (size_t)16 * NC * 264 * 4;
-    const size_t smem = 160 * 4 + (act_bytes > red_bytes ? act_bytes : red_bytes);
+    size_t smem = 160 * 4 + (act_bytes > red_bytes ? act_bytes : red_bytes);
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<f16_t, NC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 4 + 66 * 1024);
+        const int cap = 160 * 4 + 67 * 1024;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<f16_t, NC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    if (p.dtype == 2) hipLaunchKernelGGL((conv3x3_smallm<f16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
-    else if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
-    else hipLaunchKernelGGL((conv3x3_smallm<float, NC>), dim3((p.Cout + NC - 1) / NC), dim3(256), smem, s, p);
+    const unsigned grid = (unsigned)((p.Cout + NC - 1) / NC);
+    if (p.dtype == 2) hipLaunchKernelGGL((conv3x3_smallm<f16_t, NC, false>), dim3(grid), dim3(256), smem, s, p);
+    else if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC, false>), dim3(grid), dim3(256), smem, s, p);
+    else if (p.pf != nullptr && p.pf_bytes >= 1024u * grid) {
+        SmallMParams q = p;
+        q.pf_dump = (unsigned)((smem + 15) & ~(size_t)15);                    // one 1-KB slot behind everything the working waves use
+        smem = q.pf_dump + 1024;
+        hipLaunchKernelGGL((conv3x3_smallm<float, NC, true>), dim3(grid), dim3(320), smem, s, q);
+    }
+    else hipLaunchKernelGGL((conv3x3_smallm<float, NC, false>), dim3(grid), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 

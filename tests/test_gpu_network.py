@@ -166,10 +166,11 @@ def test_shared_candidate_paths_agree(gpu_device):
     e.set_candidates(None)
 
 
-@pytest.mark.parametrize("env", ["LSP_HIP_LASTCONV_STRIP", "LSP_HIP_LASTCONV_ROWS", "LSP_HIP_LASTCONV_GENERIC"])
+@pytest.mark.parametrize("env", ["LSP_HIP_LASTCONV_STRIP", "LSP_HIP_LASTCONV_ROWS", "LSP_HIP_LASTCONV_GENERIC", "LSP_HIP_LASTCONV_VALU"])
 def test_every_last_conv_variant_matches_golden(env, gpu_device, monkeypatch):
-    """The last layer has three kernels (sliding-window, channel-parallel rows, generic); the planner picks by
-    size, so each is forced once here and checked against the reference golden."""
+    """The last layer has a matrix-core kernel (the default for the shapes the generators build: every other golden test runs it) and
+    three vector-ALU kernels (sliding-window, channel-parallel rows, generic) behind it, picked by size; each of those is forced once
+    here -- LSP_HIP_LASTCONV_VALU = the by-size rule without the matrix-core kernel -- and checked against the reference golden."""
     monkeypatch.setenv(env, "1")
     for case in ("large_s128_b2", "normal_512"):
         meta, arrays, topo, sd, feat, cand = golden_problem(case)
