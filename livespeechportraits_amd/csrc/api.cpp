@@ -214,6 +214,13 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
     case kFirstConv: return "first_conv";
     case kLastConv: return l.wgemm_off >= 0 ? (l.wrl_off >= 0 && P.use_rowlast ? "last_conv (rowlast128 + pixel_shuffle_tanh)" : "last_conv (igemm3x3 + pixel_shuffle_tanh)") : "last_conv";
     default:
+        if (l.inorm && (l.wino || l.winoup)) {
+            const bool sm = l.in_route == kInSmall;
+            if (l.winoup) return l.winoup == 2 ? (sm ? "winoup3x3<2>+in_small" : "winoup3x3<2>+in_reduce_stats+in_finalize+in_apply")
+                                               : (sm ? "winoup3x3<1>+in_small" : "winoup3x3<1>+in_reduce_stats+in_finalize+in_apply");
+            return l.wino == 2 ? (sm ? "wino3x3<2>+in_small" : "wino3x3<2>+in_reduce_stats+in_finalize+in_apply")
+                               : (sm ? "wino3x3<1>+in_small" : "wino3x3<1>+in_reduce_stats+in_finalize+in_apply");
+        }
         if (l.winoup) return l.winoup == 2 ? (l.splits > 1 ? "winoup3x3<2> (split-K combined in the launch)" : "winoup3x3<2>")
                                            : (l.splits > 1 ? "winoup3x3<1> (split-K combined in the launch)" : "winoup3x3<1>");
         if (l.wino) return l.wino == 2 ? (l.splits > 1 ? "wino3x3<2> (split-K combined in the launch)" : "wino3x3<2>")
@@ -285,6 +292,24 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
     auto tptr = [&](int t) -> float * { return t < 0 ? nullptr : reinterpret_cast<float *>(h->ws + P.tensors[t].offset); };
     auto bptr = [&](int64_t off) -> const float * { return off < 0 ? nullptr : reinterpret_cast<const float *>(h->blob + off); };
     hipError_t e = hipSuccess;
+    // InstanceNorm behind a kernel that has written the complete raw conv output (+ bias) itself (the Winograd kernels: their split-K slabs are
+    // combined in the launch): statistics + normalisation (+ residual, ReLU) as separate passes over that tensor
+    auto in_after_complete_output = [&](hipError_t prev) -> hipError_t {
+        if (prev != hipSuccess) return prev;
+        float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
+        const size_t slab = (size_t)batch * P.stats_groups_max;
+        InstNormParams q{};
+        q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu; q.partial = nullptr; q.splits = 1; q.bias = nullptr;
+        q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
+        if (l.in_route == kInSmall) return launch_in_small(q, s);
+        q.psum = st; q.psq = st + slab * l.cout; q.pshift = st + 2 * slab * l.cout;
+        q.mean = st + 3 * slab * l.cout; q.rstd = q.mean + (size_t)batch * l.cout;
+        q.groups = (q.hw + 63) / 64; q.rows_per_group = 64;
+        hipError_t r = launch_in_reduce_stats(q, s);
+        if (r == hipSuccess) r = launch_in_finalize(q, s);
+        if (r == hipSuccess) r = launch_in_apply(q, s);
+        return r;
+    };
     if (l.kind == kFirstConv) {
         FirstConvParams p{};
         p.feat = feat; p.cand = cand; p.w = bptr(l.w_off); p.out = tptr(l.out);
@@ -374,22 +399,24 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         WinoUpParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.u = bptr(l.wwu_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.out = tptr(l.out);
-        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.N = l.cout; p.relu = l.relu; p.splits = l.splits;
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.N = l.cout; p.relu = l.inorm ? 0 : l.relu; p.splits = l.splits;
         if (l.splits > 1) {
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
         if (h->timing_part & 1) e = launch_winoup(p, l.winoup, s);
+        if (l.inorm) e = in_after_complete_output(e);
     } else if (l.wino) {
         WinoParams p{};
         p.src = tptr(l.src0); p.u = bptr(l.wwg_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
-        p.residual = tptr(l.res); p.out = tptr(l.out);
-        p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.cin; p.N = l.cout; p.relu = l.relu; p.splits = l.splits;
+        p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.cin; p.N = l.cout; p.relu = l.inorm ? 0 : l.relu; p.splits = l.splits;
         if (l.splits > 1) {
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
         if (h->timing_part & 1) e = launch_wino(p, l.wino, s);
+        if (l.inorm) e = in_after_complete_output(e);
     } else if (l.rowup) {
         RowUpParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wru_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);

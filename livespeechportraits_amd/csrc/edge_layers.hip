@@ -1059,8 +1059,9 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
     const long quads = (long)p.B * p.Hs * ((p.Ws + 3) / 4);
     // measured on MI355X (512x512 output): batch 1 rows 43 us / strip 55 us; batch 8 rows 270 us / strip 221 us
     const bool big = (long)p.B * p.Hs * p.Ws >= 4 * 65536;
-    // p.route: 0 = by size (the rule above), 1 strip, 2 rows, 3 generic (fixed per handle at create time, tests only)
-    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 64 && ((big && p.route == 0) || p.route == 1)) {
+    // p.route: 0 / 5 = by size (the rule above), 1 strip, 2 rows, 3 generic (fixed per handle at create time, tests only)
+    const bool by_size = p.route == 0 || p.route == 5;
+    if (p.C0 == p.C1 && p.C0 % 4 == 0 && p.C0 <= 64 && ((big && by_size) || p.route == 1)) {
         // sliding-window kernel; segment length trades window priming (2 extra columns) for parallelism
         const int seg = 32;
         const long groups = (long)p.B * p.Hs * ((p.Ws + seg - 1) / seg);
@@ -1090,7 +1091,6 @@ hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
     // route 0 (by shape) and 4: the matrix-core kernel where it applies; 5: the vector-ALU kernels by size (A-B runs)
     if ((p.route == 0 || p.route == 4) && last_conv_mfma_ok(p)) return launch_last_conv_mfma(p, s);
     if (p.route == 4) return hipErrorInvalidValue;
-    if (p.route == 5) { LastConvParams q = p; q.route = 0; return launch_last_conv(q, s); }
     if (p.dtype == 2) {
         switch (p.Cout) {
         case 1: return launch_last_conv_co<f16_t, 1>(p, s);

@@ -447,7 +447,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 // frame for the epilogue sums; tiny levels do statistics + normalisation in one workgroup per channel slab
                 const int hw = l.ho * l.ho, rhw = l.up4 ? l.hs * l.hs : hw;
                 const int wave_rows = bm == 32 ? 32 : bm / 2;
-                if (!smallm && !fullk && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
+                if (!smallm && !fullk && !wino && !winoup && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
                     route = kInFused;
                     groups_max = std::max(groups_max, (l.up4 ? 4 : 1) * rhw / wave_rows);
                 } else if (hw <= 1024) {

@@ -180,15 +180,18 @@ inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int
 static const int kWinoMinExtent = 16;     // 16x16 only from 4 frames up (wino_choice): below that the full-K kernel is as fast
 inline bool wino_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
 {
-    return dtype == 0 && stride == 1 && !up && !up4 && !inorm && c1 == 0 && hs == ho && ho >= kWinoMinExtent && ho % 16 == 0 &&
+    // InstanceNorm plans too (inorm): the kernel then writes the raw conv output (+ bias) and the statistics come from the separate passes
+    (void)inorm;
+    return dtype == 0 && stride == 1 && !up && !up4 && c1 == 0 && hs == ho && ho >= kWinoMinExtent && ho % 16 == 0 &&
            c0 % 8 == 0 && cout % 32 == 0;
 }
 // per batch: 32-channel blocks per wave (0 = keep the implicit GEMM) and K splits
 int wino_choice(int batch, int ho, int cin, int cout, int *splits);
-// the up-conv form (winoup.hip): sub-pixel up-convs of fp32 BatchNorm plans whose two sources are equally wide
+// the up-conv form (winoup.hip): sub-pixel up-convs of fp32 plans whose two sources are equally wide
 inline bool winoup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm)
 {
-    return dtype == 0 && up4 && !inorm && (c1 == c0 || c1 == 0) && c0 % 8 == 0 && cout % 32 == 0 && hs % 8 == 0;
+    (void)inorm;
+    return dtype == 0 && up4 && (c1 == c0 || c1 == 0) && c0 % 8 == 0 && cout % 32 == 0 && hs % 8 == 0;
 }
 int winoup_choice(int batch, int hs, int cin, int cout, int *splits, int force_nb = 0, int target = 1024);
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form

@@ -1,13 +1,19 @@
 // gfx950: the landmark edge map of the render loop on the device (include/lspraster.h).
 //
-// One workgroup rasterises one 64-row band of one frame, in two phases.  Phase 1, one THREAD per edge of the frame's ~88-edge list:
-// the sequential, per-edge part of the scan conversion -- the perpendicular offset (double sqrt / divide), clipping, the emulated 64-bit
-// divisions behind the DDA steps and scanline slopes, the order in which the fill's two edge chains advance -- is evaluated once into a
-// small plan in LDS (measured: done per wave instead, these ~2500 instructions per edge made the kernel 120 us whatever the edge length).
-// Phase 2, one WAVE per edge: pixels and scanlines are closed forms of the plan -- DDA step k is (base + k, (minor + k * step) >> 16), row
-// y0 + k of a fill piece has x_i + k * d_i on chain i, exactly what the sequential `x += dx` reaches -- and go to the 64 lanes.  The primitives only ever write one value, so the image is the union of their pixel sets and the order is irrelevant:
-// lanes set bits of the band's bitmask in LDS (64 rows x W bits = 4 KB at W = 512) with ds_or.  The band is then expanded to the
-// output tensor with coalesced 16-byte stores: the kernel's HBM traffic is the output itself (1 MiB fp32 per frame) plus ~1 KB of points.
+// One workgroup rasterises one 64-row band of one frame.  Everything is one THREAD per work item, in three steps separated by barriers
+// (the wave-per-edge form this replaces spent its 70 us walking 22 edges per wave one after the other, every field of an edge's plan a
+// separate LDS round trip):
+//   1. thread per edge: end points, band test, the perpendicular offset (double sqrt / divide, as OpenCV) -> the quad's four vertices;
+//   2. thread per (edge, side) and per (edge, fill): the sequential part of the scan conversion -- clipping, the DDA step, the order in
+//      which the fill's two edge chains advance and their slopes -- becomes a small plan in LDS.  The 64-bit divisions behind the steps
+//      and slopes run as one IEEE double division plus an exact integer fix-up (div_exact below) instead of the ~100-instruction emulated
+//      64-bit divide: |numerator| < 2^52, where the truncated double quotient is the integer quotient;
+//   3. thread per (edge, primitive), 12 primitives per edge (4 outline DDAs, up to 6 fill pieces, 2 end caps): pixels and scanlines are
+//      closed forms of the plan -- DDA step k is (base + k, (minor + k * step) >> 16), row y0 + k of a fill piece has x_i + k * d_i on chain
+//      i, exactly what the sequential `x += dx` reaches.  The primitives only ever write one value, so the image is the union of their pixel
+//      sets and the order is irrelevant: threads set bits of the band's bitmask in LDS (64 rows x W bits = 4 KB at W = 512) with ds_or.
+// The band is then expanded to the output tensor with coalesced 16-byte stores: the kernel's HBM traffic is the output itself (1 MiB fp32 per
+// frame) plus ~1 KB of points.
 //
 // The scan conversion follows OpenCV 4.4.0's cv::line for thickness > 1 (modules/imgproc/src/drawing.cpp: ThickLine ->
 // FillConvexPoly with a Line2 outline, Circle end caps) in 16.16 fixed point with 64-bit intermediates; doubles are used
@@ -49,6 +55,19 @@ __device__ __forceinline__ void dot(const Band &b, int x, int y)
 }
 
 struct P2 { long long x, y; };
+
+// num / den with C semantics (truncation toward zero) for den > 0, |num| < 2^52: both are exact doubles, and a quotient that is not an integer is at
+// least 1 / |num| > 2^-52 (relative) away from the next one, so the correctly rounded double quotient truncates to the right integer already; the
+// remainder test is a guard that costs four instructions (tests/test_raster.py runs the recipe against integer division, adversarial quotients
+// included).  The kernel's numerators are (dy << 16) with |dy| <= 2^28 and 2 (xe - xs) + h with 16.16 coordinates of int32 points: < 2^50.
+__device__ __forceinline__ long long div_exact(long long num, long long den)
+{
+    long long q = (long long)((double)num / (double)den);
+    const long long r = num - q * den;
+    if (num >= 0) { if (r < 0) --q; else if (r >= den) ++q; }
+    else { if (r > 0) ++q; else if (r <= -den) --q; }
+    return q;
+}
 
 // clip the segment to [0, width) x [0, height) (fixed-point extents); false = nothing left
 __device__ bool clip(long long width, long long height, P2 &p1, P2 &p2)
@@ -118,7 +137,7 @@ __device__ void plan_dda(const Band &b, P2 a, P2 e, DdaRec &r)
         const P2 t = a; a = e; e = t;
         dx = -dx; dy = -dy;
     }
-    r.step = xmajor ? (dy * ONE) / (ax | 1) : (dx * ONE) / (ay | 1);
+    r.step = xmajor ? div_exact(dy * ONE, ax | 1) : div_exact(dx * ONE, ay | 1);
     r.count = (int)((xmajor ? e.x - a.x : e.y - a.y) >> SHIFT);
     a.x += ONE >> 1;
     a.y += ONE >> 1;
@@ -130,27 +149,26 @@ __device__ void plan_dda(const Band &b, P2 a, P2 e, DdaRec &r)
     r.valid = 1;
 }
 
-// convex quad in 16.16: outline through the DDA, interior by walking the left and right edge chains from the top vertex.  The chains
-// change edge at a handful of event rows; between two events row y + k has x_i + k * d_i on chain i, exactly what k sequential
-// `x += dx` give -- one Piece per stretch.
-__device__ void plan_quad(const Band &b, const P2 (&v)[4], EdgePlan &pl)
+// convex quad in 16.16, interior: walking the left and right edge chains from the top vertex.  The chains change edge at a handful of event
+// rows; between two events row y + k has x_i + k * d_i on chain i, exactly what k sequential `x += dx` give -- one Piece per stretch.  (The
+// outline goes through plan_dda, one side per thread.)
+__device__ void plan_fill(const Band &b, const P2 (&v)[4], EdgePlan &pl)
 {
     constexpr int N = 4;
     constexpr long long HALF = ONE >> 1;
     long long xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y;
     int imin = 0;
-    P2 prev = v[N - 1];
+    int np = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (v[i].y < ymin) { ymin = v[i].y; imin = i; }
         ymax = v[i].y > ymax ? v[i].y : ymax;
         xmax = v[i].x > xmax ? v[i].x : xmax;
         xmin = v[i].x < xmin ? v[i].x : xmin;
-        plan_dda(b, prev, v[i], pl.dda[i]);
-        prev = v[i];
     }
     xmin = (xmin + HALF) >> SHIFT; xmax = (xmax + HALF) >> SHIFT;
     ymin = (ymin + HALF) >> SHIFT; ymax = (ymax + HALF) >> SHIFT;
+    pl.npieces = 0;
     if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= b.w || (int)ymin >= b.h) return;
     if (ymax > b.h - 1) ymax = b.h - 1;
     int idx[2] = {imin, imin}, ye[2], y = (int)ymin, edges = N;
@@ -160,7 +178,7 @@ __device__ void plan_quad(const Band &b, const P2 (&v)[4], EdgePlan &pl)
     // vertex access with a runtime index: 4 entries, resolved with selects (no scratch)
     auto vx = [&](int i) { return i == 0 ? v[0].x : i == 1 ? v[1].x : i == 2 ? v[2].x : v[3].x; };
     auto vy = [&](int i) { return i == 0 ? v[0].y : i == 1 ? v[1].y : i == 2 ? v[2].y : v[3].y; };
-    while (y <= (int)ymax && pl.npieces < MAX_PIECES) {
+    while (y <= (int)ymax && np < MAX_PIECES) {
         // edge changes due at row y (the sequential algorithm checks them at every row; they can only fire at y == ye[i])
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -172,7 +190,7 @@ __device__ void plan_quad(const Band &b, const P2 (&v)[4], EdgePlan &pl)
                 if (ty > y) {
                     const long long xs = vx(i0), xe = vx(i1);
                     ye[i] = ty;
-                    dxr[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                    dxr[i] = div_exact((xe - xs) * 2 + (ty - y), 2 * (ty - y));
                     x[i] = xs;
                     idx[i] = i1;
                     break;
@@ -187,15 +205,17 @@ __device__ void plan_quad(const Band &b, const P2 (&v)[4], EdgePlan &pl)
         if (ye[0] > y && ye[0] < ynext) ynext = ye[0];
         if (ye[1] > y && ye[1] < ynext) ynext = ye[1];
         if (ye[0] <= y || ye[1] <= y) ynext = y + 1;         // cannot happen (an exhausted chain ends the walk above); one row if it did
-        Piece &q = pl.pc[pl.npieces++];
+        Piece &q = pl.pc[np++];
         q.y0 = y; q.n = ynext - y; q.x0 = x[0]; q.d0 = dxr[0]; q.x1 = x[1]; q.d1 = dxr[1];
         x[0] += (long long)(ynext - y) * dxr[0];
         x[1] += (long long)(ynext - y) * dxr[1];
         y = ynext;
     }
+    pl.npieces = np;
 }
 
-__device__ void plan_edge(const Band &b, int x0, int y0, int x1, int y1, int thickness, EdgePlan &pl)
+// step 1, thread per edge: the quad around the segment (OpenCV's ThickLine), the end caps' centre and radius
+__device__ void plan_edge(int x0, int y0, int x1, int y1, int thickness, EdgePlan &pl, P2 (&q)[4])
 {
     pl.npieces = 0; pl.hasquad = 0;
     pl.cx0 = x0; pl.cy0 = y0; pl.cx1 = x1; pl.cy1 = y1;
@@ -206,36 +226,42 @@ __device__ void plan_edge(const Band &b, int x0, int y0, int x1, int y1, int thi
     double r = dx * dx + dy * dy;
     const int odd = thickness & 1;
     const int half = thickness << (SHIFT - 1);               // half the width, 16.16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = p0;
     if (fabs(r) > 2.2204460492503131e-16) {
         r = ((double)half + (double)odd * (double)ONE * 0.5) / __dsqrt_rn(r);
         const long long ox = __double2ll_rn(dy * r), oy = __double2ll_rn(dx * r);      // round half to even, like cvRound
-        const P2 q[4] = {{p0.x + ox, p0.y + oy}, {p0.x - ox, p0.y - oy}, {p1.x - ox, p1.y - oy}, {p1.x + ox, p1.y + oy}};
+        q[0] = {p0.x + ox, p0.y + oy}; q[1] = {p0.x - ox, p0.y - oy}; q[2] = {p1.x - ox, p1.y - oy}; q[3] = {p1.x + ox, p1.y + oy};
         pl.hasquad = 1;
-        plan_quad(b, q, pl);
     }
     pl.radius = (half + (int)(ONE >> 1)) >> SHIFT;
 }
 
-// ---- phase 2, one WAVE per edge: the plan is wave-uniform, pixels and scanlines go to the lanes ----
-__device__ void draw_dda(const Band &b, const DdaRec &r, int lane)
+// ---- step 3, one THREAD per primitive ----
+__device__ void draw_dda(const Band &b, const DdaRec &r)
 {
     if (!r.valid) return;
-    if (lane == 0) dot(b, r.ex, r.ey);
-    if (r.xmajor)
-        for (int k = lane; k <= r.count; k += 64) dot(b, r.base + k, (int)((r.minor + k * r.step) >> SHIFT));
-    else
-        for (int k = lane; k <= r.count; k += 64) dot(b, (int)((r.minor + k * r.step) >> SHIFT), r.base + k);
+    dot(b, r.ex, r.ey);
+    if (r.xmajor) {
+        for (int k = 0; k <= r.count; ++k) dot(b, r.base + k, (int)((r.minor + k * r.step) >> SHIFT));
+    } else {
+        // y = base + k: only the rows of this band
+        int k0 = b.y0 - r.base, k1 = b.y0 + b.rows - 1 - r.base;
+        if (k0 < 0) k0 = 0;
+        if (k1 > r.count) k1 = r.count;
+        for (int k = k0; k <= k1; ++k) dot(b, (int)((r.minor + k * r.step) >> SHIFT), r.base + k);
+    }
 }
 
-__device__ void draw_piece(const Band &b, const Piece &q, int lane)
+__device__ void draw_piece(const Band &b, const Piece &q)
 {
     constexpr long long HALF = ONE >> 1;
-    // only the rows inside this band matter: start the lanes at the band's first row of the piece
+    // only the rows inside this band matter
     int k0 = b.y0 - q.y0;
     if (k0 < 0) k0 = 0;
     int k1 = b.y0 + b.rows - q.y0;
     if (k1 > q.n) k1 = q.n;
-    for (int k = k0 + lane; k < k1; k += 64) {
+    for (int k = k0; k < k1; ++k) {
         const int yy = q.y0 + k;
         if (yy < 0) continue;
         const long long xa = q.x0 + k * q.d0, xb = q.x1 + k * q.d1;
@@ -245,8 +271,8 @@ __device__ void draw_piece(const Band &b, const Piece &q, int lane)
     }
 }
 
-// filled midpoint circle: horizontal spans; the walk is short (radius <= 16) and wave-uniform, lanes 0..3 write its four spans
-__device__ void disc(const Band &b, int cx, int cy, int radius, int lane)
+// filled midpoint circle: horizontal spans, four per step of the walk
+__device__ void disc(const Band &b, int cx, int cy, int radius)
 {
     int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
     auto row = [&](int y, int xl, int xr) {
@@ -254,11 +280,12 @@ __device__ void disc(const Band &b, int cx, int cy, int radius, int lane)
         span(b, y, xl < 0 ? 0 : xl, xr > b.w - 1 ? b.w - 1 : xr);
     };
     if (!(cx - radius < b.w && cx + radius >= 0 && cy - radius < b.h && cy + radius >= 0)) return;
+    if (cy + radius < b.y0 || cy - radius >= b.y0 + b.rows) return;
     while (dx >= dy) {
-        if (lane < 4) {
-            const int ry = (lane & 2) ? dx : dy, rx = (lane & 2) ? dy : dx;      // lanes 0,1: rows cy -/+ dy, half-width dx; 2,3: rows cy -/+ dx, half-width dy
-            row((lane & 1) ? cy + ry : cy - ry, cx - rx, cx + rx);
-        }
+        row(cy - dy, cx - dx, cx + dx);
+        row(cy + dy, cx - dx, cx + dx);
+        row(cy - dx, cx - dy, cx + dy);
+        row(cy + dx, cx - dy, cx + dy);
         ++dy;
         err += plus;
         plus += 2;
@@ -284,14 +311,15 @@ __device__ __forceinline__ int coord(const Params &p, size_t i)
     return (int)static_cast<const double *>(p.points)[i];
 }
 
-constexpr int EDGE_CHUNK = 96;             // edges planned per round (41 KB of plans in LDS)
+constexpr int EDGE_CHUNK = 96;             // edges planned per round (41 KB of plans + 6 KB of vertices in LDS)
 
 __global__ __launch_bounds__(256) void edge_map_band(const Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     EdgePlan *plans = reinterpret_cast<EdgePlan *>(lds);                       // [EDGE_CHUNK]
-    unsigned *bits = reinterpret_cast<unsigned *>(lds + sizeof(EdgePlan) * EDGE_CHUNK);
-    const int tid = threadIdx.x, lane = tid & 63, frame = blockIdx.y;
+    P2 *verts = reinterpret_cast<P2 *>(lds + sizeof(EdgePlan) * EDGE_CHUNK);   // [EDGE_CHUNK][4]
+    unsigned *bits = reinterpret_cast<unsigned *>(lds + (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK);
+    const int tid = threadIdx.x, frame = blockIdx.y;
     Band b;
     b.bits = bits; b.w = p.w; b.h = p.h; b.words = p.w >> 5;
     b.y0 = blockIdx.x * BAND;
@@ -302,6 +330,7 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
     for (int c0 = 0; c0 < p.nseg; c0 += EDGE_CHUNK) {
         const int nc = p.nseg - c0 < EDGE_CHUNK ? p.nseg - c0 : EDGE_CHUNK;
         __syncthreads();                                       // bits zeroed / the previous chunk's plans are no longer read
+        // 1. thread per edge
         if (tid < nc) {
             EdgePlan &pl = plans[tid];
             const int s = c0 + tid;
@@ -313,21 +342,36 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
                 const int lo = (y0 < y1 ? y0 : y1) - reach, hi = (y0 < y1 ? y1 : y0) + reach;
                 if (!(hi < b.y0 || lo >= b.y0 + b.rows)) {     // the edge touches this band
                     pl.skip = 0;
-                    plan_edge(b, x0, y0, x1, y1, p.thickness, pl);
+                    P2 q[4];
+                    plan_edge(x0, y0, x1, y1, p.thickness, pl, q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) verts[4 * tid + i] = q[i];
                 }
             }
         }
         __syncthreads();
-        for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < nc; e += 4) {
+        // 2. thread per (edge, outline side) and per (edge, fill); item = kind * nc + edge, so a wave mostly holds one kind
+        for (int w = tid; w < 5 * nc; w += 256) {
+            const int kind = w / nc, e = w - kind * nc;
+            EdgePlan &pl = plans[e];
+            if (pl.skip || !pl.hasquad) continue;
+            if (kind < 4) {
+                plan_dda(b, verts[4 * e + ((kind + 3) & 3)], verts[4 * e + kind], pl.dda[kind]);
+            } else {
+                const P2 v[4] = {verts[4 * e], verts[4 * e + 1], verts[4 * e + 2], verts[4 * e + 3]};
+                plan_fill(b, v, pl);
+            }
+        }
+        __syncthreads();
+        // 3. thread per (edge, primitive): 4 outline DDAs, up to 6 fill pieces, 2 end caps
+        for (int w = tid; w < 12 * nc; w += 256) {
+            const int kind = w / nc, e = w - kind * nc;
             const EdgePlan &pl = plans[e];
             if (pl.skip) continue;
-            if (pl.hasquad) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) draw_dda(b, pl.dda[i], lane);
-                for (int i = 0; i < pl.npieces; ++i) draw_piece(b, pl.pc[i], lane);
-            }
-            disc(b, pl.cx0, pl.cy0, pl.radius, lane);
-            disc(b, pl.cx1, pl.cy1, pl.radius, lane);
+            if (kind < 4) { if (pl.hasquad) draw_dda(b, pl.dda[kind]); }
+            else if (kind < 10) { if (pl.hasquad && kind - 4 < pl.npieces) draw_piece(b, pl.pc[kind - 4]); }
+            else if (kind == 10) disc(b, pl.cx0, pl.cy0, pl.radius);
+            else disc(b, pl.cx1, pl.cy1, pl.radius);
         }
     }
     __syncthreads();
@@ -367,7 +411,11 @@ int lspraster_edge_maps(const void *points_dev, int point_dtype, int batch, int 
         return fail(LSPRASTER_ERR_UNSUPPORTED, "thickness must be in 2..32 (thickness 1 is a different OpenCV routine; the reference uses 2)");
     if (height < 1 || width < 32 || width % 32 || width > LSPRASTER_MAX_WIDTH) return fail(LSPRASTER_ERR_UNSUPPORTED, "width must be a multiple of 32, <= 4096");
     Params p{points_dev, segments_dev, out_f32_dev, out_u8_dev, point_dtype, npoints, nsegments, thickness, height, width};
-    const size_t smem = sizeof(EdgePlan) * EDGE_CHUNK + (size_t)BAND * (width / 32) * sizeof(unsigned);      // <= 41 KB + 32 KB
+    const size_t smem = (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK + (size_t)BAND * (width / 32) * sizeof(unsigned);      // <= 47 KB + 32 KB
+    if (smem > 64 * 1024) {                                    // widths above 2048 only
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_map_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (ea != hipSuccess) return fail(LSPRASTER_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea));
+    }
     hipLaunchKernelGGL(edge_map_band, dim3((height + BAND - 1) / BAND, batch), dim3(256), smem, static_cast<hipStream_t>(hip_stream), p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LSPRASTER_ERR_HIP, std::string("edge_map_band launch: ") + hipGetErrorString(e));

@@ -91,6 +91,38 @@ def test_library_exports_every_lspraster_symbol_and_has_no_cpu_path():
     assert N.load().lspraster_edge_maps(None, 0, 1, 1, None, 0, 2, 512, 512, None, None, None) == -1   # argument check, no launch
 
 
+def test_division_recipe_of_the_kernel_is_exact():
+    """csrc/raster.hip div_exact(): trunc(double(num) / double(den)), then one remainder test, must equal C's integer division (truncation toward
+    zero) for den > 0 and |num| < 2^52 -- the DDA step (dy << 16) / (|dx| | 1) and the scanline slope (2 (xe - xs) + h) / (2 h) of the kernel's plans.
+    In that range a non-integer quotient is at least 2^-52 (relative) away from the next integer, so the truncated double quotient is already right
+    and the remainder test is only a guard: the count printed below is expected to be 0."""
+    def recipe(num, den):
+        q = int(float(num) / float(den))
+        r = num - q * den
+        if num >= 0:
+            if r < 0: q -= 1
+            elif r >= den: q += 1
+        else:
+            if r > 0: q += 1
+            elif r <= -den: q -= 1
+        return q
+    cdiv = lambda n, d: abs(n) // d * (1 if n >= 0 else -1)
+    rng = np.random.default_rng(11)
+    cases = []
+    for _ in range(20000):
+        den = int(rng.integers(1, 2 ** 31))
+        q = int(rng.integers(0, (2 ** 52 - 1) // den + 1))
+        for num in (q * den - 1, q * den, q * den + 1, q * den + den - 1, int(rng.integers(0, 2 ** 52))):
+            if 0 <= num < 2 ** 52:
+                cases += [(num, den), (-num, den)]
+    cases += [(2 ** 52 - 1, 1), (2 ** 52 - 1, 2 ** 31 - 1), (-(2 ** 52 - 1), 3), (0, 5), (7 << 16, 1), (-(4096 << 32) + 1, (4096 << 16) | 1)]
+    repaired = 0
+    for num, den in cases:
+        assert recipe(num, den) == cdiv(num, den), (num, den)
+        repaired += int(float(num) / float(den)) != cdiv(num, den)
+    print("%d of %d quotients needed the remainder repair" % (repaired, len(cases)))
+
+
 # ---- GPU -----------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_kernel_is_bit_exact_to_the_oracle_on_random_landmark_sets(gpu_device):

@@ -88,7 +88,11 @@ def test_planner_routes_the_stride1_convs_of_the_large_levels_through_the_winogr
         if batch == 8:
             assert all(l["split_k"] == 1 for l in big)
     assert not any(l["kernel"].startswith("wino3x3") for l in Engine("large", dtype="bf16").layers(1))
-    assert not any(l["kernel"].startswith("wino3x3") for l in Engine("large", norm="instance").layers(1))
+    # InstanceNorm plans run the same layers on the same kernel (raw conv output + bias), with the statistics / normalisation passes behind it
+    inl = Engine("large", norm="instance").layers(1)
+    assert [l["name"] for l in inl if l["kernel"].startswith("wino3x3")] == [l["name"] for l in e.layers(1) if l["kernel"].startswith("wino3x3")]
+    assert all(l["kernel"].endswith(("+in_small", "+in_reduce_stats+in_finalize+in_apply")) for l in inl if l["kernel"].startswith(("wino3x3", "winoup3x3")))
+    assert all(l["kernel"].endswith("+in_small") == (l["h_out"] <= 32) for l in inl if l["kernel"].startswith(("wino3x3", "winoup3x3")))
     e.close()
 
 
