@@ -116,7 +116,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_FUSED_SPLITK")) h->fuse_splitk = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_PREFETCH")) h->prefetch = std::strcmp(env, "0") != 0;
     h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
-                  : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : std::getenv("LSP_HIP_LASTCONV_VALU") ? 5 : 0;
+                  : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : std::getenv("LSP_HIP_LASTCONV_MFMA") ? 4 : std::getenv("LSP_HIP_LASTCONV_VALU") ? 5 : 0;
     *out = h;
     return LSPF2F_OK;
 }
@@ -372,6 +372,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out; p.out_u8 = out_u8; p.dtype = P.dtype;
         p.route = h->last_route;
         p.bias = bptr(l.shift_off);
+        p.wstream = bptr(l.wls_off);
         e = launch_last_conv(p, s);
     } else if (l.smallm) {
         SmallMParams p{};

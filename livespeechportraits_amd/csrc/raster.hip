@@ -311,6 +311,14 @@ __device__ __forceinline__ int coord(const Params &p, size_t i)
     return (int)static_cast<const double *>(p.points)[i];
 }
 
+// phase stamps of tools/raster_stamps.py (builds with -DLSPRASTER_STAMPS only): shader clock at the phase boundaries of the first 64 workgroups
+#ifdef LSPRASTER_STAMPS
+__device__ unsigned long long g_stamps[64][8];
+#define RSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 64) g_stamps[blockIdx.x + gridDim.x * blockIdx.y][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RSTAMP(i) do {} while (0)
+#endif
+
 constexpr int EDGE_CHUNK = 96;             // edges planned per round (41 KB of plans + 6 KB of vertices in LDS)
 
 __global__ __launch_bounds__(256) void edge_map_band(const Params p)
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
     P2 *verts = reinterpret_cast<P2 *>(lds + sizeof(EdgePlan) * EDGE_CHUNK);   // [EDGE_CHUNK][4]
     unsigned *bits = reinterpret_cast<unsigned *>(lds + (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK);
     const int tid = threadIdx.x, frame = blockIdx.y;
+    RSTAMP(0);
     Band b;
     b.bits = bits; b.w = p.w; b.h = p.h; b.words = p.w >> 5;
     b.y0 = blockIdx.x * BAND;
@@ -350,6 +359,7 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
             }
         }
         __syncthreads();
+        RSTAMP(1);
         // 2. thread per (edge, outline side) and per (edge, fill); item = kind * nc + edge, so a wave mostly holds one kind
         for (int w = tid; w < 5 * nc; w += 256) {
             const int kind = w / nc, e = w - kind * nc;
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
             }
         }
         __syncthreads();
+        RSTAMP(2);
         // 3. thread per (edge, primitive): 4 outline DDAs, up to 6 fill pieces, 2 end caps
         for (int w = tid; w < 12 * nc; w += 256) {
             const int kind = w / nc, e = w - kind * nc;
@@ -374,7 +385,9 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
             else disc(b, pl.cx1, pl.cy1, pl.radius);
         }
     }
+    RSTAMP(3);
     __syncthreads();
+    RSTAMP(4);
     // expand the band: 4 pixels per thread and step
     const int quads = b.rows * (p.w >> 2);
     for (int q = tid; q < quads; q += 256) {
@@ -386,6 +399,7 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
         if (p.out_u8)
             *reinterpret_cast<unsigned *>(p.out_u8 + o) = (nib & 1u ? 0xffu : 0u) | (nib & 2u ? 0xff00u : 0u) | (nib & 4u ? 0xff0000u : 0u) | (nib & 8u ? 0xff000000u : 0u);
     }
+    RSTAMP(5);
 }
 
 static thread_local std::string g_err;
@@ -398,6 +412,13 @@ using namespace lspraster;
 extern "C" {
 
 const char *lspraster_last_error(void) { return g_err.c_str(); }
+
+#ifdef LSPRASTER_STAMPS
+int lspraster_debug_stamps(unsigned long long *host_64x8)      // tools/raster_stamps.py
+{
+    return hipMemcpyFromSymbol(host_64x8, HIP_SYMBOL(lspraster::g_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int lspraster_edge_maps(const void *points_dev, int point_dtype, int batch, int npoints, const int32_t *segments_dev,
                         int nsegments, int thickness, int height, int width, float *out_f32_dev, unsigned char *out_u8_dev,
