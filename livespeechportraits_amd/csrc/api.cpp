@@ -372,7 +372,6 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.apply_tanh = l.tanh_out; p.out_u8 = out_u8; p.dtype = P.dtype;
         p.route = h->last_route;
         p.bias = bptr(l.shift_off);
-        p.wstream = bptr(l.wls_off);
         e = launch_last_conv(p, s);
     } else if (l.smallm) {
         SmallMParams p{};

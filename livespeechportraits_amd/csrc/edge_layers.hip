@@ -1049,218 +1049,6 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Last layer, lane = source pixel, weights as a SCALAR stream (fp32 plans, C0 == C1 == 64, Cout <= 4): the shipped kernel.
-// With 3 output channels no matrix shape fits: the matrix-core kernel above feeds its 4x4x1 blocks one A float per lane and instruction from LDS and
-// is bound by the LDS pipe at about half the matrix rate (ablation: arithmetic alone 115 us at batch 8, copies alone 55 us); the vector-ALU kernels
-// before it re-read every weight from LDS per pixel.  Here the 12 outputs of a source pixel (4 parities x 3 channels) are 8 packed accumulators of ONE
-// lane, the weights are wave-uniform and come through the scalar cache as SGPR-pair operands of v_pk_fma_f32 (no LDS, no vector registers), and an
-// activation value read from LDS feeds 4..16 multiply-adds: per input channel 9 neighbourhood values x their 16 (position, parity) uses x 2 packed
-// operations = 32 v_pk_fma_f32 (24 would be the minimum: the fourth channel slot idles), 16.4k cycles per 64 source pixels -> ~60 us at batch 8,
-// ~8 us at batch 1, next to 42 / 5 us of HBM time.
-//   * staging, swizzle, tile walk and epilogue are the matrix-core kernel's (8 x 32 source pixels per workgroup, 32-channel stages by LDS-DMA, two
-//     buffers, persistent tiles); a wave owns two tile rows, lane = pixel, so the 16 lanes of a ds_read_b128 group read 16 consecutive pixels
-//     -- 16 distinct bank slots under the same swizzle (tools/lastconv_model.py);
-//   * x is broadcast to both halves of the packed operation with op_sel (the value sits in the float4 the LDS read returned: no moves);
-//   * the weight stream is pre-ordered by the packer to the order the unrolled loop consumes it (pack_lastconv_stream): 64 floats per channel.
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-typedef float v16f_t __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ void pk_fma_lo(v2f_t &acc, v2f_t xp, v2f_t w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(xp), "s"(w)); }
-__device__ __forceinline__ void pk_fma_hi(v2f_t &acc, v2f_t xp, v2f_t w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(xp), "s"(w)); }
-
-// (the stream is its own `const __restrict__` kernel argument: only then may the compiler read it through the scalar cache)
-__global__ __launch_bounds__(256) void last_conv_sw(const LastConvParams p, const v2f_t *__restrict__ wstream, int ntiles)
-{
-    constexpr int WP = 40;                                    // staged pixels per tile row (34 used)
-    constexpr int STG = 10 * WP * 128;                        // one stage buffer
-    constexpr int OTB = 2 * STG;                              // output tile [4][16][68] floats
-    constexpr int DUMP = OTB + 4 * 16 * 68 * 4;
-    constexpr unsigned OOB = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    typedef __attribute__((address_space(3))) float lds_float;
-    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)sm;
-    const char *smc = reinterpret_cast<const char *>(sm);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = p.Ws >> 5, tiles_y = p.Hs >> 3;
-    const size_t frame = (size_t)p.Hs * p.Ws * 64;
-    const int H = 2 * p.Hs, W = 2 * p.Ws;
-
-    // ---- stage copies of one tile (as in last_conv_mfma): piece I = 8 consecutive tile pixels x 8 slots, global quad = slot ^ swizzle
-    unsigned vst[13];
-    i32x4 srd0, srd1;
-    auto tile_origin = [&](int tile, int &b, int &y0, int &x0) {
-        b = tile / (tiles_x * tiles_y);
-        const int r = tile - b * tiles_x * tiles_y;
-        const int ty = r / tiles_x;
-        y0 = ty * 8; x0 = (r - ty * tiles_x) * 32;
-    };
-    auto plan_copies = [&](int tile) {
-        int b, y0, x0;
-        tile_origin(tile, b, y0, x0);
-#pragma unroll
-        for (int j = 0; j < 13; ++j) {
-            const int I = 4 * j + wave;
-            const int row = I / 5, cc = 8 * (I - row * 5) + (lane >> 3);
-            const int pp = row * WP + cc, q = (lane & 7) ^ ((pp >> 1) & 7);
-            const int y = y0 - 1 + row, x = x0 - 1 + cc;
-            const bool ok = I < 50 && cc < 34 && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-            vst[j] = ok ? (unsigned)(((y * p.Ws + x) * 64 + 4 * q) * 4) : OOB;
-        }
-        srd0 = make_srd(static_cast<const float *>(p.src0) + (size_t)b * frame, (unsigned)(frame * 4));
-        srd1 = make_srd(static_cast<const float *>(p.src1) + (size_t)b * frame, (unsigned)(frame * 4));
-    };
-    auto issue = [&](int st, int buf) {
-        const unsigned dst = lds0 + (unsigned)(buf * STG + wave * 1024);
-        const int soff = (st & 1) * 128;
-        const unsigned v0[4] = {vst[0], vst[1], vst[2], vst[3]}, v1[4] = {vst[4], vst[5], vst[6], vst[7]}, v2[4] = {vst[8], vst[9], vst[10], vst[11]};
-        const unsigned v3[1] = {vst[12]};
-        const unsigned last = wave < 2 ? dst + 48 * 1024 : lds0 + (unsigned)DUMP;      // pieces 48, 49 exist; 50, 51 go to the dump slot
-        if (st < 2) {
-            dma16_group<4, 4096>(dst, v0, srd0, soff); dma16_group<4, 4096>(dst + 16384, v1, srd0, soff); dma16_group<4, 4096>(dst + 32768, v2, srd0, soff);
-            dma16_group<1, 0>(last, v3, srd0, soff);
-        } else {
-            dma16_group<4, 4096>(dst, v0, srd1, soff); dma16_group<4, 4096>(dst + 16384, v1, srd1, soff); dma16_group<4, 4096>(dst + 32768, v2, srd1, soff);
-            dma16_group<1, 0>(last, v3, srd1, soff);
-        }
-    };
-
-    // ---- lane = source pixel (R, C) of the tile; its 3x3 neighbourhood in a stage buffer
-    const int R = 2 * wave + (lane >> 5), C = lane & 31;
-    unsigned abase[9], aswz[9];
-#pragma unroll
-    for (int pos = 0; pos < 9; ++pos) {
-        const int pp = (R + pos / 3) * WP + C + pos % 3;      // tile pixel (R + dy, C + dx) sits at staged (R + 1 + dy, C + 1 + dx)
-        abase[pos] = (unsigned)(pp * 128);
-        aswz[pos] = (unsigned)(((pp >> 1) & 7) << 4);
-    }
-    v2f_t acc[4][2];                                          // [parity][channels 0|1, 2|3]
-#pragma unroll
-    for (int par = 0; par < 4; ++par) { acc[par][0] = v2f_t{0.f, 0.f}; acc[par][1] = v2f_t{0.f, 0.f}; }
-
-    auto compute = [&](int st, int buf) {
-        const char *sb = smc + buf * STG;
-        const v2f_t *__restrict__ ws = wstream + (size_t)st * (32 * 32);      // 32 pairs per channel
-        float4 a[2][9];
-        auto fetch = [&](int q, float4 (&d)[9]) {
-#pragma unroll
-            for (int pos = 0; pos < 9; ++pos) d[pos] = *reinterpret_cast<const float4 *>(sb + abase[pos] + (aswz[pos] ^ (unsigned)(q << 4)));
-        };
-        fetch(0, a[0]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (q + 1 < 8) fetch(q + 1, a[(q + 1) & 1]);
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                // one channel's 64 weights: four 16-dword scalar loads (pairs k = 0..31 in the order of the loops below)
-                const v16f_t *__restrict__ wc16 = reinterpret_cast<const v16f_t *>(ws + (4 * q + ch) * 32);
-                const v16f_t g0 = wc16[0], g1 = wc16[1], g2 = wc16[2], g3 = wc16[3];
-                auto wpair = [&](int kk) -> v2f_t {
-                    const v16f_t &g = kk < 8 ? g0 : kk < 16 ? g1 : kk < 24 ? g2 : g3;
-                    const int e = 2 * (kk & 7);
-                    return v2f_t{g[e], g[e + 1]};
-                };
-                int k = 0;
-#pragma unroll
-                for (int pos = 0; pos < 9; ++pos) {
-                    const float4 x4 = a[q & 1][pos];
-                    const v2f_t xp = (ch < 2) ? v2f_t{x4.x, x4.y} : v2f_t{x4.z, x4.w};
-                    const int dy = pos / 3 - 1, dx = pos % 3 - 1;
-#pragma unroll
-                    for (int py = (dy == 1); py <= (dy != -1); ++py)
-#pragma unroll
-                        for (int px = (dx == 1); px <= (dx != -1); ++px) {
-                            const int par = py * 2 + px;
-                            if (ch & 1) { pk_fma_hi(acc[par][0], xp, wpair(k)); pk_fma_hi(acc[par][1], xp, wpair(k + 1)); }
-                            else { pk_fma_lo(acc[par][0], xp, wpair(k)); pk_fma_lo(acc[par][1], xp, wpair(k + 1)); }
-                            k += 2;
-                        }
-                }
-            }
-        }
-    };
-
-    // ---- steps n = (tile, stage), two buffers, copies two steps ahead (13 per wave and step, landing in issue order)
-    float *ot = sm + OTB / 4;
-    const int nmine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nsteps = 4 * nmine;
-    int itile = blockIdx.x;
-    plan_copies(itile);
-    issue(0, 0);
-    issue(1, 1);
-    int ist = 2;
-    int ctile = blockIdx.x;
-    for (int n = 0; n < nsteps; ++n) {
-        const int st = n & 3, buf = n & 1;
-        if (n + 1 < nsteps) dma_wait<13>(); else dma_wait<0>();
-        __syncthreads();
-        compute(st, buf);
-        if (st == 3) {
-            // the lane's 4 parities x Cout channels -> LDS tile [n][16][68]
-#pragma unroll
-            for (int par = 0; par < 4; ++par) {
-                const int Y = 2 * R + (par >> 1), X = 2 * C + (par & 1);
-                const float v[4] = {acc[par][0].x, acc[par][0].y, acc[par][1].x, acc[par][1].y};
-#pragma unroll
-                for (int co = 0; co < 4; ++co)
-                    if (co < p.Cout) {
-                        const float pre = v[co] + (p.bias ? p.bias[co] : 0.f);
-                        ot[(co * 16 + Y) * 68 + X] = p.apply_tanh ? tanhf(pre) : pre;
-                    }
-                acc[par][0] = v2f_t{0.f, 0.f}; acc[par][1] = v2f_t{0.f, 0.f};
-            }
-        }
-        __syncthreads();                                      // this step's buffer is free; the output tile is complete
-        if (st == 3) {
-            int b, y0, x0;
-            tile_origin(ctile, b, y0, x0);
-            if (p.out)
-                for (int i = tid; i < p.Cout * 256; i += 256) {
-                    const int nn = i >> 8, Y = (i >> 4) & 15, x4 = i & 15;
-                    *reinterpret_cast<float4 *>(p.out + (((size_t)b * p.Cout + nn) * H + 2 * y0 + Y) * W + 2 * x0 + 4 * x4) =
-                        *reinterpret_cast<const float4 *>(ot + (nn * 16 + Y) * 68 + 4 * x4);
-                }
-            if (p.out_u8) {
-                const int wpr = 16 * p.Cout;                 // 4-byte words per tile row (64 pixels x Cout bytes)
-                for (int i = tid; i < 16 * wpr; i += 256) {
-                    const int Y = i / wpr, wd = i - Y * wpr;
-                    unsigned pk = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 4 * wd + e, X = k / p.Cout, nn = k - X * p.Cout;
-                        pk |= (unsigned)to_u8(ot[(nn * 16 + Y) * 68 + X]) << (8 * e);
-                    }
-                    *reinterpret_cast<unsigned *>(p.out_u8 + (((size_t)b * H + 2 * y0 + Y) * W + 2 * x0) * p.Cout + 4 * wd) = pk;
-                }
-            }
-            ctile += gridDim.x;
-        }
-        if (n + 2 < nsteps) {
-            if (ist == 4) { ist = 0; itile += gridDim.x; plan_copies(itile); }
-            issue(ist, buf);
-            ++ist;
-        }
-    }
-}
-
-void pack_lastconv_stream(const float *subpixel, int cout, float *out)
-{
-    for (int st = 0; st < 4; ++st)
-        for (int cl = 0; cl < 32; ++cl) {
-            const int c = (st >> 1) * 64 + (st & 1) * 32 + cl;
-            float *o = out + ((size_t)st * 32 + cl) * 64;
-            int k = 0;
-            for (int pos = 0; pos < 9; ++pos) {
-                const int dy = pos / 3 - 1, dx = pos % 3 - 1;
-                for (int py = (dy == 1); py <= (dy != -1); ++py)
-                    for (int px = (dx == 1); px <= (dx != -1); ++px) {
-                        const int t = (dy + 1 - py) * 2 + (dx + 1 - px);
-                        for (int co = 0; co < 4; ++co)
-                            o[k++] = co < cout ? subpixel[(((size_t)(py * 2 + px) * cout + co) * 4 + t) * 128 + c] : 0.f;
-                    }
-            }
-        }
-}
-
 static int device_cu_count()
 {
     static int cu_count[64];                                  // per device, filled on first use (racing fills write the same value)
@@ -1271,22 +1059,6 @@ static int device_cu_count()
         cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
     return cu_count[dev];
-}
-
-static hipError_t launch_last_conv_sw(const LastConvParams &p, hipStream_t s)
-{
-    const size_t smem = 2 * (10 * 40 * 128) + 4 * 16 * 68 * 4 + 1024;
-    static AttrMask attr_mask;
-    if (attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&last_conv_sw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr_done_on_this_device(attr_mask);
-    }
-    const long tiles = (long)p.B * (p.Hs / 8) * (p.Ws / 32);
-    const int cus = device_cu_count();
-    const long grid = tiles < cus ? tiles : cus;
-    hipLaunchKernelGGL(last_conv_sw, dim3((unsigned)grid), dim3(256), smem, s, p, reinterpret_cast<const v2f_t *>(p.wstream), (int)tiles);
-    return hipGetLastError();
 }
 
 static bool last_conv_mfma_ok(const LastConvParams &p)
@@ -1349,8 +1121,7 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
     // route 0 (by shape) and 4: the matrix-core kernel where it applies; 5: the vector-ALU kernels by size (A-B runs)
-    if (p.route == 0 && p.wstream != nullptr && last_conv_mfma_ok(p)) return launch_last_conv_sw(p, s);      // same shapes as the matrix-core kernel
-    if (p.route == 4 && last_conv_mfma_ok(p)) return launch_last_conv_mfma(p, s);
+    if ((p.route == 0 || p.route == 4) && last_conv_mfma_ok(p)) return launch_last_conv_mfma(p, s);
     if (p.route == 4) return hipErrorInvalidValue;
     if (p.dtype == 2) {
         switch (p.Cout) {

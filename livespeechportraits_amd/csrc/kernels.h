@@ -272,15 +272,11 @@ struct LastConvParams {
     int B, Hs, Ws, C0, C1, Cout;
     int apply_tanh;
     unsigned char *out_u8;     // optional HWC uint8 frame [B][2Hs][2Ws][Cout] = tensor2im(out); out may then be nullptr
-    int route;                 // 0 = kernel chosen by shape (scalar-stream kernel where it applies); 1 strip, 2 rows, 3 generic, 4 matrix-core, 5 the older
-                               // vector-ALU kernels by size (forced per handle: tests, A-B runs)
+    int route;                 // 0 = kernel chosen by shape (matrix-core where it applies); 1 strip, 2 rows, 3 generic, 4 matrix-core or fail, 5 the vector-ALU
+                               // kernels by size (forced per handle: tests, A-B runs)
     const float *bias;         // [Cout] conv bias added before tanh (InstanceNorm plans) or nullptr
-    const float *wstream;      // optional: the same weights as the scalar stream of last_conv_sw, [4 stages][32 channels][64] (pack_lastconv_stream)
 };
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);
-// host: sub-pixel weights [4 parities][cout][4 taps][128] -> per input channel (stage = source * 2 + half, 32 channels per stage) the 16 (position of the
-// 3x3 source neighbourhood, output parity it feeds) pairs in row-major position order, 4 floats each (output channels 0..3, zero from cout on)
-void pack_lastconv_stream(const float *subpixel, int cout, float *out);
 
 // second pass of the GEMM form of the last conv: [B][Hs][Ws][4*Cout] fp32 (channel = parity*Cout + co) ->
 // tanh -> NCHW fp32 [B][Cout][2Hs][2Ws] and/or HWC uint8 (tensor2im)

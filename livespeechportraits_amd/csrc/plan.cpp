@@ -294,11 +294,6 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
         }
-        if (l.kind == kLastConv && dtype == 0 && l.c0 == 64 && l.c1 == 64 && l.cout <= 4) {
-            off = align_up(off, 256);
-            l.wls_off = (int64_t)off;
-            off += (size_t)4 * 32 * 64 * sizeof(float);
-        }
         if (last_as_gemm(l) && l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
             off = align_up(off, 256);
             l.wrl_off = (int64_t)off;
@@ -543,7 +538,6 @@ std::string Plan::pack(void *blob, size_t bytes) const
                                 }
                         }
             if (l.wwu_off >= 0) pack_winoup_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwu_off));
-            if (l.wls_off >= 0) pack_lastconv_stream(dst, cout, reinterpret_cast<float *>(base + l.wls_off));
             if (last_as_gemm(l)) {
                 // the same pre-summed taps as one 3x3 conv on the LOW-res source: output channel par*cout + co, tap
                 // (a, b) of parity (py, px) sits at low-res offset (py - 1 + a, px - 1 + b); the other taps are zero

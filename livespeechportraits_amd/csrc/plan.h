@@ -46,7 +46,6 @@ struct LayerDesc {
     int64_t wbc_off = -1;    // bf16 plans, 512 -> Cout stride-1 layers at 16x16 / 8x8: a copy of the weights in the fragment order of bandconv.hip
     int64_t wrc_off = -1;    // bf16 plans, 64 -> 64 stride-1 layers: a copy of the weights in the fragment order of the weights-stationary kernel (rowconv.hip)
     int64_t wru_off = -1;    // bf16 plans, sub-pixel up-conv over two 128-channel sources -> 64 channels (L1.up): weights in the fragment order of rowup256
-    int64_t wls_off = -1;    // fp32 plans, last conv over two 64-channel sources: the sub-pixel weights as the scalar stream of last_conv_sw (edge_layers.hip)
     int64_t wrl_off = -1;    // bf16 plans, last conv over two 64-channel sources: the GEMM-form weights in the fragment order of rowlast128 (rowconv.hip)
     int64_t wwg_off = -1;    // fp32 plans, stride-1 single-source convs at >= 32x32: G g G^T in the fragment order of the Winograd kernel (wino.hip)
     int64_t wwu_off = -1;    // fp32 plans, sub-pixel up-convs over two equally wide sources: the 9 transformed taps in the fragment order of winoup.hip

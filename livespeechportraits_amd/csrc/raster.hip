@@ -1,14 +1,17 @@
 // gfx950: the landmark edge map of the render loop on the device (include/lspraster.h).
 //
-// One workgroup rasterises one 64-row band of one frame.  Everything is one THREAD per work item, in three steps separated by barriers
-// (the wave-per-edge form this replaces spent its 70 us walking 22 edges per wave one after the other, every field of an edge's plan a
-// separate LDS round trip):
+// One workgroup of 1024 threads rasterises one 64-row band of one frame.  Everything is one THREAD per work item, in three steps separated by
+// barriers (the wave-per-edge form this replaces spent its 70 us walking 22 edges per wave one after the other, every field of an edge's plan a
+// separate LDS round trip; phase stamps of the 256-thread form of this one -- profiles/r03_raster_stamps_thread_per_item.txt -- showed 60 of
+// 76 us in the drawing loops at ~8 cycles per dependent instruction, one wave per SIMD: hence 16 waves per workgroup):
 //   1. thread per edge: end points, band test, the perpendicular offset (double sqrt / divide, as OpenCV) -> the quad's four vertices;
 //   2. thread per (edge, side) and per (edge, fill): the sequential part of the scan conversion -- clipping, the DDA step, the order in
 //      which the fill's two edge chains advance and their slopes -- becomes a small plan in LDS.  The 64-bit divisions behind the steps
 //      and slopes run as one IEEE double division plus an exact integer fix-up (div_exact below) instead of the ~100-instruction emulated
 //      64-bit divide: |numerator| < 2^52, where the truncated double quotient is the integer quotient;
-//   3. thread per (edge, primitive), 12 primitives per edge (4 outline DDAs, up to 6 fill pieces, 2 end caps): pixels and scanlines are
+//   3. 12 primitives per edge (4 outline DDAs, up to 6 fill pieces, 2 end caps); their steps inside the band -- one outline pixel, one fill
+//      scanline, one end cap -- are counted, prefix-summed and dealt to the 1024 threads in equal shares (thread per primitive left the launch
+//      waiting for the one thread with the longest edge: 67k of 93k cycles, profiles/r03_raster_stamps_1024_threads.txt).  Pixels and scanlines are
 //      closed forms of the plan -- DDA step k is (base + k, (minor + k * step) >> 16), row y0 + k of a fill piece has x_i + k * d_i on chain
 //      i, exactly what the sequential `x += dx` reaches.  The primitives only ever write one value, so the image is the union of their pixel
 //      sets and the order is irrelevant: threads set bits of the band's bitmask in LDS (64 rows x W bits = 4 KB at W = 512) with ds_or.
@@ -29,6 +32,8 @@ namespace lspraster {
 constexpr int SHIFT = 16;
 constexpr long long ONE = 1ll << SHIFT;
 constexpr int BAND = 64;                    // rows per workgroup
+constexpr int NT = 1024;                    // threads per workgroup: the kernel is a few thousand dependent instructions per thread, and 16 waves per CU
+                                            // (4 per SIMD) is what lets the SIMDs interleave them (one wave per SIMD: ~8 cycles per instruction, 76 us per launch)
 
 struct Band {
     unsigned *bits;                         // LDS, [BAND][words]
@@ -111,7 +116,9 @@ __device__ bool clip(long long width, long long height, P2 &p1, P2 &p2)
 // divisions behind the DDA steps and the scanline slopes, the order in which the fill's two chains change edge) becomes a plan ----
 struct DdaRec {            // one outline piece: pixel k is (base + k, (minor + k * step) >> 16) (x-major) or transposed
     int valid, xmajor, count, base;
-    long long minor, step;
+    long long minor;
+    int step;              // 16.16 slope of the minor coordinate: |minor delta| <= |major delta|, so it fits 17 bits + sign and k * step is one
+                           // v_mad_i64_i32 instead of a 64 x 64 multiply per pixel
     int ex, ey;            // the rounded far end point, drawn once
 };
 struct Piece {             // scanlines y0 .. y0 + n - 1 of the fill: chain i sits at x_i + k * d_i on row y0 + k
@@ -137,7 +144,7 @@ __device__ void plan_dda(const Band &b, P2 a, P2 e, DdaRec &r)
         const P2 t = a; a = e; e = t;
         dx = -dx; dy = -dy;
     }
-    r.step = xmajor ? div_exact(dy * ONE, ax | 1) : div_exact(dx * ONE, ay | 1);
+    r.step = (int)(xmajor ? div_exact(dy * ONE, ax | 1) : div_exact(dx * ONE, ay | 1));
     r.count = (int)((xmajor ? e.x - a.x : e.y - a.y) >> SHIFT);
     a.x += ONE >> 1;
     a.y += ONE >> 1;
@@ -237,38 +244,38 @@ __device__ void plan_edge(int x0, int y0, int x1, int y1, int thickness, EdgePla
     pl.radius = (half + (int)(ONE >> 1)) >> SHIFT;
 }
 
-// ---- step 3, one THREAD per primitive ----
-__device__ void draw_dda(const Band &b, const DdaRec &r)
+// ---- step 3: the primitives' steps (one pixel of an outline, one scanline of a fill piece, one end cap) are numbered through, band-limited, and
+// dealt to the threads in equal contiguous shares ----
+// steps of a primitive inside this band: DDA = its far end point + pixels k = kbeg .. kend, piece = rows kbeg .. kend - 1
+__device__ __forceinline__ void dda_range(const Band &b, const DdaRec &r, int &kbeg, int &kend)     // inclusive; empty when kend < kbeg
 {
-    if (!r.valid) return;
-    dot(b, r.ex, r.ey);
-    if (r.xmajor) {
-        for (int k = 0; k <= r.count; ++k) dot(b, r.base + k, (int)((r.minor + k * r.step) >> SHIFT));
-    } else {
-        // y = base + k: only the rows of this band
-        int k0 = b.y0 - r.base, k1 = b.y0 + b.rows - 1 - r.base;
-        if (k0 < 0) k0 = 0;
-        if (k1 > r.count) k1 = r.count;
-        for (int k = k0; k <= k1; ++k) dot(b, (int)((r.minor + k * r.step) >> SHIFT), r.base + k);
+    kbeg = 0; kend = r.count;
+    if (!r.xmajor) {                                          // y = base + k: only the rows of this band
+        if (b.y0 - r.base > kbeg) kbeg = b.y0 - r.base;
+        if (b.y0 + b.rows - 1 - r.base < kend) kend = b.y0 + b.rows - 1 - r.base;
     }
 }
-
-__device__ void draw_piece(const Band &b, const Piece &q)
+__device__ __forceinline__ void piece_range(const Band &b, const Piece &q, int &kbeg, int &kend)    // half-open
+{
+    kbeg = b.y0 - q.y0;
+    if (kbeg < 0) kbeg = 0;
+    kend = b.y0 + b.rows - q.y0;
+    if (kend > q.n) kend = q.n;
+}
+__device__ __forceinline__ void dda_step(const Band &b, const DdaRec &r, int k)
+{
+    const int mn = (int)((r.minor + (long long)k * r.step) >> SHIFT);
+    if (r.xmajor) dot(b, r.base + k, mn); else dot(b, mn, r.base + k);
+}
+__device__ __forceinline__ void piece_step(const Band &b, const Piece &q, int k)
 {
     constexpr long long HALF = ONE >> 1;
-    // only the rows inside this band matter
-    int k0 = b.y0 - q.y0;
-    if (k0 < 0) k0 = 0;
-    int k1 = b.y0 + b.rows - q.y0;
-    if (k1 > q.n) k1 = q.n;
-    for (int k = k0; k < k1; ++k) {
-        const int yy = q.y0 + k;
-        if (yy < 0) continue;
-        const long long xa = q.x0 + k * q.d0, xb = q.x1 + k * q.d1;
-        const long long lo = xa > xb ? xb : xa, hi = xa > xb ? xa : xb;
-        const int xl = (int)((lo + HALF) >> SHIFT), xr = (int)((hi + HALF) >> SHIFT);
-        if (xr >= 0 && xl < b.w) span(b, yy, xl < 0 ? 0 : xl, xr >= b.w ? b.w - 1 : xr);
-    }
+    const int yy = q.y0 + k;
+    if (yy < 0) return;
+    const long long xa = q.x0 + k * q.d0, xb = q.x1 + k * q.d1;
+    const long long lo = xa > xb ? xb : xa, hi = xa > xb ? xa : xb;
+    const int xl = (int)((lo + HALF) >> SHIFT), xr = (int)((hi + HALF) >> SHIFT);
+    if (xr >= 0 && xl < b.w) span(b, yy, xl < 0 ? 0 : xl, xr >= b.w ? b.w - 1 : xr);
 }
 
 // filled midpoint circle: horizontal spans, four per step of the walk
@@ -320,20 +327,25 @@ __device__ unsigned long long g_stamps[64][8];
 #endif
 
 constexpr int EDGE_CHUNK = 96;             // edges planned per round (41 KB of plans + 6 KB of vertices in LDS)
+constexpr int kScanBytes = (2 * 12 * EDGE_CHUNK + 4 + 2 * (NT / 64)) * 4;       // compacted (first step, primitive) lists of a chunk + wave totals
+constexpr int kDiscSteps = 4;              // an end cap (four spans per step of its midpoint walk, radius + 1 steps) weighs this many outline pixels in the deal
 
-__global__ __launch_bounds__(256) void edge_map_band(const Params p)
+__global__ __launch_bounds__(NT) void edge_map_band(const Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     EdgePlan *plans = reinterpret_cast<EdgePlan *>(lds);                       // [EDGE_CHUNK]
     P2 *verts = reinterpret_cast<P2 *>(lds + sizeof(EdgePlan) * EDGE_CHUNK);   // [EDGE_CHUNK][4]
-    unsigned *bits = reinterpret_cast<unsigned *>(lds + (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK);
+    int *coff = reinterpret_cast<int *>(lds + (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK);        // [12 * EDGE_CHUNK + 1] first step of the i-th non-empty primitive
+    int *cprim = coff + 12 * EDGE_CHUNK + 4;                                                             // [12 * EDGE_CHUNK] which primitive that is
+    int *wsum = cprim + 12 * EDGE_CHUNK;                                                                 // [2][NT / 64] wave totals
+    unsigned *bits = reinterpret_cast<unsigned *>(lds + (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK + kScanBytes);
     const int tid = threadIdx.x, frame = blockIdx.y;
     RSTAMP(0);
     Band b;
     b.bits = bits; b.w = p.w; b.h = p.h; b.words = p.w >> 5;
     b.y0 = blockIdx.x * BAND;
     b.rows = p.h - b.y0 < BAND ? p.h - b.y0 : BAND;
-    for (int i = tid; i < BAND * b.words; i += 256) bits[i] = 0u;
+    for (int i = tid; i < BAND * b.words; i += NT) bits[i] = 0u;
     const size_t base = (size_t)frame * p.npoints * 2;
     const int reach = (p.thickness >> 1) + 2;                  // a primitive never leaves its end points' box by more than this
     for (int c0 = 0; c0 < p.nseg; c0 += EDGE_CHUNK) {
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
         __syncthreads();
         RSTAMP(1);
         // 2. thread per (edge, outline side) and per (edge, fill); item = kind * nc + edge, so a wave mostly holds one kind
-        for (int w = tid; w < 5 * nc; w += 256) {
+        for (int w = tid; w < 5 * nc; w += NT) {
             const int kind = w / nc, e = w - kind * nc;
             EdgePlan &pl = plans[e];
             if (pl.skip || !pl.hasquad) continue;
@@ -374,15 +386,95 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
         }
         __syncthreads();
         RSTAMP(2);
-        // 3. thread per (edge, primitive): 4 outline DDAs, up to 6 fill pieces, 2 end caps
-        for (int w = tid; w < 12 * nc; w += 256) {
+        // 3. primitive w = kind * nc + edge (4 outline DDAs, up to 6 fill pieces, 2 end caps): its number of steps inside this band ...
+        const int nprim = 12 * nc;
+        auto steps_of = [&](int w) -> int {
             const int kind = w / nc, e = w - kind * nc;
             const EdgePlan &pl = plans[e];
-            if (pl.skip) continue;
-            if (kind < 4) { if (pl.hasquad) draw_dda(b, pl.dda[kind]); }
-            else if (kind < 10) { if (pl.hasquad && kind - 4 < pl.npieces) draw_piece(b, pl.pc[kind - 4]); }
-            else if (kind == 10) disc(b, pl.cx0, pl.cy0, pl.radius);
-            else disc(b, pl.cx1, pl.cy1, pl.radius);
+            if (pl.skip) return 0;
+            if (kind < 4) {
+                if (!pl.hasquad || !pl.dda[kind].valid) return 0;
+                int k0, k1;
+                dda_range(b, pl.dda[kind], k0, k1);
+                return 1 + (k1 >= k0 ? k1 - k0 + 1 : 0);       // the far end point is step 0
+            }
+            if (kind < 10) {
+                if (!pl.hasquad || kind - 4 >= pl.npieces) return 0;
+                int k0, k1;
+                piece_range(b, pl.pc[kind - 4], k0, k1);
+                return k1 > k0 ? k1 - k0 : 0;
+            }
+            const int cy = kind == 10 ? pl.cy0 : pl.cy1;
+            return (cy + pl.radius < b.y0 || cy - pl.radius >= b.y0 + b.rows) ? 0 : kDiscSteps;
+        };
+        // ... exclusive prefix sums over the primitives, of their steps and of "has any" (thread: PER consecutive primitives; wave scans; wave totals
+        // through LDS): the non-empty primitives -- a small minority in any one band -- are compacted into (primitive, first step) pairs
+        constexpr int PER = (12 * EDGE_CHUNK + NT - 1) / NT, NW = NT / 64;
+        int mine[PER], sum = 0, cnt = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int w = tid * PER + i;
+            mine[i] = w < nprim ? steps_of(w) : 0;
+            sum += mine[i];
+            cnt += mine[i] > 0;
+        }
+        int incl = sum, cincl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d), cup = __shfl_up(cincl, d);
+            if ((tid & 63) >= d) { incl += up; cincl += cup; }
+        }
+        if ((tid & 63) == 63) { wsum[tid >> 6] = incl; wsum[NW + (tid >> 6)] = cincl; }
+        __syncthreads();
+        int wbase = 0, total = 0, cbase = 0, ncomp = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int t = wsum[i], c = wsum[NW + i];
+            wbase += i < (tid >> 6) ? t : 0; total += t;
+            cbase += i < (tid >> 6) ? c : 0; ncomp += c;
+        }
+        int run = wbase + incl - sum, slot = cbase + cincl - cnt;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (mine[i] > 0) { cprim[slot] = tid * PER + i; coff[slot] = run; ++slot; }
+            run += mine[i];
+        }
+        if (tid == 0) coff[ncomp] = total;
+        __syncthreads();
+        RSTAMP(6);
+        // ... and every thread takes an equal contiguous share of the steps: ONE binary search for the compacted primitive its first step belongs
+        // to, then a walk through the list (searching per primitive, or walking the uncompacted list with its runs of empty primitives, each cost
+        // more than the drawing itself: profiles/r03_raster_stamps_dealt_steps.txt)
+        const int share = (total + NT - 1) / NT;
+        int s0 = tid * share;
+        const int s1 = s0 + share < total ? s0 + share : total;
+        if (s0 < s1) {
+            int lo = 0, hi = ncomp;                           // the last i with coff[i] <= s0
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coff[mid] <= s0) lo = mid; else hi = mid; }
+            for (int i = lo; s0 < s1; ++i) {
+                const int w = cprim[i], beg = coff[i];
+                const int first = s0 - beg;
+                int last = coff[i + 1] - beg;                 // steps [first, last) of primitive w
+                if (last - first > s1 - s0) last = first + (s1 - s0);
+                const int kind = w / nc, e = w - kind * nc;
+                const EdgePlan &pl = plans[e];
+                if (kind < 4) {
+                    const DdaRec r = pl.dda[kind];
+                    int k0, k1;
+                    dda_range(b, r, k0, k1);
+                    for (int j = first; j < last; ++j) {
+                        if (j == 0) dot(b, r.ex, r.ey); else dda_step(b, r, k0 + j - 1);
+                    }
+                } else if (kind < 10) {
+                    const Piece q = pl.pc[kind - 4];
+                    int k0, k1;
+                    piece_range(b, q, k0, k1);
+                    for (int j = first; j < last; ++j) piece_step(b, q, k0 + j);
+                } else if (first == 0) {                      // an end cap counts kDiscSteps steps; the first one draws it
+                    disc(b, kind == 10 ? pl.cx0 : pl.cx1, kind == 10 ? pl.cy0 : pl.cy1, pl.radius);
+                }
+                s0 += last - first;
+            }
         }
     }
     RSTAMP(3);
@@ -390,7 +482,7 @@ __global__ __launch_bounds__(256) void edge_map_band(const Params p)
     RSTAMP(4);
     // expand the band: 4 pixels per thread and step
     const int quads = b.rows * (p.w >> 2);
-    for (int q = tid; q < quads; q += 256) {
+    for (int q = tid; q < quads; q += NT) {
         const int r = q / (p.w >> 2), x = (q - r * (p.w >> 2)) * 4;
         const unsigned nib = (bits[r * b.words + (x >> 5)] >> (x & 31)) & 15u;
         const size_t o = ((size_t)frame * p.h + b.y0 + r) * p.w + x;
@@ -432,12 +524,12 @@ int lspraster_edge_maps(const void *points_dev, int point_dtype, int batch, int 
         return fail(LSPRASTER_ERR_UNSUPPORTED, "thickness must be in 2..32 (thickness 1 is a different OpenCV routine; the reference uses 2)");
     if (height < 1 || width < 32 || width % 32 || width > LSPRASTER_MAX_WIDTH) return fail(LSPRASTER_ERR_UNSUPPORTED, "width must be a multiple of 32, <= 4096");
     Params p{points_dev, segments_dev, out_f32_dev, out_u8_dev, point_dtype, npoints, nsegments, thickness, height, width};
-    const size_t smem = (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK + (size_t)BAND * (width / 32) * sizeof(unsigned);      // <= 47 KB + 32 KB
+    const size_t smem = (sizeof(EdgePlan) + 4 * sizeof(P2)) * EDGE_CHUNK + kScanBytes + (size_t)BAND * (width / 32) * sizeof(unsigned);      // <= 57 KB + 32 KB
     if (smem > 64 * 1024) {                                    // widths above 2048 only
         const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_map_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (ea != hipSuccess) return fail(LSPRASTER_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ea));
     }
-    hipLaunchKernelGGL(edge_map_band, dim3((height + BAND - 1) / BAND, batch), dim3(256), smem, static_cast<hipStream_t>(hip_stream), p);
+    hipLaunchKernelGGL(edge_map_band, dim3((height + BAND - 1) / BAND, batch), dim3(NT), smem, static_cast<hipStream_t>(hip_stream), p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LSPRASTER_ERR_HIP, std::string("edge_map_band launch: ") + hipGetErrorString(e));
     return LSPRASTER_OK;

@@ -118,94 +118,3 @@ if __name__ == "__main__":
     check_banks()
     run()
 
-
-# ---------------------------------------------------------------------------------------------------------------------------------------
-# last_conv_sw: lane = source pixel, weights as a scalar stream.  Per input channel the 16 (position, parity) pairs of the 3x3 source
-# neighbourhood, each with two packed multiply-adds (channels 0|1 and 2|3): 64 floats per channel, in the order the kernel consumes them.
-def parities_of(pos):
-    dy, dx = pos // 3 - 1, pos % 3 - 1
-    P = {-1: [0], 0: [0, 1], 1: [1]}
-    return [(py, px) for py in P[dy] for px in P[dx]]
-
-
-def pack_stream(w, cout):
-    """w [4 par][cout][4 taps][128] -> [4 stages][32][64] (csrc/plan.cpp pack_lastconv_stream)"""
-    out = np.zeros((4, 32, 64), np.float32)
-    for st in range(4):
-        for cl in range(32):
-            c = (st >> 1) * 64 + (st & 1) * 32 + cl
-            k = 0
-            for pos in range(9):
-                dy, dx = pos // 3 - 1, pos % 3 - 1
-                for py, px in parities_of(pos):
-                    t = (dy + 1 - py) * 2 + (dx + 1 - px)
-                    for co in range(4):
-                        out[st, cl, k] = w[py * 2 + px, co, t, c] if co < cout else 0.0
-                        k += 1
-            assert k == 64
-    return out
-
-
-def run_sw(B=1, Hs=16, Ws=64, cout=3, seed=1):
-    rng = np.random.default_rng(seed)
-    s0 = rng.standard_normal((B, Hs, Ws, 64)).astype(np.float32)
-    s1 = rng.standard_normal((B, Hs, Ws, 64)).astype(np.float32)
-    w = rng.standard_normal((4, cout, 4, 128)).astype(np.float32) * 0.1
-    stream = pack_stream(w, cout)
-    out = np.zeros((B, cout, 2 * Hs, 2 * Ws), np.float64)
-    for b in range(B):
-        for y0 in range(0, Hs, TR):
-            for x0 in range(0, Ws, TC):
-                acc = np.zeros((4, 64, 4, 4), np.float64)                        # [wave][lane][parity][co]
-                for st in range(4):
-                    src, half = (s0, s1)[st >> 1], st & 1
-                    lds = stage(src, b, y0, x0, half)
-                    for wave in range(4):
-                        for lane in range(64):
-                            R, C = 2 * wave + (lane >> 5), lane & 31
-                            for q in range(8):
-                                a = []
-                                for pos in range(9):
-                                    p = (R + 1 + pos // 3 - 1) * WP + C + 1 + pos % 3 - 1
-                                    a.append(lds[p, q ^ ((p >> 1) & 7)])
-                                for ch in range(4):
-                                    k = 0
-                                    for pos in range(9):
-                                        for py, px in parities_of(pos):
-                                            for co in range(4):
-                                                acc[wave, lane, py * 2 + px, co] += float(a[pos][ch]) * float(stream[st, 4 * q + ch, k])
-                                                k += 1
-                for wave in range(4):
-                    for lane in range(64):
-                        R, C = 2 * wave + (lane >> 5), lane & 31
-                        for par in range(4):
-                            for co in range(cout):
-                                out[b, co, 2 * (y0 + R) + (par >> 1), 2 * (x0 + C) + (par & 1)] = acc[wave, lane, par, co]
-    ref = np.zeros_like(out)
-    cat = np.concatenate([s0, s1], -1).astype(np.float64)
-    pad = np.pad(cat, ((0, 0), (1, 1), (1, 1), (0, 0)))
-    for par in range(4):
-        py, px = par >> 1, par & 1
-        for t in range(4):
-            ty, tx = t >> 1, t & 1
-            sl = pad[:, ty + py: ty + py + Hs, tx + px: tx + px + Ws, :]
-            ref[:, :, py::2, px::2] += np.einsum("byxc,nc->bnyx", sl, w[par, :, t, :].astype(np.float64))
-    err = np.abs(out - ref).max()
-    print("scalar-stream model vs direct sub-pixel form: max abs", err)
-    assert err < 1e-9
-    # bank check of the A reads: lane groups of a ds_read_b128, lanes = consecutive pixels of a row
-    for wave in range(4):
-        for pos in range(9):
-            for q in range(8):
-                for grp in GROUPS:
-                    seen = {}
-                    for lane in grp:
-                        R, C = 2 * wave + (lane >> 5), lane & 31
-                        p = (R + pos // 3) * WP + C + pos % 3
-                        byte = p * 128 + (q ^ ((p >> 1) & 7)) * 16
-                        assert seen.setdefault((byte // 16) % 16, byte) == byte, ("bank conflict", wave, pos, q, lane)
-    print("scalar-stream kernel: A reads conflict-free")
-
-
-if __name__ == "__main__":
-    run_sw(Hs=8, Ws=32)

@@ -26,8 +26,9 @@ for name, sd in (("face-sized spread (sigma 30 px)", 0.06), ("all edges in one b
     assert lib.lspraster_debug_stamps(st) == 0
     t = np.array(st, dtype=np.float64).reshape(64, 8)[:8]
     print("%s: one eager launch %.1f us" % (name, e0.elapsed_time(e1) * 1000))
-    print("   band   setup  planning   drawing   barrier    expand     total   (shader cycles)")
+    print("   band   setup  planning count+scan   drawing   barrier    expand     total   (shader cycles)")
     for b in range(8):
-        d = np.diff(t[b, :6])
-        print("   %4d %7.0f %9.0f %9.0f %9.0f %9.0f %9.0f" % (b, d[0], d[1], d[2], d[3], d[4], t[b, 5] - t[b, 0]))
+        scan_end = t[b, 6] if t[b, 6] else t[b, 2]           # stamp 6 exists in the dealt-steps form only
+        print("   %4d %7.0f %9.0f %10.0f %9.0f %9.0f %9.0f %9.0f" % (b, t[b, 1] - t[b, 0], t[b, 2] - t[b, 1], scan_end - t[b, 2], t[b, 3] - scan_end,
+                                                                    t[b, 4] - t[b, 3], t[b, 5] - t[b, 4], t[b, 5] - t[b, 0]))
     print("   first start -> last end over the 8 bands: %.0f cycles" % (t[:, 5].max() - t[:, 0].min()))
