@@ -18,10 +18,11 @@ namespace lspf2f {
 // a 1-KB dump slot: no registers, its own vmcnt, so none of the four working waves ever waits for it), so that the next launch finds them on
 // the chip -- in this XCD's L2 when the next launch maps the same rows to the same workgroup index (smallm -> smallm: block b owns rows
 // 2b, 2b+1 in both), in the memory-side cache otherwise.  The wave takes part in the barriers and leaves once its requests have landed.
-template <typename T, int NC, bool PF>
+// MM = output pixels the instance is built for (batch folded in): 16, or 4 for the 2x2 level at batch 1, whose threads then do a quarter of the
+// multiply-adds and LDS reads of the 16-pixel form.
+template <typename T, int NC, bool PF, int MM>
 __global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMParams p)
 {
-    constexpr int MM = 16;                                 // max output pixels (batch folded in)
     constexpr int NJ = 5;                                  // K/4 <= 5*256 float4 per weight row (Cin <= 512... 568)
     constexpr int RS = 264;                                // reduction row pitch (floats)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -160,23 +161,28 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
         const int cap = 160 * 4 + 67 * 1024;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<f16_t, NC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<bf16_t, NC, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<f16_t, NC, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
     const unsigned grid = (unsigned)((p.Cout + NC - 1) / NC);
-    if (p.dtype == 2) hipLaunchKernelGGL((conv3x3_smallm<f16_t, NC, false>), dim3(grid), dim3(256), smem, s, p);
-    else if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC, false>), dim3(grid), dim3(256), smem, s, p);
+    const bool four = p.M <= 4;                               // fp32 plans: the 2x2 level at batch 1
+    if (p.dtype == 2) hipLaunchKernelGGL((conv3x3_smallm<f16_t, NC, false, 16>), dim3(grid), dim3(256), smem, s, p);
+    else if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC, false, 16>), dim3(grid), dim3(256), smem, s, p);
     else if (p.pf != nullptr && p.pf_bytes >= 1024u * grid) {
         SmallMParams q = p;
         q.pf_dump = (unsigned)((smem + 15) & ~(size_t)15);                    // one 1-KB slot behind everything the working waves use
         smem = q.pf_dump + 1024;
-        hipLaunchKernelGGL((conv3x3_smallm<float, NC, true>), dim3(grid), dim3(320), smem, s, q);
+        if (four) hipLaunchKernelGGL((conv3x3_smallm<float, NC, true, 4>), dim3(grid), dim3(320), smem, s, q);
+        else hipLaunchKernelGGL((conv3x3_smallm<float, NC, true, 16>), dim3(grid), dim3(320), smem, s, q);
     }
-    else hipLaunchKernelGGL((conv3x3_smallm<float, NC, false>), dim3(grid), dim3(256), smem, s, p);
+    else if (four) hipLaunchKernelGGL((conv3x3_smallm<float, NC, false, 4>), dim3(grid), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL((conv3x3_smallm<float, NC, false, 16>), dim3(grid), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 

@@ -179,6 +179,20 @@ def test_every_last_conv_variant_matches_golden(env, gpu_device, monkeypatch):
         assert np.abs(out.cpu().numpy() - arrays["out"]).max() <= TIGHT
 
 
+@pytest.mark.parametrize("env", ["LSP_HIP_PREFETCH=0", "LSP_HIP_FIRSTCONV_REGSTAGE=1"])
+def test_switches_that_move_data_differently_do_not_change_a_bit(env, gpu_device, monkeypatch):
+    """The fifth wave of the tiny-M kernel only requests bytes the NEXT launch will read, and the LDS-DMA staging of the first conv feeds the
+    same MFMA sequence as the register-staged kernel: with either switched off the forward must be bit-identical (and still on the golden)."""
+    meta, arrays, topo, sd, feat, cand = golden_problem("large_512")
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+    base = make_engine(topo, sd, gpu_device, meta["batch"]).forward(f, c).clone()
+    name, value = env.split("=")
+    monkeypatch.setenv(name, value)
+    other = make_engine(topo, sd, gpu_device, meta["batch"]).forward(f, c)
+    assert torch.equal(base, other)
+    assert np.abs(other.cpu().numpy() - arrays["out"]).max() <= TIGHT
+
+
 def test_drop_in_model_api_end_to_end(gpu_device, tmp_path):
     """The reference's own call sequence (demo.py:168-172, :266): create_model(opt) -> setup(opt) (loads a
     DataParallel-prefixed .pkl) -> eval() -> inference(feature_map, cand_image), on the GPU, against the golden."""
