@@ -115,6 +115,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") ? 1 : std::getenv("LSP_HIP_FIRSTCONV_REGSTAGE") ? 2 : 0;
     if (const char *env = std::getenv("LSP_HIP_FUSED_SPLITK")) h->fuse_splitk = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_PREFETCH")) h->prefetch = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;
     h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
                   : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : std::getenv("LSP_HIP_LASTCONV_MFMA") ? 4 : std::getenv("LSP_HIP_LASTCONV_VALU") ? 5 : 0;
     *out = h;
@@ -384,7 +385,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             const size_t li = (size_t)(&l - P.layers.data());
             if (li + 1 < P.layers.size()) {
                 const LayerDesc &n = P.layers[li + 1];
-                const int64_t off = n.smallm ? n.w_off : n.fullk ? n.wfk_off : -1;
+                const int64_t off = n.smallm ? n.w_off : n.fullk ? ((n.splits == 2 && !n.c1) ? n.wfk2_off : n.wfk_off) : -1;
                 if (off >= 0 && n.kind == kIgemm) { p.pf = h->blob + off; p.pf_bytes = (unsigned)((size_t)n.cout * 9 * n.cin * sizeof(float)); }
             }
         }
@@ -441,6 +442,12 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout;
         p.up = l.up; p.relu = l.inorm ? 0 : l.relu;
+        if (l.splits == 2) {                       // K in two halves, combined in the launch
+            p.split = 2;
+            if (!l.c1) p.w = bptr(l.wfk2_off);     // a single source read as two half-sources
+            p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
+            p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
+        }
         e = launch_fullk(p, l.fullk, s);
         if (e == hipSuccess && l.inorm) {          // InstanceNorm plans: H*W <= 256 here, the one-launch statistics route
             InstNormParams q{};
@@ -723,6 +730,8 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
     }
     (void)ws;
     const int ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
+    if (tile_m == 16 && tile_n == 16 && split_k == 2)               // K-split full-K kernel: two partial tiles per tile + arrival counters
+        return (size_t)batch * (ho * ho / 16) * (cout / 16) * (2 * 256 * sizeof(float) + sizeof(unsigned));
     const int Mout = batch * ho * ho;
     const bool up4 = upsample == 2;
     const int M = up4 ? batch * hs * hs : Mout;
@@ -860,6 +869,15 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = ho_; q.Wo = ho_; q.C0 = c0; q.C1 = c1; q.Cout = cout;
             q.up = upsample == 1; q.relu = relu;
             q.wtile = k_group == -1 ? 1 : 0;       // -1: w_packed is already in the full-K kernel's tile-blocked layout
+            if (split_k == 2 && tile_m == 16) {    // K halves: scratch = [2][tiles][256] floats + one zeroed counter per tile; a single source's w_packed is
+                                                   // packed as two half-sources
+                const size_t ntile = (size_t)batch * (ho_ * ho_ / 16) * (cout / 16);            // 16-pixel tiles x 16-channel slices
+                const size_t slab = 2 * ntile * 256 * sizeof(float);
+                if (!scratch || scratch_bytes < slab + ntile * sizeof(unsigned))
+                    return fail(LSPF2F_ERR_INVALID_ARGUMENT, "scratch too small for the K-split full-K kernel");
+                q.split = 2; q.partial = static_cast<float *>(scratch);
+                q.tile_cnt = reinterpret_cast<unsigned *>(static_cast<char *>(scratch) + slab);
+            }
 #ifdef LSPF2F_FULLK_STAMPS
             q.stamps = scratch_bytes >= (size_t)512 * 4 * 16 * 8 ? static_cast<unsigned long long *>(scratch) : nullptr;
 #endif

@@ -32,10 +32,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // WT: weights in the tile-blocked layout of pack_fullk_weights() (the shipped path: one wave load = 1 KB contiguous; the row layout
 // [Cout][tap][Cin] costs a 16-B request per lane, 4 us per 16x16 layer) -- the row-layout variant serves the conv3x3 test hook.
-template <int PB, int G, int NCH, bool WT>
+// SPLIT: K in two halves over blockIdx.y (NCH == 1 then: a workgroup sees ONE source of CC channels -- source z of a concat input, or channels
+// [z * CC, (z + 1) * CC) of a single source with 2 * CC channels per pixel); the second workgroup to finish a tile combines (ticket, fixed z order).
+template <int PB, int G, int NCH, bool WT, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
 {
-    constexpr int CC = G * 64;            // channels per source tensor
+    static_assert(!SPLIT || NCH == 1, "a split workgroup works on one source");
+    constexpr int CC = G * 64;            // channels per source tensor (per K half when SPLIT)
     constexpr int PST = CC + 4;           // LDS floats per band pixel (16 B pad)
     constexpr int NT = NCH * 9;           // taps over all sources
     constexpr int RD = 4;                 // weight ring depth in taps
@@ -73,16 +76,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
     // k-quad stride of 4G units is a multiple of 256 B for G >= 4, which is what keeps a ds_read_b128 lane group (it mixes k-quads:
     // lanes {0-3, 12-15, 20-27}, ...) on 16 distinct bank slots; any K permutation is fine as long as A and B agree.
     const int unit0 = kq * 4 * G + wave * G;
-    const int Cin = NCH * CC;
+    const int z = SPLIT ? (int)blockIdx.y : 0;
+    const int Cin = SPLIT ? 2 * CC : NCH * CC;                // input channels of the layer
+    const int pstride = (SPLIT && !p.C1) ? 2 * CC : CC;       // floats between two pixels of the source this workgroup reads
+    constexpr int NTW = SPLIT ? 18 : NT;                      // taps per N-slice in the weight layout
+    const int T0 = SPLIT ? 9 * z : 0;
     float4 ring[RD][G];
     // tap index T runs over (source, tap); one B load = this lane's 4 channels of row n0 + li
     auto load_b = [&](int T, int g) {
         const int ch = T / 9, tap = T - ch * 9;
         if constexpr (WT) {
-            const float *q = p.w + (((size_t)nt * NT + T) * 4 + wave) * G * 256;        // [nt][T][wave][g][64 lanes][4]
+            const float *q = p.w + (((size_t)nt * NTW + T0 + T) * 4 + wave) * G * 256;  // [nt][T][wave][g][64 lanes][4]
             ring[T % RD][g] = *reinterpret_cast<const float4 *>(q + g * 256 + lane * 4);
         } else {
-            const float *q = p.w + (size_t)(n0 + li) * 9 * Cin + tap * Cin + ch * CC;
+            const float *q = p.w + (size_t)(n0 + li) * 9 * Cin + tap * Cin + (SPLIT ? z : ch) * CC;
             ring[T % RD][g] = *reinterpret_cast<const float4 *>(q + (unit0 + g) * 4);
         }
     };
@@ -98,19 +105,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
     constexpr int PIECES = CC / 256;                         // 1-KB wave instructions per pixel
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        const float *src = (ch ? p.src1 : p.src0) + ((size_t)b * p.Hs + sy0) * p.Ws * CC;
+        const float *src0z = SPLIT ? (p.C1 ? (z ? p.src1 : p.src0) : p.src0 + z * CC) : (ch ? p.src1 : p.src0);
+        const float *src = src0z + ((size_t)b * p.Hs + sy0) * p.Ws * pstride;
         if constexpr (PIECES >= 1) {
-            const i32x4 rs = make_srd(src, (unsigned)npix * CC * 4u);
+            const i32x4 rs = make_srd(src, (unsigned)((npix - 1) * pstride + CC) * 4u);
             for (int px = __builtin_amdgcn_readfirstlane(wave); px < npix; px += 4)      // wave-uniform: the LDS base travels in M0
 #pragma unroll
                 for (int k = 0; k < PIECES; ++k)
-                    dma16(lds0 + (unsigned)((ch * band + px * PST) * 4 + k * 1024), (unsigned)(px * CC * 4 + k * 1024 + lane * 16), rs, 0);
+                    dma16(lds0 + (unsigned)((ch * band + px * PST) * 4 + k * 1024), (unsigned)(px * pstride * 4 + k * 1024 + lane * 16), rs, 0);
         } else {
             // fewer than 256 channels: a pixel is shorter than one 1-KB DMA piece (whose LDS destination is lane-linear) -> through registers
             const int n4 = npix * (CC / 4);
             for (int i = tid; i < n4; i += 256) {
                 const int px = i / (CC / 4), c4 = i - px * (CC / 4);
-                *reinterpret_cast<float4 *>(smem + ch * band + px * PST + c4 * 4) = *reinterpret_cast<const float4 *>(src + (size_t)i * 4);
+                *reinterpret_cast<float4 *>(smem + ch * band + px * PST + c4 * 4) = *reinterpret_cast<const float4 *>(src + (size_t)px * pstride + c4 * 4);
             }
         }
         for (int i = tid; i < CC / 4; i += 256)
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
         for (int r = 0; r < 4; ++r) red[((wave * PB + pb) * 4 + r) * 64 + lane] = s[r];
     }
     __syncthreads();
+    float vsum[PB];
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
         // thread -> (register r = wave, lane): C/D layout of the 16x16 MFMA: row (pixel) = 4 * (lane >> 4) + r, col (channel) = lane & 15
@@ -214,6 +223,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
         v += red[((1 * PB + pb) * 4 + r) * 64 + lane];
         v += red[((2 * PB + pb) * 4 + r) * 64 + lane];
         v += red[((3 * PB + pb) * 4 + r) * 64 + lane];
+        vsum[pb] = v;
+    }
+    if constexpr (SPLIT) {
+        // partial tile -> slab [z][tile][pb][thread], written through (the other half may run on another XCD); every wave drains its stores, one
+        // relaxed ticket per workgroup; the second arriver reads both slabs past its L1, adds them in z order and goes on to the epilogue
+        // (cdna_hip_programming.md Guideline 16, counter form -- the protocol of the igemm / Winograd split-K combine)
+        const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc((void *)p.partial, 0, (int)((size_t)2 * gridDim.x * PB * 256 * 4), 0x00020000);
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vsum[pb]), slab, (unsigned)(((((size_t)z * gridDim.x + blockIdx.x) * PB + pb) * 256 + tid) * 4), 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned *flag = reinterpret_cast<unsigned *>(smem);
+        if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tile_cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (flag[0] != 1u) return;
+        if (tid == 0) __hip_atomic_store(p.tile_cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const float a0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(slab, (unsigned)(((((size_t)0 * gridDim.x + blockIdx.x) * PB + pb) * 256 + tid) * 4), 0, 16));
+            const float a1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(slab, (unsigned)(((((size_t)1 * gridDim.x + blockIdx.x) * PB + pb) * 256 + tid) * 4), 0, 16));
+            vsum[pb] = a0 + a1;
+        }
+    }
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int r = wave;
+        float v = vsum[pb];
         const int pl = pb * 16 + 4 * kq + r;
         const int oy = r0 + (pl >> p.wo_log2), ox = pl & (p.Wo - 1);
         const int n = n0 + li;
@@ -254,6 +291,7 @@ bool fullk_supported(const FullKParams &p, int pb)
     if (p.Cout % 128) return false;                                         // N-slices of 16 channels, a multiple of 8 of them
     if (pb != 1 && pb != 2) return false;
     if (pb == 2 && p.Wo != 16) return false;
+    if (p.split > 1 && (pb != 1 || (p.C1 == 0 && p.C0 < 256) || !p.partial || !p.tile_cnt)) return false;   // halves of >= 128 channels (G >= 2)
     // band rows: <= nr + 2 source rows
     const int nr = pb * (16 / p.Wo);
     const int rows = (p.up ? nr / 2 + 2 : nr + 2) < p.Hs ? (p.up ? nr / 2 + 2 : nr + 2) : p.Hs;
@@ -271,6 +309,19 @@ static hipError_t launch_fullk_w(const FullKParams &p, size_t smem, hipStream_t 
         attr_done_on_this_device(attr_mask);
     }
     hipLaunchKernelGGL((conv3x3_fullk<PB, G, NCH, WT>), dim3(p.ntm * p.ntn), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+template <int G, bool WT>
+static hipError_t launch_fullk_split(const FullKParams &p, size_t smem, hipStream_t s)
+{
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_fullk<1, G, 1, WT, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    hipLaunchKernelGGL((conv3x3_fullk<1, G, 1, WT, true>), dim3(p.ntm * p.ntn, 2), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 template <int PB, int G>
@@ -293,6 +344,18 @@ hipError_t launch_fullk(const FullKParams &p_in, int pb, hipStream_t s)
     size_t smem = (size_t)(p.C1 ? 2 : 1) * ((size_t)rows * p.Ws + 1) * (p.C0 + 4) * sizeof(float);
     const size_t red = (size_t)4 * pb * 4 * 64 * sizeof(float);
     if (smem < red) smem = red;
+    if (p.split > 1) {
+        // one source of cc channels per workgroup: a concat input's source z, or half of a single source
+        const int cc = p.C1 ? p.C0 : p.C0 / 2;
+        smem = ((size_t)rows * p.Ws + 1) * (cc + 4) * sizeof(float);
+        if (smem < red) smem = red;
+        switch (cc / 64) {
+        case 8: return p.wtile ? launch_fullk_split<8, true>(p, smem, s) : launch_fullk_split<8, false>(p, smem, s);
+        case 4: return p.wtile ? launch_fullk_split<4, true>(p, smem, s) : launch_fullk_split<4, false>(p, smem, s);
+        case 2: return p.wtile ? launch_fullk_split<2, true>(p, smem, s) : launch_fullk_split<2, false>(p, smem, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
     const int g = p.C0 / 64;
     if (pb == 2) {
         if (g == 8) return launch_fullk_t<2, 8>(p, smem, s);

@@ -173,6 +173,12 @@ struct FullKParams {
     int ntm, ntn, tiles_per_img, wo_log2; // filled by launch_fullk
     int wtile;                   // weights in the tile-blocked layout of pack_fullk_weights() (the shipped path) instead of [Cout][9][Cin]
     unsigned long long *stamps;  // -DLSPF2F_FULLK_STAMPS builds: [blocks][4 waves][16] cycle counters
+    // K split in two (8x8 outputs at batch 1: 128 tiles on 256 CUs): workgroup (tile, z) takes input-channel half z -- source z of a concat input, or
+    // the lower / upper half of a single source, whose weights are then packed as pack_fullk_weights(rows, C0 / 2, 2, ...) -- and the second arriver
+    // of a tile adds the two partial tiles in z order and runs the epilogue.  partial: [2][tiles][pb][256] floats; tile_cnt: zero on entry.
+    int split;                   // 0 | 1 = off
+    float *partial;
+    unsigned *tile_cnt;
 };
 bool fullk_supported(const FullKParams &p, int pb);
 hipError_t launch_fullk(const FullKParams &p, int pb, hipStream_t s);

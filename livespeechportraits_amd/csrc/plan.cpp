@@ -305,6 +305,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             off = align_up(off, 256);
             l.wfk_off = (int64_t)off;
             off += (size_t)l.cout * 9 * l.cin * sizeof(float);
+            if (l.ho == 8 && l.c1 == 0 && l.c0 >= 256) {     // the K-split form reads a single source as two half-sources
+                off = align_up(off, 256);
+                l.wfk2_off = (int64_t)off;
+                off += (size_t)l.cout * 9 * l.cin * sizeof(float);
+            }
         }
         if (l.kind == kIgemm && wino_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             // 16/9 of the 9-tap bytes; the 9-tap copy stays (plans of other batch sizes, LSP_HIP_WINO=0)
@@ -425,7 +430,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             const int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
-            if (fullk) { bm = 16 * fullk; bn = 16; splits = 1; group = 1; }
+            if (fullk) { bm = 16 * fullk; bn = 16; splits = (p.use_fullk_split && fullk_split(batch, l.ho, l.c0, l.c1, l.cout, fullk) && (l.c1 || l.wfk2_off >= 0)) ? 2 : 1; group = 1; }
             int wsplits = 1;
             const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
             if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
@@ -560,6 +565,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
                     for (int t = 0; t < 9; ++t)
                         dst[((size_t)co * 9 + t) * cin + ci] = W[((size_t)co * cin + ci) * 9 + t];
             if (l.wfk_off >= 0) pack_fullk_weights(dst, l.c0, l.c1 ? 2 : 1, cout, reinterpret_cast<float *>(base + l.wfk_off));
+            if (l.wfk2_off >= 0) pack_fullk_weights(dst, l.c0 / 2, 2, cout, reinterpret_cast<float *>(base + l.wfk2_off));
             if (l.wwg_off >= 0) pack_wino_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwg_off));
         } else if (l.kind == kFirstConv) {
             // [ci][tap][co]  -- broadcast rows for the direct first-layer kernel

@@ -46,6 +46,7 @@ struct LayerDesc {
     int64_t wbc_off = -1;    // bf16 plans, 512 -> Cout stride-1 layers at 16x16 / 8x8: a copy of the weights in the fragment order of bandconv.hip
     int64_t wrc_off = -1;    // bf16 plans, 64 -> 64 stride-1 layers: a copy of the weights in the fragment order of the weights-stationary kernel (rowconv.hip)
     int64_t wru_off = -1;    // bf16 plans, sub-pixel up-conv over two 128-channel sources -> 64 channels (L1.up): weights in the fragment order of rowup256
+    int64_t wfk2_off = -1;   // fp32 plans, single-source 8x8 layers: the full-K kernel's weights packed as two half-sources (its K-split form at batch 1)
     int64_t wrl_off = -1;    // bf16 plans, last conv over two 64-channel sources: the GEMM-form weights in the fragment order of rowlast128 (rowconv.hip)
     int64_t wwg_off = -1;    // fp32 plans, stride-1 single-source convs at >= 32x32: G g G^T in the fragment order of the Winograd kernel (wino.hip)
     int64_t wwu_off = -1;    // fp32 plans, sub-pixel up-convs over two equally wide sources: the 9 transformed taps in the fragment order of winoup.hip
@@ -62,6 +63,7 @@ struct LayerDesc {
     int wino = 0;          // > 0: executed by the Winograd F(2x2,3x3) kernel (wino.hip) with this many 32-channel blocks per wave (1 | 2); `splits` = its K splits
     int winoup = 0;        // > 0: executed by the up-conv Winograd kernel (winoup.hip) with this many 32-channel blocks per wave; `splits` = its K splits
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
+                           // (splits == 2 with it: K in two halves over twice the workgroups, combined in the launch)
 };
 
 struct ParamDesc {         // an expected state-dict entry
@@ -86,6 +88,7 @@ struct Plan {
                                                // A-B-A-B); LSP_HIP_BANDCONV_MIN_FRAMES lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
+    bool use_fullk_split = true;   // LSP_HIP_FULLK_SPLIT=0: the full-K kernel never splits K
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
     int winoup_nb = 0, winoup_target = 1024;   // tools (LSP_HIP_WINOUP_NB / _TARGET at create): force the channel blocks per wave / the workgroup count aimed at
     bool use_winoup = true;    // fp32 plans: sub-pixel up-convs on the up-conv Winograd kernel (LSP_HIP_WINOUP=0 at create: the implicit GEMM, A-B runs)
@@ -160,6 +163,14 @@ inline bool fullk_layer(int hs, int ho, int c0, int c1, int cout, int stride, bo
     if (ho != 8 && ho != 16) return false;                    // 4x4 / 2x2 belong to the tiny-M kernel at batch 1
     if (up ? 2 * hs != ho : hs != ho) return false;
     return (c0 == 128 || c0 == 256 || c0 == 512) && (c1 == 0 || c1 == c0) && cout % 128 == 0;
+}
+// K split of the full-K kernel: when its tiles fill at most half the chip (8x8 outputs at batch 1: 4 x cout / 16 = 128 tiles on 256 CUs) and the input
+// has two sources or one of >= 256 channels to halve
+inline bool fullk_split(int batch, int ho, int c0, int c1, int cout, int pb)
+{
+    if (pb != 1 || ho != 8) return false;
+    const long tiles = (long)batch * (ho / 2) * (cout / 16);
+    return tiles <= 128 && (c1 == c0 || (c1 == 0 && c0 >= 256));
 }
 inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype)
 {
