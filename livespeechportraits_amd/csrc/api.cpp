@@ -115,7 +115,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") ? 1 : std::getenv("LSP_HIP_FIRSTCONV_REGSTAGE") ? 2 : 0;
     if (const char *env = std::getenv("LSP_HIP_FUSED_SPLITK")) h->fuse_splitk = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_PREFETCH")) h->prefetch = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;      // off unless set
     h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
                   : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : std::getenv("LSP_HIP_LASTCONV_MFMA") ? 4 : std::getenv("LSP_HIP_LASTCONV_VALU") ? 5 : 0;
     *out = h;

@@ -262,7 +262,7 @@ def test_conv3x3_full_k_kernel_k_split(cfg, gpu_device):
     got = outs[0]
     assert torch.isfinite(got).all() and torch.equal(outs[0], outs[1])
     assert (got - ref).abs().max().item() <= 3e-5
-    assert (got - whole).abs().max().item() <= 4e-6
+    assert (got - whole).abs().max().item() <= 1.5e-5           # another summation order over K = 4608 / 9216 products, outputs of a few units
 
 
 TINY_CASES = [
