@@ -107,6 +107,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_WINOUP_NB")) h->plan.winoup_nb = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_WINOUP_TARGET")) h->plan.winoup_target = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
+    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
     // environment switches are read HERE, once per handle, never on the launch path
@@ -115,7 +116,6 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") ? 1 : std::getenv("LSP_HIP_FIRSTCONV_REGSTAGE") ? 2 : 0;
     if (const char *env = std::getenv("LSP_HIP_FUSED_SPLITK")) h->fuse_splitk = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_PREFETCH")) h->prefetch = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;      // off unless set
     h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
                   : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : std::getenv("LSP_HIP_LASTCONV_MFMA") ? 4 : std::getenv("LSP_HIP_LASTCONV_VALU") ? 5 : 0;
     *out = h;

@@ -88,8 +88,8 @@ struct Plan {
                                                // A-B-A-B); LSP_HIP_BANDCONV_MIN_FRAMES lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
-    bool use_fullk_split = false;  // LSP_HIP_FULLK_SPLIT=1 at create: the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the
-                                   // workgroups (built and tested; measured null -- 11.48 vs 11.46 us per launch of the class, A-B-A-B-A-B -- so off by default)
+    bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (LSP_HIP_FULLK_SPLIT=0 at
+                                   // create: unsplit, A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
     int winoup_nb = 0, winoup_target = 1024;   // tools (LSP_HIP_WINOUP_NB / _TARGET at create): force the channel blocks per wave / the workgroup count aimed at
     bool use_winoup = true;    // fp32 plans: sub-pixel up-convs on the up-conv Winograd kernel (LSP_HIP_WINOUP=0 at create: the implicit GEMM, A-B runs)

@@ -382,3 +382,20 @@ def test_fp16_plan_takes_the_16bit_kernels_and_packs_rne_half():
     assert Engine("normal", dtype="f16").packed_bytes() == Engine("normal", dtype="bf16").packed_bytes()
     with pytest.raises(Exception):
         Engine("normal", ngf=32, num_downs=5, size=64, dtype="f16")                  # a 16-bit K-tile is 64 channels
+
+
+def test_full_k_kernel_splits_k_where_its_tiles_fill_half_the_chip(monkeypatch):
+    """8x8 outputs at batch 1: 4 x 512 / 16 = 128 tiles for 256 CUs -> the full-K kernel runs with K in two halves (split_k == 2; single sources read
+    as two half-sources, L6.up by source).  Not at 16x16 (256 tiles), not from batch 2 on, not with LSP_HIP_FULLK_SPLIT=0 (read BEFORE the plan is made)."""
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("large", max_batch=2)
+    one = {l["name"]: l for l in e.layers(1) if l["kernel"] == "conv3x3_fullk"}
+    assert len(one) == 18
+    assert sorted(n for n, l in one.items() if l["split_k"] == 2) == sorted(n for n, l in one.items() if l["h_out"] == 8) and "L6.up" in one
+    assert all(l["split_k"] == 1 for l in one.values() if l["h_out"] == 16)
+    assert all(l["split_k"] == 1 for l in e.layers(2) if l["kernel"] == "conv3x3_fullk")
+    e.close()
+    monkeypatch.setenv("LSP_HIP_FULLK_SPLIT", "0")
+    off = Engine("large")
+    assert all(l["split_k"] == 1 for l in off.layers(1) if l["kernel"] == "conv3x3_fullk")
+    off.close()

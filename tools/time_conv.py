@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time ONE conv shape through lspf2f_conv3x3 with a forced tile (GPU): median of hipEvent pairs, eager launches.
-  python tools/time_conv.py c0 c1 cout hs up tile_m tile_n [batch [k_group [dtype(0|1) [residual(0|1)]]]]"""
+  python tools/time_conv.py c0 c1 cout hs up tile_m tile_n [batch [k_group [dtype(0|1) [residual(0|1) [split_k]]]]]"""
 import ctypes, sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,7 @@ def main():
     kg = int(sys.argv[9]) if len(sys.argv) > 9 else 0        # -1: full-K tile-blocked weight layout (timing only: same bytes)
     dt = int(sys.argv[10]) if len(sys.argv) > 10 else 0
     with_res = int(sys.argv[11]) if len(sys.argv) > 11 else 0
+    split = int(sys.argv[12]) if len(sys.argv) > 12 else 0   # 2 with tile 16 16: the K-split form of the full-K kernel (no stamps then: they share the scratch)
     tdt = torch.bfloat16 if dt else torch.float32
     lib = N.load(); dev = torch.device("cuda:0")
     ho = 2 * hs if up else hs
@@ -20,12 +21,12 @@ def main():
     sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     out = torch.empty(b, ho, ho, cout, device=dev, dtype=tdt)
     res = torch.randn(b, ho, ho, cout, device=dev).to(tdt) if with_res else None
-    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, up, tm, tn, 0, 0, dt)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, up, tm, tn, split, kg, dt)
     scratch = torch.zeros(max(sb, 2048 * 4 * 16 * 8), dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run():
-        N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(w), p(sc), p(sh), p(res), p(out), b, hs, hs, c0, c1, cout, 1, up, 1, tm, tn, 0, kg, dt, p(scratch), scratch.numel(), st))
+        N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(w), p(sc), p(sh), p(res), p(out), b, hs, hs, c0, c1, cout, 1, up, 1, tm, tn, split, kg, dt, p(scratch), scratch.numel(), st))
     for _ in range(5): run()
     torch.cuda.synchronize()
     ts = []
@@ -36,7 +37,7 @@ def main():
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 100)
     ts.sort()
     st64 = scratch[:2048 * 4 * 16 * 8].view(torch.int64).view(2048, 4, 16).cpu().numpy()
-    if st64.any():
+    if st64.any() and not split:
         import numpy as np
         nb = (st64[:, 0, 0] != 0).sum()
         d = (st64[:nb] - st64[:nb, :, :1]).astype(np.float64)
