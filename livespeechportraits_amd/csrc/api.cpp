@@ -108,6 +108,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_WINOUP_TARGET")) h->plan.winoup_target = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT_TILES")) h->plan.fullk_split_max_tiles = std::atoi(env);
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
     // environment switches are read HERE, once per handle, never on the launch path
@@ -730,8 +731,10 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
     }
     (void)ws;
     const int ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
-    if (tile_m == 16 && tile_n == 16 && split_k == 2)               // K-split full-K kernel: two partial tiles per tile + arrival counters
-        return (size_t)batch * (ho * ho / 16) * (cout / 16) * (2 * 256 * sizeof(float) + sizeof(unsigned));
+    if ((tile_m == 16 || tile_m == 32) && tile_n == 16 && split_k == 2) {      // K-split full-K kernel: two partial tiles per tile + arrival counters
+        const size_t pbk = tile_m / 16;
+        return (size_t)batch * (ho * ho / (16 * pbk)) * (cout / 16) * (2 * pbk * 256 * sizeof(float) + sizeof(unsigned));
+    }
     const int Mout = batch * ho * ho;
     const bool up4 = upsample == 2;
     const int M = up4 ? batch * hs * hs : Mout;
@@ -869,10 +872,10 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = ho_; q.Wo = ho_; q.C0 = c0; q.C1 = c1; q.Cout = cout;
             q.up = upsample == 1; q.relu = relu;
             q.wtile = k_group == -1 ? 1 : 0;       // -1: w_packed is already in the full-K kernel's tile-blocked layout
-            if (split_k == 2 && tile_m == 16) {    // K halves: scratch = [2][tiles][256] floats + one zeroed counter per tile; a single source's w_packed is
+            if (split_k == 2) {    // K halves: scratch = [2][tiles][256] floats + one zeroed counter per tile; a single source's w_packed is
                                                    // packed as two half-sources
-                const size_t ntile = (size_t)batch * (ho_ * ho_ / 16) * (cout / 16);            // 16-pixel tiles x 16-channel slices
-                const size_t slab = 2 * ntile * 256 * sizeof(float);
+                const size_t ntile = (size_t)batch * (ho_ * ho_ / (16 * pb)) * (cout / 16);     // 16 pb-pixel tiles x 16-channel slices
+                const size_t slab = 2 * ntile * pb * 256 * sizeof(float);
                 if (!scratch || scratch_bytes < slab + ntile * sizeof(unsigned))
                     return fail(LSPF2F_ERR_INVALID_ARGUMENT, "scratch too small for the K-split full-K kernel");
                 q.split = 2; q.partial = static_cast<float *>(scratch);

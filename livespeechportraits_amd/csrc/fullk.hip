@@ -291,7 +291,7 @@ bool fullk_supported(const FullKParams &p, int pb)
     if (p.Cout % 128) return false;                                         // N-slices of 16 channels, a multiple of 8 of them
     if (pb != 1 && pb != 2) return false;
     if (pb == 2 && p.Wo != 16) return false;
-    if (p.split > 1 && (pb != 1 || (p.C1 == 0 && p.C0 < 256) || !p.partial || !p.tile_cnt)) return false;   // halves of >= 128 channels (G >= 2)
+    if (p.split > 1 && ((p.C1 == 0 && p.C0 < 256) || !p.partial || !p.tile_cnt)) return false;   // halves of >= 128 channels (G >= 2)
     // band rows: <= nr + 2 source rows
     const int nr = pb * (16 / p.Wo);
     const int rows = (p.up ? nr / 2 + 2 : nr + 2) < p.Hs ? (p.up ? nr / 2 + 2 : nr + 2) : p.Hs;
@@ -311,18 +311,28 @@ static hipError_t launch_fullk_w(const FullKParams &p, size_t smem, hipStream_t 
     hipLaunchKernelGGL((conv3x3_fullk<PB, G, NCH, WT>), dim3(p.ntm * p.ntn), dim3(256), smem, s, p);
     return hipGetLastError();
 }
-template <int G, bool WT>
+template <int PB, int G, bool WT>
 static hipError_t launch_fullk_split(const FullKParams &p, size_t smem, hipStream_t s)
 {
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_fullk<1, G, 1, WT, true>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_fullk<PB, G, 1, WT, true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL((conv3x3_fullk<1, G, 1, WT, true>), dim3(p.ntm * p.ntn, 2), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((conv3x3_fullk<PB, G, 1, WT, true>), dim3(p.ntm * p.ntn, 2), dim3(256), smem, s, p);
     return hipGetLastError();
+}
+template <int PB>
+static hipError_t launch_fullk_split_g(const FullKParams &p, int cc, size_t smem, hipStream_t s)
+{
+    switch (cc / 64) {
+    case 8: return p.wtile ? launch_fullk_split<PB, 8, true>(p, smem, s) : launch_fullk_split<PB, 8, false>(p, smem, s);
+    case 4: return p.wtile ? launch_fullk_split<PB, 4, true>(p, smem, s) : launch_fullk_split<PB, 4, false>(p, smem, s);
+    case 2: return p.wtile ? launch_fullk_split<PB, 2, true>(p, smem, s) : launch_fullk_split<PB, 2, false>(p, smem, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 template <int PB, int G>
 static hipError_t launch_fullk_t(const FullKParams &p, size_t smem, hipStream_t s)
@@ -349,12 +359,7 @@ hipError_t launch_fullk(const FullKParams &p_in, int pb, hipStream_t s)
         const int cc = p.C1 ? p.C0 : p.C0 / 2;
         smem = ((size_t)rows * p.Ws + 1) * (cc + 4) * sizeof(float);
         if (smem < red) smem = red;
-        switch (cc / 64) {
-        case 8: return p.wtile ? launch_fullk_split<8, true>(p, smem, s) : launch_fullk_split<8, false>(p, smem, s);
-        case 4: return p.wtile ? launch_fullk_split<4, true>(p, smem, s) : launch_fullk_split<4, false>(p, smem, s);
-        case 2: return p.wtile ? launch_fullk_split<2, true>(p, smem, s) : launch_fullk_split<2, false>(p, smem, s);
-        default: return hipErrorInvalidValue;
-        }
+        return pb == 2 ? launch_fullk_split_g<2>(p, cc, smem, s) : launch_fullk_split_g<1>(p, cc, smem, s);
     }
     const int g = p.C0 / 64;
     if (pb == 2) {

@@ -305,7 +305,7 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             off = align_up(off, 256);
             l.wfk_off = (int64_t)off;
             off += (size_t)l.cout * 9 * l.cin * sizeof(float);
-            if (l.ho == 8 && l.c1 == 0 && l.c0 >= 256) {     // the K-split form reads a single source as two half-sources
+            if (l.c1 == 0 && l.c0 >= 256) {                  // the K-split form reads a single source as two half-sources
                 off = align_up(off, 256);
                 l.wfk2_off = (int64_t)off;
                 off += (size_t)l.cout * 9 * l.cin * sizeof(float);
@@ -430,7 +430,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             const int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
-            if (fullk) { bm = 16 * fullk; bn = 16; splits = (p.use_fullk_split && fullk_split(batch, l.ho, l.c0, l.c1, l.cout, fullk) && (l.c1 || l.wfk2_off >= 0)) ? 2 : 1; group = 1; }
+            if (fullk) { bm = 16 * fullk; bn = 16; splits = (p.use_fullk_split && fullk_split(batch, l.ho, l.c0, l.c1, l.cout, fullk, p.fullk_split_max_tiles) && (l.c1 || l.wfk2_off >= 0)) ? 2 : 1; group = 1; }
             int wsplits = 1;
             const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
             if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }

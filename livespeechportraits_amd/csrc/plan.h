@@ -88,6 +88,7 @@ struct Plan {
                                                // A-B-A-B); LSP_HIP_BANDCONV_MIN_FRAMES lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
+    int fullk_split_max_tiles = 128;   // LSP_HIP_FULLK_SPLIT_TILES at create (tools): 256 also splits the 16x16 layers at batch 1
     bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (LSP_HIP_FULLK_SPLIT=0 at
                                    // create: unsplit, A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
@@ -167,11 +168,12 @@ inline bool fullk_layer(int hs, int ho, int c0, int c1, int cout, int stride, bo
 }
 // K split of the full-K kernel: when its tiles fill at most half the chip (8x8 outputs at batch 1: 4 x cout / 16 = 128 tiles on 256 CUs) and the input
 // has two sources or one of >= 256 channels to halve
-inline bool fullk_split(int batch, int ho, int c0, int c1, int cout, int pb)
+inline bool fullk_split(int batch, int ho, int c0, int c1, int cout, int pb, int max_tiles = 128)
 {
-    if (pb != 1 || ho != 8) return false;
-    const long tiles = (long)batch * (ho / 2) * (cout / 16);
-    return tiles <= 128 && (c1 == c0 || (c1 == 0 && c0 >= 256));
+    if (ho != 8 && ho != 16) return false;
+    const int nr = pb * (16 / ho);
+    const long tiles = (long)batch * (ho / nr) * (cout / 16);
+    return tiles <= max_tiles && (c1 == c0 || (c1 == 0 && c0 >= 256));
 }
 inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype)
 {

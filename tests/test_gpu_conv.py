@@ -217,21 +217,24 @@ def test_conv3x3_full_k_kernel(cfg, gpu_device):
 
 FULLK_SPLIT_CASES = [
     # b, c0, c1, cout, hs, up, bn, res, relu      (K in two halves over twice the workgroups, combined in the launch)
-    (1, 512, 0, 512, 8, False, True, True, True),      # the 8x8 res convs at batch 1: one source read as two 256-channel half-sources
-    (1, 512, 512, 512, 4, True, True, False, True),    # L6.up: 4 -> 8 over the concat, half = source
-    (1, 256, 0, 128, 8, False, False, True, False),    # 128-channel halves (G = 2), no BN, no ReLU
-    (2, 256, 256, 128, 4, False, True, False, True),   # 4x4 frames, batch 2, two sources, no upsample
-    (1, 512, 0, 128, 16, False, True, True, True),     # 16x16 in 16-pixel tiles: 16 tiles per frame
+    (1, 512, 0, 512, 8, False, True, True, True, 16),      # the 8x8 res convs at batch 1: one source read as two 256-channel half-sources
+    (1, 512, 512, 512, 4, True, True, False, True, 16),    # L6.up: 4 -> 8 over the concat, half = source
+    (1, 256, 0, 128, 8, False, False, True, False, 16),    # 128-channel halves (G = 2), no BN, no ReLU
+    (2, 256, 256, 128, 4, False, True, False, True, 16),   # 4x4 frames, batch 2, two sources, no upsample
+    (1, 512, 0, 128, 16, False, True, True, True, 16),     # 16x16 in 16-pixel tiles: 16 tiles per frame
+    (1, 512, 0, 512, 16, False, True, True, True, 32),     # 16x16 in 32-pixel tiles (two pixel blocks per workgroup): the 16x16 res convs at batch 1
+    (1, 512, 512, 256, 8, True, True, False, True, 32),    # L5.up-shaped: 8 -> 16 over the concat, 32-pixel tiles
 ]
 
 
-@pytest.mark.parametrize("cfg", FULLK_SPLIT_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d%s" % (c[0], c[1], c[2], c[3], c[4], "up" if c[5] else ""))
+@pytest.mark.parametrize("cfg", FULLK_SPLIT_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d%s_t%d" % (c[0], c[1], c[2], c[3], c[4], "up" if c[5] else "", c[9]))
 def test_conv3x3_full_k_kernel_k_split(cfg, gpu_device):
     """conv3x3_fullk with its K split in two: workgroup (tile, z) reads source z of a concat input, or channel half z of a single source (weights packed
     as two half-sources), the second arriver adds the two partial tiles in z order.  Against the fp64 convolution, against the unsplit kernel (another
     summation order: a few ulp), twice (fixed order: bit-identical; the arrival counters must be back at zero)."""
     from livespeechportraits_amd import _native as N
-    b, c0, c1, cout, hs, up, bn, res, relu = cfg
+    b, c0, c1, cout, hs, up, bn, res, relu, tm = cfg
+    pbk = tm // 16
     x0 = rnd(b, c0, hs, hs, seed=51)
     x1 = rnd(b, c1, hs, hs, seed=52) if c1 else None
     w = rnd(cout, c0 + c1, 3, 3, seed=53) * 0.05
@@ -240,25 +243,26 @@ def test_conv3x3_full_k_kernel_k_split(cfg, gpu_device):
     ho = 2 * hs if up else hs
     r = rnd(b, cout, ho, ho, seed=56) if res else None
     ref = ref_conv(x0, x1, w, scale, shift, r, 1, up, relu)
-    whole = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, up, relu, (16, 16), k_group=-1)
+    whole = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, up, relu, (tm, 16), k_group=-1)
     lib, dev = N.load(), gpu_device
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
     d0, d1 = nhwc(x0), nhwc(x1) if x1 is not None else None
     wp = (pack_fullk(w, c0, 2) if c1 else pack_fullk(w, c0 // 2, 2)).to(dev)
     dsc, dsh = (scale.to(dev), shift.to(dev)) if bn else (None, None)
     dres = nhwc(r) if r is not None else None
-    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, int(up), 16, 16, 2, -1, 0)
-    assert sb == b * (ho * ho // 16) * (cout // 16) * (2 * 256 * 4 + 4)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, int(up), tm, 16, 2, -1, 0)
+    ntile = b * (ho * ho // (16 * pbk)) * (cout // 16)
+    assert sb == ntile * (2 * pbk * 256 * 4 + 4)
     scratch = torch.zeros(sb, dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     outs = []
     for _ in range(2):
         out = torch.full((b, ho, ho, cout), float("nan"), device=dev)
-        N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(wp), p(dsc), p(dsh), p(dres), p(out), b, hs, hs, c0, c1, cout, 1, int(up), int(relu), 16, 16, 2, -1, 0,
+        N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(wp), p(dsc), p(dsh), p(dres), p(out), b, hs, hs, c0, c1, cout, 1, int(up), int(relu), tm, 16, 2, -1, 0,
                                    p(scratch), scratch.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
         outs.append(out.permute(0, 3, 1, 2).contiguous().cpu())
-        assert int(scratch[-(sb - b * (ho * ho // 16) * (cout // 16) * 2048):].view(torch.int32).abs().sum().item()) == 0      # counters left at zero
+        assert int(scratch[ntile * 2 * pbk * 1024:].view(torch.int32).abs().sum().item()) == 0      # counters left at zero
     got = outs[0]
     assert torch.isfinite(got).all() and torch.equal(outs[0], outs[1])
     assert (got - ref).abs().max().item() <= 3e-5
