@@ -185,6 +185,10 @@ inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int
     for (int pb = 1; pb <= (ho == 16 ? 2 : 1); ++pb) {
         const int nr = pb * (16 / ho);
         const long tiles = (long)batch * ((ho + nr - 1) / nr) * ntn;
+        // the band of source rows behind a tile must fit the 150 KB of LDS fullk_supported() (fullk.hip) grants: (rows * Ws + 1 zero pixel) x (C0 + 4 pad)
+        // floats per source -- 133 KB for the widest shape the generators build (4 rows x 16 px x 512 ch)
+        const int rows = std::min(up ? nr / 2 + 2 : nr + 2, hs);
+        if ((size_t)(c1 ? 2 : 1) * ((size_t)rows * hs + 1) * (c0 + 4) * sizeof(float) > 150 * 1024) continue;
         if (tiles <= 256 || (pb == (ho == 16 ? 2 : 1) && tiles <= 512)) return pb;
     }
     return 0;

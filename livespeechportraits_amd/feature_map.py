@@ -76,8 +76,9 @@ class FeatureMapRasteriser:
         else:
             res = out if out is not None else torch.empty((b, 1, s, s), dtype=torch.float32, device=self.device)
             f32, u8 = res, None
-        if res.device != self.device or not res.is_contiguous():
-            raise ValueError("out must be a contiguous tensor on %s" % self.device)
+        want = ((b, s, s), torch.uint8) if as_uint8 else ((b, 1, s, s), torch.float32)
+        if res.device != self.device or not res.is_contiguous() or tuple(res.shape) != want[0] or res.dtype != want[1]:
+            raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (want[1], list(want[0]), self.device))
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(self.device):
             N.check_raster(self.lib.lspraster_edge_maps(p(pts), N.RASTER_POINT_DTYPES[str(pts.dtype).replace("torch.", "")], b,
