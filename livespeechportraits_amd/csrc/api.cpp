@@ -109,6 +109,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
     if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT_TILES")) h->plan.fullk_split_max_tiles = std::atoi(env);
+    if (const char *env = std::getenv("LSP_HIP_FULLK_S2")) h->plan.use_fullk_s2 = std::strcmp(env, "0") != 0;
     h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
     // environment switches are read HERE, once per handle, never on the launch path
@@ -442,7 +443,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wfk_off); p.wtile = 1; p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout;
-        p.up = l.up; p.relu = l.inorm ? 0 : l.relu;
+        p.up = l.up; p.relu = l.inorm ? 0 : l.relu; p.stride = l.stride;
         if (l.splits == 2) {                       // K in two halves, combined in the launch
             p.split = 2;
             if (!l.c1) p.w = bptr(l.wfk2_off);     // a single source read as two half-sources
@@ -870,7 +871,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             q.w = static_cast<const float *>(w_packed); q.scale = scale; q.shift = shift;
             q.residual = static_cast<const float *>(residual); q.out = static_cast<float *>(out);
             q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = ho_; q.Wo = ho_; q.C0 = c0; q.C1 = c1; q.Cout = cout;
-            q.up = upsample == 1; q.relu = relu;
+            q.up = upsample == 1; q.relu = relu; q.stride = stride;
             q.wtile = k_group == -1 ? 1 : 0;       // -1: w_packed is already in the full-K kernel's tile-blocked layout
             if (split_k == 2) {    // K halves: scratch = [2][tiles][256] floats + one zeroed counter per tile; a single source's w_packed is
                                                    // packed as two half-sources
@@ -884,7 +885,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
 #ifdef LSPF2F_FULLK_STAMPS
             q.stamps = scratch_bytes >= (size_t)512 * 4 * 16 * 8 ? static_cast<unsigned long long *>(scratch) : nullptr;
 #endif
-            if (dtype != 0 || stride != 1 || upsample == 2 || !fullk_supported(q, pb))
+            if (dtype != 0 || (stride != 1 && !(stride == 2 && q.split == 2)) || upsample == 2 || !fullk_supported(q, pb))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "full-K kernel does not support this shape");
             e = launch_fullk(q, pb, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (full-K) launch");

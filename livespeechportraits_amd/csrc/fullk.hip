@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
         const int u0 = r0 - 1 < 0 ? 0 : r0 - 1, u1 = r0 + nr > 2 * p.Hs - 1 ? 2 * p.Hs - 1 : r0 + nr;
         sy0 = u0 >> 1; sy1 = (u1 >> 1) + 1;
     } else {
-        sy0 = r0 - 1 < 0 ? 0 : r0 - 1; sy1 = r0 + nr + 1 > p.Hs ? p.Hs : r0 + nr + 1;
+        // stride S: output rows r0 .. r0 + nr - 1 read source rows S r0 - 1 .. S (r0 + nr - 1) + 1
+        const int S = p.stride == 2 ? 2 : 1;
+        const int lo = S * r0 - 1, hi = S * (r0 + nr - 1) + 2;
+        sy0 = lo < 0 ? 0 : lo; sy1 = hi > p.Hs ? p.Hs : hi;
     }
     const int npix = (sy1 - sy0) * p.Ws;                     // zero pixel sits at index npix
 
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
     int aoff[PB][9];
     {
         const int hl = p.up ? 2 * p.Hs : p.Hs, wl = p.up ? 2 * p.Ws : p.Ws;
+        const int S = (!p.up && p.stride == 2) ? 2 : 1;
         const int zero = npix * PST + unit0 * 4;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_fullk(const FullKParams p)
             int rowoff[3], coloff[3];                                         // < 0: outside
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const int uy = oy + d - 1, ux = ox + d - 1;
+                const int uy = S * oy + d - 1, ux = S * ox + d - 1;
                 rowoff[d] = (oy < p.Ho && (unsigned)uy < (unsigned)hl) ? ((p.up ? uy >> 1 : uy) - sy0) * p.Ws * PST + unit0 * 4 : -1;
                 coloff[d] = (unsigned)ux < (unsigned)wl ? (p.up ? ux >> 1 : ux) * PST : -1;
             }
@@ -285,7 +289,9 @@ void pack_fullk_weights(const float *rows, int c0, int nch, int cout, float *out
 bool fullk_supported(const FullKParams &p, int pb)
 {
     if (p.Wo != 2 && p.Wo != 4 && p.Wo != 8 && p.Wo != 16) return false;
-    if (p.Ho != p.Wo || p.Hs != p.Ws || (p.up ? 2 * p.Hs != p.Ho : p.Hs != p.Ho)) return false;
+    const int S = p.stride == 2 ? 2 : 1;
+    if (S == 2 && (p.up || p.C1 != 0 || p.split < 2)) return false;        // stride 2: one source, K-split form only
+    if (p.Ho != p.Wo || p.Hs != p.Ws || (p.up ? 2 * p.Hs != p.Ho : p.Hs != S * p.Ho)) return false;
     if (p.C0 != 128 && p.C0 != 256 && p.C0 != 512) return false;          // G = C0 / 64 in {2, 4, 8}
     if (p.C1 != 0 && p.C1 != p.C0) return false;
     if (p.Cout % 128) return false;                                         // N-slices of 16 channels, a multiple of 8 of them
@@ -294,7 +300,9 @@ bool fullk_supported(const FullKParams &p, int pb)
     if (p.split > 1 && ((p.C1 == 0 && p.C0 < 256) || !p.partial || !p.tile_cnt)) return false;   // halves of >= 128 channels (G >= 2)
     // band rows: <= nr + 2 source rows
     const int nr = pb * (16 / p.Wo);
-    const int rows = (p.up ? nr / 2 + 2 : nr + 2) < p.Hs ? (p.up ? nr / 2 + 2 : nr + 2) : p.Hs;
+    const int want = p.up ? nr / 2 + 2 : S * (nr - 1) + 3;
+    const int rows = want < p.Hs ? want : p.Hs;
+    if (p.split > 1) return ((size_t)rows * p.Ws + 1) * ((p.C1 ? p.C0 : p.C0 / 2) + 4) * sizeof(float) <= 150 * 1024;      // one half-source per workgroup
     return (size_t)(p.C1 ? 2 : 1) * ((size_t)rows * p.Ws + 1) * (p.C0 + 4) * sizeof(float) <= 150 * 1024;
 }
 
@@ -350,7 +358,9 @@ hipError_t launch_fullk(const FullKParams &p_in, int pb, hipStream_t s)
     p.ntm = p.B * p.tiles_per_img;
     p.ntn = p.Cout / 16;
     p.wo_log2 = p.Wo == 16 ? 4 : p.Wo == 8 ? 3 : p.Wo == 4 ? 2 : 1;
-    const int rows = (p.up ? nr / 2 + 2 : nr + 2) < p.Hs ? (p.up ? nr / 2 + 2 : nr + 2) : p.Hs;
+    const int S = p.stride == 2 ? 2 : 1;
+    const int want_rows = p.up ? nr / 2 + 2 : S * (nr - 1) + 3;
+    const int rows = want_rows < p.Hs ? want_rows : p.Hs;
     size_t smem = (size_t)(p.C1 ? 2 : 1) * ((size_t)rows * p.Ws + 1) * (p.C0 + 4) * sizeof(float);
     const size_t red = (size_t)4 * pb * 4 * 64 * sizeof(float);
     if (smem < red) smem = red;

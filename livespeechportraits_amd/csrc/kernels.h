@@ -179,6 +179,8 @@ struct FullKParams {
     int split;                   // 0 | 1 = off
     float *partial;
     unsigned *tile_cnt;
+    int stride;                  // 0 | 1 = stride 1; 2 = stride-2 conv (Hs == 2 Ho, no upsample): the stride-2 convs of the small levels, whose 5-row bands
+                                 // fit LDS once the K split halves the channels a workgroup stages
 };
 bool fullk_supported(const FullKParams &p, int pb);
 hipError_t launch_fullk(const FullKParams &p, int pb, hipStream_t s);

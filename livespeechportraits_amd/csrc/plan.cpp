@@ -311,6 +311,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
                 off += (size_t)l.cout * 9 * l.cin * sizeof(float);
             }
         }
+        if (l.kind == kIgemm && fullk_s2_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+            off = align_up(off, 256);
+            l.wfk2_off = (int64_t)off;                        // the only full-K copy of these layers: their single source as two half-sources
+            off += (size_t)l.cout * 9 * l.cin * sizeof(float);
+        }
         if (l.kind == kIgemm && wino_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             // 16/9 of the 9-tap bytes; the 9-tap copy stays (plans of other batch sizes, LSP_HIP_WINO=0)
             off = align_up(off, 256);
@@ -429,8 +434,12 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, p.dtype, &bm, &bn, &splits, &group);
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
-            const int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
-            if (fullk) { bm = 16 * fullk; bn = 16; splits = (p.use_fullk_split && fullk_split(batch, l.ho, l.c0, l.c1, l.cout, fullk, p.fullk_split_max_tiles) && (l.c1 || l.wfk2_off >= 0)) ? 2 : 1; group = 1; }
+            int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
+            const bool fullk_s2 = !fullk && !smallm && p.use_fullk_s2 && p.use_fullk_split && l.wfk2_off >= 0 &&
+                                  fullk_s2_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype, l.inorm) &&
+                                  fullk_s2_choice(batch, l.hs, l.ho, l.c0, l.cout) > 0;
+            if (fullk_s2) { fullk = 1; bm = 16; bn = 16; splits = 2; group = 1; }
+            else if (fullk) { bm = 16 * fullk; bn = 16; splits = (p.use_fullk_split && fullk_split(batch, l.ho, l.c0, l.c1, l.cout, fullk, p.fullk_split_max_tiles) && (l.c1 || l.wfk2_off >= 0)) ? 2 : 1; group = 1; }
             int wsplits = 1;
             const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
             if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }

@@ -89,6 +89,7 @@ struct Plan {
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     int fullk_split_max_tiles = 128;   // LSP_HIP_FULLK_SPLIT_TILES at create (tools): 256 also splits the 16x16 layers at batch 1
+    bool use_fullk_s2 = true;      // LSP_HIP_FULLK_S2=0 at create: the stride-2 convs of the small levels stay on the implicit GEMM + split-K reduce
     bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (LSP_HIP_FULLK_SPLIT=0 at
                                    // create: unsplit, A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
@@ -165,6 +166,22 @@ inline bool fullk_layer(int hs, int ho, int c0, int c1, int cout, int stride, bo
     if (ho != 8 && ho != 16) return false;                    // 4x4 / 2x2 belong to the tiny-M kernel at batch 1
     if (up ? 2 * hs != ho : hs != ho) return false;
     return (c0 == 128 || c0 == 256 || c0 == 512) && (c1 == 0 || c1 == c0) && cout % 128 == 0;
+}
+// the stride-2 convs of the small levels (outputs 16x16 / 8x8 / 4x4 from a single source of 256 | 512 channels) on the K-split full-K kernel: half the
+// channels of their 5-row band fit LDS.  Batch-independent part (who gets the half-source weight copy) and the per-batch choice (pixel blocks per tile or 0).
+inline bool fullk_s2_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
+{
+    return dtype == 0 && stride == 2 && !up && !up4 && !inorm && c1 == 0 && (c0 == 256 || c0 == 512) && cout % 128 == 0 &&
+           (ho == 16 || ho == 8 || ho == 4) && hs == 2 * ho;
+}
+inline int fullk_s2_choice(int batch, int hs, int ho, int c0, int cout)
+{
+    if (batch != 1) return 0;                                 // measured at batch 1 only; from 2 frames up the implicit GEMM has rows enough
+    const int nr = 16 / ho;                                   // one 16-pixel block per tile
+    const long tiles = (long)batch * ((ho + nr - 1) / nr) * (cout / 16);
+    const int rows = std::min(2 * (nr - 1) + 3, hs);
+    if (((size_t)rows * hs + 1) * (c0 / 2 + 4) * sizeof(float) > 150 * 1024) return 0;
+    return tiles <= 512 ? 1 : 0;                              // 2 x tiles workgroups, one per CU at a time: up to four rounds
 }
 // K split of the full-K kernel: when its tiles fill at most half the chip (8x8 outputs at batch 1: 4 x cout / 16 = 128 tiles on 256 CUs) and the input
 // has two sources or one of >= 256 channels to halve

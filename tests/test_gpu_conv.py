@@ -269,6 +269,51 @@ def test_conv3x3_full_k_kernel_k_split(cfg, gpu_device):
     assert (got - whole).abs().max().item() <= 1.5e-5           # another summation order over K = 4608 / 9216 products, outputs of a few units
 
 
+FULLK_S2_CASES = [
+    # b, c0, cout, hs          (stride-2 convs of the small levels on the K-split full-K kernel; hs -> hs / 2)
+    (1, 512, 512, 32),      # L4.down: 16x16 out, 16-pixel tiles = one output row, 3 source rows
+    (1, 512, 512, 16),      # L5.down: 8x8 out, 2 output rows per tile, 5 source rows
+    (1, 512, 512, 8),       # L6.down: 4x4 out, the whole frame in one tile, every source row
+    (1, 256, 128, 16),      # 128-channel halves, one N-slice group
+    (2, 256, 256, 8),       # two frames: tiles index (frame, row block)
+]
+
+
+@pytest.mark.parametrize("cfg", FULLK_S2_CASES, ids=lambda c: "b%d_c%d_o%d_h%d" % c)
+def test_conv3x3_full_k_kernel_stride2(cfg, gpu_device):
+    """conv3x3_fullk with stride 2 (K-split form only: half the channels of the 2 nr + 1 source rows fit LDS): against the fp64 convolution, against the
+    implicit GEMM on the same problem, bit-identical repeats, counters back at zero."""
+    from livespeechportraits_amd import _native as N
+    b, c0, cout, hs = cfg
+    ho = hs // 2
+    x0 = rnd(b, c0, hs, hs, seed=61)
+    w = rnd(cout, c0, 3, 3, seed=63) * 0.05
+    scale, shift = rnd(cout, seed=64) * 0.5 + 1.0, rnd(cout, seed=65) * 0.1
+    ref = ref_conv(x0, None, w, scale, shift, None, 2, False, True)
+    gemm = run_conv(gpu_device, x0, None, w, scale, shift, None, 2, False, True)             # the implicit GEMM in the tiling its planner picks
+    lib, dev = N.load(), gpu_device
+    d0 = x0.permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = pack_fullk(w, c0 // 2, 2).to(dev)
+    dsc, dsh = scale.to(dev), shift.to(dev)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, 0, cout, 2, 0, 16, 16, 2, -1, 0)
+    ntile = b * (ho * ho // 16) * (cout // 16)
+    assert sb == ntile * (2 * 256 * 4 + 4)
+    scratch = torch.zeros(sb, dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    outs = []
+    for _ in range(2):
+        out = torch.full((b, ho, ho, cout), float("nan"), device=dev)
+        N.check(lib.lspf2f_conv3x3(p(d0), None, p(wp), p(dsc), p(dsh), None, p(out), b, hs, hs, c0, 0, cout, 2, 0, 1, 16, 16, 2, -1, 0,
+                                   p(scratch), scratch.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        outs.append(out.permute(0, 3, 1, 2).contiguous().cpu())
+        assert int(scratch[ntile * 2 * 1024:].view(torch.int32).abs().sum().item()) == 0
+    got = outs[0]
+    assert torch.isfinite(got).all() and torch.equal(outs[0], outs[1])
+    assert (got - ref).abs().max().item() <= 3e-5
+    assert (got - gemm).abs().max().item() <= 1.5e-5
+
+
 TINY_CASES = [
     # b, cin, cout, hs, stride, up, bn, res, relu     (tile 1x1 = the single-launch tiny-M kernel)
     (1, 512, 512, 4, 1, False, True, True, True),     # L6 res conv b

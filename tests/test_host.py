@@ -389,13 +389,28 @@ def test_full_k_kernel_splits_k_where_its_tiles_fill_half_the_chip(monkeypatch):
     as two half-sources, L6.up by source).  Not at 16x16 (256 tiles), not from batch 2 on, not with LSP_HIP_FULLK_SPLIT=0 (read BEFORE the plan is made)."""
     from livespeechportraits_amd.engine import Engine
     e = Engine("large", max_batch=2)
-    one = {l["name"]: l for l in e.layers(1) if l["kernel"] == "conv3x3_fullk"}
+    one = {l["name"]: l for l in e.layers(1) if l["kernel"] == "conv3x3_fullk" and l["stride"] == 1}      # (the stride-2 ones: next test)
     assert len(one) == 18
     assert sorted(n for n, l in one.items() if l["split_k"] == 2) == sorted(n for n, l in one.items() if l["h_out"] == 8) and "L6.up" in one
     assert all(l["split_k"] == 1 for l in one.values() if l["h_out"] == 16)
-    assert all(l["split_k"] == 1 for l in e.layers(2) if l["kernel"] == "conv3x3_fullk")
+    assert all(l["split_k"] == 1 for l in e.layers(2) if l["kernel"] == "conv3x3_fullk" and l["stride"] == 1)
     e.close()
     monkeypatch.setenv("LSP_HIP_FULLK_SPLIT", "0")
     off = Engine("large")
-    assert all(l["split_k"] == 1 for l in off.layers(1) if l["kernel"] == "conv3x3_fullk")
+    assert all(l["split_k"] == 1 for l in off.layers(1) if l["kernel"] == "conv3x3_fullk") and not any(l["kernel"] == "conv3x3_fullk" and l["stride"] == 2 for l in off.layers(1))
     off.close()
+
+
+def test_stride2_convs_of_the_small_levels_run_on_the_k_split_full_k_kernel(monkeypatch):
+    """L4 / L5 / L6.down at batch 1 (BatchNorm plans): half the channels of their source band fit LDS, so they leave the implicit GEMM + reduce launch for
+    conv3x3_fullk with K in two halves.  Not from batch 2 on, not under InstanceNorm plans, not with LSP_HIP_FULLK_S2=0."""
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("large", max_batch=2)
+    downs = lambda ls: {l["name"]: (l["kernel"], l["split_k"]) for l in ls if l["name"] in ("L3.down", "L4.down", "L5.down", "L6.down")}
+    one = downs(e.layers(1))
+    assert one["L4.down"] == one["L5.down"] == one["L6.down"] == ("conv3x3_fullk", 2) and one["L3.down"][0].startswith("igemm3x3")
+    assert all(k.startswith("igemm3x3") for k, _ in downs(e.layers(2)).values())
+    e.close()
+    assert all(k.startswith("igemm3x3") for k, _ in downs(Engine("large", norm="instance").layers(1)).values())
+    monkeypatch.setenv("LSP_HIP_FULLK_S2", "0")
+    assert all(k.startswith("igemm3x3") for k, _ in downs(Engine("large").layers(1)).values())
