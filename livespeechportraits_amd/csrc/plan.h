@@ -89,7 +89,9 @@ struct Plan {
     bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     int fullk_split_max_tiles = 128;   // LSP_HIP_FULLK_SPLIT_TILES at create (tools): 256 also splits the 16x16 layers at batch 1
-    bool use_fullk_s2 = true;      // LSP_HIP_FULLK_S2=0 at create: the stride-2 convs of the small levels stay on the implicit GEMM + split-K reduce
+    bool use_fullk_s2 = false;     // LSP_HIP_FULLK_S2=1 at create: the stride-2 convs of the small levels (L4/L5/L6.down at batch 1) on the K-split full-K
+                                   // kernel instead of the implicit GEMM + split-K reduce.  Built, parity-tested, and measured SLOWER for the whole forward
+                                   // (628.9 vs 634.7 frames/s, A-B-A-B) although its launches are shorter: off by default
     bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (LSP_HIP_FULLK_SPLIT=0 at
                                    // create: unsplit, A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)

@@ -401,16 +401,17 @@ def test_full_k_kernel_splits_k_where_its_tiles_fill_half_the_chip(monkeypatch):
     off.close()
 
 
-def test_stride2_convs_of_the_small_levels_run_on_the_k_split_full_k_kernel(monkeypatch):
-    """L4 / L5 / L6.down at batch 1 (BatchNorm plans): half the channels of their source band fit LDS, so they leave the implicit GEMM + reduce launch for
-    conv3x3_fullk with K in two halves.  Not from batch 2 on, not under InstanceNorm plans, not with LSP_HIP_FULLK_S2=0."""
+def test_stride2_convs_of_the_small_levels_can_run_on_the_k_split_full_k_kernel(monkeypatch):
+    """L4 / L5 / L6.down at batch 1 (BatchNorm plans): half the channels of their source band fit LDS, so conv3x3_fullk with K in two halves can run them.
+    The whole forward measured slower with it (profiles/r03_fullk_stride2_ab.txt), so the planner only does so under LSP_HIP_FULLK_S2=1 (read before the
+    plan is made); never from batch 2 on or under InstanceNorm plans."""
     from livespeechportraits_amd.engine import Engine
-    e = Engine("large", max_batch=2)
     downs = lambda ls: {l["name"]: (l["kernel"], l["split_k"]) for l in ls if l["name"] in ("L3.down", "L4.down", "L5.down", "L6.down")}
+    assert all(k.startswith("igemm3x3") for k, _ in downs(Engine("large").layers(1)).values())
+    monkeypatch.setenv("LSP_HIP_FULLK_S2", "1")
+    e = Engine("large", max_batch=2)
     one = downs(e.layers(1))
     assert one["L4.down"] == one["L5.down"] == one["L6.down"] == ("conv3x3_fullk", 2) and one["L3.down"][0].startswith("igemm3x3")
     assert all(k.startswith("igemm3x3") for k, _ in downs(e.layers(2)).values())
     e.close()
     assert all(k.startswith("igemm3x3") for k, _ in downs(Engine("large", norm="instance").layers(1)).values())
-    monkeypatch.setenv("LSP_HIP_FULLK_S2", "0")
-    assert all(k.startswith("igemm3x3") for k, _ in downs(Engine("large").layers(1)).values())
