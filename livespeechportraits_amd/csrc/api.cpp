@@ -103,6 +103,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
     if (const char *env = std::getenv("LSP_HIP_ROWUP")) h->plan.use_rowup = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_ROWLAST")) h->plan.use_rowlast = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_WINO")) h->plan.use_wino = std::strcmp(env, "0") != 0;
+    if (const char *env = std::getenv("LSP_HIP_WINO4")) h->plan.use_wino4 = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_WINOUP")) h->plan.use_winoup = std::strcmp(env, "0") != 0;
     if (const char *env = std::getenv("LSP_HIP_WINOUP_NB")) h->plan.winoup_nb = std::atoi(env);
     if (const char *env = std::getenv("LSP_HIP_WINOUP_TARGET")) h->plan.winoup_target = std::atoi(env);
@@ -217,6 +218,8 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
     case kFirstConv: return "first_conv";
     case kLastConv: return l.wgemm_off >= 0 ? (l.wrl_off >= 0 && P.use_rowlast ? "last_conv (rowlast128 + pixel_shuffle_tanh)" : "last_conv (igemm3x3 + pixel_shuffle_tanh)") : "last_conv";
     default:
+        if (l.wino4) return l.inorm ? (l.in_route == kInSmall ? "wino4_3x3+in_small" : "wino4_3x3+in_reduce_stats+in_finalize+in_apply")
+                                    : (l.splits > 1 ? "wino4_3x3 (split-K combined in the launch)" : "wino4_3x3");
         if (l.inorm && (l.wino || l.winoup)) {
             const bool sm = l.in_route == kInSmall;
             if (l.winoup) return l.winoup == 2 ? (sm ? "winoup3x3<2>+in_small" : "winoup3x3<2>+in_reduce_stats+in_finalize+in_apply")
@@ -260,6 +263,10 @@ int lspf2f_layer_info_get(const lspf2f_handle *h, int i, lspf2f_layer_info *o)
     if (l.wino) {       // Winograd F(2x2, 3x3): 16 multiplies per 2x2 outputs instead of 36; the weights it reads are the 4x4 transformed ones
         o->exec_flops_per_frame = o->flops_per_frame * 4 / 9;
         o->weight_bytes = (int64_t)l.cout * l.cin * 16 * 4;
+    }
+    if (l.wino4) {      // Winograd F(4x4, 3x3): 36 multiplies per 4x4 outputs instead of 144; 36 transformed taps per (co, ci)
+        o->exec_flops_per_frame = o->flops_per_frame / 4;
+        o->weight_bytes = (int64_t)l.cout * l.cin * 36 * 4;
     }
     o->w_offset = l.w_off; o->scale_offset = l.scale_off; o->shift_offset = l.shift_off;
     o->out_offset = l.out >= 0 ? (int64_t)h->plan.tensors[l.out].offset : -1;
@@ -408,6 +415,17 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
         if (h->timing_part & 1) e = launch_winoup(p, l.winoup, s);
+        if (l.inorm) e = in_after_complete_output(e);
+    } else if (l.wino4) {
+        WinoParams p{};
+        p.src = tptr(l.src0); p.u = bptr(l.ww4_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.cin; p.N = l.cout; p.relu = l.inorm ? 0 : l.relu; p.splits = l.splits;
+        if (l.splits > 1) {
+            p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
+            p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
+        }
+        if (h->timing_part & 1) e = launch_wino4(p, s);
         if (l.inorm) e = in_after_complete_output(e);
     } else if (l.wino) {
         WinoParams p{};
@@ -725,6 +743,11 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
         if (sp == 1) return 0;
         return (size_t)sp * batch * 4 * hs * hs * cout * sizeof(float) + (size_t)batch * (hs / 4) * (hs / 8) * (cout / (32 * (tile_m - 5000))) * sizeof(unsigned);
     }
+    if (tile_m == 6001 && k_group == -1) {                           // Winograd F(4x4, 3x3) kernel: slabs + one arrival counter per (tile-block of 16 x 32 pixels, 32 channels)
+        const int sp = split_k > 0 ? split_k : 1;
+        if (sp == 1) return 0;
+        return (size_t)sp * batch * hs * ws * cout * sizeof(float) + (size_t)batch * (hs / 16) * (ws / 32) * (cout / 32) * sizeof(unsigned);
+    }
     if ((tile_m == 4001 || tile_m == 4002) && k_group == -1) {      // Winograd kernel: slabs + one arrival counter per (tile-block, channel group)
         const int sp = split_k > 0 ? split_k : 1;
         if (sp == 1) return 0;
@@ -759,7 +782,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     const int ktc = dtype ? 64 : 32;
     if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
-    const bool wino_tile = (tile_m == 4001 || tile_m == 4002 || tile_m == 5001 || tile_m == 5002) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
+    const bool wino_tile = (tile_m == 4001 || tile_m == 4002 || tile_m == 5001 || tile_m == 5002 || tile_m == 6001) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
     if (!wino_tile && ((c0 % ktc) || (c1 % ktc) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1)))
         return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (fp32) / 64 (bf16, fp16)");
     if (cout % 4) return fail(LSPF2F_ERR_UNSUPPORTED, "cout must be a multiple of 4");
@@ -812,6 +835,25 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the up-conv Winograd kernel does not support this shape");
             e = launch_winoup(q, nbk, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (winoup) launch");
+            return LSPF2F_OK;
+        }
+        if (tile_m == 6001 && k_group == -1) {                        // the Winograd F(4x4, 3x3) kernel, w_packed in the order of pack_wino4_weights(); split_k = K splits (0: 1)
+            const int sp = split_k > 0 ? split_k : 1;
+            const size_t slab = sp > 1 ? (size_t)sp * batch * hs * ws * cout * sizeof(float) : 0;
+            const size_t ncnt = (size_t)batch * (hs / 16) * (ws / 32) * (cout / 32);
+            WinoParams q{};
+            q.src = static_cast<const float *>(src0); q.u = static_cast<const float *>(w_packed); q.scale = scale; q.shift = shift;
+            q.residual = static_cast<const float *>(residual); q.out = static_cast<float *>(out);
+            q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.N = cout; q.relu = relu; q.splits = sp;
+            if (sp > 1) {
+                if (!scratch || scratch_bytes < slab + ncnt * sizeof(unsigned)) return fail(LSPF2F_ERR_STATE, "split-K scratch missing or too small");
+                q.partial = static_cast<float *>(scratch);
+                q.tile_cnt = reinterpret_cast<unsigned *>(static_cast<char *>(scratch) + slab);   // must be zero on entry; every launch leaves it zero
+            }
+            if (dtype != 0 || c1 != 0 || stride != 1 || upsample != 0 || hs != ws || !wino4_supported(q))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "the Winograd F(4x4,3x3) kernel does not support this shape");
+            e = launch_wino4(q, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (wino4) launch");
             return LSPF2F_OK;
         }
         if ((tile_m == 4001 || tile_m == 4002) && k_group == -1) {   // 4000 + nb: the Winograd kernel, w_packed in its fragment order; split_k = K splits (0: 1)

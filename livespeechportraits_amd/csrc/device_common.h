@@ -130,7 +130,7 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, i32x4 sr
 template <int N, int STRIDE>
 __device__ __forceinline__ void dma16_group(unsigned lds_addr, const unsigned (&voff)[N], i32x4 srd, int soff)
 {
-    static_assert(N == 1 || N == 2 || N == 4 || N == 8, "piece counts of the shipped tiles");
+    static_assert(N == 1 || N == 2 || N == 3 || N == 4 || N == 8, "piece counts of the shipped tiles");
     unsigned keep;
     if constexpr (N == 1) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
@@ -143,6 +143,13 @@ __device__ __forceinline__ void dma16_group(unsigned lds_addr, const unsigned (&
                      "buffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep) : "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "s"(srd), "s"(soff), "n"(STRIDE) : "memory", "scc");
+    } else if constexpr (N == 3) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %5, %6 offen lds\n\ts_add_u32 m0, m0, %7\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %3, %5, %6 offen lds\n\ts_add_u32 m0, m0, %7\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_addr), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(srd), "s"(soff), "n"(STRIDE) : "memory", "scc");
     } else if constexpr (N == 4) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %2, %6, %7 offen lds\n\ts_add_u32 m0, m0, %8\n\ts_nop 0\n\t"

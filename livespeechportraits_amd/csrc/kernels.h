@@ -121,6 +121,12 @@ bool wino_supported(const WinoParams &p, int nb);
 hipError_t launch_wino(const WinoParams &p, int nb, hipStream_t s);
 void pack_wino_weights(const float *oihw, int cin, int cout, float *out);   // host: OIHW [cout][cin][3][3] -> [cout/32][4][cin/8][4][64][4]
 
+// Winograd F(4x4, 3x3) form of the same conv (wino4.hip): H % 16 == 0, W % 32 == 0, C % 8 == 0, N % 32 == 0.  A workgroup owns 4 x 8 tiles of
+// 4 x 4 output pixels (16 x 32 pixels) x 32 channels, one workgroup per CU; K may be split 2..8 ways like wino3x3.  Same parameter block.
+bool wino4_supported(const WinoParams &p);
+hipError_t launch_wino4(const WinoParams &p, hipStream_t s);
+void pack_wino4_weights(const float *oihw, int cin, int cout, float *out);  // host: OIHW [cout][cin][3][3] -> [cout/32][wave 4][cin/8][9][64][4]
+
 // Upsample(x2, nearest) + conv3x3 over the concat of two equally wide sources (or one) as a 9-multiply Winograd form (winoup.hip): fp32,
 // Hs % 4 == 0, Ws % 8 == 0, C0 % 8 == 0, C1 in {0, C0}, N % (32 * nb) == 0.  A workgroup (3 waves) owns 4 x 8 source pixels (8 x 16 output pixels) x
 // 32 nb channels; K may be split 2..8 ways, combined inside the launch.

@@ -104,6 +104,27 @@ int wino_choice(int batch, int ho, int cin, int cout, int *splits_out)
     return nb;
 }
 
+int wino4_choice(int batch, int ho, int cin, int cout, int *splits_out)
+{
+    // A workgroup = 32 tiles of 4 x 4 outputs (16 x 32 pixels) x 32 channels, ONE per CU (its ring slots take 112 KB of LDS): below ~one
+    // workgroup per CU the input channels are split (combined inside the launch), keeping >= 4 eight-channel steps per slice.
+    const long wgs = (long)batch * (ho / 16) * (ho / 32) * (cout / 32);
+    const int steps = cin / 8;
+    int splits = 1;
+    if (wgs < 192) {
+        splits = (int)((256 + wgs - 1) / wgs);
+        splits = std::min(splits, std::min(8, std::max(1, steps / 4)));
+        const int per = (steps + splits - 1) / splits;
+        splits = (steps + per - 1) / per;                  // every slice non-empty
+    }
+    WinoParams q{};
+    q.B = batch; q.H = ho; q.W = ho; q.C = cin; q.N = cout; q.splits = 1;
+    if (!wino4_supported(q)) return 0;
+    if (splits > 1 && wgs > (long)Plan::kTileCounters) return 0;
+    *splits_out = splits;
+    return 1;
+}
+
 int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out, int force_nb, int target)
 {
     // a workgroup = 32 source pixels (8 x 16 output pixels) x 32 nb channels, THREE waves: two such workgroups leave a CU's four SIMDs with 2, 2, 1, 1
@@ -322,6 +343,11 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             l.wwg_off = (int64_t)off;
             off += (size_t)16 * l.cout * l.cin * sizeof(float);
         }
+        if (l.kind == kIgemm && use_wino4 && wino4_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+            off = align_up(off, 256);
+            l.ww4_off = (int64_t)off;                       // 36/9 of the 9-tap bytes
+            off += (size_t)36 * l.cout * l.cin * sizeof(float);
+        }
         if (l.kind == kIgemm && winoup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wwu_off = (int64_t)off;
@@ -443,6 +469,9 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             int wsplits = 1;
             const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
             if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
+            int w4splits = 1;
+            const int wino4 = (wino && p.use_wino4 && l.ww4_off >= 0) ? wino4_choice(batch, l.ho, l.cin, l.cout, &w4splits) : 0;
+            if (wino4) { bm = 32; bn = 32; splits = w4splits; group = 1; }
             int usplits = 1;
             const int winoup = (p.use_wino && p.use_winoup && l.wwu_off >= 0) ? winoup_choice(batch, l.hs, l.cin, l.cout, &usplits, p.winoup_nb, p.winoup_target) : 0;
             if (winoup) { bm = 32; bn = 32 * winoup; splits = usplits; group = 1; }
@@ -461,7 +490,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 // frame for the epilogue sums; tiny levels do statistics + normalisation in one workgroup per channel slab
                 const int hw = l.ho * l.ho, rhw = l.up4 ? l.hs * l.hs : hw;
                 const int wave_rows = bm == 32 ? 32 : bm / 2;
-                if (!smallm && !fullk && !wino && !winoup && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
+                if (!smallm && !fullk && !wino && !wino4 && !winoup && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
                     route = kInFused;
                     groups_max = std::max(groups_max, (l.up4 ? 4 : 1) * rhw / wave_rows);
                 } else if (hw <= 1024) {
@@ -474,9 +503,10 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             }
             if (tiled) {
                 const long tiles = (long)(l.up4 ? 4 : 1) * ((M + bm - 1) / std::max(bm, 1)) * ((l.cout + bn - 1) / std::max(bn, 1));
-                (*tiled)[li].wino = wino;
+                (*tiled)[li].wino = wino4 ? 0 : wino;
+                (*tiled)[li].wino4 = wino4;
                 (*tiled)[li].winoup = winoup;
-                (*tiled)[li].fused_splitk = (wino || winoup) ? splits > 1 : p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
+                (*tiled)[li].fused_splitk = (wino || wino4 || winoup) ? splits > 1 : p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
                                             (size_t)splits * Mout * l.cout * sizeof(float) < (size_t)0x7fffffff;
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
                 (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv; (*tiled)[li].rowup = rowup;
@@ -576,6 +606,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
             if (l.wfk_off >= 0) pack_fullk_weights(dst, l.c0, l.c1 ? 2 : 1, cout, reinterpret_cast<float *>(base + l.wfk_off));
             if (l.wfk2_off >= 0) pack_fullk_weights(dst, l.c0 / 2, 2, cout, reinterpret_cast<float *>(base + l.wfk2_off));
             if (l.wwg_off >= 0) pack_wino_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwg_off));
+            if (l.ww4_off >= 0) pack_wino4_weights(W, cin, cout, reinterpret_cast<float *>(base + l.ww4_off));
         } else if (l.kind == kFirstConv) {
             // [ci][tap][co]  -- broadcast rows for the direct first-layer kernel
             for (int co = 0; co < cout; ++co)

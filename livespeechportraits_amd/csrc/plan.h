@@ -49,6 +49,7 @@ struct LayerDesc {
     int64_t wfk2_off = -1;   // fp32 plans, single-source 8x8 layers: the full-K kernel's weights packed as two half-sources (its K-split form at batch 1)
     int64_t wrl_off = -1;    // bf16 plans, last conv over two 64-channel sources: the GEMM-form weights in the fragment order of rowlast128 (rowconv.hip)
     int64_t wwg_off = -1;    // fp32 plans, stride-1 single-source convs at >= 32x32: G g G^T in the fragment order of the Winograd kernel (wino.hip)
+    int64_t ww4_off = -1;    // fp32 plans, stride-1 single-source convs at >= 32x32 (extent % 32 == 0): the 6x6 G g G^T in the order of the F(4x4,3x3) kernel (wino4.hip)
     int64_t wwu_off = -1;    // fp32 plans, sub-pixel up-convs over two equally wide sources: the 9 transformed taps in the fragment order of winoup.hip
     int64_t wgemm_off = -1;  // bf16 plans, last conv only: the same sub-pixel weights as a 9-tap [4*cout][3][3][cin] bf16 GEMM operand
     // per-batch tiling decision
@@ -61,6 +62,7 @@ struct LayerDesc {
     int rowup = 0;         // > 0: executed by rowup256 (rowconv.hip) with this many low-res rows per strip
     int rowconv = 0;       // > 0: executed by the weights-stationary 64 -> 64 bf16 kernel (rowconv.hip) with this many output rows per strip
     int wino = 0;          // > 0: executed by the Winograd F(2x2,3x3) kernel (wino.hip) with this many 32-channel blocks per wave (1 | 2); `splits` = its K splits
+    int wino4 = 0;         // 1: executed by the Winograd F(4x4,3x3) kernel (wino4.hip); `splits` = its K splits
     int winoup = 0;        // > 0: executed by the up-conv Winograd kernel (winoup.hip) with this many 32-channel blocks per wave; `splits` = its K splits
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
                            // (splits == 2 with it: K in two halves over twice the workgroups, combined in the launch)
@@ -95,6 +97,7 @@ struct Plan {
     bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (LSP_HIP_FULLK_SPLIT=0 at
                                    // create: unsplit, A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
+    bool use_wino4 = true;     // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSP_HIP_WINO4=0 at create: F(2x2,3x3), A-B runs)
     int winoup_nb = 0, winoup_target = 1024;   // tools (LSP_HIP_WINOUP_NB / _TARGET at create): force the channel blocks per wave / the workgroup count aimed at
     bool use_winoup = true;    // fp32 plans: sub-pixel up-convs on the up-conv Winograd kernel (LSP_HIP_WINOUP=0 at create: the implicit GEMM, A-B runs)
     bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
@@ -224,6 +227,13 @@ inline bool wino_layer(int hs, int ho, int c0, int c1, int cout, int stride, boo
 }
 // per batch: 32-channel blocks per wave (0 = keep the implicit GEMM) and K splits
 int wino_choice(int batch, int ho, int cin, int cout, int *splits);
+// the F(4x4, 3x3) kernel (wino4.hip): tile-blocks of 16 x 32 output pixels -> extents that are multiples of 32
+inline bool wino4_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
+{
+    return wino_layer(hs, ho, c0, c1, cout, stride, up, up4, dtype, inorm) && ho >= 32 && ho % 32 == 0;
+}
+// per batch: 1 (and the K splits) when the layer runs on it, 0 = keep wino_choice()'s answer
+int wino4_choice(int batch, int ho, int cin, int cout, int *splits);
 // the up-conv form (winoup.hip): sub-pixel up-convs of fp32 plans whose two sources are equally wide
 inline bool winoup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm)
 {

@@ -731,6 +731,103 @@ def test_conv3x3_winograd_rejects_unsupported_shapes(gpu_device):
         run_wino(gpu_device, rnd(1, 32, 32, 32), w, None, None, None, False, 2, 1)       # cout 32 needs nb = 1
 
 
+# ---- Winograd F(4x4, 3x3) kernel (csrc/wino4.hip): the same layers with 36 multiplies per 4x4 outputs ---------------------------------------
+def run_wino4(dev, x, w, scale, shift, res, relu, splits):
+    import os
+    import sys
+    from livespeechportraits_amd import _native as N
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wino_model
+    lib = N.load()
+    b, c, h, _ = x.shape
+    cout = w.shape[0]
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    d0, wp = nhwc(x), torch.from_numpy(wino_model.pack_u4(w.numpy())).to(dev)      # the numpy statement of the layout, not the library's packer
+    dsc = scale.to(dev) if scale is not None else None
+    dsh = shift.to(dev) if shift is not None else None
+    dres = nhwc(res) if res is not None else None
+    out = torch.full((b, h, h, cout), float("nan"), device=dev)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, h, h, c, 0, cout, 1, 0, 6001, 0, splits, -1, 0)
+    scratch = torch.zeros(max(sb, 4), dtype=torch.uint8, device=dev)      # slabs + arrival counters (zero on entry, left zero by the kernel)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    N.check(lib.lspf2f_conv3x3(p(d0), None, p(wp), p(dsc), p(dsh), p(dres), p(out), b, h, h, c, 0, cout, 1, 0, int(relu), 6001, 0, splits, -1, 0,
+                               p(scratch), scratch.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    if splits > 1:
+        assert not scratch[sb - 4 * (b * (h // 16) * (h // 32) * (cout // 32)):].any(), "arrival counters not left at zero"
+    return out.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+WINO4_CASES = [
+    # b, c, cout, h, splits, epilogue (scale/shift + residual + relu)
+    (1, 8, 32, 32, 1, False),             # ONE K-step: the prologue's operands are all there is
+    (1, 24, 32, 32, 1, True),             # three steps: the two-step unrolled loop ends on its first half
+    (1, 32, 32, 32, 1, False),
+    (1, 32, 64, 32, 1, True),
+    (2, 64, 64, 32, 1, True),
+    (3, 40, 96, 64, 1, True),             # 64 = 4 x 2 tile-blocks per frame, channel counts that are no power of two
+    (1, 64, 64, 64, 2, True),
+    (1, 128, 64, 32, 4, True),
+    (2, 256, 32, 32, 8, True),
+    (1, 104, 32, 32, 3, False),           # 13 K-steps in 3 slices of 5, 5, 3
+    (1, 64, 64, 256, 1, True),            # the four shapes of the `large` plan at batch 1, with the planner's splits
+    (1, 128, 128, 128, 2, True),
+    (1, 256, 256, 64, 4, True),
+    (1, 512, 512, 32, 8, True),
+]
+
+
+@pytest.mark.parametrize("cfg", WINO4_CASES, ids=lambda c: "b%d_c%d_o%d_h%d_s%d%s" % (c[:5] + ("_ep" if c[5] else "",)))
+def test_conv3x3_winograd4(cfg, gpu_device):
+    """wino4_3x3 against the fp64 convolution.  F(4x4, 3x3) multiplies its inputs by 4, 5 and 8 before it cancels them, so on DENSE unit-variance data
+    its fp32 error is ~20x the direct form's (fp32 emulation on these very problems: 1.6e-5 .. 7.7e-5 on outputs of range 4-5; F(2x2): 0.9-3.6e-6);
+    the bound is 4e-5 x range.  What the network sees is measured end to end (tools/wino4_error.py, profiles/r04_wino4x4_error.txt: 1.9e-6 on the `large`
+    golden) and asserted by the golden / batch-8 tests, which run through this kernel."""
+    b, c, cout, h, splits, ep = cfg
+    g = torch.Generator().manual_seed(2000 + c + cout + h)
+    x = torch.randn(b, c, h, h, generator=g)
+    w = torch.randn(cout, c, 3, 3, generator=g) / (3.0 * c ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5 if ep else None
+    shift = torch.randn(cout, generator=g) * 0.1 if ep else None
+    res = torch.randn(b, cout, h, h, generator=g) if ep else None
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    if ep:
+        ref = torch.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    got = run_wino4(gpu_device, x, w, scale, shift, res, ep, splits)
+    assert torch.isfinite(got).all(), "kernel left unwritten (NaN) outputs"
+    err = (got.double() - ref).abs().max().item()
+    f2 = (run_wino(gpu_device, x, w, scale, shift, res, ep, 1, 1).double() - ref).abs().max().item()
+    print("\nwino4 %s: max-abs %.2e (output range %.2f); F(2x2,3x3) on the same problem: %.2e" % (cfg, err, ref.abs().max().item(), f2))
+    assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
+    if splits > 1:       # the in-launch combine sums the slices in a fixed order, whichever workgroup arrives last
+        again = run_wino4(gpu_device, x, w, scale, shift, res, ep, splits)
+        assert torch.equal(got, again)
+
+
+def test_conv3x3_winograd4_impulse_layout(gpu_device):
+    """One-hot input and one-hot tap land on exactly one output value, for taps and pixels on tile and tile-block seams (the transforms of a
+    one-hot patch are exact in fp32: small integers times one weight)."""
+    c, h = 16, 64
+    for (ci, y, x_, co, ky, kx) in [(5, 15, 31, 11, 0, 2), (13, 16, 32, 40, 2, 0), (0, 0, 0, 63, 1, 1), (9, 63, 63, 32, 0, 0), (3, 17, 30, 1, 2, 2)]:
+        x = torch.zeros(1, c, h, h)
+        x[0, ci, y, x_] = 2.0
+        w = torch.zeros(64, c, 3, 3)
+        w[co, ci, ky, kx] = 3.0           # out[co][oy][ox] += 3 * in[ci][oy + ky - 1][ox + kx - 1]
+        exp = F.conv2d(x, w, None, 1, 1)
+        got = run_wino4(gpu_device, x, w, None, None, None, False, 1)
+        assert (got - exp).abs().max().item() <= 1e-5, (ci, y, x_, co, ky, kx)
+        assert (got[exp == 0].abs() <= 1e-5).all()
+
+
+def test_conv3x3_winograd4_rejects_unsupported_shapes(gpu_device):
+    from livespeechportraits_amd import _native as N
+    w = rnd(32, 32, 3, 3)
+    with pytest.raises(N.Lspf2fError):
+        run_wino4(gpu_device, rnd(1, 32, 16, 16), w, None, None, None, False, 1)       # 16 % 32 != 0: a tile-block is 16 x 32 pixels
+    with pytest.raises(N.Lspf2fError):
+        run_wino4(gpu_device, rnd(1, 32, 32, 32), rnd(48, 32, 3, 3), None, None, None, False, 1)       # cout % 32 != 0
+
+
 # ---- the 16-bit row / band kernels in fp16 storage (round 3: the same kernels, templated on the storage type, serve opt.fp16 plans) ----
 F16_SPECIAL = [
     # kind, args

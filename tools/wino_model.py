@@ -190,6 +190,137 @@ def upconv_direct(x0, x1, w_oihw):
     return conv_direct(up, w_oihw)
 
 
+# ---- Winograd F(4x4, 3x3) (csrc/wino4.hip) ----------------------------------------------------------------------------------------------
+# Geometry (must match wino4.hip):
+#   tile-block = 4 x 8 tiles of 4 x 4 outputs = 16 x 32 pixels; raw patch 18 x 34 pixels; MFMA row r = tile (ty = r >> 3, tx = r & 7)
+#   wave (a, b) = (w >> 1, w & 1) owns positions rows 3a..3a+2, columns 3b..3b+2 of the 6x6 transformed tile, f = 3 i + j locally
+#   raw chunk = plane_base(py & 3, px & 3) + q * hyn * hxn + (py >> 2) * hxn + (px >> 2): 16 planes of hyn x hxn pixels x 2 quads
+#   U = [n-block][wave][k-step][f][lane][4]
+BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
+AT4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+
+
+def w4_hyn(pary):
+    return 5 if pary < 2 else 4
+
+
+def w4_hxn(parx):
+    return 9 if parx < 2 else 8
+
+
+def w4_plane_base(pary, parx):
+    return (0, 340, 680, 952)[pary] + (0, 18, 36, 52)[parx] * w4_hyn(pary)
+
+
+def w4_chunk(py, px, q):
+    pary, parx = py & 3, px & 3
+    return w4_plane_base(pary, parx) + q * w4_hyn(pary) * w4_hxn(parx) + (py >> 2) * w4_hxn(parx) + (px >> 2)
+
+
+def w4_chunk_decode(ci):
+    """the kernel's prologue arithmetic: chunk id -> (py, px, q)"""
+    pary = 3 if ci >= 952 else 2 if ci >= 680 else 1 if ci >= 340 else 0
+    rem1 = ci - (0, 340, 680, 952)[pary]
+    hyn = w4_hyn(pary)
+    parx = 3 if rem1 >= 52 * hyn else 2 if rem1 >= 36 * hyn else 1 if rem1 >= 18 * hyn else 0
+    rem2 = rem1 - (0, 18, 36, 52)[parx] * hyn
+    hxn = w4_hxn(parx)
+    q, r3 = divmod(rem2, hyn * hxn)
+    hy, hx = divmod(r3, hxn)
+    return 4 * hy + pary, 4 * hx + parx, q
+
+
+def pack_u4(w_oihw):
+    """numpy restatement of pack_wino4_weights(): OIHW [N][C][3][3] -> [N/32][wave 4][C/8][f 9][64 lanes][4] (float64 in, float32 out)"""
+    n_out, c_in = w_oihw.shape[:2]
+    u = np.einsum("ia,ncab,jb->ijcn", G4, w_oihw.astype(np.float64), G4)        # [6][6][C][N]
+    out = np.zeros((n_out // 32, 4, c_in // 8, 9, 64, 4), np.float32)
+    lane = np.arange(64)
+    for i in range(6):
+        for j in range(6):
+            wave, f = (i // 3) * 2 + j // 3, (i % 3) * 3 + j % 3
+            for t in range(4):
+                ch = 4 * (lane >> 5) + t
+                for s in range(c_in // 8):
+                    for nb in range(n_out // 32):
+                        out[nb, wave, s, f, :, t] = u[i, j, 8 * s + ch, 32 * nb + (lane & 31)]
+    return out.reshape(-1)
+
+
+def _bt3(h, w):
+    """three rows of B^T on the 5-sample window w (list of arrays) = d[h .. h + 4]; the kernel's operation order"""
+    if h == 0:
+        p, q = w[4] - 4 * w[2], w[3] - 4 * w[1]
+        return [4 * w[0] + (-5 * w[2] + w[4]), p + q, p - q]
+    c, g = w[3] - w[1], w[2] - w[0]
+    return [c + 2 * g, c - 2 * g, 4 * w[0] + (-5 * w[2] + w[4])]
+
+
+def _at4(m):
+    s1, d1, s2, d2 = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4]
+    return [m[0] + s1 + s2, d1 + 2 * d2, s1 + 4 * s2, d1 + 8 * d2 + m[5]]
+
+
+def conv4_model(x_nhwc, u_packed, n_out, scale=None, shift=None, residual=None, relu=False):
+    """lane-level model of wino4_3x3 (float64 arithmetic: this checks the data flow, not rounding)"""
+    B, H, W, C = x_nhwc.shape
+    assert H % 16 == 0 and W % 32 == 0 and C % 8 == 0 and n_out % 32 == 0
+    U = u_packed.reshape(n_out // 32, 4, C // 8, 9, 64, 4).astype(np.float64)
+    out = np.zeros((B, H, W, n_out))
+    lane = np.arange(64)
+    r, q = lane & 31, lane >> 5
+    ty, tx = r >> 3, r & 7
+    for b in range(B):
+        for by in range(H // 16):
+            for bx in range(W // 32):
+                Y0, X0 = 16 * by, 32 * bx
+                for nblk in range(n_out // 32):
+                    acc = np.zeros((4, 9, 32, 32))                                  # [wave][f][row (tile)][col (n)]
+                    for s in range(C // 8):
+                        lds = np.zeros((1280, 4))                                   # 20 pieces of 64 chunks x 4 floats
+                        for ci in range(1224):
+                            py, px, qq = w4_chunk_decode(ci)
+                            assert w4_chunk(py, px, qq) == ci
+                            y, x = Y0 - 1 + py, X0 - 1 + px
+                            if 0 <= y < H and 0 <= x < W:
+                                lds[ci] = x_nhwc[b, y, x, 8 * s + 4 * qq: 8 * s + 4 * qq + 4]
+                        for wave in range(4):
+                            a, bb = wave >> 1, wave & 1
+                            t = [[None] * 5 for _ in range(3)]
+                            for xc in range(5):
+                                d = [lds[[w4_chunk(4 * ty[l] + a + yy, 4 * tx[l] + bb + xc, q[l]) for l in range(64)]] for yy in range(5)]
+                                t[0][xc], t[1][xc], t[2][xc] = _bt3(a, d)
+                            v = []
+                            for i in range(3):
+                                v += _bt3(bb, t[i])                                  # f = 3 i + j
+                            for f in range(9):
+                                ufrag = U[nblk, wave, s, f]
+                                for tt in range(4):
+                                    Am = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+                                    Am[r, q] = v[f][:, tt]; Bm[q, r] = ufrag[:, tt]
+                                    acc[wave, f] += Am @ Bm
+                    # ---- epilogue: patch [position][tile][n], then A^T M A per (tile, channel)
+                    M = np.zeros((6, 6, 32, 32))
+                    for wave in range(4):
+                        a, bb = wave >> 1, wave & 1
+                        for f in range(9):
+                            M[3 * a + f // 3, 3 * bb + f % 3] = acc[wave, f]
+                    z = [_at4([M[p, c] for p in range(6)]) for c in range(6)]       # z[c][i]
+                    for i in range(4):
+                        yrow = _at4([z[c][i] for c in range(6)])                    # [j] -> [tile][n]
+                        for j in range(4):
+                            for tile in range(32):
+                                out[b, Y0 + 4 * (tile >> 3) + i, X0 + 4 * (tile & 7) + j, 32 * nblk: 32 * nblk + 32] = yrow[j][tile]
+    if scale is not None:
+        out = out * scale + shift
+    if residual is not None:
+        out = out + residual
+    if relu:
+        out = np.maximum(out, 0)
+    return out
+
+
 def conv_direct(x_nhwc, w_oihw):
     B, H, W, C = x_nhwc.shape
     xp = np.zeros((B, H + 2, W + 2, C)); xp[:, 1:-1, 1:-1] = x_nhwc
@@ -209,4 +340,7 @@ if __name__ == "__main__":
     print("max abs diff", np.abs(got - ref).max(), "of", np.abs(ref).max())
     x0, x1 = rng.standard_normal((1, 4, 16, 8)), rng.standard_normal((1, 4, 16, 8))
     w2 = rng.standard_normal((32, 16, 3, 3)).astype(np.float32)
+    x4 = rng.standard_normal((1, 16, 32, 8))
+    w4 = rng.standard_normal((32, 8, 3, 3)).astype(np.float32)
+    print("F(4x4) max abs diff", np.abs(conv4_model(x4, pack_u4(w4), 32) - conv_direct(x4, w4)).max())
     print("up-conv max abs diff", np.abs(upconv_model(x0, x1, pack_u_up(w2), 32) - upconv_direct(x0, x1, w2)).max())
