@@ -41,6 +41,7 @@ extern "C" {
  * independent second route to the same bits.  Measured on MI355X, default network: 84 us per frame + 20 ms to fill
  * the first receptive field, against 31.5 us + 0.55 ms for the default layer-pipelined kernel. */
 #define LSPA2H_FLAG_SINGLE_WORKGROUP 1u
+#define LSPA2H_FLAG_CONSECUTIVE_BLOCKS 2u   /* tools: the pipeline's workgroups on consecutive block ids (spread over the XCDs) instead of every 8th */
 
 #define LSPA2H_LOSS_GMM 0 /* opt.loss == 'GMM': output (2*ndim+1)*ncenter, sampled */
 #define LSPA2H_LOSS_L2 1  /* opt.loss == 'L2' : output ndim, used as is (audio2headpose_model.py:182-183) */

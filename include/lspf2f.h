@@ -71,6 +71,12 @@ typedef enum lspf2f_dtype {
                                               bias (use_bias, :494 / :590) and the state dict holds `<conv>.bias` instead of
                                               the BatchNorm tensors.  fp32 only. */
 
+#define LSPF2F_FLAG_WINO4 8u               /* fp32 plans: the stride-1 ResidualBlock convs of the >= 32x32 levels (models/networks.py:650-675) run as
+                                              Winograd F(4x4,3x3) (csrc/wino4.hip) where the planner finds the shape eligible, instead of
+                                              F(2x2,3x3).  Parity: 2.0e-6 on the `large` golden (F(2x2): 1.7e-6).  Off by default: measured
+                                              slower at batch 1 and equal at batch 8.  The packed blob then carries the
+                                              6x6 transformed weights of those layers (4x their 9-tap bytes). */
+
 /* Mirrors the option fields the reference reads on this path
  * (options/base_options_feature2face.py:49-50 ngf / n_downsample_G, :40 loadSize; the
  * constructor arguments of feature2face_G.py:19-21). */
@@ -96,6 +102,14 @@ typedef struct lspf2f_handle lspf2f_handle;
 /* Replaces: Feature2Face_G.__init__ (models/feature2face_G.py:9-24) + the module construction
  * of networks.py:554-572 / 458-476.  Builds the static execution plan; touches no device. */
 int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
+/* The same with the A-B switches of tools, tests and measurements: `tune` = "key=value,key=value" (integers; NULL or "" = none; an unknown
+ * key is LSPF2F_ERR_INVALID_ARGUMENT).  The library never reads the process environment -- every switch arrives here, once per handle,
+ * before the plan is built.  Keys (default): graph (1) | wino (1), wino4 (flag), winoup (1): the Winograd kernels | wino_pre (1),
+ * wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
+ * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, rowup (1), rowlast (1), rowconv (1): kernels of the 16-bit plans |
+ * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), prefetch (1) |
+ * lastconv (0 = by shape; 1..5 force a last-conv kernel), lastconv_direct (0), firstconv (0 = by shape; 1, 2 force a first-conv kernel). */
+int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handle **out);
 int lspf2f_destroy(lspf2f_handle *h);
 const char *lspf2f_last_error(void);
 int lspf2f_abi_version(void);

@@ -36,6 +36,11 @@ extern "C" {
 #define LSPRNN_CELL_GRU 0
 #define LSPRNN_CELL_LSTM 1
 
+/* One launch per layer instead of the wavefront kernel (all layers in one launch).  The library takes this route by itself when the
+ * wavefront's L * Gw mutually polling workgroups cannot all be resident on the device (a partitioned or very small device); the per-layer
+ * kernels still need their own G = hidden_size / P (16..64) workgroups resident at once and fail with LSPRNN_ERR_UNSUPPORTED below that. */
+#define LSPRNN_FLAG_PER_LAYER 1u
+
 typedef struct lsprnn_config {
     int32_t abi_version; /* LSPRNN_ABI_VERSION */
     int32_t cell;        /* LSPRNN_CELL_* */
@@ -43,7 +48,7 @@ typedef struct lsprnn_config {
     int32_t input_size;  /* layer 0 input width, a multiple of 4 */
     int32_t hidden_size; /* 256 or 512 (the sizes the reference uses) */
     int32_t max_steps;   /* longest sequence lsprnn_forward will see (sizes the workspace) */
-    uint32_t flags;      /* reserved, 0 */
+    uint32_t flags;      /* LSPRNN_FLAG_* */
 } lsprnn_config;
 
 typedef struct lsprnn_handle lsprnn_handle;

@@ -23,12 +23,56 @@ ERR_NAMES = {
 VARIANT_IDS = {"normal": 0, "large": 1}
 DTYPE_IDS = {"f32": 0, "bf16": 1, "f16": 2}
 FLAG_KEEP_INTERMEDIATES = 1
+FLAG_NO_GRAPH = 2
 FLAG_INSTANCE_NORM = 4
+FLAG_WINO4 = 8
 NORM_IDS = {"batch": 0, "instance": 1}
 
 
 class NativeLibraryError(RuntimeError):
     pass
+
+
+# ---- switches of tools, tests and A-B runs.  The LIBRARY never reads the process environment: the switches travel as the `tune` string of
+# lspf2f_create_tuned ("key=value,..."; include/lspf2f.h lists the keys).  For shell-driven A-B scripts (tools/*.sh) the Python host maps
+# LSP_HIP_<KEY>=<int> environment variables onto those keys HERE, once per Engine; an explicit `tune=` argument wins.
+_PRESENCE_ENV = {   # legacy names whose mere presence is the switch
+    "LSP_HIP_LASTCONV_DIRECT": ("lastconv_direct", 1), "LSP_HIP_LASTCONV_STRIP": ("lastconv", 1), "LSP_HIP_LASTCONV_ROWS": ("lastconv", 2),
+    "LSP_HIP_LASTCONV_GENERIC": ("lastconv", 3), "LSP_HIP_LASTCONV_MFMA": ("lastconv", 4), "LSP_HIP_LASTCONV_VALU": ("lastconv", 5),
+    "LSP_HIP_FIRSTCONV_DIRECT": ("firstconv", 1), "LSP_HIP_FIRSTCONV_REGSTAGE": ("firstconv", 2),
+}
+_RENAMED_ENV = {"LSP_HIP_XCD": "igemm_xcd", "LSP_HIP_FULLK_SPLIT_TILES": "fullk_split_tiles"}
+
+
+def tune_string(tune=None) -> bytes:
+    """`tune` (None, a dict or a "k=v,k=v" string) merged over the LSP_HIP_* environment variables, as the library wants it."""
+    kv = {}
+    for name, val in os.environ.items():
+        if not name.startswith("LSP_HIP_"):
+            continue
+        if name in _PRESENCE_ENV:
+            k, v = _PRESENCE_ENV[name]
+            kv.setdefault(k, v)
+            continue
+        key = _RENAMED_ENV.get(name, name[len("LSP_HIP_"):].lower())
+        if key in ("tune", "dbg"):
+            continue
+        try:
+            kv[key] = int(val)
+        except ValueError:
+            raise ValueError("%s=%r: the switches of liblspf2f take integers" % (name, val))
+    if "LSP_HIP_TUNE" in os.environ:
+        tune_env = os.environ["LSP_HIP_TUNE"]
+        for tok in filter(None, (t.strip() for t in tune_env.split(","))):
+            k, v = tok.split("=")
+            kv[k.strip()] = int(v)
+    if isinstance(tune, str):
+        for tok in filter(None, (t.strip() for t in tune.split(","))):
+            k, v = tok.split("=")
+            kv[k.strip()] = int(v)
+    elif tune:
+        kv.update({k: int(v) for k, v in tune.items()})
+    return ",".join("%s=%d" % (k, v) for k, v in sorted(kv.items())).encode()
 
 
 class Lspf2fError(RuntimeError):
@@ -58,6 +102,7 @@ class LayerInfo(Structure):
 # every symbol include/lspf2f.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "lspf2f_create": (c_int, [POINTER(Config), POINTER(c_void_p)]),
+    "lspf2f_create_tuned": (c_int, [POINTER(Config), c_char_p, POINTER(c_void_p)]),
     "lspf2f_destroy": (c_int, [c_void_p]),
     "lspf2f_last_error": (c_char_p, []),
     "lspf2f_abi_version": (c_int, []),
@@ -98,6 +143,7 @@ class A2HConfig(Structure):
 A2H_ABI_VERSION = 1
 A2H_LOSS_IDS = {"GMM": 0, "L2": 1}
 A2H_FLAG_SINGLE_WORKGROUP = 1
+A2H_FLAG_CONSECUTIVE_BLOCKS = 2
 _GEN_ARGS = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int, c_void_p]
 # every symbol include/lspa2h.h declares
 A2H_SIGNATURES = {
@@ -138,6 +184,7 @@ class RNNConfig(Structure):
 
 
 RNN_ABI_VERSION = 1
+RNN_FLAG_PER_LAYER = 1
 RNN_CELL_IDS = {"GRU": 0, "LSTM": 1}
 # every symbol include/lsprnn.h declares
 RNN_SIGNATURES = {

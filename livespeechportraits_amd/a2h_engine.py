@@ -4,6 +4,7 @@ torch is plumbing here (device memory, stream); all arithmetic is in csrc/a2h.hi
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -28,7 +29,8 @@ class HeadposeEngine:
         self.cfg = N.A2HConfig(N.A2H_ABI_VERSION, residual_layers, residual_blocks, residual_channels, dilation_channels,
                                skip_channels, kernel_size, input_channels, cond_channels, hidden_size, ncenter, ndim,
                                N.A2H_LOSS_IDS[loss], max_audio_frames,
-                               N.A2H_FLAG_SINGLE_WORKGROUP if single_workgroup else 0)
+                               (N.A2H_FLAG_SINGLE_WORKGROUP if single_workgroup or os.environ.get("LSP_A2H_KERNEL") == "stream" else 0) |
+                               (N.A2H_FLAG_CONSECUTIVE_BLOCKS if os.environ.get("LSP_A2H_SPREAD", "0") not in ("", "0") else 0))   # (env: tools only)
         self.h = ctypes.c_void_p()
         N.check_a2h(self.lib.lspa2h_create(ctypes.byref(self.cfg), ctypes.byref(self.h)))
         self.ndim, self.ncenter, self.loss = ndim, ncenter, loss

@@ -840,8 +840,7 @@ static int generate_impl(lspa2h_handle *h, const float *audio_dev, int n_audio, 
     p.layers = L; p.ndim = h->cfg.ndim; p.ncenter = h->cfg.ncenter; p.nout = h->nout; p.loss = h->cfg.loss;
     p.field = h->field; p.nframe = nframe; p.frame_future = frame_future; p.sigma_scale = sigma_scale;
     for (int l = 0; l < L; ++l) { p.dil[l] = h->dil[l]; p.qoff[l] = h->qoff[l]; }
-    static const char *force = std::getenv("LSP_A2H_KERNEL");     // tools only: "stream" | "pipe"
-    const bool single = force ? std::strcmp(force, "stream") == 0 : (h->cfg.flags & LSPA2H_FLAG_SINGLE_WORKGROUP) != 0;
+    const bool single = (h->cfg.flags & LSPA2H_FLAG_SINGLE_WORKGROUP) != 0;
     char *tail = reinterpret_cast<char *>(proj + align64(rows * (size_t)L * 256));
     p.xbox = reinterpret_cast<unsigned long long *>(tail);
     p.sbox = reinterpret_cast<unsigned long long *>(tail + h->xbox_bytes());
@@ -874,8 +873,7 @@ static int generate_impl(lspa2h_handle *h, const float *audio_dev, int n_audio, 
         if (!h->pipe_fits) goto single_workgroup;            // a device too small for the pipeline: the one-workgroup kernel needs no co-residency
         // Blocks are dealt round-robin over the 8 XCDs (observed, not contractual): using every 8th block puts the
         // whole chain behind one L2.  Measured 45.4 vs 51.0 us per frame; results do not depend on it.
-        static const int spread = std::getenv("LSP_A2H_SPREAD") ? std::atoi(std::getenv("LSP_A2H_SPREAD")) : 0;   // tools: 1 = consecutive blocks
-        p.stride = spread ? 1 : 8;
+        p.stride = (h->cfg.flags & LSPA2H_FLAG_CONSECUTIVE_BLOCKS) ? 1 : 8;     // (the flag: tools only)
         hipLaunchKernelGGL(a2h_pipe, dim3((L + 1) * p.stride), dim3(NT), lds_pipe, s, p);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? LSPA2H_OK : hipfail(e, "a2h_pipe launch");

@@ -47,13 +47,14 @@ struct lspf2f_handle {
     size_t ws_size = 0;
     bool packed = false;
     bool use_graph = true;
-    bool last_direct = false;     // bf16 plans: direct last-conv kernel instead of the GEMM form (LSP_HIP_LASTCONV_DIRECT, read at create)
-    bool prefetch = true;         // LSP_HIP_PREFETCH=0 (read at create): weight-streaming layers do not request the next launch's weights
-    bool fuse_splitk = true;      // LSP_HIP_FUSED_SPLITK=0 (read at create): always combine split-K slabs with a separate launch
+    // (the next four: `tune` keys of lspf2f_create_tuned -- tools, tests, A-B runs)
+    bool last_direct = false;     // lastconv_direct=1: 16-bit plans run the direct last-conv kernel instead of the GEMM form
+    bool prefetch = true;         // prefetch=0: weight-streaming layers do not request the next launch's weights
+    bool fuse_splitk = true;      // fused_splitk=0: always combine split-K slabs with a separate launch
     bool counters_clean = false;  // the arrival counters at the head of the workspace were zeroed since it was bound
-    int first_direct = 0;         // LSP_HIP_FIRSTCONV_DIRECT (read at create): 1 = vector-ALU first conv; LSP_HIP_FIRSTCONV_REGSTAGE: 2 = register-staged matrix-core kernel
+    int first_direct = 0;         // firstconv=1: vector-ALU first conv; 2: register-staged matrix-core kernel
     int timing_part = 3;          // lspf2f_subset_timed: 1 = main kernels only, 2 = split-K reduce only, 3 = everything (always 3 on the hot path)
-    int last_route = 0;           // forced direct last-conv kernel (LSP_HIP_LASTCONV_{STRIP,ROWS,GENERIC}, read at create; tests only)
+    int last_route = 0;           // lastconv=<route>: forced direct last-conv kernel (LastConvParams::route; tests only)
     const void *cand_cached = nullptr;   // candidate stack whose first-conv contribution sits in the workspace cache
     hipStream_t cap_stream = nullptr;
     std::vector<CachedGraph> graphs;
@@ -82,45 +83,86 @@ extern "C" {
 const char *lspf2f_last_error(void) { return g_err.c_str(); }
 int lspf2f_abi_version(void) { return LSPF2F_ABI_VERSION; }
 
-int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out)
+// "key=value,key=value" -> (key, integer value) pairs; "" / NULL = none.  Whitespace around tokens is ignored.
+static bool parse_tune(const char *tune, std::vector<std::pair<std::string, int>> *out, std::string *bad)
+{
+    if (!tune) return true;
+    std::string s(tune);
+    size_t i = 0;
+    while (i < s.size()) {
+        size_t j = s.find(',', i);
+        if (j == std::string::npos) j = s.size();
+        std::string tok = s.substr(i, j - i);
+        i = j + 1;
+        const size_t a = tok.find_first_not_of(" \t"), b = tok.find_last_not_of(" \t");
+        if (a == std::string::npos) continue;
+        tok = tok.substr(a, b - a + 1);
+        const size_t eq = tok.find('=');
+        if (eq == std::string::npos || eq == 0 || eq + 1 >= tok.size()) { *bad = tok; return false; }
+        char *endp = nullptr;
+        const long v = std::strtol(tok.c_str() + eq + 1, &endp, 10);
+        if (*endp) { *bad = tok; return false; }
+        out->emplace_back(tok.substr(0, eq), (int)v);
+    }
+    return true;
+}
+
+int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out) { return lspf2f_create_tuned(cfg, nullptr, out); }
+
+int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handle **out)
 {
     if (!cfg || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (cfg->abi_version != LSPF2F_ABI_VERSION) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "ABI version mismatch");
     if (cfg->dtype != LSPF2F_DTYPE_F32 && cfg->dtype != LSPF2F_DTYPE_BF16 && cfg->dtype != LSPF2F_DTYPE_F16) return fail(LSPF2F_ERR_UNSUPPORTED, "unknown dtype");
     if (cfg->height != cfg->width) return fail(LSPF2F_ERR_UNSUPPORTED, "frames must be square (loadSize x loadSize)");
     if (cfg->max_batch < 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "max_batch must be >= 1");
+    std::vector<std::pair<std::string, int>> kv;
+    std::string bad;
+    if (!parse_tune(tune, &kv, &bad)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "tune: expected key=integer, got '" + bad + "'");
     lspf2f_handle *h = new (std::nothrow) lspf2f_handle();
     if (!h) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "out of host memory");
     h->cfg = *cfg;
-    const std::string e = h->plan.build(cfg->variant, cfg->input_nc, cfg->feat_nc, cfg->output_nc, cfg->ngf,
-                                        cfg->num_downs, cfg->height,
-                                        (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0, cfg->dtype,
-                                        (cfg->flags & LSPF2F_FLAG_INSTANCE_NORM) ? 1 : 0);
-    if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
-    if (const char *env = std::getenv("LSP_HIP_BANDCONV")) h->plan.use_bandconv = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_BLOCKS")) h->plan.bandconv_min_blocks = std::atoi(env);
-    if (const char *env = std::getenv("LSP_HIP_BANDCONV_MIN_FRAMES")) h->plan.bandconv_min_frames_small = std::atoi(env);
-    if (const char *env = std::getenv("LSP_HIP_ROWUP")) h->plan.use_rowup = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_ROWLAST")) h->plan.use_rowlast = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_WINO")) h->plan.use_wino = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_WINO4")) h->plan.use_wino4 = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_WINOUP")) h->plan.use_winoup = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_WINOUP_NB")) h->plan.winoup_nb = std::atoi(env);
-    if (const char *env = std::getenv("LSP_HIP_WINOUP_TARGET")) h->plan.winoup_target = std::atoi(env);
-    if (const char *env = std::getenv("LSP_HIP_ROWCONV")) h->plan.use_rowconv = std::strcmp(env, "0") != 0;   // read once per handle, like the switches below
-    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT")) h->plan.use_fullk_split = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_FULLK_SPLIT_TILES")) h->plan.fullk_split_max_tiles = std::atoi(env);
-    if (const char *env = std::getenv("LSP_HIP_FULLK_S2")) h->plan.use_fullk_s2 = std::strcmp(env, "0") != 0;
-    h->plan.plan_batch(cfg->max_batch);
     h->use_graph = (cfg->flags & LSPF2F_FLAG_NO_GRAPH) == 0;
-    // environment switches are read HERE, once per handle, never on the launch path
-    if (const char *env = std::getenv("LSP_HIP_GRAPH")) h->use_graph = h->use_graph && std::strcmp(env, "0") != 0;
-    h->last_direct = std::getenv("LSP_HIP_LASTCONV_DIRECT") != nullptr;
-    h->first_direct = std::getenv("LSP_HIP_FIRSTCONV_DIRECT") ? 1 : std::getenv("LSP_HIP_FIRSTCONV_REGSTAGE") ? 2 : 0;
-    if (const char *env = std::getenv("LSP_HIP_FUSED_SPLITK")) h->fuse_splitk = std::strcmp(env, "0") != 0;
-    if (const char *env = std::getenv("LSP_HIP_PREFETCH")) h->prefetch = std::strcmp(env, "0") != 0;
-    h->last_route = std::getenv("LSP_HIP_LASTCONV_STRIP") ? 1 : std::getenv("LSP_HIP_LASTCONV_ROWS") ? 2
-                  : std::getenv("LSP_HIP_LASTCONV_GENERIC") ? 3 : std::getenv("LSP_HIP_LASTCONV_MFMA") ? 4 : std::getenv("LSP_HIP_LASTCONV_VALU") ? 5 : 0;
+    Plan &P = h->plan;
+    P.use_wino4 = (cfg->flags & LSPF2F_FLAG_WINO4) != 0;
+    // The switches of tools, tests and A-B runs: applied HERE, once per handle, before the plan is built (some decide what the packed blob
+    // carries); nothing in this library reads the process environment.
+    for (const auto &e : kv) {
+        const std::string &k = e.first;
+        const int v = e.second;
+        if (k == "graph") h->use_graph = h->use_graph && v != 0;
+        else if (k == "wino") P.use_wino = v != 0;
+        else if (k == "wino4") P.use_wino4 = v != 0;
+        else if (k == "wino_pre") P.wino_pre = v != 0;
+        else if (k == "wino_xcd") P.wino_xcd = v;
+        else if (k == "wino_il") P.wino_il = v != 0;
+        else if (k == "wino_rot") P.wino_rot = v != 0;
+        else if (k == "winoup") P.use_winoup = v != 0;
+        else if (k == "winoup_nb") P.winoup_nb = v;
+        else if (k == "winoup_target") P.winoup_target = v;
+        else if (k == "igemm_xcd") P.igemm_xcd = v;
+        else if (k == "bandconv") P.use_bandconv = v != 0;
+        else if (k == "bandconv_min_blocks") P.bandconv_min_blocks = v;
+        else if (k == "bandconv_min_frames") P.bandconv_min_frames_small = v;
+        else if (k == "rowup") P.use_rowup = v != 0;
+        else if (k == "rowlast") P.use_rowlast = v != 0;
+        else if (k == "rowconv") P.use_rowconv = v != 0;
+        else if (k == "fullk_split") P.use_fullk_split = v != 0;
+        else if (k == "fullk_split_tiles") P.fullk_split_max_tiles = v;
+        else if (k == "fullk_s2") P.use_fullk_s2 = v != 0;
+        else if (k == "fused_splitk") h->fuse_splitk = v != 0;
+        else if (k == "prefetch") h->prefetch = v != 0;
+        else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
+        else if (k == "lastconv") h->last_route = v;                   // LastConvParams::route (0 = by shape)
+        else if (k == "firstconv") h->first_direct = v;                // FirstConvParams::force_direct (0 = by shape)
+        else { delete h; return fail(LSPF2F_ERR_INVALID_ARGUMENT, "tune: unknown key '" + k + "'"); }
+    }
+    const std::string e = P.build(cfg->variant, cfg->input_nc, cfg->feat_nc, cfg->output_nc, cfg->ngf,
+                                  cfg->num_downs, cfg->height,
+                                  (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0, cfg->dtype,
+                                  (cfg->flags & LSPF2F_FLAG_INSTANCE_NORM) ? 1 : 0);
+    if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
+    P.plan_batch(cfg->max_batch);
     *out = h;
     return LSPF2F_OK;
 }
@@ -436,6 +478,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
+        p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1;
         if (h->timing_part & 1) e = launch_wino(p, l.wino, s);
         if (l.inorm) e = in_after_complete_output(e);
     } else if (l.rowup) {
@@ -529,6 +572,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
                 p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
                 p.slab_bytes = (size_t)l.splits * p.Mout * l.cout * sizeof(float);
             }
+            p.xcd_force = P.igemm_xcd + 1;
             if (h->timing_part & 1) e = launch_igemm(p, l.bm, l.bn, l.group, s);
             if (e == hipSuccess && l.splits > 1 && !fused && (h->timing_part & 2)) e = launch_splitk_reduce(p, s);
         }
@@ -850,6 +894,13 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                 q.partial = static_cast<float *>(scratch);
                 q.tile_cnt = reinterpret_cast<unsigned *>(static_cast<char *>(scratch) + slab);   // must be zero on entry; every launch leaves it zero
             }
+#ifdef LSPF2F_WINO_STAMPS
+            {   // stamps live behind slabs and counters when the caller's scratch has room for them
+                const size_t used = (slab + ncnt * sizeof(unsigned) + 255) / 256 * 256;
+                const size_t blocks = ncnt * (size_t)sp;
+                if (scratch && scratch_bytes >= used + blocks * 4 * 8 * 8) q.stamps = reinterpret_cast<unsigned long long *>(static_cast<char *>(scratch) + used);
+            }
+#endif
             if (dtype != 0 || c1 != 0 || stride != 1 || upsample != 0 || hs != ws || !wino4_supported(q))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the Winograd F(4x4,3x3) kernel does not support this shape");
             e = launch_wino4(q, static_cast<hipStream_t>(hip_stream));

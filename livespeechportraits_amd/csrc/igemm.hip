@@ -661,8 +661,8 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
     const size_t eb = p.dtype ? 2 : 4;
     if ((size_t)p.B * p.Hs * p.Ws * (size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * eb > lim) return hipErrorInvalidValue;
     if ((p.C0 * eb) % 128 || (p.C1 * eb) % 128) return hipErrorInvalidValue;   // a K-tile is 128 B of channels
-    {   // XCD chunking: partition the larger operand across the 8 L2s (LSP_HIP_XCD=0/1/2 overrides, tools only)
-        static const int forced = std::getenv("LSP_HIP_XCD") ? std::atoi(std::getenv("LSP_HIP_XCD")) : -1;
+    {   // XCD chunking: partition the larger operand across the 8 L2s (xcd_force = 1 + mode overrides: `igemm_xcd` of lspf2f_create_tuned, tools only)
+        const int forced = p.xcd_force - 1;
         const size_t act = (size_t)p.B * p.Hs * p.Ws * p.Cin * eb;
         const size_t wgt = (size_t)(p.up4 ? 16 : 9) * p.Cin * p.Cout * eb;
         int rule = wgt > act ? 2 : 1;

@@ -61,7 +61,8 @@ struct IgemmParams {
     unsigned *tile_cnt;         // fused split-K: one arrival counter per (parity, M-tile, N-tile), zero between launches; nullptr = the
                                 //   partial slabs are combined by a separate splitk_reduce launch
     int out_f32;                // write fp32 output whatever the storage type (GEMM form of the last conv)
-    int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major
+    int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major (filled by launch_igemm)
+    int xcd_force;              // 0 = by rule; 1 + mode forces it (tools)
     unsigned long long *stamps; // -DLSPF2F_IGEMM_STAMPS builds: [blocks][4 waves][16] cycle counters (tools/time_conv.py)
     int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,
                                 // 4 no barrier, 8 no buffer flip, 16 no epilogue, 32 no K loop
@@ -111,8 +112,12 @@ struct WinoParams {
     float *partial;               // splits > 1: fp32 slabs [splits][B*H*W][N]
     unsigned *tile_cnt;           // splits > 1: one arrival counter per (tile-block, channel group), zero between launches
     int B, H, W, C, N, relu, splits;
+    // A-B switches of tools (all 0 = the shipped kernel): epilogue operands fetched in the epilogue instead of up front; block order 1 + mode
+    // (0 dispatch order, 1 tile-block-major, 2 channel-group-major) instead of by operand size; copies as one block ahead of the MFMAs
+    // instead of between them; the four MFMAs of an accumulator back to back instead of rotating over the accumulators
+    int nopre, xcd_force, no_il, no_rot;
     // filled by launch_wino
-    int steps_per_split, ntb, nng, tby, tbx, nmajor, xcd, nopre;
+    int steps_per_split, ntb, nng, tby, tbx, nmajor, xcd;
     size_t slab_bytes;
     FastDiv div_plane, div_fast, div_tbf, div_tbx;
     unsigned long long *stamps;   // -DLSPF2F_WINO_STAMPS builds: [blocks][4 waves][8] cycle counters (tools/wino_stamps.py)

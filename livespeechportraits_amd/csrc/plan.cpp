@@ -338,7 +338,7 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
             off += (size_t)l.cout * 9 * l.cin * sizeof(float);
         }
         if (l.kind == kIgemm && wino_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
-            // 16/9 of the 9-tap bytes; the 9-tap copy stays (plans of other batch sizes, LSP_HIP_WINO=0)
+            // 16/9 of the 9-tap bytes; the 9-tap copy stays (plans of other batch sizes, tune key `wino=0`)
             off = align_up(off, 256);
             l.wwg_off = (int64_t)off;
             off += (size_t)16 * l.cout * l.cin * sizeof(float);

@@ -83,24 +83,27 @@ struct Plan {
                                // (the reference's opt.fp16 / autocast configuration; runs on the generic kernels, the bf16-only row / band kernels stay off)
     int norm = 0;              // 0: BatchNorm2d in eval mode (folded, the shipped checkpoints); 1: InstanceNorm2d (norm_layer argument
                                // of the reference constructors, networks.py:555 / :459): conv biases on, statistics at run time, fp32 only
-    bool use_bandconv = true;  // bf16 plans: LSP_HIP_BANDCONV=0 at create puts the 16x16 / 8x8 layers back on the implicit GEMM (A-B runs)
+    bool use_bandconv = true;  // bf16 plans: tune key `bandconv=0` puts the 16x16 / 8x8 layers back on the implicit GEMM (A-B runs)
     int bandconv_min_blocks = 128;  // (16x16 / 8x8 levels; the 4x4 / 2x2 levels, one tile per 2 / 8 frames, have their own bound below)
     int bandconv_min_frames_small = 1 << 30;   // 4x4 / 2x2 levels (a tile = 2 / 8 whole frames): never by default -- at 8 frames the 64 / 16
                                                // workgroups of such a launch lose to the igemm (normal 4460 -> 4388, large 2881 -> 2840 frames/s,
-                                               // A-B-A-B); LSP_HIP_BANDCONV_MIN_FRAMES lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
-    bool use_rowup = true;     // bf16 plans: LSP_HIP_ROWUP=0 at create keeps L1.up on the implicit GEMM (A-B runs)
-    bool use_rowlast = true;   // bf16 plans: LSP_HIP_ROWLAST=0 at create keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
-    int fullk_split_max_tiles = 128;   // LSP_HIP_FULLK_SPLIT_TILES at create (tools): 256 also splits the 16x16 layers at batch 1
-    bool use_fullk_s2 = false;     // LSP_HIP_FULLK_S2=1 at create: the stride-2 convs of the small levels (L4/L5/L6.down at batch 1) on the K-split full-K
+                                               // A-B-A-B); tune key `bandconv_min_frames` lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
+    bool use_rowup = true;     // bf16 plans: tune key `rowup=0` keeps L1.up on the implicit GEMM (A-B runs)
+    bool use_rowlast = true;   // bf16 plans: tune key `rowlast=0` keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
+    int fullk_split_max_tiles = 128;   // tune key `fullk_split_tiles` (tools): 256 also splits the 16x16 layers at batch 1
+    bool use_fullk_s2 = false;     // tune key `fullk_s2=1`: the stride-2 convs of the small levels (L4/L5/L6.down at batch 1) on the K-split full-K
                                    // kernel instead of the implicit GEMM + split-K reduce.  Built, parity-tested, and measured SLOWER for the whole forward
                                    // (628.9 vs 634.7 frames/s, A-B-A-B) although its launches are shorter: off by default
-    bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (LSP_HIP_FULLK_SPLIT=0 at
+    bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (tune key `fullk_split=0` at
                                    // create: unsplit, A-B runs)
-    bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (LSP_HIP_WINO=0 at create: the implicit GEMM, A-B runs)
-    bool use_wino4 = true;     // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSP_HIP_WINO4=0 at create: F(2x2,3x3), A-B runs)
-    int winoup_nb = 0, winoup_target = 1024;   // tools (LSP_HIP_WINOUP_NB / _TARGET at create): force the channel blocks per wave / the workgroup count aimed at
-    bool use_winoup = true;    // fp32 plans: sub-pixel up-convs on the up-conv Winograd kernel (LSP_HIP_WINOUP=0 at create: the implicit GEMM, A-B runs)
-    bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (LSP_HIP_ROWCONV=0 at create: the igemm, A-B runs)
+    bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (tune key `wino=0`: the implicit GEMM, A-B runs)
+    bool use_wino4 = false;    // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSPF2F_FLAG_WINO4; measured slower at batch 1 and
+                               // equal at batch 8, DESIGN.md 4.11, so off by default); decides whether the blob carries the 6x6 transformed weights
+    bool wino_pre = true, wino_il = true, wino_rot = true;   // tools (`wino_pre` / `wino_il` / `wino_rot` of lspf2f_create_tuned): A-B switches of wino3x3
+    int wino_xcd = -1, igemm_xcd = -1;                       // tools: forced block orders (-1 = by operand size)
+    int winoup_nb = 0, winoup_target = 1024;   // tools (tune keys `winoup_nb` / `winoup_target`): force the channel blocks per wave / the workgroup count aimed at
+    bool use_winoup = true;    // fp32 plans: sub-pixel up-convs on the up-conv Winograd kernel (tune key `winoup=0`: the implicit GEMM, A-B runs)
+    bool use_rowconv = true;   // bf16 plans: 64 -> 64 layers on the weights-stationary kernel (tune key `rowconv=0`: the igemm, A-B runs)
     size_t elt() const { return dtype ? 2 : 4; }
     int ktile_channels() const { return dtype ? 64 : 32; }   // a K-tile is 128 B of channels
     bool layer_weights_typed(const LayerDesc &l) const { return l.kind == kIgemm; }   // else fp32

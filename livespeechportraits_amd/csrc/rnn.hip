@@ -292,7 +292,8 @@ struct lsprnn_handle {
     size_t blob_floats = 0;
     const float *blob = nullptr;
     float *ws = nullptr;
-    bool boxes_clean = false, wave_fit_checked = false, layer_fit_checked = false;
+    bool boxes_clean = false, wave_fit_checked = false, wave_fits = false, layer_fit_checked = false;
+    int fit_device = -1;         // the device the cached residency answers belong to
     unsigned epoch = 0;
     void add(const std::string &k, size_t n) { Slot s; s.key = k; s.numel = n; index[k] = (int)tensors.size(); tensors.push_back(std::move(s)); }
     const std::vector<float> &T(const std::string &k) const { return tensors[index.at(k)].data; }
@@ -463,8 +464,22 @@ int lsprnn_forward(lsprnn_handle *h, const float *x_dev, int T, float *out_dev, 
         if (e != hipSuccess) return hipfail(e, "hipMemsetAsync(mailboxes)");
         h->boxes_clean = true;
     }
-    const char *force = std::getenv("LSP_RNN_KERNEL");               // tools / tests: "layers" | "wave" (read per call)
-    const bool wave = force ? std::strcmp(force, "wave") == 0 : L > 1;
+    // Route: stacks run the wavefront kernel (all layers in one launch, L * Gw workgroups polling each other) unless LSPRNN_FLAG_PER_LAYER asks for
+    // one launch per layer (G polling workgroups) -- or the device cannot hold the stack at once (a partitioned or small device): then the
+    // per-layer route is taken silently.  The residency answers are cached per handle AND device.
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (dev != h->fit_device) { h->fit_device = dev; h->wave_fit_checked = h->layer_fit_checked = false; h->wave_fits = false; }
+    bool wave = (h->cfg.flags & LSPRNN_FLAG_PER_LAYER) ? false : L > 1;
+    if (wave && !h->wave_fit_checked) {
+        void (*kern0)(WaveParams) = GT == 3 ? (h->Pw == 32 ? rnn_wave<3, 32, 16> : rnn_wave<3, 16, 16>) : (h->Pw == 32 ? rnn_wave<4, 32, 16> : rnn_wave<4, 16, 16>);
+        bool ok = false;
+        const hipError_t e0 = lspgemm::fits_resident(reinterpret_cast<const void *>(kern0), NT, 0, L * h->Gw, &ok);
+        if (e0 != hipSuccess) return hipfail(e0, "occupancy query (rnn_wave)");
+        h->wave_fits = ok;
+        h->wave_fit_checked = true;
+    }
+    if (wave && !h->wave_fits) wave = false;
     if (wave) {
         lspgemm::GemmParams g{x_dev, h->blob + h->o_wih[0], nullptr, h->blob + h->o_bias[0], nullptr, xproj, T, GT * H, h->in_size(0), 1.0f, 0};
         hipError_t e = lspgemm::launch_gemm_f32(g, s);
@@ -483,13 +498,6 @@ int lsprnn_forward(lsprnn_handle *h, const float *x_dev, int T, float *out_dev, 
         p.stride = nwg <= 32 ? 8 : (nwg <= 64 ? 4 : (nwg <= 128 ? 2 : 1));
         const dim3 grid(L * h->Gw * p.stride), block(NT);
         void (*kern)(WaveParams) = GT == 3 ? (h->Pw == 32 ? rnn_wave<3, 32, 16> : rnn_wave<3, 16, 16>) : (h->Pw == 32 ? rnn_wave<4, 32, 16> : rnn_wave<4, 16, 16>);
-        if (!h->wave_fit_checked) {      // the L * Gw working blocks poll each other: they must all be resident at once (gemm_f32.h)
-            bool ok = false;
-            e = lspgemm::fits_resident(reinterpret_cast<const void *>(kern), NT, 0, nwg, &ok);
-            if (e != hipSuccess) return hipfail(e, "occupancy query (rnn_wave)");
-            if (!ok) return fail(LSPRNN_ERR_UNSUPPORTED, "rnn_wave: the stack's workgroups do not fit this device at once");
-            h->wave_fit_checked = true;
-        }
         hipLaunchKernelGGL(kern, grid, block, 0, s, p);
         e = hipGetLastError();
         return e == hipSuccess ? LSPRNN_OK : hipfail(e, "rnn_wave launch");
@@ -513,7 +521,8 @@ int lsprnn_forward(lsprnn_handle *h, const float *x_dev, int T, float *out_dev, 
             bool ok = false;
             e = lspgemm::fits_resident(reinterpret_cast<const void *>(kern), NT, 0, h->G, &ok);
             if (e != hipSuccess) return hipfail(e, "occupancy query (rnn_layer)");
-            if (!ok) return fail(LSPRNN_ERR_UNSUPPORTED, "rnn_layer: the layer's workgroups do not fit this device at once");
+            if (!ok) return fail(LSPRNN_ERR_UNSUPPORTED, "rnn_layer: the G = H / P polling workgroups of a layer (16..64) do not fit this device at once -- "
+                                                         "the recurrent kernels need at least that many free workgroup slots (include/lsprnn.h)");
             h->layer_fit_checked = true;
         }
         hipLaunchKernelGGL(kern, grid, block, 0, s, p);

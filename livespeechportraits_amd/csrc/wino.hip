@@ -18,7 +18,6 @@
 #include "device_common.h"
 #include "kernels.h"
 #include "wino_common.h"
-#include <cstdlib>
 
 namespace lspf2f {
 
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
             for (int bb = 0; bb < 2; ++bb)
                 zz[i][bb] = *reinterpret_cast<const float4 *>(smem + ((i * 2 + bb) * NB + nb) * (32 * EP) + trow * EP + cq);
         float4 sc = scv[nb], sh = shv[nb];
-        if (!pre && p.splits == 1 && p.scale) {               // LSP_HIP_WINO_PRE=0 (A-B runs): the operands are fetched here instead
+        if (!pre && p.splits == 1 && p.scale) {               // nopre (A-B runs): the operands are fetched here instead
             sc = *reinterpret_cast<const float4 *>(p.scale + n);
             sh = *reinterpret_cast<const float4 *>(p.shift + n);
         }
@@ -458,22 +457,17 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     const size_t act = (size_t)p.B * p.H * p.W * p.C * 4, wgt = (size_t)16 * p.C * p.N * 4;
     p.nmajor = wgt > act ? 1 : 0;
     p.xcd = 1;
-    static const int pre_env = std::getenv("LSP_HIP_WINO_PRE") ? std::atoi(std::getenv("LSP_HIP_WINO_PRE")) : 1;    // tools only (A-B runs)
-    static const int xcd_env = std::getenv("LSP_HIP_WINO_XCD") ? std::atoi(std::getenv("LSP_HIP_WINO_XCD")) : -1;   // 0 dispatch order, 1 tile-block-major, 2 channel-group-major
-    p.nopre = pre_env ? 0 : 1;
-    if (xcd_env == 0) p.xcd = 0;
-    if (xcd_env == 1) p.nmajor = 0;
-    if (xcd_env == 2) p.nmajor = 1;
+    if (p.xcd_force == 1) p.xcd = 0;
+    if (p.xcd_force == 2) p.nmajor = 0;
+    if (p.xcd_force == 3) p.nmajor = 1;
     p.div_plane = FastDiv::make((unsigned)(p.ntb * p.nng));
     p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
     p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));
     p.div_tbx = FastDiv::make((unsigned)p.tbx);
-    // tools only (A-B runs): LSP_HIP_WINO_IL=0 issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them;
-    // LSP_HIP_WINO_ROT=0 runs the four MFMAs of an accumulator back to back instead of rotating over the four accumulators of a channel block
-    static const int il_env = std::getenv("LSP_HIP_WINO_IL") ? std::atoi(std::getenv("LSP_HIP_WINO_IL")) : 1;
-    static const int rot_env = std::getenv("LSP_HIP_WINO_ROT") ? std::atoi(std::getenv("LSP_HIP_WINO_ROT")) : 1;
-    if (!il_env) return nb == 2 ? launch_wino_t<2, 2, false, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
-    if (!rot_env) return nb == 2 ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<1, 3, true, false>(p, s);
+    // tools only (A-B runs): no_il issues a step's copies as one block ahead of its MFMAs (ring of 2) instead of between them; no_rot runs the four
+    // MFMAs of an accumulator back to back instead of rotating over the four accumulators of a channel block
+    if (p.no_il) return nb == 2 ? launch_wino_t<2, 2, false, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
+    if (p.no_rot) return nb == 2 ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<1, 3, true, false>(p, s);
     return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);
 }
 

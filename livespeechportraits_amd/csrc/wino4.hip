@@ -27,6 +27,16 @@
 
 namespace lspf2f {
 
+// phase timestamps (tools/wino4_stamps.py; builds with -DLSPF2F_WINO_STAMPS only): s_memtime values kept in registers, written once at the end
+#ifdef LSPF2F_WINO_STAMPS
+#define W4STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4STAMP_FLUSH do { if (p.stamps && lane == 0) { unsigned long long *q_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8; \
+    for (int i_ = 0; i_ < 8; ++i_) q_[i_] = stamp_t[i_]; } } while (0)
+#else
+#define W4STAMP(i) do {} while (0)
+#define W4STAMP_FLUSH do {} while (0)
+#endif
+
 static constexpr unsigned kOOB4 = 0x80000000u;           // voffset beyond any num_records: the LDS-DMA lands zeros (image border, unused chunks)
 
 // ---- geometry shared with the host packer and tools/wino_model.py
@@ -63,6 +73,10 @@ __device__ __forceinline__ float4 f4fma(float c, float4 a, float4 b) { return ma
 template <int H>
 __device__ __forceinline__ void w4_bt3(const float4 (&w)[5], float4 &o0, float4 &o1, float4 &o2)
 {
+#ifdef W4_ABL_NOVALU          // ablation (results are garbage): no transform arithmetic, the operands are whatever was read
+    o0 = w[0]; o1 = w[1]; o2 = w[2];
+    return;
+#endif
     if constexpr (H == 0) {
         o0 = f4fma(4.f, w[0], f4fma(-5.f, w[2], w[4]));                        // 4 d0 - 5 d2 + d4
         const float4 p = f4fma(-4.f, w[2], w[4]), q = f4fma(-4.f, w[1], w[3]);   // d4 - 4 d2, d3 - 4 d1
@@ -89,6 +103,11 @@ __device__ __forceinline__ void w4_step(f32x16 (&acc)[9], const W4Ops &cur, W4Op
     const char *ns = smem_c + nslot * kW4Slot;
     float4 d[2][5], t[3][5];
     auto rd_col = [&](int x, float4 (&dst)[5]) {
+#ifdef W4_ABL_NOREAD          // ablation: no raw reads either
+#pragma unroll
+        for (int y = 0; y < 5; ++y) asm volatile("" : "+v"(dst[y].x), "+v"(dst[y].y), "+v"(dst[y].z), "+v"(dst[y].w));
+        return;
+#endif
 #pragma unroll
         for (int y = 0; y < 5; ++y) dst[y] = *reinterpret_cast<const float4 *>(ns + lp[w4_cls(A + y, B + x)] + (kW4UStage + w4_imm(A + y, B + x)));
     };
@@ -105,9 +124,13 @@ __device__ __forceinline__ void w4_step(f32x16 (&acc)[9], const W4Ops &cur, W4Op
         // the copies of step t + 2 first (a wave-uniform branch: it ends a scheduling block, so the MFMAs of the piece sit behind it with the
         // vector work they are to cover): raw pieces 0-1, raw pieces 2-4, then the nine U fragments three at a time
         if (issue) {
+#ifndef W4_ABL_NORAW
             if (k == 0) { const unsigned vv[2] = {vraw[0], vraw[1]}; dma16_group<2, 1024>(dr, vv, srd_src, ks_dma * 32); }
             if (k == 1) { const unsigned vv[3] = {vraw[2], vraw[3], vraw[4]}; dma16_group<3, 1024>(dr + 2048u, vv, srd_src, ks_dma * 32); }
+#endif
+#ifndef W4_ABL_NOU
             if (k >= 2 && k <= 4) dma16_group<3, 1024>(du + (unsigned)((k - 2) * 3072), vu, srd_u, so + (k - 2) * 3072);
+#endif
         }
         mm(3 * k); mm(3 * k + 1); mm(3 * k + 2);
         if (k == 0) {
@@ -149,7 +172,7 @@ __device__ __forceinline__ void w4_step(f32x16 (&acc)[9], const W4Ops &cur, W4Op
 
 template <int A, int B>
 __device__ __forceinline__ void w4_loop(f32x16 (&acc)[9], const char *smem_c, unsigned lds0, int wave, int lane, const unsigned (&vraw)[5],
-                                        i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, int ks_begin, int ks_end)
+                                        i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, int ks_begin, int ks_end, unsigned long long *stamp_t)
 {
     const int r = lane & 31, q = lane >> 5, ty = r >> 3, tx = r & 7;
     unsigned lp[4];
@@ -176,6 +199,7 @@ __device__ __forceinline__ void w4_loop(f32x16 (&acc)[9], const char *smem_c, un
     if (n > 1) fetch(ks_begin + 1, 1);
     dma_wait<0>();
     __syncthreads();
+    W4STAMP(2);
     W4Ops o0, o1;
     {   // operands of the first step: nothing to hide this behind
         const char *ns = smem_c;
@@ -193,11 +217,16 @@ __device__ __forceinline__ void w4_loop(f32x16 (&acc)[9], const char *smem_c, un
         for (int f = 0; f < 9; ++f) o0.u[f] = *reinterpret_cast<const float4 *>(ns + au + f * 1024);
     }
     __syncthreads();                                  // every wave holds step 0 in registers: slot 0 may be overwritten
+    W4STAMP(3);
     for (int t = 0; t < n; t += 2) {
         // step t multiplies from o0; slot 1 (step t + 1) is read into o1; step t + 2 lands in slot 0 (free: consumed into o0 one step ago)
         w4_step<A, B>(acc, o0, o1, smem_c, 1, lp, au, t + 2 < n, ks_begin + t + 2, 0, lds_u, lds_r, vraw, vu, srd_src, srd_u, soff_u0);
         dma_wait<0>();
         __syncthreads();
+#ifdef LSPF2F_WINO_STAMPS
+        if (t == 0) W4STAMP(4);
+        if (t == 2) W4STAMP(5);
+#endif
         if (t + 1 < n) {
             w4_step<A, B>(acc, o1, o0, smem_c, 0, lp, au, t + 3 < n, ks_begin + t + 3, 1, lds_u, lds_r, vraw, vu, srd_src, srd_u, soff_u0);
             dma_wait<0>();
@@ -224,6 +253,12 @@ __global__ __launch_bounds__(256, 1) void wino4_3x3(const WinoParams p)
     const char *smem_c = reinterpret_cast<const char *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef LSPF2F_WINO_STAMPS
+    unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+    unsigned long long *stamp_t = nullptr;
+#endif
+    W4STAMP(0);
     asm volatile("" :: "s"(p.src), "s"(p.u), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.partial), "s"(p.tile_cnt));
     asm volatile("" :: "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C), "s"(p.N), "s"(p.relu), "s"(p.splits), "s"(p.steps_per_split), "s"(p.ntb), "s"(p.nng),
                        "s"(p.tbx), "s"(p.nmajor), "s"(p.xcd), "s"(p.div_plane.m), "s"(p.div_plane.s1), "s"(p.div_plane.s2), "s"(p.div_fast.m),
@@ -269,12 +304,16 @@ __global__ __launch_bounds__(256, 1) void wino4_3x3(const WinoParams p)
         const int y = Y0 - 1 + 4 * hy + pary, x = X0 - 1 + 4 * hx + parx;
         const bool ok = ci < 1224 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         vraw[k] = ok ? ((unsigned)((b * p.H + y) * p.W + x) * (unsigned)p.C + (unsigned)(qd * 4)) * 4u : kOOB4;
+#ifdef W4_ABL_LINEAR_RAW      // ablation (tools/wino4_ablate_job.sh; results are garbage): every raw piece reads 1 KB of CONTIGUOUS memory instead of 64 scattered 16-B chunks
+        vraw[k] = (unsigned)(((blockIdx.x * 20 + wave * 5 + k) * 1024 + lane * 16) % (p.H * p.W * p.C * 4 - 4096));
+#endif
     }
     const i32x4 srd_src = make_srd(p.src, (unsigned)(p.B * p.H * p.W) * (unsigned)p.C * 4u);
     const i32x4 srd_u = make_srd(p.u, 36u * (unsigned)p.C * (unsigned)p.N * 4u);
     // U fragments: [n-block][wave][k-step][f 9][64 lanes][4]
     const unsigned soff_u0 = (unsigned)((n0 >> 5) * 4 + wave) * (unsigned)S * 9216u;
 
+    W4STAMP(1);
     f32x16 acc[9];
 #pragma unroll
     for (int f = 0; f < 9; ++f)
@@ -282,12 +321,13 @@ __global__ __launch_bounds__(256, 1) void wino4_3x3(const WinoParams p)
         for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
 
     switch (wave) {
-    case 0: w4_loop<0, 0>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end); break;
-    case 1: w4_loop<0, 1>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end); break;
-    case 2: w4_loop<1, 0>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end); break;
-    default: w4_loop<1, 1>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end); break;
+    case 0: w4_loop<0, 0>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end, stamp_t); break;
+    case 1: w4_loop<0, 1>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end, stamp_t); break;
+    case 2: w4_loop<1, 0>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end, stamp_t); break;
+    default: w4_loop<1, 1>(acc, smem_c, lds0, wave, lane, vraw, srd_src, srd_u, soff_u0, ks_begin, ks_end, stamp_t); break;
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
+    W4STAMP(6);
 
     // ---- epilogue.  This thread's item: tile (tid >> 3) x channels 4 (tid & 7) .. +3.  Its folded-BN scale / shift and residual pixels are requested
     // first: they land while the accumulators cross LDS.
@@ -319,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void wino4_3x3(const WinoParams p)
         }
     }
     __syncthreads();
+    W4STAMP(7);
     // Y = A^T M A for this thread's tile and channel quad: rows first (per column of M), then columns
     float4 zc[4][6];
     {
@@ -354,6 +395,10 @@ __global__ __launch_bounds__(256, 1) void wino4_3x3(const WinoParams p)
             }
         }
     }
+#ifdef LSPF2F_WINO_STAMPS
+    __builtin_amdgcn_sched_barrier(0); stamp_t[1] = __builtin_amdgcn_s_memtime() - stamp_t[1]; __builtin_amdgcn_sched_barrier(0);    // slot 1: entry-of-loop .. stores issued, as a DURATION
+#endif
+    W4STAMP_FLUSH;
     if (single) return;
 
     // ---- split-K combine inside the launch (wino3x3's protocol): write-through slabs above -> every wave drains its stores -> barrier -> one relaxed

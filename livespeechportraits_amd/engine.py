@@ -22,7 +22,8 @@ from . import _native as N
 class Engine:
     def __init__(self, variant: str = "large", input_nc: int = 13, feat_nc: int = 1,
                  output_nc: int = 3, ngf: int = 64, num_downs: int = 8, size: int = 512,
-                 max_batch: int = 1, keep_intermediates: bool = False, dtype: str = "f32", norm: str = "batch"):
+                 max_batch: int = 1, keep_intermediates: bool = False, dtype: str = "f32", norm: str = "batch",
+                 wino4: bool = False, tune=None):
         if variant not in N.VARIANT_IDS:
             raise ValueError("opt.size must be 'normal' or 'large' for the HIP renderer "
                              "(got %r; the 'small' U-Net is not on the shipped path)" % (variant,))
@@ -36,9 +37,12 @@ class Engine:
         self.ngf, self.num_downs, self.size, self.max_batch = ngf, num_downs, size, max_batch
         cfg = N.Config(N.ABI_VERSION, N.VARIANT_IDS[variant], input_nc, feat_nc, output_nc, ngf,
                        num_downs, size, size, max_batch, N.DTYPE_IDS[dtype],
-                       (N.FLAG_KEEP_INTERMEDIATES if keep_intermediates else 0) | (N.FLAG_INSTANCE_NORM if norm == "instance" else 0))
+                       (N.FLAG_KEEP_INTERMEDIATES if keep_intermediates else 0) | (N.FLAG_INSTANCE_NORM if norm == "instance" else 0) |
+                       (N.FLAG_WINO4 if wino4 else 0))
         h = ctypes.c_void_p()
-        N.check(self.lib.lspf2f_create(ctypes.byref(cfg), ctypes.byref(h)))
+        # `wino4`: the stride-1 convs of the >= 32x32 levels on the Winograd F(4x4,3x3) kernel (off by default: DESIGN.md 4.11).  `tune`: the
+        # A-B switches of tools and tests (a dict or "k=v,..." string, merged over LSP_HIP_* environment variables by N.tune_string)
+        N.check(self.lib.lspf2f_create_tuned(ctypes.byref(cfg), N.tune_string(tune), ctypes.byref(h)))
         self._h = h
         # candidate-stack cache (lspf2f_set_candidates): off by default so that a bare Engine never reuses
         # work across calls; Feature2FaceModel turns it on (the stack is constant per person)

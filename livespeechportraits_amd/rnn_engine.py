@@ -3,6 +3,7 @@ torch is plumbing (device memory, stream); the arithmetic is in csrc/rnn.hip and
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -23,11 +24,14 @@ def _require(name: str, t: torch.Tensor) -> None:
 class RecurrentEngine:
     """torch.nn.GRU / nn.LSTM (batch_first, unidirectional, zero initial state) for ONE sequence."""
 
-    def __init__(self, cell: str, num_layers: int, input_size: int, hidden_size: int, max_steps: int = 8192):
+    def __init__(self, cell: str, num_layers: int, input_size: int, hidden_size: int, max_steps: int = 8192, per_layer: Optional[bool] = None):
         if cell not in N.RNN_CELL_IDS:
             raise ValueError("cell must be 'GRU' or 'LSTM'")
         self.lib = N.load()
-        self.cfg = N.RNNConfig(N.RNN_ABI_VERSION, N.RNN_CELL_IDS[cell], num_layers, input_size, hidden_size, max_steps, 0)
+        if per_layer is None:      # tools / tests: LSP_RNN_KERNEL=layers forces one launch per layer (read HERE; the library reads no environment)
+            per_layer = os.environ.get("LSP_RNN_KERNEL") == "layers"
+        self.cfg = N.RNNConfig(N.RNN_ABI_VERSION, N.RNN_CELL_IDS[cell], num_layers, input_size, hidden_size, max_steps,
+                               N.RNN_FLAG_PER_LAYER if per_layer else 0)
         self.h = ctypes.c_void_p()
         N.check_rnn(self.lib.lsprnn_create(ctypes.byref(self.cfg), ctypes.byref(self.h)))
         self.cell, self.num_layers, self.input_size, self.hidden_size, self.max_steps = cell, num_layers, input_size, hidden_size, max_steps

@@ -60,6 +60,26 @@ def test_matches_reference_golden(case, gpu_device):
         assert terr <= TIGHT * scale * 4, "%s %s: %g" % (case, tname, terr)
 
 
+W4_BOUND = 2e-4     # the gate VERDICT r03 set for the F(4x4,3x3) route: 5x inside the contract
+
+
+@pytest.mark.parametrize("case", ["large_s128_b2", "large_512", "normal_512"])
+def test_winograd4_route_matches_reference_golden(case, gpu_device):
+    """The opt-in Winograd F(4x4,3x3) route (LSPF2F_FLAG_WINO4, csrc/wino4.hip) against the reference-generated goldens: the contract (1e-3) hard,
+    the 2e-4 gate recorded; the CPU emulation predicted 1.9e-6 / 3.9e-7 for large_512 / normal_512 (profiles/r04_wino4x4_error.txt)."""
+    from livespeechportraits_amd.engine import Engine
+    meta, arrays, topo, sd, feat, cand = golden_problem(case)
+    e = Engine(topo.variant, topo.input_nc, 1, topo.output_nc, topo.ngf, topo.num_downs, topo.size, max_batch=meta["batch"], wino4=True)
+    e.load_state_dict(sd)
+    e.bind(e.pack(), gpu_device)
+    assert any(l["kernel"].startswith("wino4_3x3") for l in e.layers(meta["batch"]))
+    got = e.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
+    err = np.abs(got - arrays["out"]).max()
+    print("%s through wino4_3x3: max-abs vs reference %.3g (contract %.0e, gate %.0e)" % (case, err, TOL, W4_BOUND))
+    assert err <= TOL
+    assert err <= W4_BOUND
+
+
 @pytest.mark.parametrize("case", ["large_s128_b2", "normal_512"])
 def test_matches_cpu_oracle_live(case, gpu_device):
     """Same comparison with the oracle executed here and now on the host CPU (no fixture)."""

@@ -113,7 +113,7 @@ def test_winograd_kernel_instances_do_not_spill(tmp_path):
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     report = ""
-    for f in ("wino.hip", "winoup.hip"):
+    for f in ("wino.hip", "winoup.hip", "wino4.hip"):
         src = os.path.join(ROOT, "livespeechportraits_amd", "csrc", f)
         p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage",
                             "-c", src, "-o", str(tmp_path / "w.o")], capture_output=True, text=True, timeout=600)
@@ -123,16 +123,19 @@ def test_winograd_kernel_instances_do_not_spill(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        if "wino3x3" not in name and "winoup3x3" not in name:
+        if "wino3x3" not in name and "winoup3x3" not in name and "wino4_3x3" not in name:
             continue
         seen += 1
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        if "wino4_3x3" in name:            # one workgroup per CU by design (two ring slots of 56 KB): 400 registers, no scratch
+            assert scratch == 0 and occ == 1, (name, scratch, occ)
+            continue
         nb = int(re.search(r"wino(?:up)?3x3ILi(\d)E", name).group(1))
         assert scratch == 0, (name, scratch)
         assert occ >= 2, (name, occ)          # two workgroups per CU share every SIMD (nb = 2: 79 KB of LDS each; nb = 1: up to three)
         assert nb in (1, 2)
-    assert seen >= 6
+    assert seen >= 7
 
 
 # ---- the up-conv form (csrc/winoup.hip): Upsample(x2, nearest) + Conv3x3 with 9 multiplies per 2x2 outputs ------------------------------
@@ -182,3 +185,82 @@ def test_upconv_packer_and_planner():
             assert wgs >= 384 and l["cin"] // 8 // l["split_k"] >= 8
     assert not any(l["kernel"].startswith("winoup3x3") for l in Engine("large", dtype="bf16").layers(1))
     e.close(); big.close()
+
+
+# ---- Winograd F(4x4, 3x3) (csrc/wino4.hip): opt-in per handle (LSPF2F_FLAG_WINO4 / Engine(wino4=True)) -------------------------------------
+def test_f4x4_transform_matrices_and_data_flow_model():
+    """Y = A^T [(G g G^T) . (B^T d B)] A with the points 0, +-1, +-2, inf reproduces a 3x3 correlation on a 6x6 patch (Lavin & Gray 2015,
+    F(4x4, 3x3)); the lane-level model of the kernel (chunk map of the 18 x 34 raw patch, 3x3 position blocks per wave, the factored
+    transforms, fragment order, accumulator patch, output scatter) convolves correctly, borders and tile-block seams included."""
+    rng = np.random.default_rng(0)
+    d, g = rng.standard_normal((6, 6)), rng.standard_normal((3, 3))
+    y = WM.AT4 @ ((WM.G4 @ g @ WM.G4.T) * (WM.BT4 @ d @ WM.BT4.T)) @ WM.AT4.T
+    ref = np.array([[(d[a:a + 3, b:b + 3] * g).sum() for b in range(4)] for a in range(4)])
+    assert np.abs(y - ref).max() < 1e-11
+    # the chunk map is a bijection of the 18 x 34 x 2 patch onto 0..1223 and the kernel's decode inverts it
+    seen = {WM.w4_chunk(py, px, q) for py in range(18) for px in range(34) for q in range(2)}
+    assert seen == set(range(1224))
+    assert all(WM.w4_chunk(*WM.w4_chunk_decode(ci)) == ci for ci in range(1224))
+    x = rng.standard_normal((2, 32, 64, 16))                    # 2 x 2 tile-blocks per frame
+    w = rng.standard_normal((64, 16, 3, 3)).astype(np.float32)
+    sc, sh = rng.standard_normal(64), rng.standard_normal(64)
+    res = rng.standard_normal((2, 32, 64, 64))
+    got = WM.conv4_model(x, WM.pack_u4(w), 64, sc, sh, res, relu=True)
+    ref = np.maximum(WM.conv_direct(x, w) * sc + sh + res, 0)
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()       # U is rounded to fp32 once; everything else is float64 here
+
+
+def test_f4x4_is_opt_in_and_its_packer_writes_the_order_the_kernel_reads():
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    topo, sd = synth.synthetic("normal", ngf=32, num_downs=5, size=128)
+    plain = Engine("normal", ngf=32, num_downs=5, size=128, max_batch=2)
+    assert not any(l["kernel"].startswith("wino4") for l in plain.layers(1))
+    e = Engine("normal", ngf=32, num_downs=5, size=128, max_batch=2, wino4=True)
+    assert e.packed_bytes() > plain.packed_bytes()              # the 6x6 transformed copy travels only when asked for
+    e.load_state_dict(sd)
+    blob = e.pack().numpy()
+    checked = 0
+    for l, c in zip(e.layers(1), topo.convs):
+        if not l["kernel"].startswith("wino4_3x3"):
+            continue
+        cin, cout = l["cin"], l["cout"]
+        assert l["h_out"] >= 32 and l["h_out"] % 32 == 0 and l["stride"] == 1 and not l["upsample"]
+        assert l["exec_flops_per_frame"] * 4 == l["flops_per_frame"] and l["weight_bytes"] == 36 * cin * cout * 4
+        w = sd[c.weight_key]
+        exp = WM.pack_u4(w)
+        off = (l["w_offset"] + cout * cin * 9 * 4 + 255) // 256 * 256 + (cout * cin * 16 * 4 + 255) // 256 * 256    # behind the 9-tap and the F(2x2) copies
+        got = blob[off: off + exp.size * 4].view(np.float32)
+        assert np.allclose(got, exp, rtol=3e-7, atol=1e-9) and (got == exp).mean() > 0.99, l["name"]
+        checked += 1
+    assert checked >= 2
+    plain.close(); e.close()
+    big = Engine("large", max_batch=8, wino4=True)
+    for batch in (1, 8):
+        w4 = [l for l in big.layers(batch) if l["kernel"].startswith("wino4_3x3")]
+        assert sorted({(l["cin"], l["h_out"]) for l in w4}) == [(64, 256), (128, 128), (256, 64), (512, 32)] and len(w4) == 32
+        for l in w4:
+            wgs = batch * (l["h_out"] // 16) * (l["h_out"] // 32) * (l["cout"] // 32) * l["split_k"]
+            assert wgs >= 256 and l["cin"] // 8 // l["split_k"] >= 4, (l["name"], wgs)     # one workgroup per CU, 256 CUs
+    assert not any(l["kernel"].startswith("wino4") for l in Engine("large", dtype="bf16", wino4=True).layers(1))
+    big.close()
+
+
+def test_tune_string_reaches_the_library_and_unknown_keys_are_errors(monkeypatch):
+    """The library reads no environment: LSP_HIP_* variables are mapped onto lspf2f_create_tuned's `tune` keys by the Python host."""
+    import pytest
+    from livespeechportraits_amd import _native as N
+    from livespeechportraits_amd.engine import Engine
+    assert not any(l["kernel"].startswith("wino") for l in Engine("normal", tune={"wino": 0}).layers(1))
+    assert any(l["kernel"].startswith("wino4") for l in Engine("normal", tune="wino4=1").layers(1))
+    monkeypatch.setenv("LSP_HIP_WINOUP", "0")
+    assert N.tune_string({"wino": 0}) == b"wino=0,winoup=0"
+    assert not any(l["kernel"].startswith("winoup") for l in Engine("normal").layers(1))
+    monkeypatch.delenv("LSP_HIP_WINOUP")
+    with pytest.raises(N.Lspf2fError, match="unknown key"):
+        Engine("normal", tune={"no_such_switch": 1})
+    import re
+    import subprocess
+    out = subprocess.run(["grep", "-c", "getenv", *[os.path.join(ROOT, "livespeechportraits_amd", "csrc", f) for f in sorted(os.listdir(os.path.join(ROOT, "livespeechportraits_amd", "csrc"))) if f.endswith((".hip", ".cpp", ".h"))]],
+                         capture_output=True, text=True).stdout
+    assert sum(int(m) for m in re.findall(r":(\d+)$", out, re.M)) <= 1      # the one left is inside #ifdef LSPF2F_ABLATE (tools/ablate.sh builds)
