@@ -266,6 +266,11 @@ int lspf2f_unet_prepare(const float *src_dev, int src_nchw, int batch, int h, in
 int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout, int apply_tanh,
                          float *out_f32_dev, unsigned char *out_u8_dev, void *hip_stream);
 
+/* Measurement aid (bench.py `roofline.clock_ghz_observed`): ONE wave spins for about `duration_us` microseconds of the constant 100 MHz
+ * counter (s_memrealtime) and writes {shader cycles (s_memtime), 100-MHz ticks} it saw to out_dev[0..1].  Launched on a side stream while
+ * the timed region runs, cycles / ticks x 0.1 is the shader clock in GHz the chip held under that load.  duration_us <= 2 000 000. */
+int lspf2f_clock_probe(unsigned long long *out_dev, unsigned duration_us, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

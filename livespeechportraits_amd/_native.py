@@ -128,6 +128,7 @@ SIGNATURES = {
     "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p, c_size_t, c_void_p]),
     "lspf2f_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "lspf2f_pixel_shuffle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "lspf2f_clock_probe": (c_int, [c_void_p, c_uint32, c_void_p]),
 }
 
 

@@ -335,6 +335,13 @@ int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout
     return e == hipSuccess ? LSPF2F_OK : hipfail(e, "pixel_shuffle launch");
 }
 
+int lspf2f_clock_probe(unsigned long long *out_dev, unsigned duration_us, void *hip_stream)
+{
+    if (!out_dev || duration_us == 0 || duration_us > 2000000u) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "clock_probe: null output or duration outside 1..2 000 000 us");
+    const hipError_t e = launch_clock_probe(out_dev, duration_us, static_cast<hipStream_t>(hip_stream));
+    return e == hipSuccess ? LSPF2F_OK : hipfail(e, "clock_probe launch");
+}
+
 }  // extern "C"
 
 static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, const float *cand, int cand_batch,

@@ -186,4 +186,24 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// bench.py's clock probe: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz reference
+__global__ __launch_bounds__(64) void clock_probe(unsigned long long *out, unsigned long long ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
+hipError_t launch_clock_probe(unsigned long long *out, unsigned duration_us, hipStream_t s)
+{
+    hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, s, out, (unsigned long long)duration_us * 100ull);
+    return hipGetLastError();
+}
+
 }  // namespace lspf2f
