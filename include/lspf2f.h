@@ -266,6 +266,13 @@ int lspf2f_unet_prepare(const float *src_dev, int src_nchw, int batch, int h, in
 int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout, int apply_tanh,
                          float *out_f32_dev, unsigned char *out_u8_dev, void *hip_stream);
 
+/* Where a layer's weights sit in the packed blob, per weight FORM (tests; -1: this handle's blob does not carry that form -- it carries only
+ * the forms the plans of batch 1 .. max_batch read).  Forms: 0 rows ([cout][tap][cin], sub-pixel rows [4][cout][2][2][cin], first conv
+ * [cin][tap][cout]; = lspf2f_layer_info.w_offset), 1 full-K tile-blocked, 2 full-K as two half-sources, 3 Winograd F(2x2,3x3) fragments,
+ * 4 Winograd F(4x4,3x3) fragments, 5 up-conv Winograd fragments, 6 rowup256 fragments, 7 bandconv512 fragments, 8 rowconv fragments,
+ * 9 GEMM form of the last conv, 10 rowlast128 fragments. */
+int64_t lspf2f_layer_form_offset(const lspf2f_handle *h, int layer, int form);
+
 /* Measurement aid (bench.py `roofline.clock_ghz_observed`): ONE wave spins for about `duration_us` microseconds of the constant 100 MHz
  * counter (s_memrealtime) and writes {shader cycles (s_memtime), 100-MHz ticks} it saw to out_dev[0..1].  Launched on a side stream while
  * the timed region runs, cycles / ticks x 0.1 is the shader clock in GHz the chip held under that load.  duration_us <= 2 000 000. */

@@ -22,6 +22,7 @@ ERR_NAMES = {
 }
 VARIANT_IDS = {"normal": 0, "large": 1}
 DTYPE_IDS = {"f32": 0, "bf16": 1, "f16": 2}
+FORM_IDS = {"rows": 0, "fullk": 1, "fullk2": 2, "wino": 3, "wino4": 4, "winoup": 5, "rowup": 6, "band": 7, "row": 8, "gemm_last": 9, "rowlast": 10}
 FLAG_KEEP_INTERMEDIATES = 1
 FLAG_NO_GRAPH = 2
 FLAG_INSTANCE_NORM = 4
@@ -129,6 +130,7 @@ SIGNATURES = {
     "lspf2f_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "lspf2f_pixel_shuffle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lspf2f_clock_probe": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "lspf2f_layer_form_offset": (c_int64, [c_void_p, c_int, c_int]),
 }
 
 

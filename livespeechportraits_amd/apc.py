@@ -44,8 +44,7 @@ class APC_encoder(nn.Module):
         if not inputs.is_cuda:
             raise RuntimeError("APC_encoder here is the MI355X path: inputs must be a device tensor (no CPU path)")
         e = self._get_engine(inputs.device, T)
-        out = e.forward_checked(inputs[0].float().contiguous()).unsqueeze(0)
         # the recurrence hands h_t between workgroups through polled mailboxes; a lost hand-off is reported through the
-        # status word only, and these features feed KNN/LLE and both downstream models: check it here (one 4-byte D2H per
-        # utterance; demo.py:189-191 moves the result to the host right after anyway)
-        return out
+        # status word only, and these features feed KNN/LLE and both downstream models: forward_checked() reads it (one 4-byte
+        # D2H per utterance; demo.py:189-191 moves the result to the host right after anyway)
+        return e.forward_checked(inputs[0].float().contiguous()).unsqueeze(0)

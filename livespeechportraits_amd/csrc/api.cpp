@@ -150,6 +150,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "fullk_split") P.use_fullk_split = v != 0;
         else if (k == "fullk_split_tiles") P.fullk_split_max_tiles = v;
         else if (k == "fullk_s2") P.use_fullk_s2 = v != 0;
+        else if (k == "all_forms") P.keep_all_forms = v != 0;
         else if (k == "fused_splitk") h->fuse_splitk = v != 0;
         else if (k == "prefetch") h->prefetch = v != 0;
         else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
@@ -160,7 +161,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
     const std::string e = P.build(cfg->variant, cfg->input_nc, cfg->feat_nc, cfg->output_nc, cfg->ngf,
                                   cfg->num_downs, cfg->height,
                                   (cfg->flags & LSPF2F_FLAG_KEEP_INTERMEDIATES) != 0, cfg->dtype,
-                                  (cfg->flags & LSPF2F_FLAG_INSTANCE_NORM) ? 1 : 0);
+                                  (cfg->flags & LSPF2F_FLAG_INSTANCE_NORM) ? 1 : 0, cfg->max_batch);
     if (!e.empty()) { delete h; return fail(LSPF2F_ERR_UNSUPPORTED, e); }
     P.plan_batch(cfg->max_batch);
     *out = h;
@@ -333,6 +334,26 @@ int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout
     ShuffleParams sp{g_dev, out_f32_dev, out_u8_dev, batch, hs, ws, cout, apply_tanh ? 1 : 0};
     const hipError_t e = launch_pixel_shuffle(sp, static_cast<hipStream_t>(hip_stream));
     return e == hipSuccess ? LSPF2F_OK : hipfail(e, "pixel_shuffle launch");
+}
+
+int64_t lspf2f_layer_form_offset(const lspf2f_handle *h, int layer, int form)
+{
+    if (!h || layer < 0 || layer >= (int)h->plan.layers.size()) return -1;
+    const LayerDesc &l = h->plan.layers[layer];
+    switch (form) {
+    case 0: return l.w_off;
+    case 1: return l.wfk_off;
+    case 2: return l.wfk2_off;
+    case 3: return l.wwg_off;
+    case 4: return l.ww4_off;
+    case 5: return l.wwu_off;
+    case 6: return l.wru_off;
+    case 7: return l.wbc_off;
+    case 8: return l.wrc_off;
+    case 9: return l.wgemm_off;
+    case 10: return l.wrl_off;
+    default: return -1;
+    }
 }
 
 int lspf2f_clock_probe(unsigned long long *out_dev, unsigned duration_us, void *hip_stream)

@@ -40,7 +40,7 @@ struct IgemmParams {
     const void *residual;       // NHWC [M][Cout] or nullptr
     void *out;                  // NHWC [M][Cout]
     float *partial;             // split-K scratch [splits][M][Cout] (splits > 1), always fp32
-    int dtype;                  // 0 = fp32, 1 = bf16
+    int dtype;                  // 0 = fp32, 1 = bf16, 2 = fp16 (16-bit storage, fp32 accumulate / epilogue)
     int B, Hs, Ws, Ho, Wo;
     int C0, C1, Cin, Cout;
     int stride;                 // 1 | 2
@@ -159,7 +159,7 @@ struct SmallMParams {
     const float *scale, *shift;  // [Cout] or nullptr
     const void *residual;        // [M][Cout] or nullptr
     void *out;                   // [M][Cout]
-    int dtype;                   // 0 = fp32, 1 = bf16
+    int dtype;                   // 0 = fp32, 1 = bf16, 2 = fp16
     int B, Hs, Ws, Ho, Wo, Cin, Cout;
     int stride, up, relu, M;
     // optional: bytes [0, pf_bytes) at pf are the weights the NEXT launch of the forward streams (another weight-streaming layer).  A fifth wave

@@ -133,7 +133,14 @@ int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out, int for
     // nb 1 / 512 605.6, nb 2 / 512 602.5, nb 2 / 1024 580.8, nb 1 / 1536 602.0, nb 1 / 2048 599.8; batch 8: nb 1 967.4, nb 2 945.8
     const long ntb = (long)batch * (hs / 4) * (hs / 8);
     const int nb = force_nb ? force_nb : 1;
+    if ((nb != 1 && nb != 2) || cout % (32 * nb)) return 0;     // a forced nb the shape cannot take: the implicit GEMM keeps the layer
     const long wgs = ntb * (cout / (32 * nb));
+    if (wgs <= 0) return 0;
+    {   // the kernel's own shape limits (2-GiB buffer offsets, extents), like wino_choice: an unsupported shape falls back instead of failing at launch
+        WinoUpParams q{};
+        q.B = batch; q.Hs = hs; q.Ws = hs; q.C0 = cin; q.C1 = 0; q.N = cout; q.splits = 1;
+        if (!winoup_supported(q, nb)) return 0;
+    }
     const int steps = cin / 8;
     int splits = 1;
     if (wgs < target * 3 / 4) {
@@ -276,8 +283,13 @@ struct Builder {
 };
 }  // namespace
 
+namespace {
+struct BatchLayout { size_t act_bytes, partial_bytes, stats_bytes; int groups_max; };
+BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, std::vector<LayerDesc> *tiled);
+}  // namespace
+
 std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc_, int ngf_, int num_downs_,
-                        int size_, bool keep, int dtype_, int norm_)
+                        int size_, bool keep, int dtype_, int norm_, int max_batch_forms)
 {
     if (norm_ != 0 && norm_ != 1) return "norm must be 0 (BatchNorm2d, eval) or 1 (InstanceNorm2d)";
     if (norm_ == 1 && dtype_ != 0) return "the InstanceNorm variant is fp32 only";
@@ -299,71 +311,112 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
     Builder b(*this);
     b.level(0, "netG.model", -1, size);
 
-    // blob layout
-    size_t off = 0;
+    // up-convs of the compute-bound levels run in sub-pixel form: 4 parities x 2x2 taps (16/9 of the 9-tap weight bytes, 4/9 of the FLOPs); the
+    // weight-streaming-bound small levels keep the 9-tap gather form.
     for (auto &l : layers) {
-        off = align_up(off, 256);
-        l.w_off = (int64_t)off;
-        // up-convs of the compute-bound levels run in sub-pixel form: 4 parities x 2x2 taps
-        // (16/9 of the 9-tap weight bytes, 4/9 of the FLOPs); the weight-streaming-bound
-        // small levels keep the 9-tap gather form.
         l.up4 = l.kind == kIgemm && l.up && l.ho >= kUp4MinExtent;
         if (l.up4) l.up = false;
-        off += (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9) * (layer_weights_typed(l) ? elt() : sizeof(float));
-        if (last_as_gemm(l)) {
+    }
+    // Blob layout.  First every weight form some kernel of this dtype could read; then, when the handle's largest batch is known, the layout
+    // is redone with ONLY the forms the plans of batch 1 .. max_batch take (the planner is run for each of them): a layer that every such plan
+    // runs on the Winograd kernel does not carry its 9-tap rows, the 16x16 layers of a one-frame handle carry neither rows nor G g G^T, ...
+    // `large` fp32 at 512x512: 1.22 GB with every form, 0.62 GB for max_batch = 1, 0.80 GB for max_batch = 8.
+    assign_offsets(nullptr);
+    if (max_batch_forms > 0 && !keep_all_forms) {
+        std::vector<unsigned> used(layers.size(), 0u);
+        for (int b = 1; b <= max_batch_forms; ++b) {
+            std::vector<LayerDesc> t = layers;
+            (void)layout_for(*this, b, nullptr, &t);
+            for (size_t i = 0; i < layers.size(); ++i) used[i] |= forms_used(t[i], *this);
+        }
+        assign_offsets(&used);
+    }
+    planned_batch = 0;
+    return "";
+}
+
+unsigned Plan::forms_used(const LayerDesc &l, const Plan &p)
+{
+    if (l.kind == kFirstConv) return kFormRows;
+    if (l.kind == kLastConv) return kFormRows | (p.last_as_gemm(l) ? kFormGemmLast : 0u);      // rows: the direct kernels (fp32 plans; `lastconv_direct` of 16-bit ones)
+    if (l.wino4) return kFormWino4;
+    if (l.wino) return kFormWino;
+    if (l.winoup) return kFormWinoUp;
+    if (l.rowup) return kFormRowUp;
+    if (l.bandconv) return kFormBand;
+    if (l.rowconv) return kFormRow;
+    if (l.fullk) return (l.stride == 2 || (l.splits == 2 && !l.c1)) ? kFormFullK2 : kFormFullK;
+    return kFormRows;
+}
+
+void Plan::assign_offsets(const std::vector<unsigned> *used)
+{
+    size_t off = 0;
+    for (size_t li = 0; li < layers.size(); ++li) {
+        LayerDesc &l = layers[li];
+        const unsigned need = used ? (*used)[li] : ~0u;
+        l.w_off = l.wgemm_off = l.wrl_off = l.wfk_off = l.wfk2_off = l.wwg_off = l.ww4_off = l.wwu_off = l.wru_off = l.wbc_off = l.wrc_off = -1;
+        l.scale_off = l.shift_off = -1;
+        if (need & kFormRows) {
+            off = align_up(off, 256);
+            l.w_off = (int64_t)off;
+            off += (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9) * (layer_weights_typed(l) ? elt() : sizeof(float));
+        }
+        if ((need & kFormGemmLast) && last_as_gemm(l)) {
             off = align_up(off, 256);
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
-        }
-        if (last_as_gemm(l) && l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
-            off = align_up(off, 256);
-            l.wrl_off = (int64_t)off;
-            off += (size_t)9 * 4 * 64 * 8 * elt();
+            if (l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
+                off = align_up(off, 256);
+                l.wrl_off = (int64_t)off;
+                off += (size_t)9 * 4 * 64 * 8 * elt();
+            }
         }
         if (l.kind == kIgemm && fullk_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype)) {
-            // HBM is plentiful (288 GB): the 16x16 / 8x8 layers keep a second, tile-blocked copy for the full-K kernel of the
-            // small-batch plans next to the row layout the implicit-GEMM kernel of the large-batch plans reads
-            off = align_up(off, 256);
-            l.wfk_off = (int64_t)off;
-            off += (size_t)l.cout * 9 * l.cin * sizeof(float);
-            if (l.c1 == 0 && l.c0 >= 256) {                  // the K-split form reads a single source as two half-sources
+            // the 16x16 / 8x8 layers in the tile-blocked layout of the full-K kernel (small-batch plans) ...
+            if (need & kFormFullK) {
+                off = align_up(off, 256);
+                l.wfk_off = (int64_t)off;
+                off += (size_t)l.cout * 9 * l.cin * sizeof(float);
+            }
+            if ((need & kFormFullK2) && l.c1 == 0 && l.c0 >= 256) {                  // ... and its K-split form, which reads a single source as two half-sources
                 off = align_up(off, 256);
                 l.wfk2_off = (int64_t)off;
                 off += (size_t)l.cout * 9 * l.cin * sizeof(float);
             }
         }
-        if (l.kind == kIgemm && fullk_s2_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+        // the stride-2 convs of the small levels on the K-split full-K kernel (tune key `fullk_s2=1`): only carried when that path is switched on
+        if (l.kind == kIgemm && (need & kFormFullK2) && use_fullk_s2 && fullk_s2_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wfk2_off = (int64_t)off;                        // the only full-K copy of these layers: their single source as two half-sources
             off += (size_t)l.cout * 9 * l.cin * sizeof(float);
         }
-        if (l.kind == kIgemm && wino_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
-            // 16/9 of the 9-tap bytes; the 9-tap copy stays (plans of other batch sizes, tune key `wino=0`)
+        if (l.kind == kIgemm && (need & kFormWino) && use_wino && wino_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
-            l.wwg_off = (int64_t)off;
+            l.wwg_off = (int64_t)off;                         // 16/9 of the 9-tap bytes
             off += (size_t)16 * l.cout * l.cin * sizeof(float);
         }
-        if (l.kind == kIgemm && use_wino4 && wino4_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+        if (l.kind == kIgemm && (need & kFormWino4) && use_wino && use_wino4 && wino4_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
-            l.ww4_off = (int64_t)off;                       // 36/9 of the 9-tap bytes
+            l.ww4_off = (int64_t)off;                         // 36/9 of the 9-tap bytes
             off += (size_t)36 * l.cout * l.cin * sizeof(float);
         }
-        if (l.kind == kIgemm && winoup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
+        if (l.kind == kIgemm && (need & kFormWinoUp) && use_wino && use_winoup && winoup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wwu_off = (int64_t)off;
             off += (size_t)9 * l.cout * l.cin * sizeof(float);
         }
-        if (l.kind == kIgemm && rowup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
+        if (l.kind == kIgemm && (need & kFormRowUp) && rowup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wru_off = (int64_t)off;
             off += (size_t)16 * l.cout * l.cin * elt();
         }
-        if (l.kind == kIgemm && bandconv_layer(l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+        if (l.kind == kIgemm && (need & kFormBand) && bandconv_layer(l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wbc_off = (int64_t)off;
             off += (size_t)l.cout * 9 * l.cin * elt();
         }
-        if (l.kind == kIgemm && rowconv_layer(l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+        if (l.kind == kIgemm && (need & kFormRow) && rowconv_layer(l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wrc_off = (int64_t)off;
             off += (size_t)l.cout * 9 * l.cin * elt();
@@ -376,9 +429,9 @@ std::string Plan::build(int variant_, int input_nc_, int feat_nc_, int output_nc
         }
     }
     blob_bytes = align_up(off, 256);
-    planned_batch = 0;
-    return "";
 }
+
+
 
 int64_t Plan::layer_flops(const LayerDesc &l) const { return 2ll * l.cout * l.cin * 9 * l.ho * l.ho; }
 
@@ -432,8 +485,6 @@ struct Arena {
     }
 };
 
-struct BatchLayout { size_t act_bytes, partial_bytes, stats_bytes; int groups_max; };
-
 BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, std::vector<LayerDesc> *tiled)
 {
     Arena a;
@@ -460,17 +511,25 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, p.dtype, &bm, &bn, &splits, &group);
             const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
-            int fullk = (smallm || l.wfk_off < 0) ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
+            // (every kernel choice below looks only at the offset of the weight form IT reads: the blob of a handle carries just the forms its
+            // batch range uses, Plan::build)
+            int fullk = smallm ? 0 : fullk_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype);
+            bool fullk_k2 = false;
+            if (fullk) {
+                const bool want = p.use_fullk_split && fullk_split(batch, l.ho, l.c0, l.c1, l.cout, fullk, p.fullk_split_max_tiles);
+                if (want && (l.c1 ? l.wfk_off >= 0 : l.wfk2_off >= 0)) fullk_k2 = true;
+                else if (l.wfk_off < 0) fullk = 0;
+            }
             const bool fullk_s2 = !fullk && !smallm && p.use_fullk_s2 && p.use_fullk_split && l.wfk2_off >= 0 &&
                                   fullk_s2_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype, l.inorm) &&
                                   fullk_s2_choice(batch, l.hs, l.ho, l.c0, l.cout) > 0;
             if (fullk_s2) { fullk = 1; bm = 16; bn = 16; splits = 2; group = 1; }
-            else if (fullk) { bm = 16 * fullk; bn = 16; splits = (p.use_fullk_split && fullk_split(batch, l.ho, l.c0, l.c1, l.cout, fullk, p.fullk_split_max_tiles) && (l.c1 || l.wfk2_off >= 0)) ? 2 : 1; group = 1; }
+            else if (fullk) { bm = 16 * fullk; bn = 16; splits = fullk_k2 ? 2 : 1; group = 1; }
             int wsplits = 1;
-            const int wino = (p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
-            if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
             int w4splits = 1;
-            const int wino4 = (wino && p.use_wino4 && l.ww4_off >= 0) ? wino4_choice(batch, l.ho, l.cin, l.cout, &w4splits) : 0;
+            const int wino4 = (p.use_wino && p.use_wino4 && l.ww4_off >= 0 && !smallm) ? wino4_choice(batch, l.ho, l.cin, l.cout, &w4splits) : 0;
+            const int wino = (!wino4 && p.use_wino && l.wwg_off >= 0 && !smallm) ? wino_choice(batch, l.ho, l.cin, l.cout, &wsplits) : 0;
+            if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
             if (wino4) { bm = 32; bn = 32; splits = w4splits; group = 1; }
             int usplits = 1;
             const int winoup = (p.use_wino && p.use_winoup && l.wwu_off >= 0) ? winoup_choice(batch, l.hs, l.cin, l.cout, &usplits, p.winoup_nb, p.winoup_target) : 0;
@@ -503,7 +562,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             }
             if (tiled) {
                 const long tiles = (long)(l.up4 ? 4 : 1) * ((M + bm - 1) / std::max(bm, 1)) * ((l.cout + bn - 1) / std::max(bn, 1));
-                (*tiled)[li].wino = wino4 ? 0 : wino;
+                (*tiled)[li].wino = wino;
                 (*tiled)[li].wino4 = wino4;
                 (*tiled)[li].winoup = winoup;
                 (*tiled)[li].fused_splitk = (wino || wino4 || winoup) ? splits > 1 : p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
@@ -557,9 +616,11 @@ std::string Plan::pack(void *blob, size_t bytes) const
         // igemm-family weights are stored in the plan's dtype; staged in fp32 then narrowed (RNE) if bf16
         const bool narrow = dtype != 0 && layer_weights_typed(l);
         const size_t wcount = (size_t)l.cout * l.cin * ((l.up4 || l.kind == kLastConv) ? 16 : 9);
-        std::vector<float> stage_buf;
-        float *dst = reinterpret_cast<float *>(base + l.w_off);
-        if (narrow) { stage_buf.resize(wcount); dst = stage_buf.data(); }
+        // the row form ([co][tap][ci], sub-pixel rows, or the first conv's [ci][tap][co]) is always staged on the host: every other form is derived
+        // from it (or from W), and it is copied into the blob only where a kernel reads it (w_off >= 0)
+        std::vector<float> stage_buf(wcount);
+        float *dst = stage_buf.data();
+        std::vector<uint16_t> rows16;                        // the same values in the plan's 16-bit storage type (RNE), for the forms regrouped from them
         const int cin = l.cin, cout = l.cout;
         if ((l.kind == kIgemm && l.up4) || l.kind == kLastConv) {
             // sub-pixel form of Upsample(x2, nearest) + Conv3x3: output parity (py, px) only ever
@@ -582,7 +643,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
                                 }
                         }
             if (l.wwu_off >= 0) pack_winoup_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwu_off));
-            if (last_as_gemm(l)) {
+            if (last_as_gemm(l) && l.wgemm_off >= 0) {
                 // the same pre-summed taps as one 3x3 conv on the LOW-res source: output channel par*cout + co, tap
                 // (a, b) of parity (py, px) sits at low-res offset (py - 1 + a, px - 1 + b); the other taps are zero
                 uint16_t *g = reinterpret_cast<uint16_t *>(base + l.wgemm_off);
@@ -615,15 +676,18 @@ std::string Plan::pack(void *blob, size_t bytes) const
                         dst[((size_t)ci * 9 + t) * cout + co] = W[((size_t)co * cin + ci) * 9 + t];
         }
         if (narrow) {
-            uint16_t *d16 = reinterpret_cast<uint16_t *>(base + l.w_off);
-            for (size_t i = 0; i < wcount; ++i) d16[i] = narrow16(stage_buf[i], dtype);    // round to nearest even
+            rows16.resize(wcount);
+            for (size_t i = 0; i < wcount; ++i) rows16[i] = narrow16(stage_buf[i], dtype);    // round to nearest even
+            if (l.w_off >= 0) std::memcpy(base + l.w_off, rows16.data(), wcount * sizeof(uint16_t));
+        } else if (l.w_off >= 0) {
+            std::memcpy(base + l.w_off, stage_buf.data(), wcount * sizeof(float));
         }
         if (l.wru_off >= 0)
-            pack_rowup_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wru_off));
+            pack_rowup_weights(rows16.data(), reinterpret_cast<uint16_t *>(base + l.wru_off));
         if (l.wbc_off >= 0)
-            pack_bandconv_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wbc_off), cout);
+            pack_bandconv_weights(rows16.data(), reinterpret_cast<uint16_t *>(base + l.wbc_off), cout);
         if (l.wrc_off >= 0)     // the same bf16 values, regrouped into the MFMA A-fragments the row kernel keeps in registers
-            pack_rowconv_weights(reinterpret_cast<const uint16_t *>(base + l.w_off), reinterpret_cast<uint16_t *>(base + l.wrc_off), l.c0);
+            pack_rowconv_weights(rows16.data(), reinterpret_cast<uint16_t *>(base + l.wrc_off), l.c0);
         if (!l.biaskey.empty()) {
             const float *bv = get(l.biaskey).data.data();
             float *sc = reinterpret_cast<float *>(base + l.scale_off);

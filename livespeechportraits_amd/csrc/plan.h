@@ -80,7 +80,8 @@ struct Plan {
     int variant = 1, nres = 2, input_nc = 13, feat_nc = 1, output_nc = 3, ngf = 64, num_downs = 8, size = 512;
     bool keep_intermediates = false;
     int dtype = 0;             // 0: fp32 activations + weights; 1: bf16 storage (fp32 accumulate), first/last-layer weights fp32; 2: fp16 storage, likewise
-                               // (the reference's opt.fp16 / autocast configuration; runs on the generic kernels, the bf16-only row / band kernels stay off)
+                               // (the reference's opt.fp16 / autocast configuration; the row / band / up-conv kernels of the 16-bit plans are templated on
+                               // the storage type, so an fp16 plan takes the same kernel per layer as the bf16 plan)
     int norm = 0;              // 0: BatchNorm2d in eval mode (folded, the shipped checkpoints); 1: InstanceNorm2d (norm_layer argument
                                // of the reference constructors, networks.py:555 / :459): conv biases on, statistics at run time, fp32 only
     bool use_bandconv = true;  // bf16 plans: tune key `bandconv=0` puts the 16x16 / 8x8 layers back on the implicit GEMM (A-B runs)
@@ -133,8 +134,15 @@ struct Plan {
     size_t counters_offset() const { return 2 * cand_cache_bytes(); }
     size_t persistent_bytes() const { return 2 * cand_cache_bytes() + kTileCounters * sizeof(unsigned); }
 
+    // max_batch_forms > 0: the blob carries only the weight forms the plans of batch 1 .. max_batch_forms read (0: every form)
     std::string build(int variant, int input_nc, int feat_nc, int output_nc, int ngf, int num_downs,
-                      int size, bool keep, int dtype = 0, int norm = 0);   // returns "" or an error message
+                      int size, bool keep, int dtype = 0, int norm = 0, int max_batch_forms = 0);   // returns "" or an error message
+    // weight forms a layer can be packed in (bit mask)
+    enum : unsigned { kFormRows = 1, kFormFullK = 2, kFormFullK2 = 4, kFormWino = 8, kFormWino4 = 16, kFormWinoUp = 32, kFormRowUp = 64,
+                      kFormBand = 128, kFormRow = 256, kFormGemmLast = 512 };
+    static unsigned forms_used(const LayerDesc &tiled, const Plan &p);   // which form the kernel chosen for a (batch-planned) layer reads
+    void assign_offsets(const std::vector<unsigned> *used);               // lays the blob out with the forms of `used` (nullptr: every form)
+    bool keep_all_forms = false;   // tune key `all_forms=1`: every form whatever the batch range (tests that look at forms other batches would use)
     void plan_batch(int batch);
     size_t workspace_bytes(int batch) const;   // without mutating the current plan
     std::string pack(void *blob, size_t bytes) const;   // "" or error

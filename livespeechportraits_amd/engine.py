@@ -264,6 +264,10 @@ class Engine:
             out.append(d)
         return out
 
+    def form_offset(self, layer: int, form: str) -> int:
+        """byte offset of a layer's weights in the packed blob in the given form (N.FORM_IDS), -1 when this handle's blob does not carry it"""
+        return int(self.lib.lspf2f_layer_form_offset(self._h, layer, N.FORM_IDS[form]))
+
     def workspace_bytes(self, batch: int) -> int:
         return int(self.lib.lspf2f_workspace_bytes(self._h, batch))
 

@@ -105,7 +105,10 @@ def test_pack_weights_matches_numpy_restatement():
     from livespeechportraits_amd import synth
     from livespeechportraits_amd.engine import Engine
     topo, sd = synth.synthetic("large", ngf=32, num_downs=6, size=128)
-    e = Engine("large", ngf=32, num_downs=6, size=128)
+    # all_forms: the blob of a plain handle carries only the weight forms its batch range reads (a Winograd layer then has no row copy); this
+    # test checks the ROW form of every layer
+    e = Engine("large", ngf=32, num_downs=6, size=128, tune={"all_forms": 1})
+    assert e.packed_bytes() > Engine("large", ngf=32, num_downs=6, size=128).packed_bytes()
     e.load_state_dict(sd)
     blob = e.pack().numpy()
     f32 = lambda off, n: blob[off:off + 4 * n].view(np.float32)
@@ -276,18 +279,20 @@ def test_bf16_plans_route_64_channel_layers_to_the_row_kernel(monkeypatch):
     monkeypatch.delenv("LSP_HIP_ROWCONV")
 
     topo, sd = synth.synthetic("normal", ngf=64, num_downs=5, size=128)      # 64-channel level at 64x64
-    s = Engine("normal", ngf=64, num_downs=5, size=128, dtype="bf16")
+    s = Engine("normal", ngf=64, num_downs=5, size=128, dtype="bf16", tune={"all_forms": 1})      # rows AND fragments in the blob
     s.load_state_dict(sd)
     blob = s.pack().numpy()
     checked = 0
     kinds = set()
-    for l, c in zip(s.layers(1), topo.convs):
+    for i, (l, c) in enumerate(zip(s.layers(1), topo.convs)):
         if not l["kernel"].startswith("rowconv"):
             continue
         ch = l["cin"]
         nbytes = ch * 9 * ch * 2
+        fo = s.form_offset(i, "row")
+        assert fo > l["w_offset"] >= 0
         rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(ch // 32, 32, 9, ch // 16, 2, 8)   # [nb][ch][tap][kc][hi][e]
-        frag = blob[l["w_offset"] + nbytes: l["w_offset"] + 2 * nbytes].view(np.uint16).reshape(ch // 32, 9, ch // 16, 2, 32, 8)
+        frag = blob[fo: fo + nbytes].view(np.uint16).reshape(ch // 32, 9, ch // 16, 2, 32, 8)
         assert np.array_equal(frag, rows.transpose(0, 2, 3, 4, 1, 5)), l["name"]
         checked += 1
         kinds.add(l["kernel"])
@@ -313,16 +318,18 @@ def test_bf16_plans_route_small_512_channel_layers_to_the_band_kernel(monkeypatc
     monkeypatch.delenv("LSP_HIP_BANDCONV")
 
     topo, sd = synth.synthetic("normal", ngf=64, num_downs=6, size=256)      # 512 channels at 16x16 and 8x8
-    s = Engine("normal", ngf=64, num_downs=6, size=256, dtype="bf16", max_batch=8)
+    s = Engine("normal", ngf=64, num_downs=6, size=256, dtype="bf16", max_batch=8, tune={"all_forms": 1})      # rows AND fragments in the blob
     s.load_state_dict(sd)
     blob = s.pack().numpy()
     checked = 0
-    for l in s.layers(8):
+    for i, l in enumerate(s.layers(8)):
         if l["kernel"] != "bandconv512":
             continue
         cout, nbytes = l["cout"], l["cout"] * 9 * 512 * 2
+        fo = s.form_offset(i, "band")
+        assert fo > l["w_offset"] >= 0
         rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(cout // 32, 32, 9, 4, 8, 2, 8)   # [cs][ch][tap][q][kc][hi][e]
-        frag = blob[l["w_offset"] + nbytes: l["w_offset"] + 2 * nbytes].view(np.uint16).reshape(cout // 32, 4, 9, 8, 2, 32, 8)
+        frag = blob[fo: fo + nbytes].view(np.uint16).reshape(cout // 32, 4, 9, 8, 2, 32, 8)
         assert np.array_equal(frag, rows.transpose(0, 3, 2, 4, 5, 1, 6)), l["name"]
         checked += 1
     assert checked >= 2
@@ -345,12 +352,15 @@ def test_bf16_plans_route_the_edge_layers_of_the_256_level_to_row_kernels(monkey
     monkeypatch.delenv("LSP_HIP_ROWUP"); monkeypatch.delenv("LSP_HIP_ROWLAST")
     assert not any(l["kernel"] == "rowup256" for l in off) and "rowlast128" not in off[-1]["kernel"]
 
+    # the blob of `e` (max_batch 8) carries L1.up's rows (one-frame plans: implicit GEMM) and its rowup256 fragments (8-frame plans)
     e.load_state_dict(synth.make_state_dict(__import__("livespeechportraits_amd.topology", fromlist=["build_topology"]).build_topology("normal"), 7))
     blob = e.pack().numpy()
-    l = [x for x in l8 if x["kernel"] == "rowup256"][0]
+    i, l = [(i, x) for i, x in enumerate(l8) if x["kernel"] == "rowup256"][0]
     nbytes = 16 * 64 * 256 * 2
+    fo = e.form_offset(i, "rowup")
+    assert fo > l["w_offset"] >= 0
     rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(4, 2, 32, 4, 16, 2, 8)        # [par][nb][ch][tap][kc][hi][e]
-    frag = blob[l["w_offset"] + nbytes: l["w_offset"] + 2 * nbytes].view(np.uint16).reshape(2, 4, 4, 16, 2, 32, 8)
+    frag = blob[fo: fo + nbytes].view(np.uint16).reshape(2, 4, 4, 16, 2, 32, 8)
     assert np.array_equal(frag, rows.transpose(1, 0, 3, 4, 5, 2, 6))
 
 
@@ -365,7 +375,7 @@ def test_fp16_plan_takes_the_16bit_kernels_and_packs_rne_half():
         assert k16 == kbf and not any(k.startswith("wino3x3") for k in k16)
     assert any(k.startswith("rowconv") for k in k16) and any(k == "bandconv512" for k in k16) and any(k == "rowup256" for k in k16)
     topo, sd = synth.synthetic("normal", ngf=64, num_downs=5, size=64)
-    e = Engine("normal", ngf=64, num_downs=5, size=64, max_batch=8, dtype="f16")
+    e = Engine("normal", ngf=64, num_downs=5, size=64, max_batch=8, dtype="f16", tune={"all_forms": 1})
     e.load_state_dict(sd)
     blob = e.pack().numpy()
     checked = 0
@@ -415,3 +425,34 @@ def test_stride2_convs_of_the_small_levels_can_run_on_the_k_split_full_k_kernel(
     assert all(k.startswith("igemm3x3") for k, _ in downs(e.layers(2)).values())
     e.close()
     assert all(k.startswith("igemm3x3") for k, _ in downs(Engine("large", norm="instance").layers(1)).values())
+
+
+def test_the_blob_carries_only_the_weight_forms_the_handle_can_run():
+    """the packed blob (what rank 0 broadcasts and every rank keeps in HBM) holds, per layer, only the weight forms the plans of
+    batch 1 .. max_batch read -- the planner is run for each of them at create.  `large` fp32 512x512 went from 878 MB (every form) to 565 MB
+    for a one-frame handle; a layer every plan runs on the Winograd kernel has no 9-tap rows, the 16x16 layers of a one-frame handle no G g G^T."""
+    from livespeechportraits_amd import _native as N
+    from livespeechportraits_amd.engine import Engine
+    e1, e8, all8 = Engine("large", max_batch=1), Engine("large", max_batch=8), Engine("large", max_batch=8, tune={"all_forms": 1})
+    assert e1.packed_bytes() <= 600e6 < 720e6 and e1.packed_bytes() < e8.packed_bytes() < all8.packed_bytes()
+    used_form = lambda l: ("wino4" if l["kernel"].startswith("wino4") else "wino" if l["kernel"].startswith("wino3x3") else "winoup" if l["kernel"].startswith("winoup")
+                           else None)
+    for e, batches in ((e1, (1,)), (e8, range(1, 9))):
+        need = [set() for _ in e.layers(1)]
+        for b in batches:
+            for i, l in enumerate(e.layers(b)):
+                f = used_form(l)
+                if f is None and l["kernel"].startswith("conv3x3_fullk"):
+                    f = "fullk2" if l["split_k"] == 2 and not l["concat"] else "fullk"
+                need[i].add(f or "rows")
+        for i, forms in enumerate(need):
+            have = {f for f in ("rows", "fullk", "fullk2", "wino", "wino4", "winoup") if e.form_offset(i, f) >= 0}
+            assert have == forms or e.layers(1)[i]["kernel"].startswith(("first_conv", "last_conv")), (i, e.layers(1)[i]["name"], have, forms)
+    # what a plan reads is there: every layer's own form offset is valid for every batch of the range
+    for b in range(1, 9):
+        for i, l in enumerate(e8.layers(b)):
+            f = used_form(l)
+            if f:
+                assert e8.form_offset(i, f) >= 0, (b, l["name"], f)
+    for e in (e1, e8, all8):
+        e.close()

@@ -38,16 +38,17 @@ def test_host_packer_writes_the_fragment_order_the_kernel_reads():
     from livespeechportraits_amd import synth
     from livespeechportraits_amd.engine import Engine
     topo, sd = synth.synthetic("normal", ngf=32, num_downs=5, size=64)
-    e = Engine("normal", ngf=32, num_downs=5, size=64, max_batch=2)
+    e = Engine("normal", ngf=32, num_downs=5, size=64, max_batch=2, tune={"all_forms": 1})      # the 9-tap rows (to identify the layer) AND the G g G^T copy
     e.load_state_dict(sd)
     blob = e.pack().numpy()
     checked = 0
-    for l in e.layers(1):
+    for i, l in enumerate(e.layers(1)):
         if not l["kernel"].startswith("wino3x3"):
             continue
         cin, cout = l["cin"], l["cout"]
         nine = cout * cin * 9 * 4
-        off = (l["w_offset"] + nine + 255) // 256 * 256
+        off = e.form_offset(i, "wino")
+        assert off > l["w_offset"] >= 0
         got = blob[off: off + cout * cin * 16 * 4].view(np.float32)
         key = [k for k in sd if k.endswith(".weight") and sd[k].shape == (cout, cin, 3, 3)]
         # identify the layer's weight through the 9-tap copy the igemm would read: [co][tap][ci]
@@ -164,13 +165,14 @@ def test_upconv_packer_and_planner():
     e.load_state_dict(sd)
     blob = e.pack().numpy()
     checked = 0
-    for l, c in zip(e.layers(1), topo.convs):
+    for i, (l, c) in enumerate(zip(e.layers(1), topo.convs)):
         if not l["kernel"].startswith("winoup3x3"):
             continue
         cin, cout = l["cin"], l["cout"]
         w = sd[c.weight_key]
         exp = WM.pack_u_up(w)
-        off = (l["w_offset"] + cout * cin * 16 * 4 + 255) // 256 * 256              # behind the sub-pixel copy
+        off = e.form_offset(i, "winoup")
+        assert off >= 0 and l["w_offset"] == -1               # every plan of this handle runs the layer on winoup3x3: no sub-pixel rows in its blob
         got = blob[off: off + exp.size * 4].view(np.float32)
         assert np.allclose(got, exp, rtol=3e-7, atol=1e-9) and (got == exp).mean() > 0.99, l["name"]
         assert l["exec_flops_per_frame"] * 4 == l["flops_per_frame"] and l["weight_bytes"] == 9 * cin * cout * 4
@@ -221,7 +223,7 @@ def test_f4x4_is_opt_in_and_its_packer_writes_the_order_the_kernel_reads():
     e.load_state_dict(sd)
     blob = e.pack().numpy()
     checked = 0
-    for l, c in zip(e.layers(1), topo.convs):
+    for i, (l, c) in enumerate(zip(e.layers(1), topo.convs)):
         if not l["kernel"].startswith("wino4_3x3"):
             continue
         cin, cout = l["cin"], l["cout"]
@@ -229,7 +231,8 @@ def test_f4x4_is_opt_in_and_its_packer_writes_the_order_the_kernel_reads():
         assert l["exec_flops_per_frame"] * 4 == l["flops_per_frame"] and l["weight_bytes"] == 36 * cin * cout * 4
         w = sd[c.weight_key]
         exp = WM.pack_u4(w)
-        off = (l["w_offset"] + cout * cin * 9 * 4 + 255) // 256 * 256 + (cout * cin * 16 * 4 + 255) // 256 * 256    # behind the 9-tap and the F(2x2) copies
+        off = e.form_offset(i, "wino4")
+        assert off >= 0 and l["w_offset"] == -1 and e.form_offset(i, "wino") == -1       # the only form of this layer the handle's plans read
         got = blob[off: off + exp.size * 4].view(np.float32)
         assert np.allclose(got, exp, rtol=3e-7, atol=1e-9) and (got == exp).mean() > 0.99, l["name"]
         checked += 1
