@@ -32,10 +32,13 @@ class Feature2FaceModel(BaseModel):
 
     def _g(self) -> Feature2Face_G:
         net = self.Feature2Face_G
-        return net.module if isinstance(net, networks.SingleDeviceParallel) else net
+        return net.module if isinstance(net, (networks.SingleDeviceParallel, networks.MultiDeviceParallel)) else net
 
     def inference(self, feature_map, cand_image):
         with torch.no_grad():
+            net = self.Feature2Face_G
+            if isinstance(net, networks.MultiDeviceParallel):      # opt.gpu_ids with several ids: the batch is sliced over all of them
+                return net.render(feature_map, cand_image)
             return self._g().render(feature_map, cand_image)
 
     def inference_image(self, feature_map, cand_image):

@@ -94,6 +94,7 @@ class Feature2FaceGenerator(nn.Module):
         self._engine: Optional[Engine] = None
         self._blob: Optional[torch.Tensor] = None      # packed weights on the device
         self._dirty = True
+        self._blob_version = 0                         # bumped whenever the packed blob is rebuilt (replicas on other devices copy it again)
         self.register_load_state_dict_post_hook(lambda *_: self.mark_dirty())
 
     # -- weight ingress ------------------------------------------------------------
@@ -125,6 +126,7 @@ class Feature2FaceGenerator(nn.Module):
             e.bind(e.pack(), device)
             self._blob = e._blob_dev
             self._dirty = False
+            self._blob_version += 1
         return e
 
     def adopt_packed(self, engine: Engine) -> None:
@@ -190,10 +192,116 @@ class SingleDeviceParallel(nn.Module):
         return self.module(*a, **kw)
 
 
+class MultiDeviceParallel(nn.Module):
+    """``nn.DataParallel(net, gpu_ids)`` of the reference (models/networks.py:392-401) with more than one id, in ONE process.
+
+    DataParallel replicates the module and broadcasts all parameters (487 MB for 'large') on EVERY forward.  Here every listed device
+    holds a replica of the PACKED blob -- one peer copy per device whenever the weights are (re)packed, never per frame -- and its own
+    engine (one liblspf2f handle per device and stream, include/lspf2f.h).  ``render`` slices the batch over the devices with
+    ``distributed.shard_range`` (contiguous, balanced: what DataParallel's scatter does), enqueues every slice on its device's stream from
+    this one host thread (the launches are asynchronous, so the devices run concurrently) and gathers the frames on ``gpu_ids[0]``,
+    DataParallel's output device.  No collective, no per-frame weight traffic.  Same ``.module`` attribute and 'module.' key prefix.
+    The multi-process route (distributed.py, one rank per GPU over RCCL) remains the one bench.py scales with."""
+
+    def __init__(self, module: nn.Module, device_ids):
+        super().__init__()
+        self.module = module
+        self.device_ids = [int(d) for d in device_ids]
+        if len(self.device_ids) < 1:
+            raise ValueError("MultiDeviceParallel needs at least one device id")
+        self._replicas = {}        # slot -> (key, Engine): engines of slots 1.. (slot 0 is the module's own)
+        self._cands = {}           # slot -> (key, tensor): the shared candidate stack on that device
+
+    # -- plumbing kept overridable for the CPU bookkeeping test (fake engines on fake devices) ------------------------------------
+    def _device(self, slot: int) -> torch.device:
+        return torch.device("cuda", self.device_ids[slot])
+
+    def _generator(self):
+        return getattr(self.module, "netG", self.module)
+
+    def _primary_engine(self, g, size: int, batch: int, device: torch.device):
+        return g._engine_for(size, batch, device)
+
+    def _make_replica(self, g, primary, device: torch.device):
+        # same configuration AND same max_batch as the primary: the blob layout depends on the batch range the handle plans for
+        e = Engine(g.variant, g.input_nc, g.feat_nc, g.output_nc, g.ngf, g.num_downs, primary.size, primary.max_batch, norm=g.norm, dtype=g.dtype)
+        e.bind(primary._blob_dev.to(device))                 # ONE peer copy of the packed blob (no re-pack, no state dict on this device)
+        e.auto_cand_cache = primary.auto_cand_cache
+        return e
+
+    def _replica(self, slot: int, g, primary):
+        key = (id(primary), g._blob_version)
+        have = self._replicas.get(slot)
+        if have is None or have[0] != key:
+            self._replicas[slot] = have = (key, self._make_replica(g, primary, self._device(slot)))
+        return have[1]
+
+    def _shared_cand(self, slot: int, cand: torch.Tensor) -> torch.Tensor:
+        key = (id(cand), cand.data_ptr(), cand._version)
+        have = self._cands.get(slot)
+        if have is None or have[0] != key:
+            self._cands[slot] = have = (key, cand.to(self._device(slot)), cand)    # (the source tensor is kept alive: the key holds its id())
+        return have[1]
+
+    @staticmethod
+    def spans(batch: int, ndev: int):
+        """[(slot, lo, hi)] -- the non-empty contiguous slices of a batch over min(ndev, batch) devices"""
+        from .distributed import shard_range
+        n = max(1, min(ndev, batch))
+        return [(r,) + shard_range(batch, r, n) for r in range(n)]
+
+    def render(self, feature_map: torch.Tensor, cand_image: Optional[torch.Tensor]) -> torch.Tensor:
+        g = self._generator()
+        b = feature_map.shape[0]
+        spans = self.spans(b, len(self.device_ids))
+        if len(spans) == 1 or not isinstance(g, Feature2FaceGenerator):
+            # one frame, one device, or the 'small' U-Net (its own host-sequenced engine): the module's device does it all
+            return self.module.render(feature_map, cand_image) if hasattr(self.module, "render") else g.render(feature_map, cand_image)
+        dev0 = self._device(0)
+        if feature_map.device != dev0:
+            raise RuntimeError("inputs must live on gpu_ids[0] = %s like DataParallel's (got %s)" % (dev0, feature_map.device))
+        per = max(hi - lo for _, lo, hi in spans)
+        primary = self._primary_engine(g, feature_map.shape[-1], per, dev0)
+        outs = []
+        for slot, lo, hi in spans:
+            e = primary if slot == 0 else self._replica(slot, g, primary)
+            f = feature_map[lo:hi].float()
+            c = None
+            if cand_image is not None:
+                c = cand_image.float()
+                if c.shape[0] == 1:
+                    c = c if slot == 0 else self._shared_cand(slot, c)      # constant per person (demo.py:89-95): copied when it changes, not per frame
+                else:
+                    c = c[lo:hi]
+                    c = c if slot == 0 else c.to(self._device(slot), non_blocking=True)
+            if slot != 0:
+                f = f.to(self._device(slot), non_blocking=True)
+            outs.append(e.forward(f.contiguous(), c.contiguous() if c is not None else None))
+        out = torch.empty((b,) + tuple(outs[0].shape[1:]), dtype=outs[0].dtype, device=dev0)
+        for (slot, lo, hi), o in zip(spans, outs):
+            out[lo:hi].copy_(o, non_blocking=True)            # peer copies onto the output device; torch orders them behind the producing streams
+        return out.half() if g.dtype == "f16" else out
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x = cat([feature_map, cand_image], 1) as the reference's G receives it (scattered along the batch like DataParallel does)"""
+        g = self._generator()
+        if not isinstance(g, Feature2FaceGenerator):
+            return self.module(x)
+        feat = x[:, :g.feat_nc].contiguous()
+        cand = x[:, g.feat_nc:].contiguous() if g.input_nc > g.feat_nc else None
+        return self.render(feat, cand)
+
+
 def init_net(net: nn.Module, init_type="normal", init_gain=0.02, gpu_ids=()):
+    """networks.py:380-402 of the reference: initialise, move to gpu_ids[0], wrap.  One id -> SingleDeviceParallel; several ->
+    MultiDeviceParallel (the batch is sliced over every listed device, like nn.DataParallel(net, gpu_ids))."""
     init_weights(net, init_type, init_gain)
     if len(gpu_ids) > 0:
         if not torch.cuda.is_available():
             raise RuntimeError("gpu_ids=%r but no ROCm device is visible" % (list(gpu_ids),))
-        net = SingleDeviceParallel(net.to("cuda:%d" % gpu_ids[0]))
+        bad = [g for g in gpu_ids if not 0 <= int(g) < torch.cuda.device_count()]
+        if bad:
+            raise RuntimeError("gpu_ids=%r: no such device(s) %r (%d visible)" % (list(gpu_ids), bad, torch.cuda.device_count()))
+        net = net.to("cuda:%d" % gpu_ids[0])
+        net = SingleDeviceParallel(net) if len(gpu_ids) == 1 else MultiDeviceParallel(net, gpu_ids)
     return net

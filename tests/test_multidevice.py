@@ -1,0 +1,133 @@
+"""opt.gpu_ids with more than one id: MultiDeviceParallel (livespeechportraits_amd/networks.py) stands where the reference wraps G in
+nn.DataParallel(net, gpu_ids) (models/networks.py:392-401).  CPU: the slicing / replica / gather bookkeeping with fake engines.  GPU: two
+replicas on the ONE device a gpurun box has (gpu_ids = [0, 0]) against the single-device output bit for bit, and [0, 1] where two devices exist."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from livespeechportraits_amd import networks
+from livespeechportraits_amd.networks import Feature2FaceGenerator, MultiDeviceParallel
+
+
+class FakeEngine:
+    """frame i -> a function of frame i alone (so slicing cannot change results), remembers what it was asked to render"""
+    def __init__(self, slot, size, max_batch):
+        self.slot, self.size, self.max_batch, self.calls = slot, size, max_batch, []
+        self._blob_dev = torch.zeros(8, dtype=torch.uint8)
+        self.auto_cand_cache = False
+
+    def forward(self, feat, cand):
+        assert feat.shape[0] <= self.max_batch and feat.is_contiguous()
+        self.calls.append((tuple(feat.shape), None if cand is None else tuple(cand.shape)))
+        c = cand if cand is not None else torch.zeros(1, 12, *feat.shape[2:])
+        return (feat * 2.0 + c[:, :3].expand(feat.shape[0], -1, -1, -1) * 0.5).contiguous()
+
+
+class FakeParallel(MultiDeviceParallel):
+    def __init__(self, module, ids):
+        super().__init__(module, ids)
+        self.made, self.cand_copies = [], 0
+
+    def _device(self, slot):
+        return torch.device("cpu")
+
+    def _primary_engine(self, g, size, batch, device):
+        if getattr(self, "_p", None) is None or self._p.max_batch < batch:
+            self._p = FakeEngine(0, size, batch)
+            g._blob_version += 1
+        return self._p
+
+    def _make_replica(self, g, primary, device):
+        e = FakeEngine(len(self.made) + 1, primary.size, primary.max_batch)
+        self.made.append(e)
+        return e
+
+    def _shared_cand(self, slot, cand):
+        before = self._cands.get(slot)
+        out = super()._shared_cand(slot, cand)
+        if self._cands.get(slot) is not before:
+            self.cand_copies += 1
+        return out
+
+
+def test_slicing_replicas_and_gather_bookkeeping():
+    g = Feature2FaceGenerator("normal", ngf=32, num_downs=5)
+    assert MultiDeviceParallel.spans(8, 3) == [(0, 0, 3), (1, 3, 6), (2, 6, 8)]            # contiguous, balanced, first ranks take the extra frame
+    assert MultiDeviceParallel.spans(2, 8) == [(0, 0, 1), (1, 1, 2)]                      # fewer frames than devices: the idle devices get nothing
+    assert MultiDeviceParallel.spans(1, 4) == [(0, 0, 1)]
+    par = FakeParallel(g, [0, 1, 2])
+    rng = np.random.default_rng(0)
+    feat = torch.from_numpy(rng.standard_normal((8, 1, 32, 32)).astype(np.float32))
+    cand = torch.from_numpy(rng.standard_normal((1, 12, 32, 32)).astype(np.float32))
+    want = FakeEngine(9, 32, 8).forward(feat, cand)
+    got = par.render(feat, cand)
+    assert torch.equal(got, want)                                  # frame order survives the scatter / gather
+    assert par._p.calls == [((3, 1, 32, 32), (1, 12, 32, 32))] and [e.calls for e in par.made] == [[((3, 1, 32, 32), (1, 12, 32, 32))], [((2, 1, 32, 32), (1, 12, 32, 32))]]
+    assert par.cand_copies == 2                                    # the shared candidate stack went to devices 1 and 2 once each ...
+    par.render(feat, cand)
+    assert par.cand_copies == 2 and len(par.made) == 2             # ... and neither it nor the replicas are rebuilt for the next frame batch
+    cand.add_(1.0)                                                 # a new person: in-place edit bumps the tensor version
+    par.render(feat, cand)
+    assert par.cand_copies == 4
+    g._blob_version += 1                                           # the weights were repacked (checkpoint reload): replicas copy the new blob
+    par.render(feat, cand)
+    assert len(par.made) == 4
+    # per-frame candidates are sliced with the frames
+    cand8 = torch.from_numpy(rng.standard_normal((8, 12, 32, 32)).astype(np.float32))
+    assert torch.equal(par.render(feat, cand8), FakeEngine(9, 32, 8).forward(feat, cand8))
+    assert par.made[-1].calls[-1] == ((2, 1, 32, 32), (2, 12, 32, 32))
+    # forward(x) takes the concatenated input the reference's G receives
+    x = torch.cat([feat, cand8], 1)
+    assert torch.equal(par(x), FakeEngine(9, 32, 8).forward(feat, cand8))
+
+
+def test_init_net_wraps_by_the_number_of_ids(monkeypatch):
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(torch.nn.Module, "to", lambda self, *a, **k: self)
+    g = Feature2FaceGenerator("normal", ngf=32, num_downs=5)
+    one = networks.init_net(g, gpu_ids=[2])
+    assert isinstance(one, networks.SingleDeviceParallel) and one.module is g
+    many = networks.init_net(g, gpu_ids=[0, 1, 3])
+    assert isinstance(many, MultiDeviceParallel) and many.device_ids == [0, 1, 3] and many.module is g
+    assert all(k.startswith("module.") for k in many.state_dict())          # the DataParallel key prefix checkpoints carry
+    with pytest.raises(RuntimeError, match="no such device"):
+        networks.init_net(g, gpu_ids=[0, 7])
+
+
+def _opt(gpu_ids, size="normal"):
+    return argparse.Namespace(gpu_ids=gpu_ids, isTrain=False, size=size, ngf=32, n_downsample_G=5, fp16=0, checkpoints_dir="/tmp", name="x",
+                              load_epoch="latest", verbose=False, task="Feature2Face", model="feature2face")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0, 1]])
+def test_multi_id_inference_equals_single_device_bit_for_bit(ids, gpu_device):
+    """gpu_ids = [0, 0]: two replicas (two handles, two blob copies, two workspaces) on the one device of a gpurun box -- every code path of
+    MultiDeviceParallel short of a second physical device; [0, 1] runs where one exists."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.feature2face_model import Feature2FaceModel
+    if max(ids) >= torch.cuda.device_count():
+        pytest.skip("needs %d devices" % (max(ids) + 1))
+    topo, sd = synth.synthetic("normal", ngf=32, num_downs=5, size=64)
+    single, multi = Feature2FaceModel(_opt([0])), Feature2FaceModel(_opt(ids))
+    assert isinstance(multi.Feature2Face_G, MultiDeviceParallel)
+    for m in (single, multi):
+        m.Feature2Face_G.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        m.eval()
+    feat, cand = synth.make_inputs(5, 64, seed=11, cand_batch=1)
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+    # bit for bit against the single-device model rendering the SAME slices (a plan's tiling and split-K depend on the batch it is given, so a
+    # 5-frame call and a 3 + 2 split round differently in the last bit: tests/test_gpu_network.py::test_batch_consistency_and_determinism)
+    spans = MultiDeviceParallel.spans(5, len(ids))
+    sliced = lambda cc: torch.cat([single.inference(f[lo:hi].contiguous(), cc if cc.shape[0] == 1 else cc[lo:hi].contiguous()) for _, lo, hi in spans])
+    want = sliced(c)
+    got = multi.inference(f, c)
+    assert got.device == f.device and torch.equal(got, want)
+    assert (got - single.inference(f, c)).abs().max().item() <= 2e-6
+    assert torch.equal(multi.inference(f, c), want)                # replicas and candidate copies reused
+    c8 = torch.from_numpy(synth.make_inputs(5, 64, seed=12, cand_batch=5)[1]).to(gpu_device)
+    assert torch.equal(multi.inference(f, c8), sliced(c8))
+    assert torch.equal(multi.inference(f[:1], c), single.inference(f[:1], c))        # one frame: device 0 alone
