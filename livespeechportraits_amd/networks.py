@@ -112,7 +112,8 @@ class Feature2FaceGenerator(nn.Module):
             e = Engine(self.variant, self.input_nc, self.feat_nc, self.output_nc, self.ngf,
                        self.num_downs, size, mb, norm=self.norm, dtype=self.dtype)
             # The packed layout depends on the frame size (an up-conv switches to the 16-tap sub-pixel form once it writes
-            # >= 32x32, plan.cpp), not on the batch: the blob is reused only when just max_batch grew.
+            # >= 32x32, plan.cpp) and on the batch range the handle plans for (the blob carries only the weight forms those plans
+            # read): the blob is reused when just max_batch grew AND the wider range reads the same forms (same size in bytes).
             if same_size and not self._dirty and self._blob is not None and self._blob.device == device \
                     and self._blob.numel() == e.packed_bytes():
                 e.bind(self._blob)

@@ -167,11 +167,15 @@ def test_frame_size_switch_on_a_live_model_repacks(gpu_device):
         assert err <= TIGHT, (size, err)
         outs.setdefault(size, []).append(out)
     assert np.array_equal(outs[512][0], outs[512][1])
-    # growing only the batch keeps the blob (no re-pack): same storage afterwards
-    blob_ptr = g._blob.data_ptr()
+    # growing the batch: the blob carries the weight forms of the handle's batch range (round 4), so it is kept only when the wider range reads
+    # the same forms (same size in bytes) and re-packed otherwise -- either way the frames are right
+    blob_ptr, nbytes = g._blob.data_ptr(), g._blob.numel()
     feat, cand = synth.make_inputs(3, 512, seed=543, cand_batch=1)
-    g.render(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device))
-    assert g._blob.data_ptr() == blob_ptr and g._engine.max_batch == 3
+    out3 = g.render(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
+    assert g._engine.max_batch == 3
+    assert (g._blob.data_ptr() == blob_ptr) == (Engine("normal", size=512, max_batch=3).packed_bytes() == nbytes)
+    ref3 = torch_oracle.inference(sdt, torch.from_numpy(feat), torch.from_numpy(cand).expand(3, -1, -1, -1), 1, 8).numpy()
+    assert np.abs(out3 - ref3).max() <= TIGHT
     # and a blob of another size is refused outright
     with pytest.raises(ValueError, match="bad packed blob"):
         Engine("normal", size=256).bind(g._blob)
