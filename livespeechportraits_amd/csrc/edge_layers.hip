@@ -839,8 +839,13 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
 //     5 ds_read_b128 per 16 MFMAs.  Weights sit in LDS as [parity * 4 + channel][tap][128] with a row pitch of 516 floats (16 rows -> 16 bank slots).
 //   * the accumulators (4 registers per tile: the group's 4 pixels) go through LDS once more so that the NCHW fp32 rows and the HWC uint8 rows
 //     leave as full 16-byte / 4-byte coalesced stores; tanh and tensor2im as in the other kernels.
-__global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, int ntiles)
+// NW = waves per workgroup: 4 (round 3: a wave = 2 tile rows = 4 MFMA tiles) or 8 (round 4: a wave = 1 tile row = 2 MFMA tiles; TWO waves per SIMD --
+// one wave alone issues a 2-pass v_mfma_f32_4x4x1 only every ~13 cycles, measured with both operands in registers: profiles/r04_lastconv_ab.txt)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void last_conv_mfma(const LastConvParams p, int ntiles)
 {
+    constexpr int NT = 16 / NW;                               // MFMA tiles (16 pixels) per wave
+    constexpr int NPC = (52 + NW - 1) / NW;                   // stage pieces per wave and step (50 real ones)
     constexpr int WP = 40;                                    // staged pixels per tile row (34 used)
     constexpr int LWB = 16 * 516 * 4;                         // weight bytes in LDS
     constexpr int STG = 10 * WP * 128;                        // one stage buffer
@@ -860,15 +865,15 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
     {
         const i32x4 srd = make_srd(p.w, (unsigned)(4 * p.Cout * 512 * 4));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int Wp = 4 * j + wave, row = Wp >> 1, par = row >> 2, n = row & 3;
+        for (int j = 0; j < 32 / NW; ++j) {
+            const int Wp = NW * j + wave, row = Wp >> 1, par = row >> 2, n = row & 3;
             const unsigned voff[1] = {n < p.Cout ? (unsigned)((((par * p.Cout + n) * 512) + (Wp & 1) * 256 + lane * 4) * 4) : OOB};
             dma16_group<1, 0>(lds0 + (unsigned)(row * 2064 + (Wp & 1) * 1024), voff, srd, 0);
         }
     }
     // ---- stage copies of one tile: piece I = 8 consecutive tile pixels (row I / 5, columns 8 (I % 5) ..) x 8 slots; lane -> (pixel, slot), global
     // quad = slot ^ swizzle.  The copy side runs two stages ahead of the arithmetic and may already be in the workgroup's next tile.
-    unsigned vst[13];
+    unsigned vst[NPC];
     i32x4 srd0, srd1;
     auto tile_origin = [&](int tile, int &b, int &y0, int &x0) {
         b = tile / (tiles_x * tiles_y);
@@ -880,8 +885,8 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
         int b, y0, x0;
         tile_origin(tile, b, y0, x0);
 #pragma unroll
-        for (int j = 0; j < 13; ++j) {
-            const int I = 4 * j + wave;
+        for (int j = 0; j < NPC; ++j) {
+            const int I = NW * j + wave;
             const int row = I / 5, cc = 8 * (I - row * 5) + (lane >> 3);
             const int pp = row * WP + cc, q = (lane & 7) ^ ((pp >> 1) & 7);
             const int y = y0 - 1 + row, x = x0 - 1 + cc;
@@ -894,67 +899,69 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
     auto issue = [&](int st, int buf) {
         const unsigned dst = lds0 + (unsigned)(LWB + buf * STG + wave * 1024);
         const int soff = (st & 1) * 128;
-        const unsigned v0[4] = {vst[0], vst[1], vst[2], vst[3]}, v1[4] = {vst[4], vst[5], vst[6], vst[7]}, v2[4] = {vst[8], vst[9], vst[10], vst[11]};
-        const unsigned v3[1] = {vst[12]};
-        const unsigned last = wave < 2 ? dst + 48 * 1024 : lds0 + (unsigned)DUMP;      // pieces 48, 49 exist; 50, 51 go to the dump slot
-        if (st < 2) {
-            dma16_group<4, 4096>(dst, v0, srd0, soff); dma16_group<4, 4096>(dst + 16384, v1, srd0, soff); dma16_group<4, 4096>(dst + 32768, v2, srd0, soff);
-            dma16_group<1, 0>(last, v3, srd0, soff);
+        const unsigned last = wave < 2 ? dst + 48 * 1024 : lds0 + (unsigned)DUMP;      // pieces 48, 49 exist; the others of that round go to the dump slot
+        const i32x4 srd = st < 2 ? srd0 : srd1;
+        if constexpr (NW == 4) {
+            const unsigned v0[4] = {vst[0], vst[1], vst[2], vst[3]}, v1[4] = {vst[4], vst[5], vst[6], vst[7]}, v2[4] = {vst[8], vst[9], vst[10], vst[11]};
+            const unsigned v3[1] = {vst[12]};
+            dma16_group<4, 4096>(dst, v0, srd, soff); dma16_group<4, 4096>(dst + 16384, v1, srd, soff); dma16_group<4, 4096>(dst + 32768, v2, srd, soff);
+            dma16_group<1, 0>(last, v3, srd, soff);
         } else {
-            dma16_group<4, 4096>(dst, v0, srd1, soff); dma16_group<4, 4096>(dst + 16384, v1, srd1, soff); dma16_group<4, 4096>(dst + 32768, v2, srd1, soff);
-            dma16_group<1, 0>(last, v3, srd1, soff);
+            const unsigned v0[4] = {vst[0], vst[1], vst[2], vst[3]}, v1[2] = {vst[4], vst[5]}, v2[1] = {vst[6]};
+            dma16_group<4, 8192>(dst, v0, srd, soff); dma16_group<2, 8192>(dst + 32768, v1, srd, soff);
+            dma16_group<1, 0>(last, v2, srd, soff);
         }
     };
 
     // ---- operand addresses.  lane = (g, parity, i): as A the i-th pixel of group g, as B / D output channel n = i
     const int g = lane >> 4, par = (lane >> 2) & 3, mi = lane & 3;
     const int py = par >> 1, px = par & 1;
-    unsigned abase[4][4], aswz[4][4];                        // [tile][tap]: byte offset of the pixel inside a stage buffer, its slot swizzle (<< 4)
+    unsigned abase[NT][4], aswz[NT][4];                      // [tile][tap]: byte offset of the pixel inside a stage buffer, its slot swizzle (<< 4)
 #pragma unroll
-    for (int tau = 0; tau < 4; ++tau)
+    for (int tau = 0; tau < NT; ++tau)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int R = 2 * wave + (tau >> 1), Cb = 16 * (tau & 1);
+            const int R = NW == 4 ? 2 * wave + (tau >> 1) : wave, Cb = NW == 4 ? 16 * (tau & 1) : 16 * tau;
             const int pp = (R + (t >> 1) + py) * WP + Cb + 4 * g + mi + (t & 1) + px;
             abase[tau][t] = (unsigned)(pp * 128);
             aswz[tau][t] = (unsigned)(((pp >> 1) & 7) << 4);
         }
     const unsigned brow = (unsigned)((par * 4 + mi) * 2064);
-    f32x4acc acc[4];
+    f32x4acc acc[NT];
 #pragma unroll
-    for (int tau = 0; tau < 4; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+    for (int tau = 0; tau < NT; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int st, int buf) {
         const char *sb = smc + LWB + buf * STG;
         const char *wb = smc + brow + (unsigned)(((st >> 1) * 64 + (st & 1) * 32) * 4);
-        float4 a_cur[4], a_nxt[4], b_cur, b_nxt;
-        auto fetch = [&](int it, float4 (&a)[4], float4 &bv) {
+        float4 a_cur[NT], a_nxt[NT], b_cur, b_nxt;
+        auto fetch = [&](int it, float4 (&a)[NT], float4 &bv) {
             const int t = it >> 3, q = it & 7;
             bv = *reinterpret_cast<const float4 *>(wb + t * 512 + q * 16);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) a[tau] = *reinterpret_cast<const float4 *>(sb + abase[tau][t] + (aswz[tau][t] ^ (unsigned)(q << 4)));
+            for (int tau = 0; tau < NT; ++tau) a[tau] = *reinterpret_cast<const float4 *>(sb + abase[tau][t] + (aswz[tau][t] ^ (unsigned)(q << 4)));
         };
 #ifdef LC_ABL_NOMFMA                                         // timing builds of tools/lastconv_ablate.sh: copies only
         return;
 #endif
 #ifdef LC_PF2                                                // operands two iterations ahead (three register sets)
-        float4 a3[3][4], b3[3];
+        float4 a3[3][NT], b3[3];
         fetch(0, a3[0], b3[0]);
         fetch(1, a3[1], b3[1]);
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             if (it + 2 < 32) fetch(it + 2, a3[(it + 2) % 3], b3[(it + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);
-            const float4 (&ac)[4] = a3[it % 3];
+            const float4 (&ac)[NT] = a3[it % 3];
             const float4 bc = b3[it % 3];
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].x, bc.x, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].x, bc.x, acc[tau], 0, 0, 0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].y, bc.y, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].y, bc.y, acc[tau], 0, 0, 0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].z, bc.z, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].z, bc.z, acc[tau], 0, 0, 0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].w, bc.w, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(ac[tau].w, bc.w, acc[tau], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         return;
@@ -965,22 +972,22 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
             if (it + 1 < 32) fetch(it + 1, a_nxt, b_nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].x, b_cur.x, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].x, b_cur.x, acc[tau], 0, 0, 0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].y, b_cur.y, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].y, b_cur.y, acc[tau], 0, 0, 0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].z, b_cur.z, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].z, b_cur.z, acc[tau], 0, 0, 0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].w, b_cur.w, acc[tau], 0, 0, 0);
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_cur[tau].w, b_cur.w, acc[tau], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) a_cur[tau] = a_nxt[tau];
+            for (int tau = 0; tau < NT; ++tau) a_cur[tau] = a_nxt[tau];
             b_cur = b_nxt;
         }
     };
 
     // ---- steps n = (tile, stage): copy of step n + 2 goes out when step n's buffer is free.  A wave's copies land in issue order: weights (8), then
-    // 13 per step, so "at most 13 in flight" = step n has landed.
+    // NPC per step, so "at most NPC in flight" = step n has landed.
     float *ot = sm + OTB / 4;
     const int nmine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // tiles blockIdx.x, + gridDim.x, ...
     const int nsteps = 4 * nmine;
@@ -992,15 +999,15 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
     int ctile = blockIdx.x;
     for (int n = 0; n < nsteps; ++n) {
         const int st = n & 3, buf = n & 1;
-        if (n + 1 < nsteps) dma_wait<13>(); else dma_wait<0>();
+        if (n + 1 < nsteps) dma_wait<NPC>(); else dma_wait<0>();
         __syncthreads();
         compute(st, buf);
         if (st == 3 && mi < p.Cout) {
             // acc[tile][r] = output (row 2 R + py, column 2 (Cb + 4 g + r) + px) of channel mi -> LDS tile [n][16][68]
             const float bias = p.bias ? p.bias[mi] : 0.f;
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) {
-                const int Y = 2 * (2 * wave + (tau >> 1)) + py, Xb = 2 * (16 * (tau & 1) + 4 * g) + px;
+            for (int tau = 0; tau < NT; ++tau) {
+                const int Y = 2 * (NW == 4 ? 2 * wave + (tau >> 1) : wave) + py, Xb = 2 * ((NW == 4 ? 16 * (tau & 1) : 16 * tau) + 4 * g) + px;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pre = acc[tau][r] + bias;
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
         }
         if (st == 3) {
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();                                      // this step's buffer is free; the output tile is complete
         if (st == 3) {
@@ -1018,14 +1025,14 @@ __global__ __launch_bounds__(256) void last_conv_mfma(const LastConvParams p, in
             int b, y0, x0;
             tile_origin(ctile, b, y0, x0);
             if (p.out)
-                for (int i = tid; i < p.Cout * 256; i += 256) {
+                for (int i = tid; i < p.Cout * 256; i += 64 * NW) {
                     const int nn = i >> 8, Y = (i >> 4) & 15, x4 = i & 15;
                     *reinterpret_cast<float4 *>(p.out + (((size_t)b * p.Cout + nn) * H + 2 * y0 + Y) * W + 2 * x0 + 4 * x4) =
                         *reinterpret_cast<const float4 *>(ot + (nn * 16 + Y) * 68 + 4 * x4);
                 }
             if (p.out_u8) {
                 const int wpr = 16 * p.Cout;                 // 4-byte words per tile row (64 pixels x Cout bytes)
-                for (int i = tid; i < 16 * wpr; i += 256) {
+                for (int i = tid; i < 16 * wpr; i += 64 * NW) {
                     const int Y = i / wpr, wd = i - Y * wpr;
                     unsigned pk = 0;
 #pragma unroll
@@ -1067,12 +1074,13 @@ static bool last_conv_mfma_ok(const LastConvParams &p)
            (size_t)p.Hs * p.Ws * 256 < 0x80000000ull;
 }
 
-static hipError_t launch_last_conv_mfma(const LastConvParams &p, hipStream_t s)
+template <int NW>
+static hipError_t launch_last_conv_mfma_t(const LastConvParams &p, hipStream_t s)
 {
     const size_t smem = 16 * 516 * 4 + 2 * (10 * 40 * 128) + 4 * 16 * 68 * 4 + 1024;
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&last_conv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&last_conv_mfma<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
@@ -1081,8 +1089,12 @@ static hipError_t launch_last_conv_mfma(const LastConvParams &p, hipStream_t s)
     const long tiles = (long)p.B * (p.Hs / 8) * (p.Ws / 32);
     const int cus = device_cu_count();
     const long grid = tiles < cus ? tiles : cus;
-    hipLaunchKernelGGL(last_conv_mfma, dim3((unsigned)grid), dim3(256), smem, s, p, (int)tiles);
+    hipLaunchKernelGGL(last_conv_mfma<NW>, dim3((unsigned)grid), dim3(64 * NW), smem, s, p, (int)tiles);
     return hipGetLastError();
+}
+static hipError_t launch_last_conv_mfma(const LastConvParams &p, hipStream_t s)
+{
+    return p.route == 4 ? launch_last_conv_mfma_t<4>(p, s) : launch_last_conv_mfma_t<8>(p, s);     // route 4: the four-wave form of round 3 (A-B runs, tests)
 }
 
 template <typename T, int CO>
@@ -1120,7 +1132,9 @@ static hipError_t launch_last_conv_co(const LastConvParams &p, hipStream_t s)
 
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
-    // route 0 (by shape) and 4: the matrix-core kernel where it applies; 5: the vector-ALU kernels by size (A-B runs)
+    // route 0 (by shape): the matrix-core kernel in its eight-wave form where it applies; 4 its four-wave form of round 3 "or fail" (A-B runs, tests);
+    // 5: the vector-ALU kernels by size.  (A weights-stationary form with both operands in registers was built in round 4, parity-green and slower --
+    // one wave per SIMD issues a 2-pass MFMA only every ~13 cycles -- and removed: profiles/r04_lastconv_ab.txt.)
     if ((p.route == 0 || p.route == 4) && last_conv_mfma_ok(p)) return launch_last_conv_mfma(p, s);
     if (p.route == 4) return hipErrorInvalidValue;
     if (p.dtype == 2) {

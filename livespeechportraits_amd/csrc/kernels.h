@@ -291,8 +291,8 @@ struct LastConvParams {
     int B, Hs, Ws, C0, C1, Cout;
     int apply_tanh;
     unsigned char *out_u8;     // optional HWC uint8 frame [B][2Hs][2Ws][Cout] = tensor2im(out); out may then be nullptr
-    int route;                 // 0 = kernel chosen by shape (matrix-core where it applies); 1 strip, 2 rows, 3 generic, 4 matrix-core or fail, 5 the vector-ALU
-                               // kernels by size (forced per handle: tests, A-B runs)
+    int route;                 // 0 = kernel chosen by shape (the matrix-core kernel, eight waves, where it applies); 1 strip, 2 rows, 3 generic, 4 the matrix-core kernel in
+                               // its four-wave form of round 3 or fail, 5 the vector-ALU kernels by size (forced per handle: tests, A-B runs)
     const float *bias;         // [Cout] conv bias added before tanh (InstanceNorm plans) or nullptr
 };
 hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s);
