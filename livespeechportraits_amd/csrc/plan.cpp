@@ -351,7 +351,7 @@ unsigned Plan::forms_used(const LayerDesc &l, const Plan &p)
 
 void Plan::assign_offsets(const std::vector<unsigned> *used)
 {
-    size_t off = 0;
+    size_t off = (size_t)blob_pad_kb * 1024;          // tools (tune key `blob_pad_kb`): where the weights sit relative to the workspace's channel interleave
     for (size_t li = 0; li < layers.size(); ++li) {
         LayerDesc &l = layers[li];
         const unsigned need = used ? (*used)[li] : ~0u;
@@ -522,7 +522,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             }
             const bool fullk_s2 = !fullk && !smallm && p.use_fullk_s2 && p.use_fullk_split && l.wfk2_off >= 0 &&
                                   fullk_s2_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype, l.inorm) &&
-                                  fullk_s2_choice(batch, l.hs, l.ho, l.c0, l.cout) > 0;
+                                  fullk_s2_choice(batch, l.hs, l.ho, l.c0, l.cout, p.use_fullk_s2) > 0;
             if (fullk_s2) { fullk = 1; bm = 16; bn = 16; splits = 2; group = 1; }
             else if (fullk) { bm = 16 * fullk; bn = 16; splits = fullk_k2 ? 2 : 1; group = 1; }
             int wsplits = 1;

@@ -92,9 +92,10 @@ struct Plan {
     bool use_rowup = true;     // bf16 plans: tune key `rowup=0` keeps L1.up on the implicit GEMM (A-B runs)
     bool use_rowlast = true;   // bf16 plans: tune key `rowlast=0` keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     int fullk_split_max_tiles = 128;   // tune key `fullk_split_tiles` (tools): 256 also splits the 16x16 layers at batch 1
-    bool use_fullk_s2 = false;     // tune key `fullk_s2=1`: the stride-2 convs of the small levels (L4/L5/L6.down at batch 1) on the K-split full-K
-                                   // kernel instead of the implicit GEMM + split-K reduce.  Built, parity-tested, and measured SLOWER for the whole forward
-                                   // (628.9 vs 634.7 frames/s, A-B-A-B) although its launches are shorter: off by default
+    int use_fullk_s2 = 0;          // tune key `fullk_s2`: the stride-2 convs of the small levels at batch 1 on the K-split full-K kernel instead of the implicit
+                                   // GEMM + split-K reduce: 1 = L4 / L5 / L6.down (16x16, 8x8, 4x4 outputs), 2 = only those writing <= 8x8 (L5 / L6.down).
+                                   // Round 3 measured 1 as SLOWER for the whole forward although two of its three launches are shorter; round 4 found why
+                                   // (tools/s2_layer_delta.py): L4.down itself loses 8 us and two far-away up-convs lose 9 us each
     bool use_fullk_split = true;   // the 8x8 layers at batch 1 run the full-K kernel with K in two halves over twice the workgroups (tune key `fullk_split=0` at
                                    // create: unsplit, A-B runs)
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (tune key `wino=0`: the implicit GEMM, A-B runs)
@@ -142,6 +143,7 @@ struct Plan {
                       kFormBand = 128, kFormRow = 256, kFormGemmLast = 512 };
     static unsigned forms_used(const LayerDesc &tiled, const Plan &p);   // which form the kernel chosen for a (batch-planned) layer reads
     void assign_offsets(const std::vector<unsigned> *used);               // lays the blob out with the forms of `used` (nullptr: every form)
+    int blob_pad_kb = 0;           // tune key `blob_pad_kb` (tools): empty KB in front of the first layer's weights
     bool keep_all_forms = false;   // tune key `all_forms=1`: every form whatever the batch range (tests that look at forms other batches would use)
     void plan_batch(int batch);
     size_t workspace_bytes(int batch) const;   // without mutating the current plan
@@ -190,8 +192,9 @@ inline bool fullk_s2_layer(int hs, int ho, int c0, int c1, int cout, int stride,
     return dtype == 0 && stride == 2 && !up && !up4 && !inorm && c1 == 0 && (c0 == 256 || c0 == 512) && cout % 128 == 0 &&
            (ho == 16 || ho == 8 || ho == 4) && hs == 2 * ho;
 }
-inline int fullk_s2_choice(int batch, int hs, int ho, int c0, int cout)
+inline int fullk_s2_choice(int batch, int hs, int ho, int c0, int cout, int level = 1)
 {
+    if (level == 2 && ho > 8) return 0;
     if (batch != 1) return 0;                                 // measured at batch 1 only; from 2 frames up the implicit GEMM has rows enough
     const int nr = 16 / ho;                                   // one 16-pixel block per tile
     const long tiles = (long)batch * ((ho + nr - 1) / nr) * (cout / 16);
