@@ -48,23 +48,25 @@ static constexpr int kW4Patch = 36 * 32 * 32 * 4;         // epilogue: [position
 
 // Raw patch in LDS: 16 planes by (py & 3, px & 3) so that the 32 tiles a fragment read touches (4 pixels apart) are consecutive 16-B chunks.
 // Plane (pary, parx) holds hyn x hxn pixels x 2 quads: hyn = 5 for pary < 2 (patch rows 16, 17 exist), else 4; hxn = 9 for parx < 2, else 8.
+// (Adjacent pixels of a plane are 32 B apart: a fragment read is a 2-way bank conflict, which the LDS has room for -- reads overlap the MFMAs.)
 __host__ __device__ constexpr int w4_hyn(int pary) { return pary < 2 ? 5 : 4; }
 __host__ __device__ constexpr int w4_hxn(int parx) { return parx < 2 ? 9 : 8; }
 __host__ __device__ constexpr int w4_plane_base(int pary, int parx)
 {
     return (pary == 0 ? 0 : pary == 1 ? 340 : pary == 2 ? 680 : 952) + (parx == 0 ? 0 : parx == 1 ? 18 : parx == 2 ? 36 : 52) * w4_hyn(pary);
 }
-// chunk of patch pixel (py, px) = (4 hy + pary, 4 hx + parx), channel quad q
+// chunk of patch pixel (py, px) = (4 hy + pary, 4 hx + parx), channel quad q.  The two quads of a pixel are ADJACENT chunks: the copy's lanes 2i, 2i + 1
+// then ask for 32 contiguous bytes of one cache line instead of 16 bytes of two (the raw pieces are line-count-bound, not byte-bound)
 __host__ __device__ constexpr int w4_chunk(int py, int px, int q)
 {
-    return w4_plane_base(py & 3, px & 3) + q * w4_hyn(py & 3) * w4_hxn(px & 3) + (py >> 2) * w4_hxn(px & 3) + (px >> 2);
+    return w4_plane_base(py & 3, px & 3) + ((py >> 2) * w4_hxn(px & 3) + (px >> 2)) * 2 + q;
 }
 // lane-dependent part of a fragment-read address, by plane class cls = 2 (pary >= 2) + (parx >= 2): lane (tile ty, tx; quad q)
 __host__ __device__ constexpr int w4_cls(int dy, int dx) { return ((dy & 3) >= 2 ? 2 : 0) + ((dx & 3) >= 2 ? 1 : 0); }
 // ... and the compile-time part for patch offset (dy, dx): the tile's pixel (4 ty + dy, 4 tx + dx)
 __host__ __device__ constexpr int w4_imm(int dy, int dx)
 {
-    return 16 * (w4_plane_base(dy & 3, dx & 3) + (dy >> 2) * w4_hxn(dx & 3) + (dx >> 2));
+    return 16 * (w4_plane_base(dy & 3, dx & 3) + ((dy >> 2) * w4_hxn(dx & 3) + (dx >> 2)) * 2);
 }
 
 __device__ __forceinline__ float4 f4fma(float c, float4 a, float4 b) { return make_float4(fmaf(c, a.x, b.x), fmaf(c, a.y, b.y), fmaf(c, a.z, b.z), fmaf(c, a.w, b.w)); }
@@ -178,8 +180,8 @@ __device__ __forceinline__ void w4_loop(f32x16 (&acc)[9], const char *smem_c, un
     unsigned lp[4];
 #pragma unroll
     for (int cls = 0; cls < 4; ++cls) {
-        const int hyn = (cls & 2) ? 4 : 5, hxn = (cls & 1) ? 8 : 9;
-        lp[cls] = (unsigned)(16 * (q * hyn * hxn + ty * hxn + tx));
+        const int hxn = (cls & 1) ? 8 : 9;
+        lp[cls] = (unsigned)(16 * ((ty * hxn + tx) * 2 + q));
     }
     const unsigned au = (unsigned)(wave * 9216 + lane * 16);                 // this wave's nine fragments inside a slot's U region
     const unsigned vu[3] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + 1024), (unsigned)(lane * 16 + 2048)};
@@ -195,11 +197,13 @@ __device__ __forceinline__ void w4_loop(f32x16 (&acc)[9], const char *smem_c, un
     };
     const int n = ks_end - ks_begin;
     if (n <= 0) return;
+    // step 0 alone first: ISSUING a step's 14 pieces takes a wave ~1 500 cycles (the raw pieces are 64 scattered 16-byte requests each), so step 1 goes
+    // out only once step 0 has landed -- its flight then rides under the first operands' reads and transform
     fetch(ks_begin, 0);
-    if (n > 1) fetch(ks_begin + 1, 1);
     dma_wait<0>();
     __syncthreads();
     W4STAMP(2);
+    if (n > 1) fetch(ks_begin + 1, 1);
     W4Ops o0, o1;
     {   // operands of the first step: nothing to hide this behind
         const char *ns = smem_c;
@@ -216,6 +220,7 @@ __device__ __forceinline__ void w4_loop(f32x16 (&acc)[9], const char *smem_c, un
 #pragma unroll
         for (int f = 0; f < 9; ++f) o0.u[f] = *reinterpret_cast<const float4 *>(ns + au + f * 1024);
     }
+    dma_wait<0>();                                    // step 1 has landed meanwhile (this wave's pieces; the barrier covers the others')
     __syncthreads();                                  // every wave holds step 0 in registers: slot 0 may be overwritten
     W4STAMP(3);
     for (int t = 0; t < n; t += 2) {
@@ -297,9 +302,7 @@ __global__ __launch_bounds__(256, 1) void wino4_3x3(const WinoParams p)
         const int parx = rem1 >= 52 * hyn ? 3 : rem1 >= 36 * hyn ? 2 : rem1 >= 18 * hyn ? 1 : 0;
         const int rem2 = rem1 - (parx == 3 ? 52 : parx == 2 ? 36 : parx == 1 ? 18 : 0) * hyn;
         const int hxn = parx < 2 ? 9 : 8;
-        const int psz = hyn * hxn;
-        const int qd = rem2 >= psz ? 1 : 0;
-        const int r3 = rem2 - qd * psz;
+        const int qd = rem2 & 1, r3 = rem2 >> 1;
         const int hy = parx < 2 ? r3 / 9 : r3 >> 3, hx = r3 - hy * hxn;
         const int y = Y0 - 1 + 4 * hy + pary, x = X0 - 1 + 4 * hx + parx;
         const bool ok = ci < 1224 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;

@@ -194,7 +194,7 @@ def upconv_direct(x0, x1, w_oihw):
 # Geometry (must match wino4.hip):
 #   tile-block = 4 x 8 tiles of 4 x 4 outputs = 16 x 32 pixels; raw patch 18 x 34 pixels; MFMA row r = tile (ty = r >> 3, tx = r & 7)
 #   wave (a, b) = (w >> 1, w & 1) owns positions rows 3a..3a+2, columns 3b..3b+2 of the 6x6 transformed tile, f = 3 i + j locally
-#   raw chunk = plane_base(py & 3, px & 3) + q * hyn * hxn + (py >> 2) * hxn + (px >> 2): 16 planes of hyn x hxn pixels x 2 quads
+#   raw chunk = plane_base(py & 3, px & 3) + ((py >> 2) * hxn + (px >> 2)) * 2 + q: 16 planes of hyn x hxn pixels x 2 quads, a pixel's quads adjacent
 #   U = [n-block][wave][k-step][f][lane][4]
 BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64)
 G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
@@ -215,7 +215,7 @@ def w4_plane_base(pary, parx):
 
 def w4_chunk(py, px, q):
     pary, parx = py & 3, px & 3
-    return w4_plane_base(pary, parx) + q * w4_hyn(pary) * w4_hxn(parx) + (py >> 2) * w4_hxn(parx) + (px >> 2)
+    return w4_plane_base(pary, parx) + ((py >> 2) * w4_hxn(parx) + (px >> 2)) * 2 + q
 
 
 def w4_chunk_decode(ci):
@@ -226,7 +226,7 @@ def w4_chunk_decode(ci):
     parx = 3 if rem1 >= 52 * hyn else 2 if rem1 >= 36 * hyn else 1 if rem1 >= 18 * hyn else 0
     rem2 = rem1 - (0, 18, 36, 52)[parx] * hyn
     hxn = w4_hxn(parx)
-    q, r3 = divmod(rem2, hyn * hxn)
+    r3, q = divmod(rem2, 2)
     hy, hx = divmod(r3, hxn)
     return 4 * hy + pary, 4 * hx + parx, q
 
