@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void last_conv_strip(const LastConvParams p, i
 //   * the accumulators (4 registers per tile: the group's 4 pixels) go through LDS once more so that the NCHW fp32 rows and the HWC uint8 rows
 //     leave as full 16-byte / 4-byte coalesced stores; tanh and tensor2im as in the other kernels.
 // NW = waves per workgroup: 4 (round 3: a wave = 2 tile rows = 4 MFMA tiles) or 8 (round 4: a wave = 1 tile row = 2 MFMA tiles; TWO waves per SIMD --
-// one wave alone issues a 2-pass v_mfma_f32_4x4x1 only every ~13 cycles, measured with both operands in registers: profiles/r04_lastconv_ab.txt)
+// a single wave per SIMD neither keeps the 2-pass v_mfma_f32_4x4x1 pipe busy (9-13 cycles per instruction measured) nor covers its own waits: profiles/r04_lastconv_ab.txt)
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void last_conv_mfma(const LastConvParams p, int ntiles)
 {
@@ -1134,7 +1134,7 @@ hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
     // route 0 (by shape): the matrix-core kernel in its eight-wave form where it applies; 4 its four-wave form of round 3 "or fail" (A-B runs, tests);
     // 5: the vector-ALU kernels by size.  (A weights-stationary form with both operands in registers was built in round 4, parity-green and slower --
-    // one wave per SIMD issues a 2-pass MFMA only every ~13 cycles -- and removed: profiles/r04_lastconv_ab.txt.)
+    // its 400 registers allow one wave per SIMD -- and removed: profiles/r04_lastconv_ab.txt.)
     if ((p.route == 0 || p.route == 4) && last_conv_mfma_ok(p)) return launch_last_conv_mfma(p, s);
     if (p.route == 4) return hipErrorInvalidValue;
     if (p.dtype == 2) {
