@@ -49,6 +49,9 @@ def self_launch(n):
         port = sk.getsockname()[1]
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool only support dmabuf IPC; without it RCCL's hipIpcGetMemHandle fails with "invalid
+        # argument" as soon as two ranks exchange buffer handles.  The build / GPU images export it already; a child launched from a shell that
+        # dropped it would only fail at the first collective, so it is pinned here (a platform setting, not a tuning switch).
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r % ndev), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LSP_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -248,7 +251,8 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC passes (offline: rocprofv3 --pmc cannot run inside this process);
     # only quoted for the workload it was measured on
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_%s_b%d_%s.json" % (a.variant, B, a.dtype))
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_%s_b%d_%s.json" % (r, a.variant, B, a.dtype)) for r in ("r04", "r03")) if os.path.exists(q)),
+                    os.path.join(ROOT, "profiles", "r04_pmc_%s_b%d_%s.json" % (a.variant, B, a.dtype)))
     family = "wino3x3" if dom["kernel"].startswith("wino3x3") else dom["kernel"].split("<")[0]
     if a.size == 512 and os.path.exists(pmc_path):
         pj = json.load(open(pmc_path))
