@@ -74,8 +74,9 @@ def test_matches_reference_golden(case, gpu_device):
     f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
     out = e.forward(f, c)
     err = np.abs(out.cpu().numpy() - ref)
-    print("\n%s: max-abs vs the reference module %.2e (mean %.2e); routes %s" % (
-        case, err.max(), err.mean(), sorted({l["kernel"] for l in e.layers(meta["batch"]) if "in_" in l["kernel"]})))
+    print("\n%s: max-abs vs the reference module %.2e (mean %.2e) -- the contract is %.0e: %s; routes %s" % (
+        case, err.max(), err.mean(), TOL, "inside" if err.max() <= TOL else "OUTSIDE (see the reference's own spread below: a wider, labelled bound applies)",
+        sorted({l["kernel"] for l in e.layers(meta["batch"]) if "in_" in l["kernel"]})))
     # the reference's own distance from exact arithmetic on this case (float64 oracle), for scale
     from oracle import torch_oracle
     sd64 = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in sd.items() if v.dtype == np.float32}
