@@ -262,6 +262,16 @@ def test_tune_string_reaches_the_library_and_unknown_keys_are_errors(monkeypatch
     monkeypatch.delenv("LSP_HIP_WINOUP")
     with pytest.raises(N.Lspf2fError, match="unknown key"):
         Engine("normal", tune={"no_such_switch": 1})
+    # switches of the Python host share the prefix and never reach the library; a typo in the environment is a warning, not a broken run
+    monkeypatch.setenv("LSP_HIP_CAND_CACHE", "0")
+    assert N.tune_string() == b""
+    monkeypatch.setenv("LSP_HIP_WINOO", "0")
+    with pytest.warns(UserWarning, match="LSP_HIP_WINOO"):
+        assert N.tune_string() == b""
+    monkeypatch.delenv("LSP_HIP_WINOO"); monkeypatch.delenv("LSP_HIP_CAND_CACHE")
+    # every key the host forwards is one the library accepts
+    for k in sorted(N.TUNE_KEYS):
+        Engine("normal", tune={k: 1}).close()
     import re
     import subprocess
     out = subprocess.run(["grep", "-c", "getenv", *[os.path.join(ROOT, "livespeechportraits_amd", "csrc", f) for f in sorted(os.listdir(os.path.join(ROOT, "livespeechportraits_amd", "csrc"))) if f.endswith((".hip", ".cpp", ".h"))]],
