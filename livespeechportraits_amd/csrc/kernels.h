@@ -116,6 +116,7 @@ struct WinoParams {
     // (0 dispatch order, 1 tile-block-major, 2 channel-group-major) instead of by operand size; copies as one block ahead of the MFMAs
     // instead of between them; the four MFMAs of an accumulator back to back instead of rotating over the accumulators
     int nopre, xcd_force, no_il, no_rot;
+    int ureg;                   // one channel block per wave: U fragments by plain loads into registers instead of LDS-DMA + ds_read (wino.hip, UR form)
     // filled by launch_wino
     int steps_per_split, ntb, nng, tby, tbx, nmajor, xcd;
     size_t slab_bytes;

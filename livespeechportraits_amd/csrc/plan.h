@@ -101,6 +101,7 @@ struct Plan {
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (tune key `wino=0`: the implicit GEMM, A-B runs)
     bool use_wino4 = false;    // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSPF2F_FLAG_WINO4; measured slower at batch 1 and
                                // equal at batch 8, DESIGN.md 4.11, so off by default); decides whether the blob carries the 6x6 transformed weights
+    bool wino_ureg = true;       // `wino_ureg`: wino3x3<1> keeps its U fragments in registers (wino.hip UR form)
     bool wino_pre = true, wino_il = true, wino_rot = true;   // tools (`wino_pre` / `wino_il` / `wino_rot` of lspf2f_create_tuned): A-B switches of wino3x3
     int wino_xcd = -1, igemm_xcd = -1;                       // tools: forced block orders (-1 = by operand size)
     int winoup_nb = 0, winoup_target = 1024;   // tools (tune keys `winoup_nb` / `winoup_target`): force the channel blocks per wave / the workgroup count aimed at

@@ -43,9 +43,9 @@ static constexpr int kRawStage = kRawPieces * 1024;        // bytes per ring slo
 __host__ __device__ constexpr int wino_u_stage(int nb) { return 4 * 4 * nb * 1024; }              // 4 waves x (4 j x nb) pieces
 __host__ __device__ constexpr int wino_raw_base(int nb, int ns) { return ns * wino_u_stage(nb); }
 __host__ __device__ constexpr int wino_dump(int nb, int ns) { return wino_raw_base(nb, ns) + ns * kRawStage; }
-__host__ __device__ constexpr int wino_lds_bytes(int nb, int ns)
+__host__ __device__ constexpr int wino_lds_bytes(int nb, int ns, bool ur = false)
 {
-    const int loop = wino_dump(nb, ns) + 1024;
+    const int loop = (ur ? ns * kRawStage : wino_dump(nb, ns)) + 1024;     // ur: the raw ring alone (U fragments go to registers)
     const int patch = 4 * 2 * nb * 32 * 36 * 4;             // epilogue: [wave][b][nb][32 tiles][36]
     return loop > patch ? loop : patch;
 }
@@ -192,7 +192,115 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
 }
 
 
-template <int NB, int NS, bool IL, bool ROT>
+// ---- UR form of the K loop (one channel block per wave, ring of 3): the wave's U fragments never touch LDS.  They are private to the wave anyway
+// (fragment order, one 16-byte load per lane and MFMA quad), so each is ONE buffer_load_dwordx4 into the registers the MFMA reads, two steps ahead,
+// instead of an LDS-DMA piece + a ds_read_b128: per step 4 plain loads replace 4 of the 6 LDS-DMA pieces (each of which holds the issuing wave for
+// 40-150 cycles) and 4 of the 12 fragment reads, and the workgroup's LDS drops from 67 to 37 KB.  The loads are inline asm like the copies, for the
+// same reason (the compiler does not see the copies, so its own vmcnt arithmetic would over-wait): the registers of step t + 2 are "defined" at the
+// issue; their first use is an MFMA whose A operand comes from LDS reads behind the barrier that follows the counted wait of step t + 1, so it cannot
+// move above their arrival.  What the compiler must NOT do is copy such a register while its load is in flight (a tied "+v" operand on the wait
+// makes it do exactly that): tests/test_wino_cpu.py checks the generated code for moves out of the three register sets.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void uload16(f32x4v &dst, unsigned voff, i32x4 srd, unsigned soff)
+{
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff), "n"(OFF) : "memory");
+}
+template <int V> struct IntC { static constexpr int value = V; };
+
+template <int ROW>
+__device__ __forceinline__ void wino_loop_ur(const WinoParams &p, f32x16 (&acc)[4][1], const char *smem_c, unsigned lds0, int wave, int lane,
+                                             unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0,
+                                             int ks_begin, int ks_end, unsigned long long *first_landed)
+{
+    constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
+    constexpr int DUMP = 3 * kRawStage;
+    const int r = lane & 31, q = lane >> 5, ty = r >> 3, tx = r & 7;
+    unsigned araw[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int dy = k == 0 ? RA : RB;
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int chunk = (((dy & 1) * 2 + (dx & 1)) * 2 + q) * 45 + (ty + (dy >> 1)) * 9 + tx + (dx >> 1);
+            araw[k][dx] = (unsigned)(chunk * 16);
+        }
+    }
+    const unsigned vu = (unsigned)(lane * 16);
+    const unsigned lds_r0 = lds0 + (unsigned)(wave * 1024);
+    const unsigned lds_r1 = wave < 2 ? lds_r0 + 4096u : lds0 + (unsigned)DUMP;
+    auto fetch_raw = [&](int ks, int slot) {
+        dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
+    };
+    f32x4v ur[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ur[a][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = ks_end - ks_begin;
+    if (nsteps <= 0) return;
+    {
+        const unsigned so = soff_u0 + (unsigned)ks_begin * 4096u;
+        fetch_raw(ks_begin, 0);
+        uload16<0>(ur[0][0], vu, srd_u, so); uload16<1024>(ur[0][1], vu, srd_u, so); uload16<2048>(ur[0][2], vu, srd_u, so); uload16<3072>(ur[0][3], vu, srd_u, so);
+        if (nsteps > 1) {
+            fetch_raw(ks_begin + 1, 1);
+            uload16<0>(ur[1][0], vu, srd_u, so + 4096u); uload16<1024>(ur[1][1], vu, srd_u, so + 4096u);
+            uload16<2048>(ur[1][2], vu, srd_u, so + 4096u); uload16<3072>(ur[1][3], vu, srd_u, so + 4096u);
+            dma_wait<6>();
+        } else {
+            dma_wait<0>();
+        }
+    }
+    __syncthreads();
+#ifdef LSPF2F_WINO_STAMPS
+    *first_landed = __builtin_amdgcn_s_memtime();
+#endif
+    // one K-step on register set S (= ring slot of the raw patch); the loads of step t + 2 go into set (S + 2) % 3, last read in step t - 1
+    auto step = [&](auto Sc, int t) {
+        constexpr int S = decltype(Sc)::value, S2 = (S + 2) % 3;
+        const char *rawp = smem_c + S * kRawStage;
+        float4 d[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
+        const bool issue = t + 2 < nsteps;
+        const unsigned so = soff_u0 + (unsigned)(ks_begin + t + 2) * 4096u;
+        float4 tt[4], v[4];
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            if constexpr (ROW == 0 || ROW == 3) tt[dx] = f4sub(d[0][dx], d[1][dx]);
+            else if constexpr (ROW == 1) tt[dx] = f4add(d[0][dx], d[1][dx]);
+            else tt[dx] = f4sub(d[1][dx], d[0][dx]);
+        }
+        v[0] = f4sub(tt[0], tt[2]); v[1] = f4add(tt[1], tt[2]); v[2] = f4sub(tt[2], tt[1]); v[3] = f4sub(tt[1], tt[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = c == 0 ? v[j].x : c == 1 ? v[j].y : c == 2 ? v[j].z : v[j].w;
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ur[S][j][c], acc[j][0], 0, 0, 0);
+            }
+            if (issue) {
+                if (c == 0) fetch_raw(ks_begin + t + 2, S2);
+                if (c == 1) { uload16<0>(ur[S2][0], vu, srd_u, so); uload16<1024>(ur[S2][1], vu, srd_u, so); }
+                if (c == 2) { uload16<2048>(ur[S2][2], vu, srd_u, so); uload16<3072>(ur[S2][3], vu, srd_u, so); }
+            }
+        }
+        // step t + 1 has landed: everything but the six loads issued in THIS iteration (this wave's; the barrier covers the other waves' raw pieces)
+        if (issue) dma_wait<6>(); else dma_wait<0>();
+        __syncthreads();
+    };
+    for (int t = 0; t < nsteps; t += 3) {                   // (one exit: with a break per step hipcc copies the accumulators between register sets)
+        step(IntC<0>{}, t);
+        if (t + 1 < nsteps) step(IntC<1>{}, t + 1);
+        if (t + 2 < nsteps) step(IntC<2>{}, t + 2);
+    }
+}
+
+
+template <int NB, int NS, bool IL, bool ROT, bool UR = false>
 __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -286,6 +394,15 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
+    if constexpr (UR) {
+        static_assert(NB == 1 && NS == 3, "the register form exists for one channel block per wave");
+        switch (wave) {
+        case 0: wino_loop_ur<0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
+        case 1: wino_loop_ur<1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
+        case 2: wino_loop_ur<2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
+        default: wino_loop_ur<3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
+        }
+    } else
     switch (wave) {
     case 0: wino_loop<NB, NS, IL, ROT, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
     case 1: wino_loop<NB, NS, IL, ROT, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
@@ -428,17 +545,17 @@ bool wino_supported(const WinoParams &p, int nb)
     return true;
 }
 
-template <int NB, int NS, bool IL, bool ROT>
+template <int NB, int NS, bool IL, bool ROT, bool UR = false>
 static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
 {
-    constexpr int smem = wino_lds_bytes(NB, NS);
+    constexpr int smem = wino_lds_bytes(NB, NS, UR);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, ROT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, ROT, UR>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL((wino3x3<NB, NS, IL, ROT>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wino3x3<NB, NS, IL, ROT, UR>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
@@ -468,6 +585,7 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     // MFMAs of an accumulator back to back instead of rotating over the four accumulators of a channel block
     if (p.no_il) return nb == 2 ? launch_wino_t<2, 2, false, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
     if (p.no_rot) return nb == 2 ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<1, 3, true, false>(p, s);
+    if (nb == 1 && p.ureg) return launch_wino_t<1, 3, true, true, true>(p, s);
     return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);
 }
 

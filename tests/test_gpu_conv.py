@@ -654,7 +654,7 @@ def run_wino(dev, x, w, scale, shift, res, relu, nb, splits):
     dsh = shift.to(dev) if shift is not None else None
     dres = nhwc(res) if res is not None else None
     out = torch.full((b, h, h, cout), float("nan"), device=dev)
-    sb = lib.lspf2f_conv3x3_scratch_bytes(b, h, h, c, 0, cout, 1, 0, 4000 + nb, 0, splits, -1, 0)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, h, h, c, 0, cout, 1, 0, 4000 + nb, 0, splits, -1, 0)       # nb = 3: tile 4003, nb = 1 with U in registers
     scratch = torch.zeros(max(sb, 4), dtype=torch.uint8, device=dev)      # slabs + arrival counters (zero on entry, left zero by the kernel)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     N.check(lib.lspf2f_conv3x3(p(d0), None, p(wp), p(dsc), p(dsh), p(dres), p(out), b, h, h, c, 0, cout, 1, 0, int(relu), 4000 + nb, 0, splits, -1, 0,
@@ -677,6 +677,17 @@ WINO_CASES = [
     (1, 128, 128, 128, 1, 1, True),
     (1, 256, 256, 64, 1, 2, True),
     (1, 512, 512, 32, 1, 4, True),
+    # tile 4003 ("nb" 3): one channel block per wave with the U fragments in registers -- the form the plans take
+    (1, 32, 32, 32, 3, 1, False),         # 4 K-steps
+    (1, 8, 32, 16, 3, 1, False),          # one K-step: nothing is ever prefetched
+    (1, 16, 32, 16, 3, 1, True),          # two
+    (3, 40, 96, 48, 3, 1, True),          # five
+    (1, 64, 64, 64, 3, 2, True),
+    (2, 256, 32, 16, 3, 8, True),
+    (1, 104, 32, 32, 3, 3, False),        # slices of 5, 5, 3 steps
+    (1, 128, 128, 128, 3, 1, True),
+    (1, 256, 256, 64, 3, 2, True),
+    (1, 512, 512, 32, 3, 4, True),
 ]
 
 

@@ -1,0 +1,103 @@
+"""wino3x3 UR form: the U fragments are loaded by inline-asm buffer_load_dwordx4 into registers two K-steps ahead of their use.  The compiler does not
+know that these registers are in flight, so nothing but the MFMAs may touch them between the first load and the last MFMA of a wave's loop -- a
+v_mov / spill of such a register would read whatever the register held before its load landed.  This script disassembles the kernel (or reads a
+.s file) and checks exactly that, per wave-row instance.  Used by tests/test_wino_cpu.py; prints the register sets."""
+import re
+import subprocess
+import sys
+
+
+KERNEL = "_ZN6lspf2f7wino3x3ILi1ELi3ELb1ELb1ELb1E"          # wino3x3<1, 3, true, true, UR = true>
+
+
+def compile_to_asm(src, hipcc="hipcc"):
+    """device assembly of one source with the flags csrc/Makefile builds it with"""
+    return subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-S", "--cuda-device-only", src, "-o", "-"],
+                          check=True, capture_output=True, text=True).stdout
+
+
+def kernel_text(asm, mangled_prefix):
+    lines = asm.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix) and l.rstrip().endswith(tuple(":")) or (l.startswith(mangled_prefix) and ":" in l[:len(mangled_prefix) + 80]))
+    end = next((i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end")), len(lines))
+    return lines[start:end]
+
+
+def regs_of(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check(lines):
+    """regions checked: every K loop (blocks the asm printer marks as part of a loop that holds the MFMAs) and each prologue (first asm load of a
+    wave-row instance .. its loop header).  Behind a loop every load has landed (the last step waits vmcnt(0)), so the epilogue may reuse the registers."""
+    load_re = re.compile(r"\s*buffer_load_dwordx4 (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\], s\d+ offen offset:")
+    label_re = re.compile(r"^(\.LBB\d+_\d+):(.*)$")
+    loop_of = [None] * len(lines)
+    cur = None
+    for i, l in enumerate(lines):
+        m = label_re.match(l)
+        if m:
+            c = m.group(2)
+            if "Loop Header" in c:
+                cur = m.group(1)[2:]
+            elif "in Loop: Header=" in c:
+                cur = re.search(r"Header=(BB\d+_\d+)", c).group(1)
+            else:
+                cur = None
+        loop_of[i] = cur
+    kloops = {loop_of[i] for i, l in enumerate(lines) if "v_mfma_f32_32x32x2_f32" in l and loop_of[i]}
+    region = [loop_of[i] in kloops for i in range(len(lines))]
+    loads = [i for i, l in enumerate(lines) if load_re.match(l)]
+    if not loads or not kloops:
+        raise AssertionError("no register-form U loads / K loops in this kernel")
+    for i in loads:                                          # prologues: from a load outside the loops to the next K-loop block
+        if not region[i]:
+            j = i
+            while j < len(lines) and not region[j] and j < i + 200:
+                region[j] = True
+                if re.match(r"\s*(s_branch|s_endpgm|s_setpc)", lines[j]):          # the block chain of this prologue ends here (its tail blocks sit by the loop)
+                    break
+                j += 1
+    ureg = set()
+    for i in loads:
+        ureg |= regs_of(load_re.match(lines[i]).group(1))
+    nm = sum("v_mfma_f32_32x32x2_f32" in l for l in lines)
+    bad = []
+    for i, l0 in enumerate(lines):
+        if not region[i]:
+            continue
+        l = l0.split(";")[0].strip()
+        if not l or l.startswith((".", "s_")) or load_re.match(l0):
+            continue
+        toks = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+        touched = set().union(*[regs_of(t) for t in toks]) if toks else set()
+        if not (touched & ureg):
+            continue
+        if l.startswith("v_mfma_f32_32x32x2_f32"):
+            ops = [o.strip() for o in l[len("v_mfma_f32_32x32x2_f32"):].split(",")]      # D, A, B, C: only B may be a U register
+            if not (regs_of(ops[0]) | regs_of(ops[1]) | regs_of(ops[3])) & ureg:
+                continue
+        bad.append((i, l0))
+    return sorted(ureg), len(loads), nm, bad
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else "livespeechportraits_amd/csrc/wino.hip"
+    if src.endswith(".s"):
+        asm = open(src).read()
+    else:
+        asm = compile_to_asm(src)
+    lines = kernel_text(asm, KERNEL)
+    ureg, nl, nm, bad = check(lines)
+    print("U registers: v%d..v%d (%d), %d loads, %d MFMAs, %d foreign touches" % (ureg[0], ureg[-1], len(ureg), nl, nm, len(bad)))
+    for i, l in bad[:20]:
+        print("  line %d: %s" % (i, l.strip()))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
