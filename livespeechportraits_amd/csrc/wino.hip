@@ -200,13 +200,6 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
 // issue; their first use is an MFMA whose A operand comes from LDS reads behind the barrier that follows the counted wait of step t + 1, so it cannot
 // move above their arrival.  What the compiler must NOT do is copy such a register while its load is in flight (a tied "+v" operand on the wait
 // makes it do exactly that): tests/test_wino_cpu.py checks the generated code for moves out of the three register sets.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ void uload16(f32x4v &dst, unsigned voff, i32x4 srd, unsigned soff)
-{
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff), "n"(OFF) : "memory");
-}
-template <int V> struct IntC { static constexpr int value = V; };
 
 template <int ROW>
 __device__ __forceinline__ void wino_loop_ur(const WinoParams &p, f32x16 (&acc)[4][1], const char *smem_c, unsigned lds0, int wave, int lane,
@@ -236,7 +229,7 @@ __device__ __forceinline__ void wino_loop_ur(const WinoParams &p, f32x16 (&acc)[
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ur[a][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(ur[a][j]));      // "defined" without an instruction: no write may trail the first load
     const int nsteps = ks_end - ks_begin;
     if (nsteps <= 0) return;
     {

@@ -140,18 +140,19 @@ def test_winograd_kernel_instances_do_not_spill(tmp_path):
 
 
 def test_register_form_never_touches_a_u_register_in_flight():
-    """wino3x3's UR form loads its U fragments by inline asm two K-steps ahead; hipcc does not know those registers are in flight.  A tied asm
+    """The UR form of wino3x3 loads its U fragments by inline asm two K-steps ahead; hipcc does not know those registers are in flight.  A tied asm
     operand once made it copy them BEFORE the counted wait (stale values, caught on the CPU by reading the assembly): nothing but the MFMAs' B
     operand may name one of the 48 registers inside the K loops and their prologues."""
     import shutil
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_ureg_asm as C
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    asm = C.compile_to_asm(os.path.join(ROOT, "livespeechportraits_amd", "csrc", "wino.hip"), hipcc)
-    ureg, nloads, nmfma, bad = C.check(C.kernel_text(asm, C.KERNEL))
-    assert len(ureg) == 48 and nmfma == 4 * 3 * 16, (len(ureg), nmfma)          # three sets of four fragments; 4 wave rows x 3 unrolled steps x 16 MFMAs
-    assert nloads == 4 * (2 * 4 + 3 * 4), nloads                                  # per wave row: two prologue steps and three loop steps of four loads
-    assert not bad, bad[:5]
+    for f, kernels in C.KERNELS.items():
+        asm = C.compile_to_asm(os.path.join(ROOT, "livespeechportraits_amd", "csrc", f), hipcc)
+        for prefix, nreg, nmfma, nloads in kernels:
+            ureg, nl, nm, bad = C.check(C.kernel_text(asm, prefix))
+            assert (len(ureg), nm, nl) == (nreg, nmfma, nloads), (prefix, len(ureg), nm, nl)      # three register sets; every unrolled step found
+            assert not bad, (prefix, bad[:5])
 
 
 # ---- the up-conv form (csrc/winoup.hip): Upsample(x2, nearest) + Conv3x3 with 9 multiplies per 2x2 outputs ------------------------------

@@ -85,18 +85,25 @@ def check(lines):
     return sorted(ureg), len(loads), nm, bad
 
 
+KERNELS = {                      # file -> [(mangled prefix, U registers, MFMAs, loads)]
+    "wino.hip": [(KERNEL, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4))],
+}
+
+
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else "livespeechportraits_amd/csrc/wino.hip"
-    if src.endswith(".s"):
-        asm = open(src).read()
-    else:
-        asm = compile_to_asm(src)
-    lines = kernel_text(asm, KERNEL)
-    ureg, nl, nm, bad = check(lines)
-    print("U registers: v%d..v%d (%d), %d loads, %d MFMAs, %d foreign touches" % (ureg[0], ureg[-1], len(ureg), nl, nm, len(bad)))
-    for i, l in bad[:20]:
-        print("  line %d: %s" % (i, l.strip()))
-    return 1 if bad else 0
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "livespeechportraits_amd", "csrc")
+    rc = 0
+    for f, kernels in KERNELS.items():
+        asm = compile_to_asm(os.path.join(root, f))
+        for prefix, nreg, nmfma, nloads in kernels:
+            ureg, nl, nm, bad = check(kernel_text(asm, prefix))
+            print("%s %s: U registers v%d..v%d (%d, expected %d), %d loads (%d), %d MFMAs (%d), %d foreign touches" % (
+                f, prefix[12:], ureg[0], ureg[-1], len(ureg), nreg, nl, nloads, nm, nmfma, len(bad)))
+            for i, l in bad[:20]:
+                print("  line %d: %s" % (i, l.strip()))
+            rc |= 1 if bad or len(ureg) != nreg or nm != nmfma or nl != nloads else 0
+    return rc
 
 
 if __name__ == "__main__":

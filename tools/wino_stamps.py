@@ -16,6 +16,9 @@ from livespeechportraits_amd import _native as N   # noqa: E402
 def main():
     c, h, nb, sp = [int(a) for a in sys.argv[1:5]]
     b = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    tile = 4000 + nb                                         # nb = 3: tile 4003, one channel block per wave with the U fragments in registers
+    if nb == 3:
+        nb = 1
     lib, dev = N.load(), torch.device("cuda:0")
     x = torch.randn(b, h, h, c, device=dev)
     wu = torch.randn(16 * c * c, device=dev) * 0.02
@@ -29,7 +32,7 @@ def main():
     scr = torch.zeros(used + blocks * 4 * 8 * 8, dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    run = lambda: N.check(lib.lspf2f_conv3x3(p(x), None, p(wu), p(sc), p(sh), p(res), p(out), b, h, h, c, 0, c, 1, 0, 1, 4000 + nb, 0, sp, -1, 0, p(scr), scr.numel(), st))
+    run = lambda: N.check(lib.lspf2f_conv3x3(p(x), None, p(wu), p(sc), p(sh), p(res), p(out), b, h, h, c, 0, c, 1, 0, 1, tile, 0, sp, -1, 0, p(scr), scr.numel(), st))
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -44,7 +47,7 @@ def main():
         print("no stamps: the library was not built with -DLSPF2F_WINO_STAMPS"); return
     names = ["entry", "prologue done (descriptors, epilogue operands requested)", "first step landed + barrier", "K loop done", "Z patch written + barrier",
              "epilogue stores issued", "ticket taken (split-K)", "combine done (last arriver)"]
-    print("c%d h%d nb%d splits %d batch %d: %d workgroups, %.1f us per launch (eager, weights warm)" % (c, h, nb, sp, b, blocks, us))
+    print("c%d h%d nb%d%s splits %d batch %d: %d workgroups, %.1f us per launch (eager, weights warm)" % (c, h, nb, " (U in registers)" if tile == 4003 else "", sp, b, blocks, us))
     d = t - t[:, :, :1]
     for i, n_ in enumerate(names):
         col = d[:, :, i][t[:, :, i] != 0]
