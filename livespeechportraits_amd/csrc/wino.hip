@@ -50,15 +50,61 @@ __host__ __device__ constexpr int wino_lds_bytes(int nb, int ns, bool ur = false
     return loop > patch ? loop : patch;
 }
 
+// The copies of one wave: two raw-patch pieces per K-step by LDS-DMA, and its own U fragments -- by LDS-DMA into its slice of the U ring, or (UR form,
+// one channel block per wave) by plain loads into registers.  Built once in the kernel: the first step(s) are requested BEFORE the epilogue operands'
+// address arithmetic, which then runs under their latency instead of ahead of it.
+template <int NB, int NS, bool UR>
+struct WinoCopy {
+    static constexpr int USTAGE = wino_u_stage(NB);
+    static constexpr int RAWB = UR ? 0 : wino_raw_base(NB, NS);
+    static constexpr int DUMP = UR ? NS * kRawStage : wino_dump(NB, NS);
+    static constexpr int PIECES = 2 + 4 * NB;                               // loads of either kind this wave issues per step
+    unsigned lds_u, lds_r0, lds_r1, vraw0, vraw1, soff_u0, soff_nb, vlane;
+    i32x4 srd_src, srd_u;
+    int wave;
+    __device__ __forceinline__ void init(unsigned lds0, int wave_, int lane, unsigned vr0, unsigned vr1, i32x4 ssrc, i32x4 su, unsigned so0, unsigned sonb)
+    {
+        wave = wave_; vraw0 = vr0; vraw1 = vr1; srd_src = ssrc; srd_u = su; soff_u0 = so0; soff_nb = sonb;
+        vlane = (unsigned)(lane * 16);
+        lds_u = lds0 + (unsigned)(wave * (4 * NB * 1024));
+        lds_r0 = lds0 + (unsigned)(RAWB + wave * 1024);
+        lds_r1 = wave < 2 ? lds_r0 + 4096u : lds0 + (unsigned)DUMP;      // pieces 4, 5 exist for waves 0, 1 only; the others feed the dump slot
+    }
+    __device__ __forceinline__ void raw(int ks, int slot) const
+    {
+        dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
+    }
+    // the wave's four j fragments of one channel block: consecutive 1-KB pieces in memory and in LDS (dma16_group advances M0; the per-piece
+    // voffsets are registers rather than instruction offsets, which the LDS-DMA form would also add to the LDS address)
+    __device__ __forceinline__ void u2(int ks, int slot, int nb, int h) const        // two of them: half h (0 | 1) of channel block nb
+    {
+        const unsigned vv[2] = {vlane + (unsigned)(2 * h) * 1024u, vlane + (unsigned)(2 * h + 1) * 1024u};
+        dma16_group<2, 1024>(lds_u + (unsigned)(slot * USTAGE + nb * 4096 + h * 2048), vv, srd_u, (int)(soff_u0 + (unsigned)nb * soff_nb + (unsigned)ks * 4096u));
+    }
+    __device__ __forceinline__ void step(int ks, int slot) const                     // a whole step through LDS
+    {
+        raw(ks, slot);
+        const unsigned vu[4] = {vlane, vlane + 1024u, vlane + 2048u, vlane + 3072u};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            dma16_group<4, 1024>(lds_u + (unsigned)(slot * USTAGE + nb * 4096), vu, srd_u, (int)(soff_u0 + (unsigned)nb * soff_nb + (unsigned)ks * 4096u));
+    }
+    template <int H>
+    __device__ __forceinline__ void ureg2(f32x4v (&dst)[4], int ks) const            // UR: half H of the step's four fragments into registers
+    {
+        const unsigned so = soff_u0 + (unsigned)ks * 4096u;
+        uload16<2048 * H>(dst[2 * H], vlane, srd_u, so); uload16<2048 * H + 1024>(dst[2 * H + 1], vlane, srd_u, so);
+    }
+};
+
 // The K loop of one wave.  ROW = its row i of B^T d B: t = d[ra] (+|-) d[rb] per patch column, then the column transform.
 //   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3
-template <int NB, int NS, bool IL, bool ROT, int ROW>
-__device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][NB], const char *smem_c, unsigned lds0, int wave, int lane,
-                                          unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0, unsigned soff_nb,
+template <int NB, int NS, bool IL, bool ROT, int ROW, int EPL, class EpiLoads>
+__device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][NB], const char *smem_c, int wave, int lane,
                                           int ks_begin, int ks_end, unsigned long long *first_landed)
 {
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
-    constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB, NS), DUMP = wino_dump(NB, NS);
+    constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB, NS);
     constexpr int PIECES = 2 + 4 * NB;                                      // LDS-DMA instructions this wave issues per step
     // fragment-read addresses: lane (tile r = l & 31 -> ty = r >> 3, tx = r & 7; channel quad q = l >> 5) reads patch pixel
     // (2 ty + dy, 2 tx + dx); chunk = ((pary * 2 + parx) * 2 + q) * 45 + hy * 9 + hx with (py, px) = (2 hy + pary, 2 hx + parx)
@@ -74,32 +120,17 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
         }
     }
     const unsigned au = (unsigned)(wave * (4 * NB * 1024) + lane * 16);     // this wave's fragments inside a U ring slot
-    // the wave's four j fragments of one channel block: consecutive 1-KB pieces in memory and in LDS (dma16_group advances M0; the per-piece
-    // voffsets are registers rather than instruction offsets, which the LDS-DMA form would also add to the LDS address)
-    const unsigned vu[4] = {(unsigned)(lane * 16), (unsigned)(lane * 16 + 1024), (unsigned)(lane * 16 + 2048), (unsigned)(lane * 16 + 3072)};
-    const unsigned lds_u = lds0 + (unsigned)(wave * (4 * NB * 1024));
-    const unsigned lds_r0 = lds0 + (unsigned)(RAWB + wave * 1024);
-    const unsigned lds_r1 = wave < 2 ? lds_r0 + 4096u : lds0 + (unsigned)DUMP;   // pieces 4, 5 exist for waves 0, 1 only; the others feed the dump slot
+    auto fetch_raw = [&](int ks, int slot) { cp.raw(ks, slot); };
+    auto fetch_u2 = [&](int ks, int slot, int nb, int h) { cp.u2(ks, slot, nb, h); };
+    auto fetch = [&](int ks, int slot) { cp.step(ks, slot); };
 
-    auto fetch_raw = [&](int ks, int slot) {
-        dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
-    };
-    // two of the wave's U pieces: half h (0 | 1) of channel block nb
-    auto fetch_u2 = [&](int ks, int slot, int nb, int h) {
-        const unsigned vv[2] = {vu[2 * h], vu[2 * h + 1]};
-        dma16_group<2, 1024>(lds_u + (unsigned)(slot * USTAGE + nb * 4096 + h * 2048), vv, srd_u, (int)(soff_u0 + (unsigned)nb * soff_nb + (unsigned)ks * 4096u));
-    };
-    auto fetch = [&](int ks, int slot) {
-        fetch_raw(ks, slot);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            dma16_group<4, 1024>(lds_u + (unsigned)(slot * USTAGE + nb * 4096), vu, srd_u, (int)(soff_u0 + (unsigned)nb * soff_nb + (unsigned)ks * 4096u));
-    };
-
+    // step 0 (and step 1 with a ring of 3) requested first; behind them the kernel's EPL epilogue-operand loads, whose address arithmetic then runs
+    // under the copies' latency instead of ahead of it (loads return in order: the first wait allows for exactly those younger ones)
     const int nsteps = ks_end - ks_begin;
-    if (nsteps <= 0) return;
     fetch(ks_begin, 0);
-    if (NS > 2 && nsteps > 1) { fetch(ks_begin + 1, 1); dma_wait<PIECES>(); } else dma_wait<0>();
+    if (NS > 2 && nsteps > 1) fetch(ks_begin + 1, 1);
+    epi_loads();
+    if (NS > 2 && nsteps > 1) dma_wait<PIECES + EPL>(); else dma_wait<EPL>();
     __syncthreads();
 #ifdef LSPF2F_WINO_STAMPS
     *first_landed = __builtin_amdgcn_s_memtime();
@@ -201,13 +232,11 @@ __device__ __forceinline__ void wino_loop(const WinoParams &p, f32x16 (&acc)[4][
 // move above their arrival.  What the compiler must NOT do is copy such a register while its load is in flight (a tied "+v" operand on the wait
 // makes it do exactly that): tests/test_wino_cpu.py checks the generated code for moves out of the three register sets.
 
-template <int ROW>
-__device__ __forceinline__ void wino_loop_ur(const WinoParams &p, f32x16 (&acc)[4][1], const char *smem_c, unsigned lds0, int wave, int lane,
-                                             unsigned vraw0, unsigned vraw1, i32x4 srd_src, i32x4 srd_u, unsigned soff_u0,
+template <int ROW, int EPL, class EpiLoads>
+__device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, 3, true> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][1], const char *smem_c, int lane,
                                              int ks_begin, int ks_end, unsigned long long *first_landed)
 {
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
-    constexpr int DUMP = 3 * kRawStage;
     const int r = lane & 31, q = lane >> 5, ty = r >> 3, tx = r & 7;
     unsigned araw[2][4];
 #pragma unroll
@@ -219,32 +248,23 @@ __device__ __forceinline__ void wino_loop_ur(const WinoParams &p, f32x16 (&acc)[
             araw[k][dx] = (unsigned)(chunk * 16);
         }
     }
-    const unsigned vu = (unsigned)(lane * 16);
-    const unsigned lds_r0 = lds0 + (unsigned)(wave * 1024);
-    const unsigned lds_r1 = wave < 2 ? lds_r0 + 4096u : lds0 + (unsigned)DUMP;
-    auto fetch_raw = [&](int ks, int slot) {
-        dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
-    };
+    // The three register sets.  Requests, loop and uses stay inside this function (one per wave row): across the kernel's switch hipcc gives the sets
+    // other registers per branch and copies them at the branch -- in flight.
     f32x4v ur[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(ur[a][j]));      // "defined" without an instruction: no write may trail the first load
+    // steps 0 and 1 requested first; behind them the kernel's EPL epilogue-operand loads (see wino_loop)
     const int nsteps = ks_end - ks_begin;
-    if (nsteps <= 0) return;
-    {
-        const unsigned so = soff_u0 + (unsigned)ks_begin * 4096u;
-        fetch_raw(ks_begin, 0);
-        uload16<0>(ur[0][0], vu, srd_u, so); uload16<1024>(ur[0][1], vu, srd_u, so); uload16<2048>(ur[0][2], vu, srd_u, so); uload16<3072>(ur[0][3], vu, srd_u, so);
-        if (nsteps > 1) {
-            fetch_raw(ks_begin + 1, 1);
-            uload16<0>(ur[1][0], vu, srd_u, so + 4096u); uload16<1024>(ur[1][1], vu, srd_u, so + 4096u);
-            uload16<2048>(ur[1][2], vu, srd_u, so + 4096u); uload16<3072>(ur[1][3], vu, srd_u, so + 4096u);
-            dma_wait<6>();
-        } else {
-            dma_wait<0>();
-        }
+    cp.raw(ks_begin, 0);
+    cp.template ureg2<0>(ur[0], ks_begin); cp.template ureg2<1>(ur[0], ks_begin);
+    if (nsteps > 1) {
+        cp.raw(ks_begin + 1, 1);
+        cp.template ureg2<0>(ur[1], ks_begin + 1); cp.template ureg2<1>(ur[1], ks_begin + 1);
     }
+    epi_loads();
+    if (nsteps > 1) dma_wait<6 + EPL>(); else dma_wait<EPL>();
     __syncthreads();
 #ifdef LSPF2F_WINO_STAMPS
     *first_landed = __builtin_amdgcn_s_memtime();
@@ -259,7 +279,6 @@ __device__ __forceinline__ void wino_loop_ur(const WinoParams &p, f32x16 (&acc)[
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
         const bool issue = t + 2 < nsteps;
-        const unsigned so = soff_u0 + (unsigned)(ks_begin + t + 2) * 4096u;
         float4 tt[4], v[4];
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
@@ -276,9 +295,9 @@ __device__ __forceinline__ void wino_loop_ur(const WinoParams &p, f32x16 (&acc)[
                 acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ur[S][j][c], acc[j][0], 0, 0, 0);
             }
             if (issue) {
-                if (c == 0) fetch_raw(ks_begin + t + 2, S2);
-                if (c == 1) { uload16<0>(ur[S2][0], vu, srd_u, so); uload16<1024>(ur[S2][1], vu, srd_u, so); }
-                if (c == 2) { uload16<2048>(ur[S2][2], vu, srd_u, so); uload16<3072>(ur[S2][3], vu, srd_u, so); }
+                if (c == 0) cp.raw(ks_begin + t + 2, S2);
+                if (c == 1) cp.template ureg2<0>(ur[S2], ks_begin + t + 2);
+                if (c == 2) cp.template ureg2<1>(ur[S2], ks_begin + t + 2);
             }
         }
         // step t + 1 has landed: everything but the six loads issued in THIS iteration (this wave's; the barrier covers the other waves' raw pieces)
@@ -350,28 +369,36 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
     const unsigned soff_nb = 4u * (unsigned)S * 4096u;                               // one n-block further
     const unsigned soff_u0 = (unsigned)((n0 >> 5) * 4 + wave) * (unsigned)S * 4096u;
 
+    constexpr int EPL = 6 * NB;                                    // epilogue-operand loads below: always issued, so that the waits can count them
+    WinoCopy<NB, NS, UR> cp;
+    cp.init(lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb);
+
     // Epilogue operands requested BEFORE the K loop (the igemm's trick): folded-BN scale / shift of this thread's channel quads and its residual
-    // pixels.  In the epilogue they would be dependent global round trips with the matrix pipe idle; here they ride under the first fetch.  They
-    // are older than every LDS-DMA piece and loads return in order, so the loop's waits are unaffected.
+    // pixels.  In the epilogue they would be dependent global round trips with the matrix pipe idle; here they ride under the first fetch (their
+    // address arithmetic too: they are issued BEHIND it).  Buffer loads through descriptors whose range is zero when the operand is absent or not
+    // wanted (split-K slices): always EPL instructions, zeros for the absent ones -- loads return in order, so the loop's first wait allows for
+    // exactly EPL younger ones and every later wait is unaffected.
     const int trow = tid >> 3, cq = (tid & 7) * 4;                 // this thread's tile (ty = trow >> 3, tx = trow & 7) and channel quad
     const int oy = Y0 + 2 * (trow >> 3), ox = X0 + 2 * (trow & 7);
     const bool pre = p.splits == 1 && !p.nopre;
+    const bool pre_sc = pre && p.scale != nullptr, pre_res = pre && p.residual != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_scale = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.scale), 0, pre_sc ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_shift = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.shift), 0, pre_sc ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.residual), 0, pre_res ? (int)((unsigned)(p.B * p.H * p.W) * (unsigned)p.N * 4u) : 0, 0x00020000);
     float4 scv[NB], shv[NB], rpre[NB][4];
+    auto epi_loads = [&]() {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + nb * 32 + cq;
-        scv[nb] = make_float4(1.f, 1.f, 1.f, 1.f); shv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pre && p.scale) {
-            scv[nb] = *reinterpret_cast<const float4 *>(p.scale + n);
-            shv[nb] = *reinterpret_cast<const float4 *>(p.shift + n);
-        }
+        scv[nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_scale, (unsigned)n * 4u, 0, 0));
+        shv[nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_shift, (unsigned)n * 4u, 0, 0));
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) {
-            rpre[nb][ab] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pre && p.residual)
-                rpre[nb][ab] = *reinterpret_cast<const float4 *>(p.residual + (((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1))) * p.N + n);
+            const unsigned pix = (unsigned)((b * p.H + oy + (ab >> 1)) * p.W + ox + (ab & 1));
+            rpre[nb][ab] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (pix * (unsigned)p.N + (unsigned)n) * 4u, 0, 0));
         }
     }
+    };
     WSTAMP(1);
 #ifdef LSPF2F_WINO_STAMPS
     unsigned long long *fl = &stamp_t[2];
@@ -390,17 +417,18 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
     if constexpr (UR) {
         static_assert(NB == 1 && NS == 3, "the register form exists for one channel block per wave");
         switch (wave) {
-        case 0: wino_loop_ur<0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
-        case 1: wino_loop_ur<1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
-        case 2: wino_loop_ur<2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
-        default: wino_loop_ur<3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, ks_begin, ks_end, fl); break;
+        case 0: wino_loop_ur<0, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        case 1: wino_loop_ur<1, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        case 2: wino_loop_ur<2, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        default: wino_loop_ur<3, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
         }
-    } else
-    switch (wave) {
-    case 0: wino_loop<NB, NS, IL, ROT, 0>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    case 1: wino_loop<NB, NS, IL, ROT, 1>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    case 2: wino_loop<NB, NS, IL, ROT, 2>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
-    default: wino_loop<NB, NS, IL, ROT, 3>(p, acc, smem_c, lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb, ks_begin, ks_end, fl); break;
+    } else {
+        switch (wave) {
+        case 0: wino_loop<NB, NS, IL, ROT, 0, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
+        case 1: wino_loop<NB, NS, IL, ROT, 1, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
+        case 2: wino_loop<NB, NS, IL, ROT, 2, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
+        default: wino_loop<NB, NS, IL, ROT, 3, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
+        }
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)
     WSTAMP(3);
@@ -437,6 +465,7 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
             for (int bb = 0; bb < 2; ++bb)
                 zz[i][bb] = *reinterpret_cast<const float4 *>(smem + ((i * 2 + bb) * NB + nb) * (32 * EP) + trow * EP + cq);
         float4 sc = scv[nb], sh = shv[nb];
+        if (!pre_sc) { sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f); }
         if (!pre && p.splits == 1 && p.scale) {               // nopre (A-B runs): the operands are fetched here instead
             sc = *reinterpret_cast<const float4 *>(p.scale + n);
             sh = *reinterpret_cast<const float4 *>(p.shift + n);
