@@ -137,6 +137,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "wino_xcd") P.wino_xcd = v;
         else if (k == "wino_il") P.wino_il = v != 0;
         else if (k == "wino_ureg") P.wino_ureg = v != 0;
+        else if (k == "in_wino_stats") P.in_wino_stats = v != 0;
         else if (k == "wino_rot") P.wino_rot = v != 0;
         else if (k == "winoup") P.use_winoup = v != 0;
         else if (k == "winoup_nb") P.winoup_nb = v;
@@ -269,6 +270,7 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
             const bool sm = l.in_route == kInSmall;
             if (l.winoup) return l.winoup == 2 ? (sm ? "winoup3x3<2>+in_small" : "winoup3x3<2>+in_reduce_stats+in_finalize+in_apply")
                                                : (sm ? "winoup3x3<1>+in_small" : "winoup3x3<1>+in_reduce_stats+in_finalize+in_apply");
+            if (l.in_route == kInWino) return l.wino == 2 ? "wino3x3<2>(stats)+in_finalize+in_apply" : "wino3x3<1>(stats)+in_finalize+in_apply";
             return l.wino == 2 ? (sm ? "wino3x3<2>+in_small" : "wino3x3<2>+in_reduce_stats+in_finalize+in_apply")
                                : (sm ? "wino3x3<1>+in_small" : "wino3x3<1>+in_reduce_stats+in_finalize+in_apply");
         }
@@ -509,8 +511,24 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
         p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1; p.ureg = P.wino_ureg ? 1 : 0;
-        if (h->timing_part & 1) e = launch_wino(p, l.wino, s);
-        if (l.inorm) e = in_after_complete_output(e);
+        if (l.inorm && l.in_route == kInWino) {
+            // the kernel's epilogue (or its split-K combine) leaves the sums of every tile-block of 128 pixels: finalize + normalise only
+            float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
+            const size_t slab = (size_t)batch * P.stats_groups_max;
+            InstNormParams q{};
+            q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu; q.partial = nullptr; q.splits = 1; q.bias = nullptr;
+            q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
+            q.psum = st; q.psq = st + slab * l.cout; q.pshift = st + 2 * slab * l.cout;
+            q.mean = st + 3 * slab * l.cout; q.rstd = q.mean + (size_t)batch * l.cout;
+            q.groups = q.hw / 128; q.rows_per_group = 128;
+            p.psum = q.psum; p.psq = q.psq; p.pshift = q.pshift;
+            if (h->timing_part & 1) e = launch_wino(p, l.wino, s);
+            if (e == hipSuccess) e = launch_in_finalize(q, s);
+            if (e == hipSuccess) e = launch_in_apply(q, s);
+        } else {
+            if (h->timing_part & 1) e = launch_wino(p, l.wino, s);
+            if (l.inorm) e = in_after_complete_output(e);
+        }
     } else if (l.rowup) {
         RowUpParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wru_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);

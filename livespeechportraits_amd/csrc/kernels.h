@@ -117,6 +117,8 @@ struct WinoParams {
     // instead of between them; the four MFMAs of an accumulator back to back instead of rotating over the accumulators
     int nopre, xcd_force, no_il, no_rot;
     int ureg;                   // one channel block per wave: U fragments by plain loads into registers instead of LDS-DMA + ds_read (wino.hip, UR form)
+    float *psum, *psq, *pshift; // InstanceNorm plans: per (frame, tile-block, channel) sums of (x - c), (x - c)^2 and the shift c (the tile-block's first pixel) of the
+                                // 128 output pixels a workgroup writes, [B][tile-blocks per frame][N]; nullptr = no statistics (see instnorm.hip)
     // filled by launch_wino
     int steps_per_split, ntb, nng, tby, tbx, nmajor, xcd;
     size_t slab_bytes;

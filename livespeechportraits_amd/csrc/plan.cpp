@@ -554,6 +554,9 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                     groups_max = std::max(groups_max, (l.up4 ? 4 : 1) * rhw / wave_rows);
                 } else if (hw <= 1024) {
                     route = kInSmall;
+                } else if (wino && !wino4 && p.in_wino_stats) {
+                    route = kInWino;                         // one group per tile-block of 8 x 16 output pixels
+                    groups_max = std::max(groups_max, hw / 128);
                 } else {
                     route = kInReduce;
                     groups_max = std::max(groups_max, (hw + 63) / 64);

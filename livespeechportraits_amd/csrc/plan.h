@@ -16,7 +16,7 @@ namespace lspf2f {
 enum LayerKind { kFirstConv = 0, kIgemm = 1, kLastConv = 2 };
 // InstanceNorm plans, per layer and batch: kInFused = sums in the igemm epilogue (wave shuffles), kInReduce = a streaming pass
 // that also folds the split-K partials, kInSmall = one workgroup per (frame, 32 channels) does statistics + normalisation
-enum InRoute { kInNone = 0, kInFused = 1, kInReduce = 2, kInSmall = 3 };
+enum InRoute { kInNone = 0, kInFused = 1, kInReduce = 2, kInSmall = 3, kInWino = 4 };   // kInWino: sums in the Winograd kernel's epilogue (per tile-block of 128 pixels)
 
 struct TensorDesc {        // an activation tensor in the workspace (NHWC)
     std::string name;
@@ -101,6 +101,7 @@ struct Plan {
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (tune key `wino=0`: the implicit GEMM, A-B runs)
     bool use_wino4 = false;    // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSPF2F_FLAG_WINO4; measured slower at batch 1 and
                                // equal at batch 8, DESIGN.md 4.11, so off by default); decides whether the blob carries the 6x6 transformed weights
+    bool in_wino_stats = true;   // `in_wino_stats`: InstanceNorm plans take a wino3x3 layer's statistics from its epilogue instead of a pass over its output
     bool wino_ureg = true;       // `wino_ureg`: wino3x3<1> keeps its U fragments in registers (wino.hip UR form)
     bool wino_pre = true, wino_il = true, wino_rot = true;   // tools (`wino_pre` / `wino_il` / `wino_rot` of lspf2f_create_tuned): A-B switches of wino3x3
     int wino_xcd = -1, igemm_xcd = -1;                       // tools: forced block orders (-1 = by operand size)

@@ -37,6 +37,7 @@ static constexpr unsigned kOOBw = 0x80000000u;   // voffset beyond any num_recor
 
 static constexpr int kRawPieces = 6;                       // 360 chunks of 16 B (10 x 18 pixels x 2 channel quads) in 6 pieces of 64
 static constexpr int kRawStage = kRawPieces * 1024;        // bytes per ring slot
+static constexpr int kWinoStatsScratch = (8 + 4 * 8 * 2) * 16;   // InstanceNorm plans (wino_stats below)
 
 // LDS: [ns ring slots of U fragments][ns ring slots of raw patch][1 KB dump]; ns = ring depth (2, or 3 with one channel block per wave:
 // its K-step is 1024 cycles of MFMA per wave, less than a loaded L2 round trip, so the copy of step t + 2 is in flight while step t multiplies)
@@ -47,8 +48,10 @@ __host__ __device__ constexpr int wino_lds_bytes(int nb, int ns, bool ur = false
 {
     const int loop = (ur ? ns * kRawStage : wino_dump(nb, ns)) + 1024;     // ur: the raw ring alone (U fragments go to registers)
     const int patch = 4 * 2 * nb * 32 * 36 * 4;             // epilogue: [wave][b][nb][32 tiles][36]
-    return loop > patch ? loop : patch;
+    return (loop > patch ? loop : patch) + kWinoStatsScratch;
 }
+// behind the patch: the InstanceNorm statistics of a workgroup meet here -- the shift [8 quads] and the waves' partial sums [4][8][2], float4 each
+__host__ __device__ constexpr int wino_stats_base(int nb, int ns, bool ur = false) { return wino_lds_bytes(nb, ns, ur) - kWinoStatsScratch; }
 
 // The copies of one wave: two raw-patch pieces per K-step by LDS-DMA, and its own U fragments -- by LDS-DMA into its slice of the U ring, or (UR form,
 // one channel block per wave) by plain loads into registers.  Built once in the kernel: the first step(s) are requested BEFORE the epilogue operands'
@@ -312,8 +315,47 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, 3, true> &cp, con
 }
 
 
+// InstanceNorm plans: the statistics of the 128 output pixels x 4 channels-per-thread a workgroup has just computed (v[0..3] = this thread's 2 x 2 pixels of
+// one channel quad, raw conv output + bias), in the form in_finalize merges (instnorm.hip): sums of d = v - c and d^2 with c = the tile-block's first pixel, so that
+// no E[x^2] - mean^2 of raw values is ever formed.  Fixed order: xor-shuffles over the wave's 8 tiles, then the four waves in order -> bit-reproducible.
+__device__ __forceinline__ void wino_stats(const WinoParams &p, float4 *scratch, const float4 (&v)[4], int tid, size_t g)
+{
+    float4 *cs = scratch, *part = scratch + 8;
+    const int qi = tid & 7, wave = tid >> 6, lane = tid & 63;
+    __syncthreads();                                          // the previous channel block's readers are done with the scratch
+    if (tid < 8) cs[qi] = v[0];                               // tile 0's pixel (0, 0): the tile-block's first pixel
+    __syncthreads();
+    const float4 c = cs[qi];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 d = make_float4(v[k].x - c.x, v[k].y - c.y, v[k].z - c.z, v[k].w - c.w);
+        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
+        s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
+    }
+    if (lane < 8) { part[(wave * 8 + lane) * 2] = s1; part[(wave * 8 + lane) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 8) {
+        float4 a = part[tid * 2], q2 = part[tid * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 x = part[(w * 8 + tid) * 2], y = part[(w * 8 + tid) * 2 + 1];
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            q2.x += y.x; q2.y += y.y; q2.z += y.z; q2.w += y.w;
+        }
+        *reinterpret_cast<float4 *>(p.psum + g) = a;
+        *reinterpret_cast<float4 *>(p.psq + g) = q2;
+        *reinterpret_cast<float4 *>(p.pshift + g) = c;
+    }
+}
+
 template <int NB, int NS, bool IL, bool ROT, bool UR = false>
-__global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const WinoParams p)
+__global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef __attribute__((address_space(3))) float lds_float;
@@ -470,6 +512,7 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
             sc = *reinterpret_cast<const float4 *>(p.scale + n);
             sh = *reinterpret_cast<const float4 *>(p.shift + n);
         }
+        float4 vst[4];                                       // InstanceNorm plans: the four finished pixels of this channel quad
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -487,8 +530,11 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     *reinterpret_cast<float4 *>(p.out + e) = v;
+                    vst[a * 2 + bb] = v;
                 }
             }
+        if (p.psum && p.splits == 1)
+            wino_stats(p, reinterpret_cast<float4 *>(smem + wino_stats_base(NB, NS, UR) / 4), vst, tid, ((size_t)b * (size_t)(p.tby * p.tbx) + (size_t)tbi) * p.N + n);
     }
     WSTAMP(5);
     if (p.splits == 1) { WSTAMP_FLUSH; return; }
@@ -527,6 +573,7 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + nb * 32 + cq;
         const float4 sc = sc2[nb], sh = sh2[nb];
+        float4 vst2[4];
         float4 tsl[4][8];
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) {                       // all slab loads of this channel quad in flight at once
@@ -550,7 +597,9 @@ __global__ __launch_bounds__(256, NB == 2 || NS == 3 ? 2 : 3) void wino3x3(const
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4 *>(p.out + e) = v;
+            vst2[ab] = v;
         }
+        if (p.psum) wino_stats(p, reinterpret_cast<float4 *>(smem + wino_stats_base(NB, NS, UR) / 4), vst2, tid, ((size_t)b * (size_t)(p.tby * p.tbx) + (size_t)tbi) * p.N + n);
     }
     WSTAMP(7);
     WSTAMP_FLUSH;
