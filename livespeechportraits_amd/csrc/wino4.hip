@@ -69,7 +69,17 @@ __host__ __device__ constexpr int w4_imm(int dy, int dx)
     return 16 * (w4_plane_base(dy & 3, dx & 3) + ((dy >> 2) * w4_hxn(dx & 3) + (dx >> 2)) * 2);
 }
 
-__device__ __forceinline__ float4 f4fma(float c, float4 a, float4 b) { return make_float4(fmaf(c, a.x, b.x), fmaf(c, a.y, b.y), fmaf(c, a.z, b.z), fmaf(c, a.w, b.w)); }
+// c * a + b as two v_pk_fma_f32 (see f4add in wino_common.h: a VALU instruction costs the wave ~5 cycles of its MFMA stream, packed or not)
+__device__ __forceinline__ float4 f4fma(float c, float4 a, float4 b)
+{
+#ifdef LSPF2F_NO_PK
+    return make_float4(fmaf(c, a.x, b.x), fmaf(c, a.y, b.y), fmaf(c, a.z, b.z), fmaf(c, a.w, b.w));
+#else
+    const v2f cc = {c, c};
+    const v2f lo = __builtin_elementwise_fma(cc, v2f{a.x, a.y}, v2f{b.x, b.y}), hi = __builtin_elementwise_fma(cc, v2f{a.z, a.w}, v2f{b.z, b.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+#endif
+}
 
 // Three rows of B^T applied to a 5-sample window w = d[H .. H+4] of the 6 patch samples (H = 0: rows 0, 1, 2; H = 1: rows 3, 4, 5): 6 operations
 template <int H>
