@@ -201,10 +201,11 @@ def test_every_last_conv_variant_matches_golden(env, gpu_device, monkeypatch):
         assert np.abs(out.cpu().numpy() - arrays["out"]).max() <= TIGHT
 
 
-@pytest.mark.parametrize("env", ["LSP_HIP_PREFETCH=0", "LSP_HIP_FIRSTCONV_REGSTAGE=1"])
+@pytest.mark.parametrize("env", ["LSP_HIP_PREFETCH=0", "LSP_HIP_FIRSTCONV_REGSTAGE=1", "LSP_HIP_WINO_UREG=0"])
 def test_switches_that_move_data_differently_do_not_change_a_bit(env, gpu_device, monkeypatch):
-    """The fifth wave of the tiny-M kernel only requests bytes the NEXT launch will read, and the LDS-DMA staging of the first conv feeds the
-    same MFMA sequence as the register-staged kernel: with either switched off the forward must be bit-identical (and still on the golden)."""
+    """The fifth wave of the tiny-M kernel only requests bytes the NEXT launch will read, the LDS-DMA staging of the first conv feeds the
+    same MFMA sequence as the register-staged kernel, and wino3x3's U fragments are the same values whether they reach the MFMA through LDS or
+    straight from a load (round 4): with any of them switched the forward must be bit-identical (and still on the golden)."""
     meta, arrays, topo, sd, feat, cand = golden_problem("large_512")
     f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
     base = make_engine(topo, sd, gpu_device, meta["batch"]).forward(f, c).clone()
