@@ -611,6 +611,7 @@ bool wino_supported(const WinoParams &p, int nb)
     if (p.B < 1 || p.H % 8 || p.W % 16 || p.C % 8 || p.C < 8 || p.N % (32 * nb)) return false;
     const size_t lim = 0x7fffffffull;                      // 32-bit buffer offsets with the top bit reserved as the out-of-range marker
     if ((size_t)p.B * p.H * p.W * p.C * 4 > lim || (size_t)16 * p.C * p.N * 4 > lim) return false;
+    if ((size_t)p.B * p.H * p.W * p.N * 4 > lim) return false;          // the residual is read through a buffer descriptor with 32-bit offsets too
     if (p.splits < 1 || p.splits > 8) return false;
     if (p.splits > 1 && (!p.partial || !p.tile_cnt || (size_t)p.splits * p.B * p.H * p.W * p.N * 4 > lim)) return false;
     return true;
