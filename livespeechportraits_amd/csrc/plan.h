@@ -183,7 +183,7 @@ inline bool bandconv_layer(int ho, int c0, int c1, int cout, int stride, bool up
 inline bool fullk_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype)
 {
     if (dtype != 0 || stride != 1 || up4) return false;
-    if (ho != 8 && ho != 16) return false;                    // 4x4 / 2x2 belong to the tiny-M kernel at batch 1
+    if (ho != 2 && ho != 4 && ho != 8 && ho != 16) return false;     // (4x4 / 2x2 belong to the tiny-M kernel while the batch has <= 16 output pixels: fullk_choice)
     if (up ? 2 * hs != ho : hs != ho) return false;
     return (c0 == 128 || c0 == 256 || c0 == 512) && (c1 == 0 || c1 == c0) && cout % 128 == 0;
 }
@@ -220,9 +220,14 @@ inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int
     if ((c0 != 128 && c0 != 256 && c0 != 512) || (c1 != 0 && c1 != c0) || cout % 128) return 0;
     // whole tiles must fit one dispatch wave of the chip with room to spare: <= 512 workgroups (2 per CU on 256 CUs)
     const int ntn = cout / 16;
+    // 4x4 / 2x2 frames (a tile = one whole frame, 16 / 4 of its 16 rows used): from the batch the tiny-M kernel stops taking (> 16 output pixels) up.  Measured per layer,
+    // 512 -> 512 (tools/time_conv.py): 4x4 at 2 / 4 / 8 frames 9.1 / 8.9 / 9.3 us against 13.5 / 15.1 / 20.1 for igemm + reduce; 2x2 at 8 frames 8.7 against 13.7
+    if (ho <= 4 && (long)batch * ho * ho <= 16) return 0;
     for (int pb = 1; pb <= (ho == 16 ? 2 : 1); ++pb) {
         const int nr = pb * (16 / ho);
         const long tiles = (long)batch * ((ho + nr - 1) / nr) * ntn;
+        // 8x8 frames: up to four rounds of workgroups still beat the split-K implicit GEMM (8 frames: 28.1 against 35.6 us)
+        if (ho == 8 && tiles > 512 && tiles <= 1024) return 1;
         // the band of source rows behind a tile must fit the 150 KB of LDS fullk_supported() (fullk.hip) grants: (rows * Ws + 1 zero pixel) x (C0 + 4 pad)
         // floats per source -- 133 KB for the widest shape the generators build (4 rows x 16 px x 512 ch)
         const int rows = std::min(up ? nr / 2 + 2 : nr + 2, hs);
