@@ -139,6 +139,8 @@ int lspf2f_bind_weights(lspf2f_handle *h, const void *dev_blob, size_t bytes);
 
 /* ---- workspace --------------------------------------------------------------------------- */
 
+/* Bytes a workspace must have to run ANY batch of 1 .. `batch` frames (the per-batch plans differ in kernels and split-K scratch, so the need of a
+ * smaller batch can exceed that of a larger one; the returned value covers them all). */
 size_t lspf2f_workspace_bytes(const lspf2f_handle *h, int batch);
 int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes);
 

@@ -234,7 +234,11 @@ int lspf2f_bind_weights(lspf2f_handle *h, const void *dev_blob, size_t bytes)
 size_t lspf2f_workspace_bytes(const lspf2f_handle *h, int batch)
 {
     if (!h || batch < 1) return 0;
-    return h->plan.workspace_bytes(batch);
+    // enough for EVERY batch of 1 .. batch frames: the plans of different batch sizes pick different kernels (split-K slabs come and go), so the need is
+    // not monotonic in the batch -- a handle planned for 5 frames may need more for 3 of them than for 5
+    size_t need = 0;
+    for (int b = 1; b <= batch; ++b) need = std::max(need, h->plan.workspace_bytes(b));
+    return need;
 }
 
 int lspf2f_bind_workspace(lspf2f_handle *h, void *dev_workspace, size_t bytes)

@@ -125,8 +125,11 @@ int wino4_choice(int batch, int ho, int cin, int cout, int *splits_out)
     return 1;
 }
 
-int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out, int force_nb, int target)
+int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out, int force_nb, int target, bool small_level)
 {
+    // the up-conv that writes 16 x 16 (1024 -> 512 from 8 x 8): one or two frames stay on the full-K kernel (25 us at one frame), from four frames up this
+    // kernel takes it -- 39.2 against 93.6 us for the implicit GEMM over the upsampled 9 taps at 4 frames, 58.1 against 170.3 at 8 (tools/time_conv.py)
+    if (small_level && batch < 4) return 0;
     // a workgroup = 32 source pixels (8 x 16 output pixels) x 32 nb channels, THREE waves: two such workgroups leave a CU's four SIMDs with 2, 2, 1, 1
     // waves, four give every SIMD three.  So: one channel block per wave (115 registers, 28 KB of LDS: five fit) and K splits -- >= 8 eight-channel
     // steps each -- until there are ~4 workgroups per CU.  Measured, `large` fp32 (A-B-A-B, one session): nb 1 / 1024 workgroups 610.6 frames/s,
@@ -401,7 +404,7 @@ void Plan::assign_offsets(const std::vector<unsigned> *used)
             l.ww4_off = (int64_t)off;                         // 36/9 of the 9-tap bytes
             off += (size_t)36 * l.cout * l.cin * sizeof(float);
         }
-        if (l.kind == kIgemm && (need & kFormWinoUp) && use_wino && use_winoup && winoup_layer(l.hs, l.c0, l.c1, l.cout, l.up4, dtype, l.inorm)) {
+        if (l.kind == kIgemm && (need & kFormWinoUp) && use_wino && use_winoup && winoup_layer(l.hs, l.c0, l.c1, l.cout, l.up4 || l.up, dtype, l.inorm)) {
             off = align_up(off, 256);
             l.wwu_off = (int64_t)off;
             off += (size_t)9 * l.cout * l.cin * sizeof(float);
@@ -532,7 +535,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             if (wino) { bm = 32; bn = 32 * wino; splits = wsplits; group = 1; }
             if (wino4) { bm = 32; bn = 32; splits = w4splits; group = 1; }
             int usplits = 1;
-            const int winoup = (p.use_wino && p.use_winoup && l.wwu_off >= 0) ? winoup_choice(batch, l.hs, l.cin, l.cout, &usplits, p.winoup_nb, p.winoup_target) : 0;
+            const int winoup = (p.use_wino && p.use_winoup && l.wwu_off >= 0) ? winoup_choice(batch, l.hs, l.cin, l.cout, &usplits, p.winoup_nb, p.winoup_target, !l.up4) : 0;
             if (winoup) { bm = 32; bn = 32 * winoup; splits = usplits; group = 1; }
             const int rowconv = p.use_rowconv && l.wrc_off >= 0 ? rowconv_rows(batch, l.ho, l.ho, l.c0) : 0;
             if (rowconv) { bm = (l.c0 == 64 ? 64 : 32) * rowconv; bn = l.c0; splits = 1; group = 1; }
@@ -673,6 +676,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
             if (l.wfk2_off >= 0) pack_fullk_weights(dst, l.c0 / 2, 2, cout, reinterpret_cast<float *>(base + l.wfk2_off));
             if (l.wwg_off >= 0) pack_wino_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwg_off));
             if (l.ww4_off >= 0) pack_wino4_weights(W, cin, cout, reinterpret_cast<float *>(base + l.ww4_off));
+            if (l.wwu_off >= 0) pack_winoup_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwu_off));      // an up-conv below the sub-pixel extent that larger batches run on winoup3x3
         } else if (l.kind == kFirstConv) {
             // [ci][tap][co]  -- broadcast rows for the direct first-layer kernel
             for (int co = 0; co < cout; ++co)

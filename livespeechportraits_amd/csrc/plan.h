@@ -256,12 +256,13 @@ inline bool wino4_layer(int hs, int ho, int c0, int c1, int cout, int stride, bo
 // per batch: 1 (and the K splits) when the layer runs on it, 0 = keep wino_choice()'s answer
 int wino4_choice(int batch, int ho, int cin, int cout, int *splits);
 // the up-conv form (winoup.hip): sub-pixel up-convs of fp32 plans whose two sources are equally wide
-inline bool winoup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm)
+// (any Upsample + Conv3x3 layer: those below kUp4MinExtent keep their 9-tap rows for the full-K kernel / implicit GEMM and take this kernel from the batch where it wins)
+inline bool winoup_layer(int hs, int c0, int c1, int cout, bool up_any, int dtype, bool inorm)
 {
     (void)inorm;
-    return dtype == 0 && up4 && (c1 == c0 || c1 == 0) && c0 % 8 == 0 && cout % 32 == 0 && hs % 8 == 0;
+    return dtype == 0 && up_any && (c1 == c0 || c1 == 0) && c0 % 8 == 0 && cout % 32 == 0 && hs % 8 == 0;
 }
-int winoup_choice(int batch, int hs, int cin, int cout, int *splits, int force_nb = 0, int target = 1024);
+int winoup_choice(int batch, int hs, int cin, int cout, int *splits, int force_nb = 0, int target = 1024, bool small_level = false);
 static const int kUp4MinExtent = 32;   // up-convs writing >= 32x32 use the sub-pixel form
 
 }  // namespace lspf2f

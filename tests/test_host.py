@@ -456,3 +456,15 @@ def test_the_blob_carries_only_the_weight_forms_the_handle_can_run():
                 assert e8.form_offset(i, f) >= 0, (b, l["name"], f)
     for e in (e1, e8, all8):
         e.close()
+
+
+def test_workspace_bytes_covers_every_smaller_batch():
+    """The plans of different batch sizes pick different kernels, so the scratch a batch needs is not monotonic in it (a 5-frame handle of this
+    small net needs more for 3 frames -- an 18-way split-K slab -- than for 5, where the up-conv runs on winoup3x3): lspf2f_workspace_bytes(b)
+    covers every batch of 1 .. b frames, which is what lets a host bind ONE workspace for max_batch (it failed on the GPU before: -5 STATE)."""
+    from livespeechportraits_amd import _native as N
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("normal", 13, 1, 3, 32, 5, 64, max_batch=5)
+    need = [int(N.load().lspf2f_workspace_bytes(e._h, b)) for b in range(1, 6)]
+    assert need == sorted(need) and need[2] == need[4]          # monotone; the 3-frame plan sets the size of the 5-frame handle
+    e.close()
