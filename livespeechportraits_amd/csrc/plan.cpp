@@ -127,9 +127,10 @@ int wino4_choice(int batch, int ho, int cin, int cout, int *splits_out)
 
 int winoup_choice(int batch, int hs, int cin, int cout, int *splits_out, int force_nb, int target, bool small_level)
 {
-    // the up-conv that writes 16 x 16 (1024 -> 512 from 8 x 8): one or two frames stay on the full-K kernel (25 us at one frame), from four frames up this
-    // kernel takes it -- 39.2 against 93.6 us for the implicit GEMM over the upsampled 9 taps at 4 frames, 58.1 against 170.3 at 8 (tools/time_conv.py)
-    if (small_level && batch < 4) return 0;
+    // the up-conv that writes 16 x 16 (1024 -> 512 from 8 x 8) runs here from two frames up (tools/time_conv.py, per layer): 28.3 against 47.8 us for the full-K kernel at
+    // two frames, 39.2 against 93.6 (implicit GEMM over the upsampled 9 taps) at four, 58.1 against 170.3 at eight.  One frame keeps the full-K kernel: 21.3 against 25.1 us
+    // when timed alone, but the whole forward is 0.6 % SLOWER with it (653.2 vs 657.0 frames/s, A-B-A-B of two libraries: profiles/r04_fullk_small_levels_batch.txt)
+    if (small_level && batch < 2) return 0;
     // a workgroup = 32 source pixels (8 x 16 output pixels) x 32 nb channels, THREE waves: two such workgroups leave a CU's four SIMDs with 2, 2, 1, 1
     // waves, four give every SIMD three.  So: one channel block per wave (115 registers, 28 KB of LDS: five fit) and K splits -- >= 8 eight-channel
     // steps each -- until there are ~4 workgroups per CU.  Measured, `large` fp32 (A-B-A-B, one session): nb 1 / 1024 workgroups 610.6 frames/s,

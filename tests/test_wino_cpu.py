@@ -203,9 +203,9 @@ def test_upconv_packer_and_planner():
     big = Engine("large", max_batch=8)
     for batch in (1, 8):
         ups = [l for l in big.layers(batch) if l["kernel"].startswith("winoup3x3")]
-        # the sub-pixel up-convs (>= 32x32 outputs); from 4 frames up also L5.up (8x8 -> 16x16), which keeps the full-K kernel below that; L6 / L7.up stay 9-tap
-        assert [l["name"] for l in ups] == (["L5.up"] if batch >= 4 else []) + ["L4.up", "L3.up", "L2.up", "L1.up"]
-        if batch >= 4:
+        # the sub-pixel up-convs (>= 32x32 outputs); from 2 frames up also L5.up (8x8 -> 16x16), which keeps the full-K kernel at one frame; L6 / L7.up stay 9-tap
+        assert [l["name"] for l in ups] == (["L5.up"] if batch >= 2 else []) + ["L4.up", "L3.up", "L2.up", "L1.up"]
+        if batch >= 2:
             assert ups[0]["flops_per_frame"] == ups[0]["exec_flops_per_frame"] * 4 and ups[0]["split_k"] == 4
         for l in ups:
             wgs = batch * (l["h_in"] // 4) * (l["h_in"] // 8) * (l["cout"] // l["tile_n"]) * l["split_k"]
