@@ -60,6 +60,15 @@ def test_fp32_batch8_full_size_every_frame(variant, gpu_device, oracle_b8):
     # the batch-1 plan on frame 5 agrees with the batch-8 plan (different tilings, same arithmetic)
     one = e.forward(torch.from_numpy(feat[5:6]).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
     assert np.abs(one[0] - out[5]).max() <= 1e-5      # measured 4.1e-6: other tiles and split-K factors, other summation order
+    # every batch size in between has a plan of its own (which kernel takes the 8x8 / 4x4 / 2x2 levels and the small up-convs depends on the
+    # frame count: plan.h fullk_choice, plan.cpp winoup_choice / wino_choice): each against the oracle's frames
+    kernels = {}
+    for b in range(2, 8):
+        got = e.forward(torch.from_numpy(feat[:b]).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
+        err = np.abs(got - ref[:b]).max()
+        kernels[b] = sorted({l["kernel"].split(" ")[0] for l in e.layers(b) if l["name"].startswith(("L5.", "L6.", "L7."))})
+        assert err <= TIGHT, (b, err)
+    print("   small-level kernels per batch: %s" % kernels)
 
 
 @pytest.mark.parametrize("variant", ["normal", "large"])
