@@ -237,6 +237,9 @@ int lspf2f_subset_timed(lspf2f_handle *h, const float *feat_dev, const float *ca
  *   the packer adds for those layers); split_k = K slices (1..8, 0 = 1) combined inside the launch -- the scratch then holds the slabs
  *   followed by one arrival counter per (tile-block, channel group), which must be ZERO on entry and is left zero.  4003 = 4001 with the wave's U
  *   fragments loaded straight into registers instead of through LDS (the form the plans take; same operands, same results bit for bit).
+ *   k_group == -4 (fp32, any tile, stride 1, one source of 4 ci channels, ci a multiple of 32): the 3x3 conv on a SPACE-TO-DEPTH image that equals Conv2d(k4, s2, p1)
+ *   (channel (dy * 2 + dx) * ci + c of pixel (y, x) = channel c of pixel (2y + dy, 2x + dx)); only 16 of the 36 (tap, quarter) pairs carry weights, and w_packed holds
+ *   just those: [cout][live pairs in tap-major, quarter-minor order][ci] -- 16/36 of the matrix work of the dense form (the `small` U-Net's down-convs).
  *   6001 (with k_group == -1) = the Winograd F(4x4,3x3) kernel (fp32, one source, stride 1, hs % 16 == 0, ws % 32 == 0, c0 % 8 == 0,
  *   cout % 32 == 0): w_packed holds the 6x6 G g G^T in the order [cout/32][wave (a, b) 4][c0/8][f 9][64 lanes][4] -- position
  *   (3a + f / 3, 3b + f % 3), lane as above; split_k and scratch as for 4001 with tile-blocks of 16 x 32 pixels x 32 channels. */

@@ -213,8 +213,8 @@ int lspf2f_pack_weights(lspf2f_handle *h, void *host_blob, size_t bytes)
     const std::string e = h->plan.pack(host_blob, bytes);
     if (!e.empty())
         return fail(e.rfind("missing", 0) == 0 ? LSPF2F_ERR_MISSING_TENSOR : LSPF2F_ERR_INVALID_ARGUMENT, e);
-    // the fp32 copies are no longer needed once packed
-    for (auto &p : h->plan.params) { std::vector<float>().swap(p.data); }
+    // the fp32 copies are no longer needed once packed; a second pack of the same handle needs the tensors set again (it answers MISSING_TENSOR, it used to crash)
+    for (auto &p : h->plan.params) { std::vector<float>().swap(p.data); p.set = false; }
     h->packed = true;
     return LSPF2F_OK;
 }
@@ -862,7 +862,8 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
     int bm = tile_m, bn = tile_n, sp = split_k;
     if (!bm || !bn || !sp) {
         int a, b, c, g;
-        choose_tiling(M, cout, (up4 ? 4 : 9) * (c0 + c1) / ktc, up4 ? 4 : 1, upsample == 1, dtype, &a, &b, &c, &g);
+        const int kt = k_group == -4 ? 16 * (c0 / 4) / ktc : (up4 ? 4 : 9) * (c0 + c1) / ktc;      // -4: the 16 live (tap, quarter) pairs of a space-to-depth 4x4 / s2 conv
+        choose_tiling(M, cout, kt, up4 ? 4 : 1, upsample == 1, dtype, &a, &b, &c, &g);
         if (!bm || !bn) { bm = a; bn = b; }
         if (!sp) sp = c;
     }
@@ -894,7 +895,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
         q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs); q.Wo = q.Ho;
         q.Cin = c0; q.Cout = cout; q.stride = stride; q.up = upsample == 1; q.relu = relu; q.M = batch * q.Ho * q.Wo;
         q.dtype = dtype;
-        const bool want = (tile_m == 1 && tile_n == 1) || (tile_m == 0 && tile_n == 0 && split_k == 0);
+        const bool want = (tile_m == 1 && tile_n == 1) || (tile_m == 0 && tile_n == 0 && split_k == 0 && k_group != -4);
         if (want && c1 == 0 && upsample != 2 && smallm_supported(q)) {
             e = launch_smallm(q, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (tiny-M) launch");
@@ -1011,7 +1012,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
         }
         int pb = 0;
         if ((tile_m == 16 || tile_m == 32) && tile_n == 16) pb = tile_m / 16;
-        else if (tile_m == 0 && tile_n == 0 && split_k == 0)
+        else if (tile_m == 0 && tile_n == 0 && split_k == 0 && k_group != -4)
             pb = fullk_choice(batch, hs, ho_, c0, c1, cout, stride, upsample == 1, upsample == 2, dtype);
         if (pb) {
             FullKParams q{};
@@ -1053,6 +1054,21 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     p.M = p.up4 ? batch * hs * ws : p.Mout;
     p.dtype = dtype;
     p.ktiles_total = (p.up4 ? 4 : 9) * p.Cin / ktc;
+    if (k_group == -4) {
+        // Conv2d(k4, s2, p1) as a 3x3 conv on the space-to-depth image (c0 = 4 ci, channel = (dy * 2 + dx) * ci + c): tap row ty reads sub-rows {1}, {0, 1}, {0} for
+        // ty = 0, 1, 2 (columns alike), so 16 of the 36 (tap, quarter) pairs carry weights; w_packed = [cout][those 16 in tap-major order][ci]
+        if (dtype != 0 || stride != 1 || upsample || c1 || c0 % 4 || (c0 / 4) % ktc) return fail(LSPF2F_ERR_UNSUPPORTED, "k_group -4 (space-to-depth 4x4 / s2 taps): fp32, one source of 4 x ci channels, ci a multiple of 32");
+        static const unsigned sub[3] = {2u, 3u, 1u};          // live sub-rows of tap row 0, 1, 2 as a bit set over dy
+        p.kmask = 0;
+        for (int ty = 0; ty < 3; ++ty)
+            for (int tx = 0; tx < 3; ++tx)
+                for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx)
+                        if (((sub[ty] >> dy) & 1u) && ((sub[tx] >> dx) & 1u)) p.kmask |= 1ull << ((ty * 3 + tx) * 4 + dy * 2 + dx);
+        p.kblk = c0 / 4;
+        p.ktiles_total = 16 * p.kblk / ktc;
+        k_group = 0;
+    }
     int bm = tile_m, bn = tile_n, sp = split_k, grp = k_group;
     {
         int a, b, c, g;

@@ -52,7 +52,7 @@ static constexpr int LDK = 32;   // LDS row pitch in floats (128 B, unpadded: th
 // T = storage type of activations and weights: float (exact fp32 MFMA, v_mfma_f32_32x32x2_f32) or bf16_t
 // (v_mfma_f32_32x32x16_bf16, fp32 accumulate and epilogue).  A K-tile is always 128 B of channels (32 fp32 /
 // 64 bf16), so the LDS geometry, the DMA pieces and the swizzle are identical for both.
-template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP>
+template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP, bool KM = false>      // KM: masked K (p.kmask), its own instances so that the others carry none of it
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
 {
     constexpr int EB = (int)sizeof(T);               // element bytes
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
         a_b0[i] = (unsigned)a_pix0[i] * ((unsigned)p.C0 * (unsigned)EB) + (unsigned)lqb;
         a_b1[i] = (unsigned)a_pix0[i] * ((unsigned)p.C1 * (unsigned)EB) + (unsigned)lqb;
     }
-    const int K = ntap * p.Cin;
+    const int K = KM ? p.ktiles_total * BKE : ntap * p.Cin;     // elements per weight row (masked K: only the live tiles are stored)
     const T *wbase = static_cast<const T *>(p.w) + (size_t)par * p.Cout * K;
     unsigned b_off[PB];                                  // byte offset of this thread's weight row, or OOB
 #pragma unroll
@@ -186,6 +186,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
     // concatenated input
     int tap = (int)p.div_cin.div((unsigned)(kt_begin * BKE));
     int c = kt_begin * BKE - tap * p.Cin;
+    // masked K (p.kmask: the space-to-depth form of a 4x4 / stride-2 conv): only the live (tap, channel quarter) pairs have K-tiles; the cursor steps over the others
+    auto skip_dead = [&]() {
+        while (tap < 9 && !((p.kmask >> (tap * 4 + c / p.kblk)) & 1ull)) {
+            c += p.kblk;
+            if (c >= p.Cin) { c = 0; ++tap; }
+        }
+    };
+    if constexpr (KM) {
+        tap = 0; c = 0;
+        skip_dead();
+        for (int i = 0; i < kt_begin; ++i) {           // (split-K slices: walk to the slice's first live tile)
+            c += BKE;
+            if (c == p.Cin) { c = 0; ++tap; }
+            if (c % p.kblk == 0) skip_dead();
+        }
+    }
     int ky = p.up4 ? tap >> 1 : (tap * 11) >> 5, kx = tap - ky * tw;     // tap / tw for tap <= 8
 
     // Stage K-tiles kt .. kt+G-1 into LDS buffer `buf` with buffer_load ... lds (LDS-DMA): no staging
@@ -231,6 +247,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                 if (c == p.Cin) {
                     c = 0; ++tap; ++kx;
                     if (kx == tw) { kx = 0; ++ky; }
+                }
+                if (KM && c % p.kblk == 0) {
+                    skip_dead();
+                    ky = (tap * 11) >> 5; kx = tap - ky * 3;
                 }
             }
         }
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_few(const IgemmParams p)
     reduce_epilogue<T>(p, i, s);
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP>
+template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP, bool KM = false>
 static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
 {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
@@ -591,7 +611,7 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
     if (smem < smem_patch) smem = smem_patch;
     static AttrMask attr_mask;   // raise the dynamic-LDS cap once per instantiation and device
     if (smem_max > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3<T, BM, BN, WGM, WGN, G, UP>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm3x3<T, BM, BN, WGM, WGN, G, UP, KM>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
@@ -601,7 +621,7 @@ static hipError_t launch_igemm_t(const IgemmParams &p, hipStream_t s)
     q.div_gx = FastDiv::make((unsigned)(ntm * ntn * npar));
     q.div_tile = FastDiv::make((unsigned)(p.xcd == 2 ? ntm : ntn));
     q.div_cin = FastDiv::make((unsigned)p.Cin);
-    hipLaunchKernelGGL((igemm3x3<T, BM, BN, WGM, WGN, G, UP>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
+    hipLaunchKernelGGL((igemm3x3<T, BM, BN, WGM, WGN, G, UP, KM>), dim3(ntm * ntn * npar, p.splits), dim3(64 * WGM * WGN),
                        smem, s, q);
     return hipGetLastError();
 }
@@ -620,6 +640,29 @@ bool igemm_group_supported(int bm, int bn, int g, bool up)
     if (g == 2) return (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
     if (g == 4) return (bm == 64 && bn == 64) || (bm == 32 && bn == 64);
     return false;
+}
+
+// masked K (the space-to-depth form of a 4x4 / stride-2 conv, lspf2f_conv3x3 with k_group -4): fp32, no upsample; its own instances of the kernel
+static hipError_t launch_igemm_masked(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
+{
+    if (p.dtype != 0 || p.up || p.up4) return hipErrorInvalidValue;
+    if (g == 4) {
+        if (bm == 64 && bn == 64) return launch_igemm_t<float, 64, 64, 2, 2, 4, false, true>(p, s);
+        if (bm == 32 && bn == 64) return launch_igemm_t<float, 32, 64, 1, 2, 4, false, true>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (g == 2) {
+        if (bm == 128 && bn == 64) return launch_igemm_t<float, 128, 64, 2, 2, 2, false, true>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<float, 64, 64, 2, 2, 2, false, true>(p, s);
+        return hipErrorInvalidValue;
+    }
+    if (bm == 128 && bn == 128) return launch_igemm_t<float, 128, 128, 2, 2, 1, false, true>(p, s);
+    if (bm == 128 && bn == 64) return launch_igemm_t<float, 128, 64, 2, 2, 1, false, true>(p, s);
+    if (bm == 64 && bn == 128) return launch_igemm_t<float, 64, 128, 2, 2, 1, false, true>(p, s);
+    if (bm == 64 && bn == 64) return launch_igemm_t<float, 64, 64, 2, 2, 1, false, true>(p, s);
+    if (bm == 32 && bn == 128) return launch_igemm_t<float, 32, 128, 1, 4, 1, false, true>(p, s);
+    if (bm == 32 && bn == 64) return launch_igemm_t<float, 32, 64, 1, 2, 1, false, true>(p, s);
+    return hipErrorInvalidValue;
 }
 
 template <typename T>
@@ -672,6 +715,7 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
         if (rule == 1 && p.splits > 1 && p.dtype == 0) rule = 0;
         p.xcd = forced >= 0 ? forced : rule;
     }
+    if (p.kmask) return launch_igemm_masked(p, bm, bn, g, s);
     if (p.dtype == 2) return launch_igemm_typed<f16_t>(p, bm, bn, g, s);
     return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
 }

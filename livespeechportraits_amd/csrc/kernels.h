@@ -64,6 +64,8 @@ struct IgemmParams {
     int xcd;                    // block->tile order: 0 dispatch order, 1 per-XCD chunks m-major, 2 per-XCD chunks n-major (filled by launch_igemm)
     int xcd_force;              // 0 = by rule; 1 + mode forces it (tools)
     unsigned long long *stamps; // -DLSPF2F_IGEMM_STAMPS builds: [blocks][4 waves][16] cycle counters (tools/time_conv.py)
+    unsigned long long kmask;   // 0 = every (tap, channel) K-tile exists.  Else bit (tap * 4 + j) says whether channel quarter j of tap `tap` does: the space-to-depth form of a
+    int kblk;                   //   4x4 / stride-2 conv (lspf2f_conv3x3, k_group -4) has 16 live (tap, quarter) pairs of 36; kblk = channels per quarter; w holds only the live ones, in order
     int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,
                                 // 4 no barrier, 8 no buffer flip, 16 no epilogue, 32 no K loop
 };

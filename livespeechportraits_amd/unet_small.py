@@ -46,6 +46,25 @@ def pack_down(w: np.ndarray, s2d_channels: int) -> np.ndarray:
     return out
 
 
+_LIVE = {0: (1,), 1: (0, 1), 2: (0,)}                   # 3x3 tap row (column) -> the space-to-depth sub-rows (sub-columns) that carry a 4x4 tap
+
+
+def pack_down_live(w: np.ndarray) -> np.ndarray:
+    """[co][ci][4][4] -> [co][16 live (tap, quarter) pairs][ci]: the 3x3 / space-to-depth form WITHOUT its 20 zero blocks, in the order the kernel's K cursor
+    walks them (tap-major, quarter (dy * 2 + dx) minor) -- lspf2f_conv3x3 with k_group = -4 (include/lspf2f.h)."""
+    co, ci = w.shape[:2]
+    inv = {v: k for k, v in _KY.items()}                 # (ty, dy) -> ky
+    blocks = []
+    for ty in range(3):
+        for tx in range(3):
+            for dy in range(2):
+                for dx in range(2):
+                    if dy in _LIVE[ty] and dx in _LIVE[tx]:
+                        blocks.append(w[:, :, inv[(ty, dy)], inv[(tx, dx)]])
+    assert len(blocks) == 16
+    return np.ascontiguousarray(np.stack(blocks, axis=1))          # [co][16][ci]
+
+
 def pack_up(wt: np.ndarray) -> np.ndarray:
     """ConvTranspose2d weight [ci][co][4][4] -> sub-pixel form [4 parities][co][2][2][ci]."""
     ci, co = wt.shape[:2]
@@ -84,11 +103,12 @@ def block_keys(num_downs: int, prefix: str = "model"):
 
 
 class SmallUnetEngine:
-    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, graph: bool = False):
+    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, graph: bool = False, live_taps: bool = True):
         if ngf % 32 or num_downs < 5 or not (1 <= output_nc <= 4):
             raise ValueError("ngf must be a multiple of 32, num_downs >= 5, output_nc <= 4")
         self.lib = N.load()
         self.use_graph = graph
+        self.live_taps = live_taps                # down-convs issue only the 16 live (tap, quarter) K blocks of the 36 (round 4); False: the dense form (A-B, tests)
         self._graphs: Dict[tuple, tuple] = {}     # (B, S, out_u8) -> (CUDAGraph, static input, static output, scratch)
         self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
         self.chans = [ngf * min(2 ** i, 8) for i in range(num_downs)]
@@ -111,7 +131,8 @@ class SmallUnetEngine:
         for k, (dc, dbn, uc, ubn) in enumerate(keys):
             cin = self.input_nc if k == 0 else self.chans[k - 1]
             s2d = self.s2d0 if k == 0 else 4 * cin
-            e = {"down_w": up(pack_down(sd[dc + ".weight"], s2d)), "s2d": s2d, "cin": cin, "cout": self.chans[k]}
+            live = self.live_taps and k > 0 and cin % 32 == 0              # (block 0: 23 input channels, padded to 96 -- its quarters are not K-tile aligned)
+            e = {"down_w": up(pack_down_live(sd[dc + ".weight"]) if live else pack_down(sd[dc + ".weight"], s2d)), "down_live": live, "s2d": s2d, "cin": cin, "cout": self.chans[k]}
             e["down_scale"], e["down_shift"] = (up(t) for t in _fold_bn(sd, dbn)) if dbn else (None, None)
             wt = sd[uc + ".weight"]
             if k == 0:
@@ -127,16 +148,16 @@ class SmallUnetEngine:
         self.layers, self.device = L, dev
 
     # ---- launches ---------------------------------------------------------------------------------
-    def _conv(self, src0, src1, w, scale, shift, out, stride, upsample, relu):
+    def _conv(self, src0, src1, w, scale, shift, out, stride, upsample, relu, k_group=0):
         b, hs, ws, c0 = src0.shape
         c1 = src1.shape[3] if src1 is not None else 0
         cout = out.shape[3]
-        sb = self.lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, upsample, 0, 0, 0, 0, 0)
+        sb = self.lib.lspf2f_conv3x3_scratch_bytes(b, hs, ws, c0, c1, cout, stride, upsample, 0, 0, 0, k_group, 0)
         if self._scratch is None or self._scratch.numel() < sb:
             self._scratch = torch.empty(max(sb, 256), dtype=torch.uint8, device=self.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         N.check(self.lib.lspf2f_conv3x3(p(src0), p(src1), p(w), p(scale), p(shift), None, p(out), b, hs, ws, c0, c1, cout,
-                                        stride, upsample, int(relu), 0, 0, 0, 0, 0, p(self._scratch), self._scratch.numel(),
+                                        stride, upsample, int(relu), 0, 0, 0, k_group, 0, p(self._scratch), self._scratch.numel(),
                                         ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def _prepare(self, src, nchw, b, h, w, c, slope, s2d, s2d_c, relu):
@@ -189,7 +210,7 @@ class SmallUnetEngine:
                 h //= 2
                 inner = k == nd - 1
                 d = new(B, h, h, L[k]["cout"])
-                self._conv(y, None, L[k]["down_w"], L[k]["down_scale"], L[k]["down_shift"], d, 1, 0, relu=inner)
+                self._conv(y, None, L[k]["down_w"], L[k]["down_scale"], L[k]["down_shift"], d, 1, 0, relu=inner, k_group=-4 if L[k]["down_live"] else 0)
                 if inner:
                     break                                                                     # stored as relu(d): only the up-conv reads it
                 y = new(B, h // 2, h // 2, 4 * L[k]["cout"])

@@ -49,7 +49,7 @@ def _worker(rank, world, port, tmp):
         eng.load_state_dict(sd)
         blob = eng.pack()
     buf = D.broadcast_blob(blob, eng.packed_bytes(), torch.device("cpu"))
-    ref = Engine("normal", ngf=32, num_downs=5, size=64)
+    ref = Engine("normal", ngf=32, num_downs=5, size=64, max_batch=4)      # the same configuration: the blob carries the weight forms of the plans of 1 .. max_batch frames
     ref.load_state_dict(sd)
     assert torch.equal(buf, ref.pack()), "rank %d received a different blob" % rank
     # binding needs a device: on CPU this must fail loudly, never fall back

@@ -469,3 +469,19 @@ def test_workspace_bytes_covers_every_smaller_batch():
         need = [int(N.load().lspf2f_workspace_bytes(e._h, b)) for b in range(1, 9)]
         assert need == sorted(need) and need[0] > 0, (cfg, need)      # never less than any smaller batch needs
         e.close()
+
+
+def test_a_second_pack_needs_the_tensors_again():
+    """lspf2f_pack_weights frees the handle's fp32 copies of the state dict (the packed blob is what lives on); packing the same handle again without setting the
+    tensors again must answer MISSING_TENSOR -- it dereferenced the freed vectors before round 4's last day -- and works, bit for bit, once they are set again."""
+    from livespeechportraits_amd import _native as N, synth
+    from livespeechportraits_amd.engine import Engine
+    topo, sd = synth.synthetic("normal", ngf=32, num_downs=5, size=64)
+    e = Engine("normal", ngf=32, num_downs=5, size=64)
+    e.load_state_dict(sd)
+    first = e.pack().clone()
+    with pytest.raises(N.Lspf2fError, match="MISSING_TENSOR"):
+        e.pack()
+    e.load_state_dict(sd)
+    assert torch.equal(e.pack(), first)
+    e.close()

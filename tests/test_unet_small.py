@@ -61,7 +61,46 @@ def test_container_keys_and_weight_mappings():
     assert (out2 - ref).abs().max() < 1e-5                                     # GEMM form + pixel shuffle
 
 
+def test_live_tap_packing_is_the_dense_form_without_its_zero_blocks():
+    """lspf2f_conv3x3(k_group = -4): of the 36 (tap, channel quarter) blocks of the 3x3 / space-to-depth form of Conv2d(k4, s2, p1) only 16 carry weights.  The K
+    cursor of the kernel walks taps 0..8 and, inside a tap, the quarters whose bit is set in the mask api.cpp builds (tap row 0 -> sub-row 1, row 1 -> both, row 2 ->
+    sub-row 0; columns alike); pack_down_live must hold exactly the non-zero blocks of pack_down in that order, and the rest of pack_down must be zero."""
+    from livespeechportraits_amd.unet_small import pack_down, pack_down_live
+    rng = np.random.default_rng(3)
+    co, ci = 6, 32
+    w = rng.standard_normal((co, ci, 4, 4)).astype(np.float32)
+    dense, live = pack_down(w, 4 * ci), pack_down_live(w)
+    sub = {0: (1,), 1: (0, 1), 2: (0,)}                      # the rule of api.cpp (static const unsigned sub[3] = {2, 3, 1} as bit sets over dy)
+    k = 0
+    for tap in range(9):
+        for q in range(4):
+            blk = dense[:, tap // 3, tap % 3, q * ci:(q + 1) * ci]
+            if (q >> 1) in sub[tap // 3] and (q & 1) in sub[tap % 3]:
+                assert np.array_equal(live[:, k, :], blk) and np.abs(blk).min() > 0
+                k += 1
+            else:
+                assert not blk.any()
+    assert k == 16 and live.shape == (co, 16, ci)
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_live_tap_down_convs_agree_with_the_dense_form(gpu_device):
+    """the down-convs with only their 16 live K blocks (default) against the dense 3x3 / space-to-depth form (live_taps=False): the same products in the same order,
+    minus exact zeros -- equal up to the split-K boundaries the shorter K moves; both on the reference golden"""
+    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    meta, sd, x, ref = load_case("small_512")
+    outs = []
+    for live in (True, False):
+        e = SmallUnetEngine(23, 3, meta["num_downs"], meta["ngf"], live_taps=live)
+        e.load_state_dict(sd, "model", gpu_device)
+        assert any(l["down_live"] for l in e.layers) == live
+        outs.append(e.forward(torch.from_numpy(x).to(gpu_device)).cpu().numpy())
+        assert np.abs(outs[-1] - ref).max() <= TOL
+    print("\nlive vs dense down-convs: max-abs %.2e" % np.abs(outs[0] - outs[1]).max())
+    assert np.abs(outs[0] - outs[1]).max() <= 5e-6
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["small_s64_b2", "small_512"])
 def test_engine_matches_reference(name):
