@@ -2,7 +2,9 @@
 models/feature2face_G.py:16-17 with a 23-channel input) on the MI355X, built from the library's existing kernels:
 
   Conv2d(k4, s2, p1)           -> lspf2f_unet_prepare (space-to-depth + the in-place LeakyReLU) + lspf2f_conv3x3 on 4x the
-                                  channels with the 16 real taps scattered into a 3x3 pattern (20 of 36 blocks are zero)
+                                  channels with the 16 real taps scattered into a 3x3 pattern; 20 of its 36 (tap, channel quarter)
+                                  blocks are zero, and k_group = -4 makes the kernel's K cursor walk only the 16 live ones
+                                  (pack_down_live; block 0 with its 23 padded input channels keeps the dense pack_down)
   ConvTranspose2d(k4, s2, p1)  -> lspf2f_conv3x3 in sub-pixel form (upsample = 2): 4 output parities x 2x2 taps
   last ConvTranspose + Tanh    -> 3x3 GEMM with N = 4 parities x 3 on the low-res source + lspf2f_pixel_shuffle (tanh)
 
