@@ -83,6 +83,65 @@ def test_live_tap_packing_is_the_dense_form_without_its_zero_blocks():
     assert k == 16 and live.shape == (co, 16, ci)
 
 
+@pytest.mark.parametrize("ci,bke", [(32, 32), (64, 32), (128, 32), (512, 32)])
+def test_masked_k_cursor_walks_exactly_the_live_tiles(ci, bke):
+    """A restatement of the K cursor igemm3x3<..., KM = true> runs (csrc/igemm.hip: skip_dead, the walk to a split-K slice's first tile, the advance per K-tile) with
+    the mask api.cpp builds for k_group = -4: the tiles it visits, in order, are the K-tiles pack_down_live stores, they cover every non-zero weight of the dense form
+    once, and any split of the range into slices visits the same sequence."""
+    from livespeechportraits_amd.unet_small import pack_down, pack_down_live
+    cin, kblk = 4 * ci, ci
+    sub = (2, 3, 1)
+    kmask = 0
+    for ty in range(3):
+        for tx in range(3):
+            for dy in range(2):
+                for dx in range(2):
+                    if (sub[ty] >> dy) & 1 and (sub[tx] >> dx) & 1:
+                        kmask |= 1 << ((ty * 3 + tx) * 4 + dy * 2 + dx)
+    total = 16 * kblk // bke
+
+    def walk(kt_begin, kt_end):
+        st = {"tap": 0, "c": 0}
+
+        def skip_dead():
+            while st["tap"] < 9 and not (kmask >> (st["tap"] * 4 + st["c"] // kblk)) & 1:
+                st["c"] += kblk
+                if st["c"] >= cin:
+                    st["c"] = 0; st["tap"] += 1
+
+        def advance():
+            st["c"] += bke
+            if st["c"] == cin:
+                st["c"] = 0; st["tap"] += 1
+            if st["c"] % kblk == 0:
+                skip_dead()
+        skip_dead()
+        for _ in range(kt_begin):
+            advance()
+        out = []
+        for _ in range(kt_begin, kt_end):
+            out.append((st["tap"], st["c"]))
+            advance()
+        return out
+    full = walk(0, total)
+    assert len(full) == total and all(t < 9 for t, _ in full)
+    rng = np.random.default_rng(ci)
+    w = rng.standard_normal((3, ci, 4, 4)).astype(np.float32)
+    dense, live = pack_down(w, cin).reshape(3, 9, cin), pack_down_live(w).reshape(3, -1)
+    covered = np.zeros((9, cin), bool)
+    for kt, (tap, c) in enumerate(full):
+        assert np.array_equal(live[:, kt * bke:(kt + 1) * bke], dense[:, tap, c:c + bke]), (kt, tap, c)
+        assert not covered[tap, c:c + bke].any()
+        covered[tap, c:c + bke] = True
+    assert np.array_equal(covered, np.abs(dense).sum(0) > 0)
+    for splits in (2, 3, 5, 7, 16):
+        per = (total + splits - 1) // splits
+        seq = []
+        for z in range(splits):
+            seq += walk(min(z * per, total), min((z + 1) * per, total))
+        assert seq == full, splits
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_live_tap_down_convs_agree_with_the_dense_form(gpu_device):
