@@ -485,3 +485,27 @@ def test_a_second_pack_needs_the_tensors_again():
     e.load_state_dict(sd)
     assert torch.equal(e.pack(), first)
     e.close()
+
+
+def test_planner_choices_of_the_small_levels_per_batch():
+    """Which kernel takes the 16x16 ... 2x2 levels of `large` depends on the frame count (round 4 measured every cell: profiles/r04_fullk_small_levels_batch.txt):
+    the tiny-M kernel while the level has <= 16 output pixels, the full-K kernel above that (one launch, no reduction), wino3x3 for the 16x16 level from 4 frames,
+    winoup3x3 for the up-conv that writes 16x16 from 2 frames; the stride-2 convs stay on the implicit GEMM."""
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("large", max_batch=8)
+    want = {
+        #     L4.d.res (16x16)   L5.d.res (8x8)    L6.d.res (4x4)     L7.d.res (2x2)     L7.up (-> 4x4)     L5.up (-> 16x16)
+        1: ("conv3x3_fullk", "conv3x3_fullk", "conv3x3_smallm", "conv3x3_smallm", "conv3x3_smallm", "conv3x3_fullk"),
+        2: ("conv3x3_fullk", "conv3x3_fullk", "conv3x3_fullk", "conv3x3_smallm", "conv3x3_fullk", "winoup3x3<1>"),
+        4: ("wino3x3<1>", "conv3x3_fullk", "conv3x3_fullk", "conv3x3_smallm", "conv3x3_fullk", "winoup3x3<1>"),
+        5: ("wino3x3<1>", "conv3x3_fullk", "conv3x3_fullk", "conv3x3_fullk", "conv3x3_fullk", "winoup3x3<1>"),
+        8: ("wino3x3<1>", "conv3x3_fullk", "conv3x3_fullk", "conv3x3_fullk", "conv3x3_fullk", "winoup3x3<1>"),
+    }
+    names = ("L4.d.res0.a", "L5.d.res0.a", "L6.d.res0.a", "L7.d.res0.a", "L7.up", "L5.up")
+    for b, exp in want.items():
+        by = {l["name"]: l["kernel"].split(" ")[0] for l in e.layers(b)}
+        assert tuple(by[n] for n in names) == exp, (b, [by[n] for n in names])
+        assert all(by[n].startswith("igemm3x3") for n in ("L5.down", "L6.down")), b
+    # one-frame handles carry no full-K tiles for the 4x4 / 2x2 levels (the blob holds only what the batch range reads)
+    assert Engine("large", max_batch=1).packed_bytes() < Engine("large", max_batch=2).packed_bytes() < e.packed_bytes()
+    e.close()
