@@ -15,6 +15,9 @@
 // in the order the MFMA wants them: one 1-KB LDS-DMA piece = the B fragment of 4 MFMAs; a wave copies exactly the fragments it alone uses.
 // Per 8 input channels a wave issues 16 NB MFMAs for 8 + 4 NB fragment reads.  The four waves meet once, in the epilogue: the column half of
 // the output transform in registers, the row half across waves through an LDS patch.
+// Round 4, one channel block per wave (the form batch-1 plans take): the U fragments skip LDS altogether -- one plain buffer_load_dwordx4 per fragment into the
+// registers the MFMA reads, two K-steps ahead (wino_loop_ur below; the K loop then runs at 96 % of MFMA issue).  InstanceNorm plans: the epilogue also leaves the
+// per-(frame, channel) sums of its 128 pixels (wino_stats).
 #include "device_common.h"
 #include "kernels.h"
 #include "wino_common.h"
