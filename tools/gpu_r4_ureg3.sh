@@ -1,5 +1,6 @@
 #!/bin/bash
 # winoup3x3 UR form: parity on the conv shapes and goldens, A-B-A-B against the LDS forms (LSP_HIP_WINO_UREG=0 switches both Winograd kernels back)
+# (record of a session: the register forms of winoup3x3 and the tiles 5003-5006 lived in that session's working tree only -- profiles/r04_winoup_ureg_ab.txt; the script still runs, against the shipped kernels)
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r4ureg; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_conv.py -m gpu -q -s -k "winograd_upconv" > $OUT/pytest_upconv.log 2>&1; echo "upconv tests rc=$?"; grep "^winoup (.*, [34], [0-9], " $OUT/pytest_upconv.log | head -14; tail -2 $OUT/pytest_upconv.log
 timeout 900 python -m pytest tests/test_gpu_network.py tests/test_instance_norm.py -m gpu -x -q -k "golden or batch8" > $OUT/pytest_net2.log 2>&1; echo "network tests rc=$?"; tail -2 $OUT/pytest_net2.log

@@ -1,5 +1,6 @@
 #!/bin/bash
 # winoup3x3 register forms (2 | 3 sets) against the LDS form: parity, whole-forward A-B, in-graph kernel durations from a kernel trace
+# (record of a session: the `winoup_ureg` key and the register forms of winoup3x3 lived in that session's working tree only -- profiles/r04_winoup_ureg_ab.txt; with the shipped library the three arms are the same kernel)
 R=$GRAFT_REPO_ROOT; cd $R; OUT=$R/gpurun_out/r4ureg; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_gpu_conv.py -m gpu -q -k "winograd_upconv" > $OUT/pytest_upconv.log 2>&1; echo "upconv tests rc=$?"; tail -2 $OUT/pytest_upconv.log
 run() { python bench.py --no-cpu-baseline --no-extra --steps 100 --batch $2 2>/dev/null | python -c "
