@@ -161,6 +161,39 @@ def test_register_form_never_touches_a_u_register_in_flight():
             assert not bad, (prefix, bad[:5])
 
 
+def test_the_asm_check_itself_catches_a_copy_of_an_in_flight_register():
+    """tools/check_ureg_asm.py on a hand-made listing: a clean loop passes, a v_mov out of a U register inside the loop (what the tied wait operand produced) and a
+    spill of one in the prologue are both reported; uses of the same registers behind the loop are not."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_ureg_asm as C
+    clean = """
+	;;#ASMSTART
+	buffer_load_dwordx4 v[10:13], v1, s[4:7], s0 offen offset:0
+	;;#ASMEND
+	s_branch .LBB0_1
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+	ds_read_b128 v[40:43], v2
+	v_pk_add_f32 v[40:41], v[40:41], v[42:43]
+	v_mfma_f32_32x32x2_f32 v[100:115], v40, v10, v[100:115]
+	;;#ASMSTART
+	buffer_load_dwordx4 v[14:17], v1, s[4:7], s0 offen offset:0x400
+	;;#ASMEND
+	v_mfma_f32_32x32x2_f32 v[100:115], v41, v11, v[100:115]
+	s_cbranch_vccz .LBB0_1
+.LBB0_2:
+	v_mov_b32_e32 v10, 0
+	global_store_dword v[50:51], v11, off
+""".splitlines()
+    ureg, nl, nm, bad = C.check(clean)
+    assert ureg == list(range(10, 18)) and nl == 2 and nm == 2 and not bad
+    copied = [l if "v_pk_add_f32" not in l else l + "\n\tv_mov_b64_e32 v[60:61], v[14:15]" for l in clean]
+    assert [b[1].strip() for b in C.check("\n".join(copied).splitlines())[3]] == ["v_mov_b64_e32 v[60:61], v[14:15]"]
+    spilled = [l if "s_branch .LBB0_1" not in l else "\tscratch_store_dwordx4 off, v[10:13], off offset:16\n" + l for l in clean]
+    assert len(C.check("\n".join(spilled).splitlines())[3]) == 1
+    wrong_operand = [l.replace("v40, v10, v[100:115]", "v10, v40, v[100:115]") for l in clean]          # a U register as the A operand
+    assert len(C.check(wrong_operand)[3]) == 1
+
+
 # ---- the up-conv form (csrc/winoup.hip): Upsample(x2, nearest) + Conv3x3 with 9 multiplies per 2x2 outputs ------------------------------
 def test_upconv_form_is_exact_and_its_data_flow_model_convolves():
     """Row 2 of B^T d B vanishes on an upsampled patch (rows a, b, b, c): 9 of the 16 transformed positions carry everything."""
