@@ -272,6 +272,7 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
                                     : (l.splits > 1 ? "wino4_3x3 (split-K combined in the launch)" : "wino4_3x3");
         if (l.inorm && (l.wino || l.winoup)) {
             const bool sm = l.in_route == kInSmall;
+            if (l.winoup && l.in_route == kInWino) return l.winoup == 2 ? "winoup3x3<2>(stats)+in_finalize+in_apply" : "winoup3x3<1>(stats)+in_finalize+in_apply";
             if (l.winoup) return l.winoup == 2 ? (sm ? "winoup3x3<2>+in_small" : "winoup3x3<2>+in_reduce_stats+in_finalize+in_apply")
                                                : (sm ? "winoup3x3<1>+in_small" : "winoup3x3<1>+in_reduce_stats+in_finalize+in_apply");
             if (l.in_route == kInWino) return l.wino == 2 ? "wino3x3<2>(stats)+in_finalize+in_apply" : "wino3x3<1>(stats)+in_finalize+in_apply";
@@ -492,8 +493,24 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
-        if (h->timing_part & 1) e = launch_winoup(p, l.winoup, s);
-        if (l.inorm) e = in_after_complete_output(e);
+        if (l.inorm && l.in_route == kInWino) {
+            // the kernel's epilogue (or its split-K combine) leaves the sums of every tile-block of 128 output pixels: finalize + normalise only
+            float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
+            const size_t slab = (size_t)batch * P.stats_groups_max;
+            InstNormParams q{};
+            q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu; q.partial = nullptr; q.splits = 1; q.bias = nullptr;
+            q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
+            q.psum = st; q.psq = st + slab * l.cout; q.pshift = st + 2 * slab * l.cout;
+            q.mean = st + 3 * slab * l.cout; q.rstd = q.mean + (size_t)batch * l.cout;
+            q.groups = q.hw / 128; q.rows_per_group = 128;
+            p.psum = q.psum; p.psq = q.psq; p.pshift = q.pshift;
+            if (h->timing_part & 1) e = launch_winoup(p, l.winoup, s);
+            if (e == hipSuccess) e = launch_in_finalize(q, s);
+            if (e == hipSuccess) e = launch_in_apply(q, s);
+        } else {
+            if (h->timing_part & 1) e = launch_winoup(p, l.winoup, s);
+            if (l.inorm) e = in_after_complete_output(e);
+        }
     } else if (l.wino4) {
         WinoParams p{};
         p.src = tptr(l.src0); p.u = bptr(l.ww4_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);

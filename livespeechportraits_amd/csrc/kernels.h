@@ -148,6 +148,7 @@ struct WinoUpParams {
     float *partial;               // splits > 1: fp32 slabs [splits][B*4*Hs*Ws][N]
     unsigned *tile_cnt;           // splits > 1: arrival counters, zero between launches
     int B, Hs, Ws, C0, C1, N, relu, splits;
+    float *psum, *psq, *pshift;   // InstanceNorm plans: per (frame, tile-block, channel) sums over the 128 output pixels a workgroup writes, as in WinoParams; nullptr = none
     // filled by launch_winoup
     int steps_per_split, ntb, nng, tby, tbx, nmajor;
     size_t slab_bytes;

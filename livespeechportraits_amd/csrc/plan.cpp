@@ -556,7 +556,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 if (!smallm && !fullk && !wino && !wino4 && !winoup && splits == 1 && rhw >= 1024 && rhw % wave_rows == 0) {
                     route = kInFused;
                     groups_max = std::max(groups_max, (l.up4 ? 4 : 1) * rhw / wave_rows);
-                } else if (wino && !wino4 && p.in_wino_stats) {
+                } else if ((wino || winoup) && !wino4 && p.in_wino_stats) {
                     // one group per tile-block of 8 x 16 output pixels; also at 32 x 32 and below, where in_small would put a 512-channel frame on 16 workgroups
                     // (57.9 -> 33 us per layer at 32 x 32, batch 1)
                     route = kInWino;

@@ -24,6 +24,7 @@ namespace lspf2f {
 
 static constexpr unsigned kOOBu = 0x80000000u;
 static constexpr int kUpRawStage = 2 * 1024;                // 120 chunks (6 x 10 pixels x 2 channel quads) in 2 pieces of 64
+static constexpr int kWinoUpStatsScratch = (8 + 3 * 8 * 2) * 16;   // InstanceNorm plans: the shift [8 quads] and the three waves' partial sums [3][8][2], float4 each (winoup_stats)
 
 __host__ __device__ constexpr int winoup_u_stage(int nb) { return 3 * 3 * nb * 1024; }          // 3 waves x (3 j x nb) pieces
 __host__ __device__ constexpr int winoup_raw_base(int nb) { return 2 * winoup_u_stage(nb); }
@@ -32,8 +33,9 @@ __host__ __device__ constexpr int winoup_lds_bytes(int nb)
 {
     const int loop = winoup_dump(nb) + 1024;
     const int patch = 3 * 2 * nb * 32 * 36 * 4;               // epilogue: [wave][b][nb][32 tiles][36]
-    return loop > patch ? loop : patch;
+    return (loop > patch ? loop : patch) + kWinoUpStatsScratch;
 }
+__host__ __device__ constexpr int winoup_stats_base(int nb) { return winoup_lds_bytes(nb) - kWinoUpStatsScratch; }
 
 template <int NB, int ROW>      // ROW = 0, 1, 2: rows 0, 1, 3 of the transformed tile
 __device__ __forceinline__ void winoup_loop(const WinoUpParams &p, f32x16 (&acc)[3][NB], const char *smem_c, unsigned lds0, int wave, int lane,
@@ -120,6 +122,48 @@ __device__ __forceinline__ void winoup_loop(const WinoUpParams &p, f32x16 (&acc)
         cur ^= 1;
     }
     (void)PIECES;
+}
+
+// InstanceNorm plans: the statistics of the 128 output pixels a workgroup has just computed, in the form in_finalize merges (see wino_stats in wino.hip).  A thread
+// holds one or two (source pixel, channel quad) items of a channel block -- tid and tid + 192 of 256, the same quad -- i.e. 4 or 8 finished output pixels.
+__device__ __forceinline__ void winoup_stats(const WinoUpParams &p, float4 *scratch, const float4 (&v)[2][4], bool second, int tid, size_t g)
+{
+    float4 *cs = scratch, *part = scratch + 8;
+    const int qi = tid & 7, wave = tid >> 6, lane = tid & 63;
+    __syncthreads();                                          // the previous channel block's readers are done with the scratch
+    if (tid < 8) cs[qi] = v[0][0];                            // item tid: source pixel 0 of the tile-block, output pixel (0, 0)
+    __syncthreads();
+    const float4 c = cs[qi];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (it == 1 && !second) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 d = make_float4(v[it][k].x - c.x, v[it][k].y - c.y, v[it][k].z - c.z, v[it][k].w - c.w);
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+        }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
+        s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
+    }
+    if (lane < 8) { part[(wave * 8 + lane) * 2] = s1; part[(wave * 8 + lane) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 8) {
+        float4 a = part[tid * 2], q2 = part[tid * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < 3; ++w) {
+            const float4 x = part[(w * 8 + tid) * 2], y = part[(w * 8 + tid) * 2 + 1];
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            q2.x += y.x; q2.y += y.y; q2.z += y.z; q2.w += y.w;
+        }
+        *reinterpret_cast<float4 *>(p.psum + g) = a;
+        *reinterpret_cast<float4 *>(p.psq + g) = q2;
+        *reinterpret_cast<float4 *>(p.pshift + g) = c;
+    }
 }
 
 template <int NB>
@@ -229,7 +273,8 @@ __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
     const int Ho = 2 * p.Hs, Wo = 2 * p.Ws;
     const size_t npix = (size_t)p.B * Ho * Wo;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+        float4 vkeep[2][4];                                      // InstanceNorm plans: this thread's finished pixels of the channel block
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int item = tid + it * 192;                     // 256 (tile, channel quad) items per channel block over 192 threads
@@ -257,9 +302,14 @@ __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
                         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                         *reinterpret_cast<float4 *>(p.out + e) = v;
+                        vkeep[it][a * 2 + bb] = v;
                     }
                 }
         }
+        if (p.psum && p.splits == 1)
+            winoup_stats(p, reinterpret_cast<float4 *>(smem + winoup_stats_base(NB) / 4), vkeep, tid + 192 < 256, tid,
+                         ((size_t)b * (size_t)(p.tby * p.tbx) + (size_t)tbi) * p.N + (size_t)(n0 + nb * 32 + (tid & 7) * 4));
+    }
     if (p.splits == 1) return;
 
     // ---- split-K combine inside the launch: the protocol of wino.hip / igemm.hip (write-through slabs, drain, ticket, last arriver sums in z order)
@@ -272,7 +322,8 @@ __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
     if (flag[0] != (unsigned)p.splits - 1u) return;
     if (tid == 0) __hip_atomic_store(p.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+        float4 vkeep2[2][4];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int item = tid + it * 192;
@@ -301,8 +352,13 @@ __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4 *>(p.out + e) = v;
+                vkeep2[it][ab] = v;
             }
         }
+        if (p.psum)
+            winoup_stats(p, reinterpret_cast<float4 *>(smem + winoup_stats_base(NB) / 4), vkeep2, tid + 192 < 256, tid,
+                         ((size_t)b * (size_t)(p.tby * p.tbx) + (size_t)tbi) * p.N + (size_t)(n0 + nb * 32 + (tid & 7) * 4));
+    }
 }
 
 bool winoup_supported(const WinoUpParams &p, int nb)
