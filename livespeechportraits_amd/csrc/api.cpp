@@ -155,6 +155,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "all_forms") P.keep_all_forms = v != 0;
         else if (k == "blob_pad_kb") P.blob_pad_kb = v < 0 ? 0 : v;
         else if (k == "fused_splitk") h->fuse_splitk = v != 0;
+        else if (k == "fused_splitk16") P.fused_splitk16 = v != 0;
         else if (k == "prefetch") h->prefetch = v != 0;
         else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
         else if (k == "lastconv") h->last_route = v;                   // LastConvParams::route (0 = by shape)

@@ -574,7 +574,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 (*tiled)[li].wino = wino;
                 (*tiled)[li].wino4 = wino4;
                 (*tiled)[li].winoup = winoup;
-                (*tiled)[li].fused_splitk = (wino || wino4 || winoup) ? splits > 1 : p.dtype == 0 && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
+                (*tiled)[li].fused_splitk = (wino || wino4 || winoup) ? splits > 1 : (p.dtype == 0 || p.fused_splitk16) && !rowconv && !bandconv && !rowup && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
                                             (size_t)splits * Mout * l.cout * sizeof(float) < (size_t)0x7fffffff;
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
                 (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv; (*tiled)[li].rowup = rowup;
