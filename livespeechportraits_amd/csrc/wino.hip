@@ -28,7 +28,9 @@ namespace lspf2f {
 #ifdef LSPF2F_WINO_STAMPS
 #define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define WSTAMP_DECL unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+// slot 6 (the split-K ticket stamp) carries, when it is unused, where the wave ran: bit 63 | HW_REG_XCC_ID << 32 | HW_REG_HW_ID (wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13)
 #define WSTAMP_FLUSH do { if (p.stamps && lane == 0) { unsigned long long *q_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8; \
+    if (stamp_t[6] == 0) stamp_t[6] = (1ull << 63) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
     for (int i_ = 0; i_ < 8; ++i_) q_[i_] = stamp_t[i_]; } } while (0)
 #else
 #define WSTAMP(i) do {} while (0)

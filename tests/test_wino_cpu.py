@@ -336,3 +336,41 @@ def test_tune_string_reaches_the_library_and_unknown_keys_are_errors(monkeypatch
     out = subprocess.run(["grep", "-c", "getenv", *[os.path.join(ROOT, "livespeechportraits_amd", "csrc", f) for f in sorted(os.listdir(os.path.join(ROOT, "livespeechportraits_amd", "csrc"))) if f.endswith((".hip", ".cpp", ".h"))]],
                          capture_output=True, text=True).stdout
     assert sum(int(m) for m in re.findall(r":(\d+)$", out, re.M)) <= 1      # the one left is inside #ifdef LSPF2F_ABLATE (tools/ablate.sh builds)
+
+
+def test_stamp_tail_analysis_finds_a_slow_xcd():
+    """tools/wino_stamps.py: the placement-aware reading of a stamp build's output (which SIMDs end late, and is it a late start, a whole CU, a whole XCD or
+    scattered) on a synthetic launch: 512 workgroups, two per CU, four waves each on the four SIMDs, per-XCD counters with unrelated origins, XCD 3 slower."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wino_stamps", os.path.join(ROOT, "tools", "wino_stamps.py"))
+    ws = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ws)
+    rng = np.random.default_rng(0)
+    blocks, steps = 512, 16
+    raw = np.zeros((blocks, 4, 8), np.int64)
+    hw = np.zeros((blocks, 4), np.int64)
+    for b in range(blocks):
+        xcc, slot = b % 8, b // 8                                 # 64 workgroups per XCD = 32 CUs x 2
+        cu_lin, second = slot % 32, slot // 32
+        se, cu = cu_lin // 8, cu_lin % 8
+        origin = 1_000_000 * (xcc + 1) * 7                        # counters of different XCDs are not comparable
+        entry = origin + 300 * second + int(rng.integers(0, 200))
+        for w in range(4):
+            loop = steps * 2132 + (7000 if xcc == 3 else 0) + int(rng.integers(0, 300))
+            raw[b, w, 0] = entry
+            raw[b, w, 1] = entry + 1900
+            raw[b, w, 2] = entry + 4100
+            raw[b, w, 3] = entry + 4100 + loop
+            raw[b, w, 4] = raw[b, w, 3] + 1500
+            raw[b, w, 5] = raw[b, w, 4] + 3200
+            hw[b, w] = -(1 << 63) | (xcc << 32) | (se << 13) | (cu << 8) | (w << 4) | second     # bit 63 set, as WSTAMP_FLUSH leaves it
+    assert ws.place(hw)[0].max() == 7 and set(ws.place(hw)[4].ravel()) == {0, 1, 2, 3}
+    r = ws.tail_analysis(raw, hw, steps)
+    assert (r["xcds"], r["cus"], r["simds"]) == (8, 256, 1024) and r["waves_per_simd"] == {2: 1024}
+    assert r["entry_skew"]["max"] < 600                            # taken per XCD: the unrelated origins do not show
+    assert set(r["tail"]["slow_simds_per_xcd"]) == {3}             # the slow tenth sits on XCD 3 ...
+    hist = r["tail"]["slow_simds_per_cu_hist"]
+    assert sum(v for k, v in hist.items() if k >= 3) >= 0.6 * sum(hist.values())      # ... mostly as whole CUs, not scattered SIMDs
+    assert r["launch_cycles_per_xcd"][3] > r["launch_cycles_per_xcd"][0] + 6000
+    assert abs(r["tail"].get("corr_entry_vs_end", 0.0)) < 0.3      # not explained by a late start
+    assert 0.75 < r["simd_window"]["issue_share_median"] < 1.0     # 2 x 16 x 1024 issue cycles inside a ~34.4 k window
