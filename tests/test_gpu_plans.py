@@ -86,6 +86,18 @@ def test_bf16_batch8_full_size_every_frame(variant, gpu_device, oracle_b8):
     print("\n%s bf16 batch 8 vs fp32 oracle: per-frame max-abs %s | mean-abs %s (declared %.0e / %.1e)" % (
         variant, " ".join("%.1e" % v for v in per.max(1)), " ".join("%.1e" % v for v in per.mean(1)), tol_max, tol_mean))
     assert (per.max(1) <= tol_max).all() and (per.mean(1) <= tol_mean).all()
+    if variant == "normal":
+        # the tune key fused_splitk16 (A-B switch: the 2..8-way K-splits of 16-bit plans combined inside the igemm launch; measured 1.1 % slower, off by default,
+        # profiles/r04_bf16_fused_splitk_ab.txt): the same declared tolerance; the two arms differ by bf16 roundings (2.0e-4 on outputs of magnitude 0.1 in the A-B run)
+        f = Engine(variant, size=512, max_batch=8, dtype="bf16", tune={"fused_splitk16": 1})
+        assert sum("combined in the launch" in l["kernel"] for l in f.layers(8)) == 10 and not any("combined in the launch" in l["kernel"] for l in e.layers(8))
+        f.load_state_dict(sd)
+        f.bind(f.pack(), gpu_device)
+        out2 = f.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)).cpu().numpy()
+        per2 = np.abs(out2 - ref).reshape(8, -1)
+        print("   fused_splitk16=1: per-frame max-abs %s; vs the default arm %.1e" % (" ".join("%.1e" % v for v in per2.max(1)), np.abs(out2 - out).max()))
+        assert (per2.max(1) <= tol_max).all() and (per2.mean(1) <= tol_mean).all() and np.abs(out2 - out).max() <= 2 * tol_max
+        f.close()
 
 
 @pytest.mark.parametrize("variant", ["normal", "large"])
