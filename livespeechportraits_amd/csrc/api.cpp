@@ -156,6 +156,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "blob_pad_kb") P.blob_pad_kb = v < 0 ? 0 : v;
         else if (k == "fused_splitk") h->fuse_splitk = v != 0;
         else if (k == "fused_splitk16") P.fused_splitk16 = v != 0;
+        else if (k == "out_wt") P.out_wt = v;
         else if (k == "prefetch") h->prefetch = v != 0;
         else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
         else if (k == "lastconv") h->last_route = v;                   // LastConvParams::route (0 = by shape)
@@ -490,6 +491,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.u = bptr(l.wwu_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.N = l.cout; p.relu = l.inorm ? 0 : l.relu; p.splits = l.splits;
+        p.out_wt = P.out_wt;
         if (l.splits > 1) {
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
@@ -532,7 +534,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
-        p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1; p.ureg = P.wino_ureg ? 1 : 0;
+        p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1; p.ureg = P.wino_ureg ? 1 : 0; p.out_wt = P.out_wt;
         if (l.inorm && l.in_route == kInWino) {
             // the kernel's epilogue (or its split-K combine) leaves the sums of every tile-block of 128 pixels: finalize + normalise only
             float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);

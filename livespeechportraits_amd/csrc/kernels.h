@@ -119,6 +119,7 @@ struct WinoParams {
     // instead of between them; the four MFMAs of an accumulator back to back instead of rotating over the accumulators
     int nopre, xcd_force, no_il, no_rot;
     int ureg;                   // one channel block per wave: U fragments by plain loads into registers instead of LDS-DMA + ds_read (wino.hip, UR form)
+    int out_wt;                 // tune key `out_wt`: the output leaves through write-through (sc1) stores (wino.hip WT instances; A-B runs)
     float *psum, *psq, *pshift; // InstanceNorm plans: per (frame, tile-block, channel) sums of (x - c), (x - c)^2 and the shift c (the tile-block's first pixel) of the
                                 // 128 output pixels a workgroup writes, [B][tile-blocks per frame][N]; nullptr = no statistics (see instnorm.hip)
     // filled by launch_wino
@@ -148,6 +149,7 @@ struct WinoUpParams {
     float *partial;               // splits > 1: fp32 slabs [splits][B*4*Hs*Ws][N]
     unsigned *tile_cnt;           // splits > 1: arrival counters, zero between launches
     int B, Hs, Ws, C0, C1, N, relu, splits;
+    int out_wt;                   // tune key `out_wt`: write-through output stores (winoup3x3<NB, true>)
     float *psum, *psq, *pshift;   // InstanceNorm plans: per (frame, tile-block, channel) sums over the 128 output pixels a workgroup writes, as in WinoParams; nullptr = none
     // filled by launch_winoup
     int steps_per_split, ntb, nng, tby, tbx, nmajor;

@@ -102,6 +102,7 @@ struct Plan {
     bool use_wino4 = false;    // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSPF2F_FLAG_WINO4; measured slower at batch 1 and
                                // equal at batch 8, DESIGN.md 4.11, so off by default); decides whether the blob carries the 6x6 transformed weights
     bool in_wino_stats = true;   // `in_wino_stats`: InstanceNorm plans take a wino3x3 layer's statistics from its epilogue instead of a pass over its output
+    int out_wt = 0;              // `out_wt`: 1 = wino3x3 / winoup3x3 write their output through (sc1 stores) instead of leaving it dirty in L2 for the end-of-kernel write-back (A-B, round 5)
     bool fused_splitk16 = false; // `fused_splitk16`: 16-bit plans combine 2..8 K-splits inside the igemm launch like the fp32 plans do (off until measured: round 5)
     bool wino_ureg = true;       // `wino_ureg`: wino3x3<1> keeps its U fragments in registers (wino.hip UR form)
     bool wino_pre = true, wino_il = true, wino_rot = true;   // tools (`wino_pre` / `wino_il` / `wino_rot` of lspf2f_create_tuned): A-B switches of wino3x3

@@ -359,7 +359,9 @@ __device__ __forceinline__ void wino_stats(const WinoParams &p, float4 *scratch,
     }
 }
 
-template <int NB, int NS, bool IL, bool ROT, bool UR = false>
+// WT (tune key `out_wt`, A-B runs of round 5): the finished output leaves through write-through (sc1) buffer stores instead of plain ones, so that it is not left
+// dirty in the XCD's L2 for the end-of-kernel write-back (the guide prices a dependent boundary at + B / 6 TB/s behind B dirty bytes)
+template <int NB, int NS, bool IL, bool ROT, bool UR = false, bool WT = false>
 __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
     __syncthreads();
     WSTAMP(4);
     const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.splits > 1 ? (int)p.slab_bytes : 0, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, WT ? (int)((size_t)p.B * p.H * p.W * p.N * 4) : 0, 0x00020000);   // <= 2 GB: wino_supported
     const size_t npix = (size_t)p.B * p.H * p.W;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -534,7 +537,8 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
                     if (!pre && p.residual) rv = *reinterpret_cast<const float4 *>(p.residual + e);
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *reinterpret_cast<float4 *>(p.out + e) = v;
+                    if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (unsigned)(e * 4), 0, 16);
+                    else *reinterpret_cast<float4 *>(p.out + e) = v;
                     vst[a * 2 + bb] = v;
                 }
             }
@@ -601,7 +605,8 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
             const float4 rv = rv2[nb][ab];
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4 *>(p.out + e) = v;
+            if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (unsigned)(e * 4), 0, 16);
+            else *reinterpret_cast<float4 *>(p.out + e) = v;
             vst2[ab] = v;
         }
         if (p.psum) wino_stats(p, reinterpret_cast<float4 *>(smem + wino_stats_base(NB, NS, UR) / 4), vst2, tid, ((size_t)b * (size_t)(p.tby * p.tbx) + (size_t)tbi) * p.N + n);
@@ -622,17 +627,17 @@ bool wino_supported(const WinoParams &p, int nb)
     return true;
 }
 
-template <int NB, int NS, bool IL, bool ROT, bool UR = false>
+template <int NB, int NS, bool IL, bool ROT, bool UR = false, bool WT = false>
 static hipError_t launch_wino_t(const WinoParams &q, hipStream_t s)
 {
     constexpr int smem = wino_lds_bytes(NB, NS, UR);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, ROT, UR>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3x3<NB, NS, IL, ROT, UR, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL((wino3x3<NB, NS, IL, ROT, UR>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wino3x3<NB, NS, IL, ROT, UR, WT>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(256), smem, s, q);
     return hipGetLastError();
 }
 
@@ -662,6 +667,10 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     // MFMAs of an accumulator back to back instead of rotating over the four accumulators of a channel block
     if (p.no_il) return nb == 2 ? launch_wino_t<2, 2, false, false>(p, s) : launch_wino_t<1, 2, false, false>(p, s);
     if (p.no_rot) return nb == 2 ? launch_wino_t<2, 2, true, false>(p, s) : launch_wino_t<1, 3, true, false>(p, s);
+    if (p.out_wt) {
+        if (nb == 1 && p.ureg) return launch_wino_t<1, 3, true, true, true, true>(p, s);
+        return nb == 2 ? launch_wino_t<2, 2, true, true, false, true>(p, s) : launch_wino_t<1, 3, true, true, false, true>(p, s);
+    }
     if (nb == 1 && p.ureg) return launch_wino_t<1, 3, true, true, true>(p, s);
     return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);
 }

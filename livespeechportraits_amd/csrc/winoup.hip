@@ -166,7 +166,7 @@ __device__ __forceinline__ void winoup_stats(const WinoUpParams &p, float4 *scra
     }
 }
 
-template <int NB>
+template <int NB, bool WT = false>      // WT: write-through output stores (tune key `out_wt`, see wino.hip)
 __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.splits > 1 ? (int)p.slab_bytes : 0, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, WT ? (int)((size_t)p.B * 4 * p.Hs * p.Ws * p.N * 4) : 0, 0x00020000);   // <= 2 GB: launch_winoup
     const int Ho = 2 * p.Hs, Wo = 2 * p.Ws;
     const size_t npix = (size_t)p.B * Ho * Wo;
 #pragma unroll
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
                     } else {
                         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                        *reinterpret_cast<float4 *>(p.out + e) = v;
+                        if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (unsigned)(e * 4), 0, 16);
+                        else *reinterpret_cast<float4 *>(p.out + e) = v;
                         vkeep[it][a * 2 + bb] = v;
                     }
                 }
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(192, 2) void winoup3x3(const WinoUpParams p)
                     if (sl < p.splits) { v.x += tsl[sl].x; v.y += tsl[sl].y; v.z += tsl[sl].z; v.w += tsl[sl].w; }
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4 *>(p.out + e) = v;
+                if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (unsigned)(e * 4), 0, 16);
+                else *reinterpret_cast<float4 *>(p.out + e) = v;
                 vkeep2[it][ab] = v;
             }
         }
@@ -372,17 +375,17 @@ bool winoup_supported(const WinoUpParams &p, int nb)
     return true;
 }
 
-template <int NB>
+template <int NB, bool WT = false>
 static hipError_t launch_winoup_t(const WinoUpParams &q, hipStream_t s)
 {
     constexpr int smem = winoup_lds_bytes(NB);
     static AttrMask attr_mask;
     if (smem > 64 * 1024 && attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&winoup3x3<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&winoup3x3<NB, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    hipLaunchKernelGGL(winoup3x3<NB>, dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(192), smem, s, q);
+    hipLaunchKernelGGL((winoup3x3<NB, WT>), dim3((unsigned)(q.ntb * q.nng * q.splits)), dim3(192), smem, s, q);
     return hipGetLastError();
 }
 
@@ -403,6 +406,7 @@ hipError_t launch_winoup(const WinoUpParams &p_in, int nb, hipStream_t s)
     p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
     p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));
     p.div_tbx = FastDiv::make((unsigned)p.tbx);
+    if (p.out_wt && (size_t)p.B * 4 * p.Hs * p.Ws * p.N * 4 <= 0x7fffffffull) return nb == 2 ? launch_winoup_t<2, true>(p, s) : launch_winoup_t<1, true>(p, s);
     return nb == 2 ? launch_winoup_t<2>(p, s) : launch_winoup_t<1>(p, s);
 }
 

@@ -7,7 +7,8 @@ import subprocess
 import sys
 
 
-KERNEL = "_ZN6lspf2f7wino3x3ILi1ELi3ELb1ELb1ELb1E"          # wino3x3<1, 3, true, true, UR = true>
+KERNEL = "_ZN6lspf2f7wino3x3ILi1ELi3ELb1ELb1ELb1ELb0E"      # wino3x3<1, 3, true, true, UR = true, WT = false>
+KERNEL_WT = "_ZN6lspf2f7wino3x3ILi1ELi3ELb1ELb1ELb1ELb1E"   # ... with write-through output stores (tune key out_wt)
 
 
 def compile_to_asm(src, hipcc="hipcc"):
@@ -86,7 +87,7 @@ def check(lines):
 
 
 KERNELS = {                      # file -> [(mangled prefix, U registers, MFMAs, loads)]
-    "wino.hip": [(KERNEL, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4))],
+    "wino.hip": [(KERNEL, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4)), (KERNEL_WT, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4))],
 }
 
 
