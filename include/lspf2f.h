@@ -105,7 +105,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
 /* The same with the A-B switches of tools, tests and measurements: `tune` = "key=value,key=value" (integers; NULL or "" = none; an unknown
  * key is LSPF2F_ERR_INVALID_ARGUMENT).  The library never reads the process environment -- every switch arrives here, once per handle,
  * before the plan is built.  Keys (default): graph (1) | wino (1), wino4 (flag), winoup (1): the Winograd kernels | wino_ureg (1:
- * U fragments of wino3x3<1> in registers), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
+ * U fragments of wino3x3<1> in registers; 2: four register sets), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
  * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, rowup (1), rowlast (1), rowconv (1): kernels of the 16-bit plans |
  * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), fused_splitk16 (0: the 16-bit plans combine 2..8 K-splits in the launch too), out_wt (0; 1: the Winograd kernels write their output through to memory, sc1 stores), prefetch (1) |
  * lastconv (0 = by shape; 1..5 force a last-conv kernel), lastconv_direct (0), firstconv (0 = by shape; 1, 2 force a first-conv kernel). */
@@ -236,7 +236,8 @@ int lspf2f_subset_timed(lspf2f_handle *h, const float *feat_dev, const float *ca
  *   [cout/32][xi-row 4][c0/8][j 4][64 lanes][4] (lane l: output channel 32 nblock + (l & 31), input channels 8 s + 4 (l >> 5) .. + 3, the copy
  *   the packer adds for those layers); split_k = K slices (1..8, 0 = 1) combined inside the launch -- the scratch then holds the slabs
  *   followed by one arrival counter per (tile-block, channel group), which must be ZERO on entry and is left zero.  4003 = 4001 with the wave's U
- *   fragments loaded straight into registers instead of through LDS (the form the plans take; same operands, same results bit for bit).
+ *   fragments loaded straight into registers instead of through LDS (the form the plans take; same operands, same results bit for bit); 4004 = 4003 with four
+ *   register sets instead of three (operands requested three K-steps ahead; tune key wino_ureg=2).
  *   k_group == -4 (fp32, any tile, stride 1, one source of 4 ci channels, ci a multiple of 32): the 3x3 conv on a SPACE-TO-DEPTH image that equals Conv2d(k4, s2, p1)
  *   (channel (dy * 2 + dx) * ci + c of pixel (y, x) = channel c of pixel (2y + dy, 2x + dx)); only 16 of the 36 (tap, quarter) pairs carry weights, and w_packed holds
  *   just those: [cout][live pairs in tap-major, quarter-minor order][ci] -- 16/36 of the matrix work of the dense form (the `small` U-Net's down-convs).

@@ -136,7 +136,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "wino_pre") P.wino_pre = v != 0;
         else if (k == "wino_xcd") P.wino_xcd = v;
         else if (k == "wino_il") P.wino_il = v != 0;
-        else if (k == "wino_ureg") P.wino_ureg = v != 0;
+        else if (k == "wino_ureg") P.wino_ureg = v;
         else if (k == "in_wino_stats") P.in_wino_stats = v != 0;
         else if (k == "wino_rot") P.wino_rot = v != 0;
         else if (k == "winoup") P.use_winoup = v != 0;
@@ -534,7 +534,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
-        p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1; p.ureg = P.wino_ureg ? 1 : 0; p.out_wt = P.out_wt;
+        p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1; p.ureg = P.wino_ureg; p.out_wt = P.out_wt;
         if (l.inorm && l.in_route == kInWino) {
             // the kernel's epilogue (or its split-K combine) leaves the sums of every tile-block of 128 pixels: finalize + normalise only
             float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
@@ -864,8 +864,8 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
         if (sp == 1) return 0;
         return (size_t)sp * batch * hs * ws * cout * sizeof(float) + (size_t)batch * (hs / 16) * (ws / 32) * (cout / 32) * sizeof(unsigned);
     }
-    if ((tile_m == 4001 || tile_m == 4002 || tile_m == 4003) && k_group == -1) {      // Winograd kernel: slabs + one arrival counter per (tile-block, channel group)
-        if (tile_m == 4003) tile_m = 4001;                           // (the register form of nb = 1)
+    if ((tile_m == 4001 || tile_m == 4002 || tile_m == 4003 || tile_m == 4004) && k_group == -1) {      // Winograd kernel: slabs + one arrival counter per (tile-block, channel group)
+        if (tile_m == 4003 || tile_m == 4004) tile_m = 4001;         // (the register forms of nb = 1)
         const int sp = split_k > 0 ? split_k : 1;
         if (sp == 1) return 0;
         return (size_t)sp * batch * hs * ws * cout * sizeof(float) + (size_t)batch * (hs / 8) * (ws / 16) * (cout / (32 * (tile_m - 4000))) * sizeof(unsigned);
@@ -900,7 +900,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     const int ktc = dtype ? 64 : 32;
     if (!src0 || !w_packed || !out) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (hs != ws) return fail(LSPF2F_ERR_UNSUPPORTED, "square tensors only");
-    const bool wino_tile = (tile_m == 4001 || tile_m == 4002 || tile_m == 4003 || tile_m == 5001 || tile_m == 5002 || tile_m == 6001) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
+    const bool wino_tile = (tile_m == 4001 || tile_m == 4002 || tile_m == 4003 || tile_m == 4004 || tile_m == 5001 || tile_m == 5002 || tile_m == 6001) && k_group == -1;     // its K-step is 8 channels, checked by wino_supported()
     if (!wino_tile && ((c0 % ktc) || (c1 % ktc) || c0 <= 0 || c1 < 0 || (c1 > 0 && !src1)))
         return fail(LSPF2F_ERR_UNSUPPORTED, "channel counts must be multiples of 32 (fp32) / 64 (bf16, fp16)");
     if (cout % 4) return fail(LSPF2F_ERR_UNSUPPORTED, "cout must be a multiple of 4");
@@ -981,8 +981,8 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (wino4) launch");
             return LSPF2F_OK;
         }
-        if ((tile_m == 4001 || tile_m == 4002 || tile_m == 4003) && k_group == -1) {   // 4000 + nb: the Winograd kernel, w_packed in its fragment order; split_k = K splits (0: 1)
-            const bool ureg = tile_m == 4003;           // 4003: nb = 1 with the U fragments in registers (the form the plans take), 4001: through LDS
+        if ((tile_m == 4001 || tile_m == 4002 || tile_m == 4003 || tile_m == 4004) && k_group == -1) {   // 4000 + nb: the Winograd kernel, w_packed in its fragment order; split_k = K splits (0: 1)
+            const int ureg = tile_m == 4003 ? 1 : tile_m == 4004 ? 2 : 0;      // 4003: nb = 1 with the U fragments in registers (the form the plans take; 4004: four register sets), 4001: through LDS
             if (ureg) tile_m = 4001;
             const int sp = split_k > 0 ? split_k : 1;
             const size_t slab = sp > 1 ? (size_t)sp * batch * hs * ws * cout * sizeof(float) : 0;
@@ -990,7 +990,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             WinoParams q{};
             q.src = static_cast<const float *>(src0); q.u = static_cast<const float *>(w_packed); q.scale = scale; q.shift = shift;
             q.residual = static_cast<const float *>(residual); q.out = static_cast<float *>(out);
-            q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.N = cout; q.relu = relu; q.splits = sp; q.ureg = ureg ? 1 : 0;
+            q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.N = cout; q.relu = relu; q.splits = sp; q.ureg = ureg;
             if (sp > 1) {
                 if (!scratch || scratch_bytes < slab + ncnt * sizeof(unsigned)) return fail(LSPF2F_ERR_STATE, "split-K scratch missing or too small");
                 q.partial = static_cast<float *>(scratch);

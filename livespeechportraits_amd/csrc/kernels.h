@@ -118,7 +118,7 @@ struct WinoParams {
     // (0 dispatch order, 1 tile-block-major, 2 channel-group-major) instead of by operand size; copies as one block ahead of the MFMAs
     // instead of between them; the four MFMAs of an accumulator back to back instead of rotating over the accumulators
     int nopre, xcd_force, no_il, no_rot;
-    int ureg;                   // one channel block per wave: U fragments by plain loads into registers instead of LDS-DMA + ds_read (wino.hip, UR form)
+    int ureg;                   // one channel block per wave: U fragments by plain loads into registers instead of LDS-DMA + ds_read (wino.hip, UR form); 2: four register sets
     int out_wt;                 // tune key `out_wt`: the output leaves through write-through (sc1) stores (wino.hip WT instances; A-B runs)
     float *psum, *psq, *pshift; // InstanceNorm plans: per (frame, tile-block, channel) sums of (x - c), (x - c)^2 and the shift c (the tile-block's first pixel) of the
                                 // 128 output pixels a workgroup writes, [B][tile-blocks per frame][N]; nullptr = no statistics (see instnorm.hip)

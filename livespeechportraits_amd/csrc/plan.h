@@ -104,7 +104,7 @@ struct Plan {
     bool in_wino_stats = true;   // `in_wino_stats`: InstanceNorm plans take a wino3x3 layer's statistics from its epilogue instead of a pass over its output
     int out_wt = 0;              // `out_wt`: 1 = wino3x3 / winoup3x3 write their output through (sc1 stores) instead of leaving it dirty in L2 for the end-of-kernel write-back (A-B, round 5)
     bool fused_splitk16 = false; // `fused_splitk16`: 16-bit plans combine 2..8 K-splits inside the igemm launch like the fp32 plans do (off until measured: round 5)
-    bool wino_ureg = true;       // `wino_ureg`: wino3x3<1> keeps its U fragments in registers (wino.hip UR form)
+    int wino_ureg = 1;           // `wino_ureg`: wino3x3<1> keeps its U fragments in registers (wino.hip UR form: 1 = three register sets, two steps ahead; 2 = four sets, A-B arm)
     bool wino_pre = true, wino_il = true, wino_rot = true;   // tools (`wino_pre` / `wino_il` / `wino_rot` of lspf2f_create_tuned): A-B switches of wino3x3
     int wino_xcd = -1, igemm_xcd = -1;                       // tools: forced block orders (-1 = by operand size)
     int winoup_nb = 0, winoup_target = 1024;   // tools (tune keys `winoup_nb` / `winoup_target`): force the channel blocks per wave / the workgroup count aimed at

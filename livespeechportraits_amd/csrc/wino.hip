@@ -240,10 +240,13 @@ __device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, con
 // move above their arrival.  What the compiler must NOT do is copy such a register while its load is in flight (a tied "+v" operand on the wait
 // makes it do exactly that): tests/test_wino_cpu.py checks the generated code for moves out of the three register sets.
 
-template <int ROW, int EPL, class EpiLoads>
-__device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, 3, true> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][1], const char *smem_c, int lane,
+// NS = register sets = ring slots of the raw patch = how far ahead a step's operands are requested (NS - 1 steps): 3 is the shipped form, 4 (tune key
+// `wino_ureg=2`, 16 more registers) an A-B arm of round 5 for the waves whose loads take longer than two steps.
+template <int ROW, int EPL, int NS, class EpiLoads>
+__device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][1], const char *smem_c, int lane,
                                              int ks_begin, int ks_end, unsigned long long *first_landed)
 {
+    static_assert(NS == 3 || NS == 4, "register sets");
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
     const int r = lane & 31, q = lane >> 5, ty = r >> 3, tx = r & 7;
     unsigned araw[2][4];
@@ -258,12 +261,12 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, 3, true> &cp, con
     }
     // The three register sets.  Requests, loop and uses stay inside this function (one per wave row): across the kernel's switch hipcc gives the sets
     // other registers per branch and copies them at the branch -- in flight.
-    f32x4v ur[3][4];
+    f32x4v ur[NS][4];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < NS; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(ur[a][j]));      // "defined" without an instruction: no write may trail the first load
-    // steps 0 and 1 requested first; behind them the kernel's EPL epilogue-operand loads (see wino_loop)
+    // steps 0 .. NS - 2 requested first; behind them the kernel's EPL epilogue-operand loads (see wino_loop)
     const int nsteps = ks_end - ks_begin;
     cp.raw(ks_begin, 0);
     cp.template ureg2<0>(ur[0], ks_begin); cp.template ureg2<1>(ur[0], ks_begin);
@@ -271,22 +274,30 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, 3, true> &cp, con
         cp.raw(ks_begin + 1, 1);
         cp.template ureg2<0>(ur[1], ks_begin + 1); cp.template ureg2<1>(ur[1], ks_begin + 1);
     }
+    if constexpr (NS == 4) {
+        if (nsteps > 2) {
+            cp.raw(ks_begin + 2, 2);
+            cp.template ureg2<0>(ur[2], ks_begin + 2); cp.template ureg2<1>(ur[2], ks_begin + 2);
+        }
+    }
     epi_loads();
-    if (nsteps > 1) dma_wait<6 + EPL>(); else dma_wait<EPL>();
+    // step 0 has landed when only the younger loads can be outstanding: 6 per further requested step + the epilogue operands
+    if (NS == 4 && nsteps > 2) dma_wait<12 + EPL>(); else if (nsteps > 1) dma_wait<6 + EPL>(); else dma_wait<EPL>();
     __syncthreads();
 #ifdef LSPF2F_WINO_STAMPS
     *first_landed = __builtin_amdgcn_s_memtime();
 #endif
-    // one K-step on register set S (= ring slot of the raw patch); the loads of step t + 2 go into set (S + 2) % 3, last read in step t - 1
+    // one K-step on register set S (= ring slot of the raw patch); the loads of step t + NS - 1 go into set (S + NS - 1) % NS, last read in step t - 1
+    constexpr int AHEAD = NS - 1;
     auto step = [&](auto Sc, int t) {
-        constexpr int S = decltype(Sc)::value, S2 = (S + 2) % 3;
+        constexpr int S = decltype(Sc)::value, S2 = (S + AHEAD) % NS;
         const char *rawp = smem_c + S * kRawStage;
         float4 d[2][4];
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) d[k][dx] = *reinterpret_cast<const float4 *>(rawp + araw[k][dx]);
-        const bool issue = t + 2 < nsteps;
+        const bool issue = t + AHEAD < nsteps;
         float4 tt[4], v[4];
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
@@ -303,19 +314,24 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, 3, true> &cp, con
                 acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ur[S][j][c], acc[j][0], 0, 0, 0);
             }
             if (issue) {
-                if (c == 0) cp.raw(ks_begin + t + 2, S2);
-                if (c == 1) cp.template ureg2<0>(ur[S2], ks_begin + t + 2);
-                if (c == 2) cp.template ureg2<1>(ur[S2], ks_begin + t + 2);
+                if (c == 0) cp.raw(ks_begin + t + AHEAD, S2);
+                if (c == 1) cp.template ureg2<0>(ur[S2], ks_begin + t + AHEAD);
+                if (c == 2) cp.template ureg2<1>(ur[S2], ks_begin + t + AHEAD);
             }
         }
-        // step t + 1 has landed: everything but the six loads issued in THIS iteration (this wave's; the barrier covers the other waves' raw pieces)
-        if (issue) dma_wait<6>(); else dma_wait<0>();
+        // step t + 1 has landed: everything but the loads of the steps behind it -- six per step (this wave's; the barrier covers the other waves' raw pieces)
+        if constexpr (NS == 3) {
+            if (issue) dma_wait<6>(); else dma_wait<0>();
+        } else {
+            if (issue) dma_wait<12>(); else if (t + 2 < nsteps) dma_wait<6>(); else dma_wait<0>();
+        }
         __syncthreads();
     };
-    for (int t = 0; t < nsteps; t += 3) {                   // (one exit: with a break per step hipcc copies the accumulators between register sets)
+    for (int t = 0; t < nsteps; t += NS) {                  // (one exit: with a break per step hipcc copies the accumulators between register sets)
         step(IntC<0>{}, t);
         if (t + 1 < nsteps) step(IntC<1>{}, t + 1);
         if (t + 2 < nsteps) step(IntC<2>{}, t + 2);
+        if constexpr (NS == 4) { if (t + 3 < nsteps) step(IntC<3>{}, t + 3); }
     }
 }
 
@@ -464,12 +480,12 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
     if constexpr (UR) {
-        static_assert(NB == 1 && NS == 3, "the register form exists for one channel block per wave");
+        static_assert(NB == 1 && (NS == 3 || NS == 4), "the register form exists for one channel block per wave");
         switch (wave) {
-        case 0: wino_loop_ur<0, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
-        case 1: wino_loop_ur<1, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
-        case 2: wino_loop_ur<2, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
-        default: wino_loop_ur<3, EPL>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        case 0: wino_loop_ur<0, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        case 1: wino_loop_ur<1, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        case 2: wino_loop_ur<2, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        default: wino_loop_ur<3, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
         }
     } else {
         switch (wave) {
@@ -671,6 +687,7 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
         if (nb == 1 && p.ureg) return launch_wino_t<1, 3, true, true, true, true>(p, s);
         return nb == 2 ? launch_wino_t<2, 2, true, true, false, true>(p, s) : launch_wino_t<1, 3, true, true, false, true>(p, s);
     }
+    if (nb == 1 && p.ureg == 2) return launch_wino_t<1, 4, true, true, true>(p, s);       // four register sets (A-B arm)
     if (nb == 1 && p.ureg) return launch_wino_t<1, 3, true, true, true>(p, s);
     return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);
 }

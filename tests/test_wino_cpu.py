@@ -374,3 +374,55 @@ def test_stamp_tail_analysis_finds_a_slow_xcd():
     assert r["launch_cycles_per_xcd"][3] > r["launch_cycles_per_xcd"][0] + 6000
     assert abs(r["tail"].get("corr_entry_vs_end", 0.0)) < 0.3      # not explained by a late start
     assert 0.75 < r["simd_window"]["issue_share_median"] < 1.0     # 2 x 16 x 1024 issue cycles inside a ~34.4 k window
+
+
+def _ur_loop_model(nsteps, ns, epl):
+    """The request / wait protocol of wino_loop_ur<ROW, EPL, NS> (csrc/wino.hip) as a queue model: a wave's loads complete in issue order, `wait(n)` = s_waitcnt
+    vmcnt(n) returns once at most n are outstanding.  Returns, per step, the loads still in flight when its MFMAs start (none of them may be its own) and the ring
+    slot / register set it reads and the one it refills."""
+    q, log = [], []
+    wait = lambda n: q.__delitem__(slice(0, max(0, len(q) - n)))
+    issue = lambda step: q.extend([("s", step)] * 6)              # 2 raw-patch pieces + 4 U fragments
+    issue(0)
+    if nsteps > 1:
+        issue(1)
+    if ns == 4 and nsteps > 2:
+        issue(2)
+    q.extend([("e", -1)] * epl)                                    # epilogue operands, requested behind the first steps
+    wait(12 + epl if ns == 4 and nsteps > 2 else 6 + epl if nsteps > 1 else epl)
+    ahead = ns - 1
+    t = 0
+    while t < nsteps:
+        for s in range(ns):
+            if t + s >= nsteps:
+                break
+            cur = t + s
+            assert cur % ns == s
+            inflight = [x for x in q if x == ("s", cur)]
+            will_issue = cur + ahead < nsteps
+            log.append((cur, len(inflight), s, (s + ahead) % ns if will_issue else None))
+            if will_issue:
+                issue(cur + ahead)
+            if ns == 3:
+                wait(6 if will_issue else 0)
+            else:
+                wait(12 if will_issue else 6 if cur + 2 < nsteps else 0)
+            # after the wait (and the barrier): step cur + 1 must have landed
+            assert not [x for x in q if x == ("s", cur + 1)], (nsteps, ns, cur, q)
+        t += ns
+    assert not [x for x in q if x[0] == "s"]                      # nothing of the K loop is left in flight behind it
+    return log
+
+
+def test_register_form_wait_protocol_for_three_and_four_sets():
+    """every step's operands have landed when its MFMAs start, the set it refills is the one read one step earlier, nothing is left in flight at the end -- for the
+    shipped three-set form and the four-set A-B arm (tile 4004 / wino_ureg=2), any step count (split-K slices of 2..64 steps), any number of epilogue loads"""
+    for ns in (3, 4):
+        for nsteps in range(1, 40):
+            for epl in (0, 6, 12):
+                log = _ur_loop_model(nsteps, ns, epl)
+                assert [l[0] for l in log] == list(range(nsteps))
+                assert all(l[1] == 0 for l in log), (ns, nsteps, epl, log)               # own loads landed
+                for cur, _, s, refill in log:
+                    if refill is not None:
+                        assert refill == (cur + ns - 1) % ns and refill == (cur - 1) % ns    # the set / slot last read in step cur - 1

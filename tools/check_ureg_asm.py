@@ -8,6 +8,7 @@ import sys
 
 
 KERNEL = "_ZN6lspf2f7wino3x3ILi1ELi3ELb1ELb1ELb1ELb0E"      # wino3x3<1, 3, true, true, UR = true, WT = false>
+KERNEL_NS4 = "_ZN6lspf2f7wino3x3ILi1ELi4ELb1ELb1ELb1ELb0E"  # four register sets, three steps ahead (tune key wino_ureg=2)
 KERNEL_WT = "_ZN6lspf2f7wino3x3ILi1ELi3ELb1ELb1ELb1ELb1E"   # ... with write-through output stores (tune key out_wt)
 
 
@@ -87,7 +88,8 @@ def check(lines):
 
 
 KERNELS = {                      # file -> [(mangled prefix, U registers, MFMAs, loads)]
-    "wino.hip": [(KERNEL, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4)), (KERNEL_WT, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4))],
+    "wino.hip": [(KERNEL, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4)), (KERNEL_WT, 48, 4 * 3 * 16, 4 * (2 * 4 + 3 * 4)),
+                 (KERNEL_NS4, 64, 4 * 4 * 16, 4 * (3 * 4 + 4 * 4))],
 }
 
 

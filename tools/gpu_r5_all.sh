@@ -4,4 +4,5 @@
 cd $GRAFT_REPO_ROOT
 bash tools/gpu_r5_outwt.sh
 bash tools/gpu_r5_env.sh
+bash tools/gpu_r5_ur4.sh
 bash tools/gpu_r5_tail.sh

@@ -5,7 +5,7 @@
 set -e
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r5tail; mkdir -p $OUT
 make -C livespeechportraits_amd/csrc -B -j32 CXXFLAGS="-O3 -std=c++17 -fPIC -DLSPF2F_WINO_STAMPS" > $OUT/build.log 2>&1
-for a in "128 128 3 1" "128 128 3 1" "64 256 2 1" "256 64 3 2" "512 32 3 4" "64 256 2 1 8"; do
+for a in "128 128 3 1" "128 128 4 1" "128 128 3 1" "64 256 2 1" "256 64 3 2" "512 32 3 4" "64 256 2 1 8"; do
   timeout 120 python tools/wino_stamps.py $a 2>&1 | grep -v amdgpu.ids
 done | tee $OUT/stamps.txt
 make -C livespeechportraits_amd/csrc -B -j32 > $OUT/rebuild.log 2>&1

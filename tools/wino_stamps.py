@@ -90,8 +90,8 @@ def tail_report(raw, hw, steps):
 def main():
     c, h, nb, sp = [int(a) for a in sys.argv[1:5]]
     b = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-    tile = 4000 + nb                                         # nb = 3: tile 4003, one channel block per wave with the U fragments in registers
-    if nb == 3:
+    tile = 4000 + nb                                         # nb = 3: tile 4003, one channel block per wave with the U fragments in registers; 4: tile 4004, four register sets
+    if nb in (3, 4):
         nb = 1
     lib, dev = N.load(), torch.device("cuda:0")
     x = torch.randn(b, h, h, c, device=dev)
@@ -126,7 +126,7 @@ def main():
     t = raw.astype(np.float64)
     names = ["entry", "prologue done (descriptors, epilogue operands requested)", "first step landed + barrier", "K loop done", "Z patch written + barrier",
              "epilogue stores issued", "ticket taken (split-K)", "combine done (last arriver)"]
-    print("c%d h%d nb%d%s splits %d batch %d: %d workgroups, %.1f us per launch (eager, weights warm)" % (c, h, nb, " (U in registers)" if tile == 4003 else "", sp, b, blocks, us))
+    print("c%d h%d nb%d%s splits %d batch %d: %d workgroups, %.1f us per launch (eager, weights warm)" % (c, h, nb, " (U in registers)" if tile == 4003 else " (U in registers, four sets)" if tile == 4004 else "", sp, b, blocks, us))
     d = t - t[:, :, :1]
     for i, n_ in enumerate(names):
         col = d[:, :, i][t[:, :, i] != 0]
