@@ -72,6 +72,20 @@ def self_launch(n):
     sys.exit(rc)
 
 
+def leave_group():
+    """Tear the process group down without ever holding the job: the other ranks leave as soon as their part is done (rank 0 goes on alone with the roofline and CPU
+    legs for a minute), and a backend teardown that waits for a peer that has already gone must not keep a finished measurement from returning -- a watchdog ends the
+    process (status 0: the result line is out, or this rank has nothing to print) if destroy_process_group() has not returned after 30 s."""
+    import threading
+    t = threading.Timer(30.0, lambda: os._exit(0))
+    t.daemon = True
+    t.start()
+    try:
+        dist.destroy_process_group()
+    finally:
+        t.cancel()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +197,7 @@ def main():
 
     if rank != 0:
         if world > 1:
-            dist.destroy_process_group()
+            leave_group()
         return
 
     ms_per_step = 1e3 * elapsed / a.steps
@@ -405,8 +419,9 @@ def main():
     if extra:
         line["extra"] = extra
     print(json.dumps(line))
+    sys.stdout.flush()
     if world > 1:
-        dist.destroy_process_group()
+        leave_group()
 
 
 def torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a):
