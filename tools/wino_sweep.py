@@ -50,8 +50,8 @@ def main():
             scr = torch.zeros(max(sb, 4), dtype=torch.uint8, device=dev)
             t = timed(lambda: N.check(lib.lspf2f_conv3x3(p(x), None, p(w9), p(sc), p(sh), p(res), p(out), b, h, h, c, 0, c, 1, 0, 1, 0, 0, 0, 0, 0, p(scr), scr.numel(), st)))
             print("b%d c%d h%d  igemm (planner tile)        %7.1f us  %6.1f TFLOP/s algorithmic" % (b, c, h, t, gf / t), flush=True)
-            for nb in (1, 3, 2):                                         # 3 = tile 4003: nb = 1 with the U fragments in registers
-                nbk = 1 if nb == 3 else nb
+            for nb in (1, 3, 4, 2):                                      # 3 = tile 4003: nb = 1 with the U fragments in registers; 4 = tile 4004: four register sets
+                nbk = 1 if nb in (3, 4) else nb
                 if c % (32 * nbk):
                     continue
                 for sp in (1, 2, 4, 8):
@@ -66,7 +66,7 @@ def main():
                     except N.Lspf2fError as ex:
                         print("b%d c%d h%d  wino<%d> split %d: %s" % (b, c, h, nb, sp, ex))
                         continue
-                    print("b%d c%d h%d  wino<%s> split %d (%5d WGs) %7.1f us  %6.1f TFLOP/s algorithmic  %5.1f executed" % (b, c, h, "1r" if nb == 3 else str(nb), sp, wgs, t, gf / t, gf * 4 / 9 / t), flush=True)
+                    print("b%d c%d h%d  wino<%s> split %d (%5d WGs) %7.1f us  %6.1f TFLOP/s algorithmic  %5.1f executed" % (b, c, h, "1r" if nb == 3 else "1r4" if nb == 4 else str(nb), sp, wgs, t, gf / t, gf * 4 / 9 / t), flush=True)
 
 
 main()
