@@ -28,6 +28,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared below are exported */
+#pragma GCC visibility push(default)
+
 #define LSPA2H_ABI_VERSION 1
 
 #define LSPA2H_OK 0
@@ -118,6 +121,7 @@ int lspa2h_generate_timed(lspa2h_handle *h, const float *audio_dev, int n_audio,
                           const float *expq_dev, float sigma_scale, int frame_future, float *out_dev, int nframe, void *stream,
                           float *precompute_ms, float *loop_ms);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared below are exported */
+#pragma GCC visibility push(default)
+
 #define LSPF2F_ABI_VERSION 1
 
 typedef enum lspf2f_status {
@@ -285,6 +288,7 @@ int64_t lspf2f_layer_form_offset(const lspf2f_handle *h, int layer, int form);
  * the timed region runs, cycles / ticks x 0.1 is the shader clock in GHz the chip held under that load.  duration_us <= 2 000 000. */
 int lspf2f_clock_probe(unsigned long long *out_dev, unsigned duration_us, void *hip_stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared below are exported */
+#pragma GCC visibility push(default)
+
 #define LSPLLE_OK 0
 #define LSPLLE_ERR_INVALID_ARGUMENT (-1)
 #define LSPLLE_ERR_UNSUPPORTED (-2)
@@ -53,6 +56,7 @@ int lsplle_knn(const float *feats_dev, int n, const float *db_dev, int m, int d,
 int lsplle_solve(const float *feats_dev, int n, const float *db_dev, int m, int d, const int64_t *ind_dev, int K,
                  double *weights_dev, float *fuse_dev, float *blend_dev, float percent, void *stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared below are exported */
+#pragma GCC visibility push(default)
+
 #define LSPMEL_OK 0
 #define LSPMEL_ERR_INVALID_ARGUMENT (-1)
 #define LSPMEL_ERR_SHAPE (-2)
@@ -51,6 +54,7 @@ int lspmel_compute(const float *audio_dev, int64_t nsamples, const float *basis_
 
 const char *lspmel_last_error(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

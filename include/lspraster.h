@@ -25,6 +25,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared below are exported */
+#pragma GCC visibility push(default)
+
 #define LSPRASTER_OK 0
 #define LSPRASTER_ERR_INVALID_ARGUMENT (-1)
 #define LSPRASTER_ERR_UNSUPPORTED (-2)
@@ -53,6 +56,7 @@ int lspraster_edge_maps(const void *points_dev, int point_dtype, int batch, int 
 
 const char *lspraster_last_error(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: exactly the functions declared below are exported */
+#pragma GCC visibility push(default)
+
 #define LSPRNN_ABI_VERSION 1
 
 #define LSPRNN_OK 0
@@ -80,6 +83,7 @@ int lsprnn_status(lsprnn_handle *h, void *stream, uint32_t *code);
 int lsprnn_linear(const float *x_dev, const float *w_dev, const float *scale_dev, const float *shift_dev, float *y_dev,
                   int M, int N, int K, int leaky, void *stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

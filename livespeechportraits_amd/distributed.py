@@ -87,7 +87,20 @@ def setup_engine(engine, state_dict, device: torch.device, src: int = 0) -> None
             raise ValueError("rank %d must hold the state dict" % src)
         engine.load_state_dict(state_dict)
         blob = engine.pack()
-    engine.bind(broadcast_blob(blob, engine.packed_bytes(), device, src))
+    nbytes = engine.packed_bytes()
+    if dist.is_initialized():
+        # The blob layout depends on the handle's configuration AND on the batch range it plans for (the blob carries only the weight forms the plans of batch
+        # 1..max_batch read): ranks built with different max_batch would enter a size-mismatched collective.  One tiny all_reduce (min and max of
+        # (bytes, max_batch, frame size)) turns that hang / corruption into an error on every rank.
+        mine = torch.tensor([nbytes, int(getattr(engine, "max_batch", 0)), int(getattr(engine, "size", 0))], dtype=torch.int64,
+                            device=device if dist.get_backend() == "nccl" else "cpu")
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("ranks disagree on the packed blob: (bytes, max_batch, frame size) here %s, across ranks min %s max %s -- build every rank's engine "
+                               "with the same configuration and max_batch" % (mine.tolist(), lo.tolist(), hi.tolist()))
+    engine.bind(broadcast_blob(blob, nbytes, device, src))
 
 
 def render_sharded(engine, feature_maps: torch.Tensor, cand_image: torch.Tensor, gather: bool = False,

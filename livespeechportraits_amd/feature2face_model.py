@@ -52,6 +52,9 @@ class Feature2FaceModel(BaseModel):
                 x = feature_map if cand_image is None else torch.cat(
                     [feature_map, cand_image.expand(feature_map.shape[0], -1, -1, -1)], 1)
                 return g._get_engine(x.device).forward(x.float(), out_u8=True)
+            net = self.Feature2Face_G
+            if isinstance(net, networks.MultiDeviceParallel):    # several gpu_ids: sliced over all of them like inference(), uint8 fused on every device
+                return net.render_image(feature_map, cand_image)
             e = g._engine_for(feature_map.shape[-1], feature_map.shape[0], feature_map.device)
             return e.forward_image(feature_map.float(), cand_image.float() if cand_image is not None else None)
 

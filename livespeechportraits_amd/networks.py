@@ -94,18 +94,27 @@ class Feature2FaceGenerator(nn.Module):
         self._engine: Optional[Engine] = None
         self._blob: Optional[torch.Tensor] = None      # packed weights on the device
         self._dirty = True
+        self._adopted = False                          # the bound blob arrived packed (adopt_packed): this module's own parameters are NOT its source
         self._blob_version = 0                         # bumped whenever the packed blob is rebuilt (replicas on other devices copy it again)
         self.register_load_state_dict_post_hook(lambda *_: self.mark_dirty())
 
     # -- weight ingress ------------------------------------------------------------
     def mark_dirty(self):
         self._dirty = True
+        self._adopted = False                          # a state dict was loaded (or the weights re-initialised): the module's parameters are the source again
 
     def _key_prefix(self) -> str:
         return "netG.model"
 
     def _engine_for(self, size: int, batch: int, device: torch.device) -> Engine:
         e = self._engine
+        if self._adopted and e is not None and (e.size != size or e.max_batch < batch or e.device != device):
+            # the weights came packed from another rank (distributed.setup_engine); this rank's parameters are init_weights() noise, so a
+            # re-pack for another frame size / batch range / device would silently bind garbage
+            raise RuntimeError(
+                "this generator renders from a packed blob adopted from another rank (adopt_packed): it serves %dx%d frames in batches of <= %d on %s; "
+                "asked for %dx%d, batch %d on %s.  Build the adopted engine with the final max_batch (distributed.setup_engine(max_batch=...)) or "
+                "load a state dict on this rank." % (e.size, e.size, e.max_batch, e.device, size, size, batch, device))
         if e is None or e.size != size or e.max_batch < batch:
             same_size = e is not None and e.size == size
             mb = max(batch, e.max_batch) if same_size else batch
@@ -134,6 +143,8 @@ class Feature2FaceGenerator(nn.Module):
         """Use an engine whose weights were bound elsewhere (multi-GPU: the blob arrived by
         RCCL broadcast, this rank never saw a state dict)."""
         self._engine, self._blob, self._dirty = engine, engine._blob_dev, False
+        self._adopted = True
+        self._blob_version += 1
 
     # -- forward ---------------------------------------------------------------------
     def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor]) -> torch.Tensor:
@@ -234,14 +245,18 @@ class MultiDeviceParallel(nn.Module):
         key = (id(primary), g._blob_version)
         have = self._replicas.get(slot)
         if have is None or have[0] != key:
+            if have is not None and hasattr(have[1], "close"):
+                have[1].close()                               # the replaced replica's handle, blob copy and workspace go now, not at interpreter exit
             self._replicas[slot] = have = (key, self._make_replica(g, primary, self._device(slot)))
         return have[1]
 
     def _shared_cand(self, slot: int, cand: torch.Tensor) -> torch.Tensor:
+        """the per-person candidate stack on device `slot`, as fp32: keyed on the CALLER's tensor (identity, storage, version), so a half / double stack
+        is converted and peer-copied when it changes, not on every frame"""
         key = (id(cand), cand.data_ptr(), cand._version)
         have = self._cands.get(slot)
         if have is None or have[0] != key:
-            self._cands[slot] = have = (key, cand.to(self._device(slot)), cand)    # (the source tensor is kept alive: the key holds its id())
+            self._cands[slot] = have = (key, cand.float().to(self._device(slot)).contiguous(), cand)    # (the source tensor is kept alive: the key holds its id())
         return have[1]
 
     @staticmethod
@@ -252,11 +267,21 @@ class MultiDeviceParallel(nn.Module):
         return [(r,) + shard_range(batch, r, n) for r in range(n)]
 
     def render(self, feature_map: torch.Tensor, cand_image: Optional[torch.Tensor]) -> torch.Tensor:
+        return self._render(feature_map, cand_image, image=False)
+
+    def render_image(self, feature_map: torch.Tensor, cand_image: Optional[torch.Tensor]) -> torch.Tensor:
+        """render() + util.tensor2im fused into every device's last kernel: uint8 [B,H,W,3] frames gathered on gpu_ids[0] (a quarter of the fp32 peer traffic)"""
+        return self._render(feature_map, cand_image, image=True)
+
+    def _render(self, feature_map: torch.Tensor, cand_image: Optional[torch.Tensor], image: bool) -> torch.Tensor:
         g = self._generator()
         b = feature_map.shape[0]
         spans = self.spans(b, len(self.device_ids))
-        if len(spans) == 1 or not isinstance(g, Feature2FaceGenerator):
-            # one frame, one device, or the 'small' U-Net (its own host-sequenced engine): the module's device does it all
+        if not isinstance(g, Feature2FaceGenerator):
+            # the 'small' U-Net (its own host-sequenced engine): the module's device does it all.  (The uint8 route of that generator is
+            # Feature2FaceModel.inference_image's own branch; it never reaches this class.)
+            if image:
+                raise RuntimeError("render_image over several devices serves the normal / large generators")
             return self.module.render(feature_map, cand_image) if hasattr(self.module, "render") else g.render(feature_map, cand_image)
         dev0 = self._device(0)
         if feature_map.device != dev0:
@@ -269,19 +294,22 @@ class MultiDeviceParallel(nn.Module):
             f = feature_map[lo:hi].float()
             c = None
             if cand_image is not None:
-                c = cand_image.float()
-                if c.shape[0] == 1:
-                    c = c if slot == 0 else self._shared_cand(slot, c)      # constant per person (demo.py:89-95): copied when it changes, not per frame
+                if cand_image.shape[0] == 1:
+                    c = self._shared_cand(slot, cand_image)                 # constant per person (demo.py:89-95): converted / copied when it changes, not per frame
                 else:
-                    c = c[lo:hi]
+                    c = cand_image[lo:hi].float()
                     c = c if slot == 0 else c.to(self._device(slot), non_blocking=True)
             if slot != 0:
                 f = f.to(self._device(slot), non_blocking=True)
-            outs.append(e.forward(f.contiguous(), c.contiguous() if c is not None else None))
-        out = torch.empty((b,) + tuple(outs[0].shape[1:]), dtype=outs[0].dtype, device=dev0)
-        for (slot, lo, hi), o in zip(spans, outs):
-            out[lo:hi].copy_(o, non_blocking=True)            # peer copies onto the output device; torch orders them behind the producing streams
-        return out.half() if g.dtype == "f16" else out
+            run = e.forward_image if image else e.forward
+            outs.append(run(f.contiguous(), c.contiguous() if c is not None else None))
+        if len(spans) == 1:                                   # one frame (or one device): nothing to gather
+            out = outs[0]
+        else:
+            out = torch.empty((b,) + tuple(outs[0].shape[1:]), dtype=outs[0].dtype, device=dev0)
+            for (slot, lo, hi), o in zip(spans, outs):
+                out[lo:hi].copy_(o, non_blocking=True)        # peer copies onto the output device; torch orders them behind the producing streams
+        return out.half() if (g.dtype == "f16" and not image) else out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x = cat([feature_map, cand_image], 1) as the reference's G receives it (scattered along the batch like DataParallel does)"""

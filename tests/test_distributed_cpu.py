@@ -52,6 +52,14 @@ def _worker(rank, world, port, tmp):
     ref = Engine("normal", ngf=32, num_downs=5, size=64, max_batch=4)      # the same configuration: the blob carries the weight forms of the plans of 1 .. max_batch frames
     ref.load_state_dict(sd)
     assert torch.equal(buf, ref.pack()), "rank %d received a different blob" % rank
+    # ranks whose engines plan for different batch ranges would enter a size-mismatched broadcast: setup_engine refuses on EVERY rank first
+    mis = Engine("normal", ngf=32, num_downs=5, size=64, max_batch=4 if rank == 0 else 8)
+    try:
+        D.setup_engine(mis, sd if rank == 0 else None, torch.device("cpu"))
+        raised = False
+    except RuntimeError as ex:
+        raised = "ranks disagree" in str(ex)
+    assert raised, "rank %d: mismatched max_batch went through" % rank
     # binding needs a device: on CPU this must fail loudly, never fall back
     try:
         eng.bind(buf)

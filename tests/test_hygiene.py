@@ -102,3 +102,32 @@ def test_the_built_library_links_only_hip_and_system_libraries():
     foreign = [l for l in libs if not ok.search(l)]
     assert not foreign, foreign
     assert not [l for l in libs if re.search(r"torch|rocblas|hipblas|MIOpen|rccl", l, re.I)], libs      # PyTorch and the vendor libraries are not behind the C ABI
+
+
+def _declared_functions():
+    """names of the C functions include/*.h declare (a declaration = `<type> name(` at the start of a line, outside comments and macros)"""
+    names = set()
+    for path in _files(os.path.join(ROOT, "include"), (".h",)):
+        src = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        for line in src.split("\n"):
+            if line.startswith(("#", " ", "\t", "}", "typedef")):
+                continue
+            m = re.match(r"[A-Za-z_][A-Za-z0-9_ \*]*?\b(lsp[a-z0-9]+_[A-Za-z0-9_]+)\s*\(", line)
+            if m:
+                names.add(m.group(1))
+    return names
+
+
+def test_the_library_exports_its_headers_and_nothing_else():
+    """A thin C-ABI library: `nm -D` lists exactly the functions include/*.h declares -- no mangled C++ internals, kernel stubs or template
+    instantiations (csrc/Makefile: -fvisibility=hidden + csrc/exports.map; the headers open a `#pragma GCC visibility push(default)` region)."""
+    so = os.path.join(PKG, "liblspf2f.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built (build() makes it)")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.strip().split("\n") if l.strip()}
+    declared = _declared_functions()
+    assert len(declared) > 60, sorted(declared)
+    assert not (exported - declared), "exported but not declared in include/*.h: %s" % sorted(exported - declared)
+    assert not (declared - exported), "declared in include/*.h but not exported: %s" % sorted(declared - exported)
+    assert not [s for s in exported if s.startswith("_Z")]

@@ -94,18 +94,27 @@ KERNELS = {                      # file -> [(mangled prefix, U registers, MFMAs,
 
 
 def main():
+    import argparse
     import os
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--hipcc", default="hipcc")
+    ap.add_argument("--quiet", action="store_true", help="print only failures (the Makefile step)")
+    a = ap.parse_args()
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "livespeechportraits_amd", "csrc")
     rc = 0
     for f, kernels in KERNELS.items():
-        asm = compile_to_asm(os.path.join(root, f))
+        asm = compile_to_asm(os.path.join(root, f), a.hipcc)
         for prefix, nreg, nmfma, nloads in kernels:
             ureg, nl, nm, bad = check(kernel_text(asm, prefix))
-            print("%s %s: U registers v%d..v%d (%d, expected %d), %d loads (%d), %d MFMAs (%d), %d foreign touches" % (
-                f, prefix[12:], ureg[0], ureg[-1], len(ureg), nreg, nl, nloads, nm, nmfma, len(bad)))
+            fail = bool(bad) or len(ureg) != nreg or nm != nmfma or nl != nloads
+            if fail or not a.quiet:
+                print("%s %s: U registers v%d..v%d (%d, expected %d), %d loads (%d), %d MFMAs (%d), %d foreign touches" % (
+                    f, prefix[12:], ureg[0], ureg[-1], len(ureg), nreg, nl, nloads, nm, nmfma, len(bad)))
             for i, l in bad[:20]:
                 print("  line %d: %s" % (i, l.strip()))
-            rc |= 1 if bad or len(ureg) != nreg or nm != nmfma or nl != nloads else 0
+            rc |= 1 if fail else 0
+    if rc:
+        print("check_ureg_asm: this toolchain's wino3x3 touches a U register in flight -- do NOT ship this build (csrc/wino.hip, UR form)", file=sys.stderr)
     return rc
 
 
