@@ -108,9 +108,9 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
 /* The same with the A-B switches of tools, tests and measurements: `tune` = "key=value,key=value" (integers; NULL or "" = none; an unknown
  * key is LSPF2F_ERR_INVALID_ARGUMENT).  The library never reads the process environment -- every switch arrives here, once per handle,
  * before the plan is built.  Keys (default): graph (1) | wino (1), wino4 (flag), winoup (1): the Winograd kernels | wino_ureg (1:
- * U fragments of wino3x3<1> in registers; 2: four register sets), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
+ * U fragments of wino3x3<1> in registers; 2: four register sets), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), wino_prio (0; 1 | 2: wino3x3<1> sets its wave priority by K-loop progress, the workgroup behind | ahead leads), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
  * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, rowup (1), rowlast (1), rowconv (1): kernels of the 16-bit plans |
- * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), fused_splitk16 (0: the 16-bit plans combine 2..8 K-splits in the launch too), out_wt (0; 1: the Winograd kernels write their output through to memory, sc1 stores), prefetch (1) |
+ * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), fused_splitk16 (0: the 16-bit plans combine 2..8 K-splits in the launch too), out_wt (1: the Winograd kernels write their output through to memory, sc1 stores; 0: plain stores, left dirty in L2), prefetch (1) |
  * lastconv (0 = by shape; 1..5 force a last-conv kernel), lastconv_direct (0), firstconv (0 = by shape; 1, 2 force a first-conv kernel). */
 int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handle **out);
 int lspf2f_destroy(lspf2f_handle *h);
@@ -282,6 +282,16 @@ int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout
  * 4 Winograd F(4x4,3x3) fragments, 5 up-conv Winograd fragments, 6 rowup256 fragments, 7 bandconv512 fragments, 8 rowconv fragments,
  * 9 GEMM form of the last conv, 10 rowlast128 fragments. */
 int64_t lspf2f_layer_form_offset(const lspf2f_handle *h, int layer, int form);
+
+/* Hazard-test aid (tests/test_gpu_hazards.py; SURVEY.md section 5 "race detection"): every byte of the bound workspace a forward may only use as
+ * SCRATCH -- the activation arena, the split-K partial slabs, the InstanceNorm statistics, the per-forward candidate slot, and the per-person
+ * candidate cache too when none is set -- is overwritten with `byte` (0xFF: every fp32 / bf16 / fp16 word becomes a NaN) on `hip_stream`.  A
+ * forward that follows must produce the same bits as before: a kernel that reads a workspace word before this forward's own producer wrote it, or
+ * that relies on what the previous forward left behind, turns NaN.  The arrival counters of the in-launch split-K combines are persistent state
+ * (each last arriver resets its own; zero between launches is the protocol's invariant), so they are NOT poisoned but READ BACK:
+ * *nonzero_counters = how many of them a finished forward left non-zero (0 is the only healthy answer).  Synchronises `hip_stream`.  Graphs stay cached:
+ * the next forward replays the same hipGraph on the poisoned workspace. */
+int lspf2f_debug_poison(lspf2f_handle *h, unsigned char byte, void *hip_stream, unsigned *nonzero_counters);
 
 /* Measurement aid (bench.py `roofline.clock_ghz_observed`): ONE wave spins for about `duration_us` microseconds of the constant 100 MHz
  * counter (s_memrealtime) and writes {shader cycles (s_memtime), 100-MHz ticks} it saw to out_dev[0..1].  Launched on a side stream while

@@ -46,7 +46,7 @@ _RENAMED_ENV = {"LSP_HIP_XCD": "igemm_xcd", "LSP_HIP_FULLK_SPLIT_TILES": "fullk_
 # the keys lspf2f_create_tuned knows (include/lspf2f.h); an LSP_HIP_* variable that maps to none of them is a switch of the Python host
 # (LSP_HIP_CAND_CACHE, networks.py) or a typo: it is not handed to the library (a typo gets a warning)
 TUNE_KEYS = frozenset((
-    "graph", "wino", "wino4", "wino_pre", "wino_ureg", "in_wino_stats", "wino_xcd", "wino_il", "wino_rot", "winoup", "winoup_nb", "winoup_target", "igemm_xcd",
+    "graph", "wino", "wino4", "wino_pre", "wino_ureg", "wino_prio", "in_wino_stats", "wino_xcd", "wino_il", "wino_rot", "winoup", "winoup_nb", "winoup_target", "igemm_xcd",
     "bandconv", "bandconv_min_blocks", "bandconv_min_frames", "rowup", "rowlast", "rowconv", "fullk_split", "fullk_split_tiles", "fullk_s2",
     "all_forms", "blob_pad_kb", "fused_splitk", "fused_splitk16", "out_wt", "prefetch", "lastconv_direct", "lastconv", "firstconv"))
 _HOST_ENV = frozenset(("LSP_HIP_CAND_CACHE", "LSP_HIP_TUNE"))
@@ -142,6 +142,7 @@ SIGNATURES = {
     "lspf2f_pixel_shuffle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lspf2f_clock_probe": (c_int, [c_void_p, c_uint32, c_void_p]),
     "lspf2f_layer_form_offset": (c_int64, [c_void_p, c_int, c_int]),
+    "lspf2f_debug_poison": (c_int, [c_void_p, ctypes.c_ubyte, c_void_p, POINTER(c_uint32)]),
 }
 
 

@@ -157,6 +157,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "fused_splitk") h->fuse_splitk = v != 0;
         else if (k == "fused_splitk16") P.fused_splitk16 = v != 0;
         else if (k == "out_wt") P.out_wt = v;
+        else if (k == "wino_prio") P.wino_prio = v;
         else if (k == "prefetch") h->prefetch = v != 0;
         else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
         else if (k == "lastconv") h->last_route = v;                   // LastConvParams::route (0 = by shape)
@@ -534,7 +535,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());
         }
-        p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1; p.ureg = P.wino_ureg; p.out_wt = P.out_wt;
+        p.nopre = P.wino_pre ? 0 : 1; p.xcd_force = P.wino_xcd + 1; p.no_il = P.wino_il ? 0 : 1; p.no_rot = P.wino_rot ? 0 : 1; p.ureg = P.wino_ureg; p.out_wt = P.out_wt; p.prio = P.wino_prio;
         if (l.inorm && l.in_route == kInWino) {
             // the kernel's epilogue (or its split-K combine) leaves the sums of every tile-block of 128 pixels: finalize + normalise only
             float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
@@ -744,6 +745,36 @@ int lspf2f_forward_ex(lspf2f_handle *h, const float *feat_dev, const float *cand
     }
     const hipError_t e = hipGraphLaunch(g->exec, s);
     if (e != hipSuccess) return hipfail(e, "hipGraphLaunch");
+    return LSPF2F_OK;
+}
+
+int lspf2f_debug_poison(lspf2f_handle *h, unsigned char byte, void *hip_stream, unsigned *nonzero_counters)
+{
+    if (!h) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->ws) return fail(LSPF2F_ERR_STATE, "workspace not bound (lspf2f_bind_workspace)");
+    const Plan &P = h->plan;
+    if (h->ws_size < P.persistent_bytes()) return fail(LSPF2F_ERR_STATE, "workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    hipError_t e = hipSuccess;
+    // head of the workspace: [slot 0: per-person candidate cache][slot 1: per-forward candidate slot][arrival counters]; everything behind is scratch
+    const size_t cc = P.cand_cache_bytes();
+    if (!h->cand_cached) e = hipMemsetAsync(h->ws, byte, cc, s);
+    if (e == hipSuccess) e = hipMemsetAsync(h->ws + cc, byte, cc, s);
+    if (e == hipSuccess && h->ws_size > P.persistent_bytes()) e = hipMemsetAsync(h->ws + P.persistent_bytes(), byte, h->ws_size - P.persistent_bytes(), s);
+    if (e != hipSuccess) return hipfail(e, "hipMemsetAsync (poison)");
+    if (nonzero_counters) {
+        *nonzero_counters = 0;
+        if (h->counters_clean) {          // (before the first forward on this binding the counters are whatever the allocation held: nothing to check)
+            std::vector<unsigned> host(Plan::kTileCounters);
+            e = hipMemcpyAsync(host.data(), h->ws + P.counters_offset(), Plan::kTileCounters * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return hipfail(e, "read-back of the split-K arrival counters");
+            for (unsigned v : host) *nonzero_counters += v != 0;
+            return LSPF2F_OK;
+        }
+    }
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hipfail(e, "hipStreamSynchronize (poison)");
     return LSPF2F_OK;
 }
 

@@ -120,6 +120,8 @@ struct WinoParams {
     int nopre, xcd_force, no_il, no_rot;
     int ureg;                   // one channel block per wave: U fragments by plain loads into registers instead of LDS-DMA + ds_read (wino.hip, UR form); 2: four register sets
     int out_wt;                 // tune key `out_wt`: the output leaves through write-through (sc1) stores (wino.hip WT instances; A-B runs)
+    int prio;                   // tune key `wino_prio` (UR form, A-B arm of round 5): wave priority by K-loop progress -- 1 = the wave that is BEHIND gets the matrix pipe (3 - step / 4: the two
+                                // workgroups of a CU advance together), 2 = the wave that is AHEAD (step / 4: the older workgroup runs away and its epilogue overlaps the younger's loop)
     float *psum, *psq, *pshift; // InstanceNorm plans: per (frame, tile-block, channel) sums of (x - c), (x - c)^2 and the shift c (the tile-block's first pixel) of the
                                 // 128 output pixels a workgroup writes, [B][tile-blocks per frame][N]; nullptr = no statistics (see instnorm.hip)
     // filled by launch_wino

@@ -102,8 +102,9 @@ struct Plan {
     bool use_wino4 = false;    // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSPF2F_FLAG_WINO4; measured slower at batch 1 and
                                // equal at batch 8, DESIGN.md 4.11, so off by default); decides whether the blob carries the 6x6 transformed weights
     bool in_wino_stats = true;   // `in_wino_stats`: InstanceNorm plans take a wino3x3 layer's statistics from its epilogue instead of a pass over its output
-    int out_wt = 0;              // `out_wt`: 1 = wino3x3 / winoup3x3 write their output through (sc1 stores) instead of leaving it dirty in L2 for the end-of-kernel write-back (A-B, round 5)
+    int out_wt = 1;              // `out_wt`: wino3x3 / winoup3x3 write their output through (sc1 stores) instead of leaving it dirty in L2 for the end-of-kernel write-back: bit-identical, +0.6 % at batch 1, +0.3 % at batch 8, +1.0 % `normal` batch 1 (A-B-A-B x3, profiles/r05_outwt_ab.txt); 0 = plain stores
     bool fused_splitk16 = false; // `fused_splitk16`: 16-bit plans combine 2..8 K-splits inside the igemm launch like the fp32 plans do (off until measured: round 5)
+    int wino_prio = 0;           // `wino_prio`: wino3x3<1> register form sets its wave priority by K-loop progress (1 = the workgroup behind leads, 2 = the one ahead; A-B arm of round 5)
     int wino_ureg = 1;           // `wino_ureg`: wino3x3<1> keeps its U fragments in registers (wino.hip UR form: 1 = three register sets, two steps ahead; 2 = four sets, A-B arm)
     bool wino_pre = true, wino_il = true, wino_rot = true;   // tools (`wino_pre` / `wino_il` / `wino_rot` of lspf2f_create_tuned): A-B switches of wino3x3
     int wino_xcd = -1, igemm_xcd = -1;                       // tools: forced block orders (-1 = by operand size)

@@ -244,7 +244,7 @@ __device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, con
 // `wino_ureg=2`, 16 more registers) an A-B arm of round 5 for the waves whose loads take longer than two steps.
 template <int ROW, int EPL, int NS, class EpiLoads>
 __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][1], const char *smem_c, int lane,
-                                             int ks_begin, int ks_end, unsigned long long *first_landed)
+                                             int ks_begin, int ks_end, unsigned long long *first_landed, int prio_mode)
 {
     static_assert(NS == 3 || NS == 4, "register sets");
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
@@ -291,6 +291,13 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, co
     constexpr int AHEAD = NS - 1;
     auto step = [&](auto Sc, int t) {
         constexpr int S = decltype(Sc)::value, S2 = (S + AHEAD) % NS;
+        // `wino_prio` arm: two workgroups share every SIMD of a CU and the OLDER one wins the matrix pipe at equal priority (it leaves the loop after 28 000 cycles,
+        // the younger after 39 600, profiles/r05_wino_tail_stamps.txt).  Priority outranks age: by progress quarter, 1 = the one behind leads, 2 = the one ahead.
+        // (t and prio_mode are wave-uniform scalars: s_cmp / s_cbranch around one s_setprio)
+        if (prio_mode && (t & 3) == 0) {
+            const int lvl = prio_mode == 1 ? 3 - (t >> 2) : (t >> 2);
+            if (lvl <= 0) __builtin_amdgcn_s_setprio(0); else if (lvl == 1) __builtin_amdgcn_s_setprio(1); else if (lvl == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+        }
         const char *rawp = smem_c + S * kRawStage;
         float4 d[2][4];
 #pragma unroll
@@ -333,6 +340,7 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, co
         if (t + 2 < nsteps) step(IntC<2>{}, t + 2);
         if constexpr (NS == 4) { if (t + 3 < nsteps) step(IntC<3>{}, t + 3); }
     }
+    if (prio_mode) __builtin_amdgcn_s_setprio(0);
 }
 
 
@@ -482,10 +490,10 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
     if constexpr (UR) {
         static_assert(NB == 1 && (NS == 3 || NS == 4), "the register form exists for one channel block per wave");
         switch (wave) {
-        case 0: wino_loop_ur<0, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
-        case 1: wino_loop_ur<1, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
-        case 2: wino_loop_ur<2, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
-        default: wino_loop_ur<3, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl); break;
+        case 0: wino_loop_ur<0, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
+        case 1: wino_loop_ur<1, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
+        case 2: wino_loop_ur<2, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
+        default: wino_loop_ur<3, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
         }
     } else {
         switch (wave) {

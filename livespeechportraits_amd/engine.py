@@ -219,6 +219,18 @@ class Engine:
                                                ctypes.c_void_p(stream)))
         return (out_u8, out) if also_float else out_u8
 
+    def debug_poison(self, byte: int = 0xFF) -> int:
+        """Hazard-test aid (lspf2f_debug_poison): every scratch byte of the bound workspace becomes ``byte`` (0xFF = NaN in every float format); returns how
+        many split-K arrival counters the finished forwards left non-zero (0 is the only healthy answer).  The cached graphs stay: the next forward replays
+        on the poisoned workspace and must produce the same bits."""
+        if self._ws is None:
+            raise RuntimeError("no workspace bound")
+        n = ctypes.c_uint32(0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            N.check(self.lib.lspf2f_debug_poison(self._h, int(byte) & 0xFF, ctypes.c_void_p(stream), ctypes.byref(n)))
+        return int(n.value)
+
     def forward_timed(self, feat, cand, out=None):
         b = self._check_inputs(feat, cand)
         if out is None:

@@ -1,0 +1,206 @@
+"""Hazard suite of the renderer's own kernels (SURVEY.md section 5 "race detection").
+
+The generator's kernels bypass what a compiler or a framework would check for them: wino3x3 keeps U fragments in registers that are still in flight
+behind hipcc's back (counted vmcnt waits, csrc/wino.hip), the split-K layers combine inside the launch on arrival tickets, the concat / upsample /
+residual tensors are never materialised, and every forward replays ONE hipGraph over a shared, liveness-packed workspace.  A parity test on an idle
+GPU with identical inputs cannot see a stale read (the stale value is the right value).  Four dynamic checks, every one bit-for-bit:
+
+  poison       every scratch byte of the workspace (activation arena, split-K slabs, statistics, per-forward candidate slot) becomes NaN between
+               forwards (lspf2f_debug_poison); the output must not change a bit and no arrival counter may be left non-zero;
+  alternate    A, B, A, B with fully distinct frame batches (no shared prefix) through ONE engine at 1, 3 and 8 frames, fp32 and bf16 -- every
+               result equals what a FRESH handle (new plan, new graph, NaN-filled workspace) renders for that input;
+  under load   the renderer on one stream while a second engine saturates the device on another, 20 repetitions, bit-stable;
+  serialized   one golden run in a process with AMD_SERIALIZE_KERNEL=3 (the HIP runtime waits for every kernel before and after its launch):
+               the same bits as the free-running graph replay.
+
+The reference semantics these protect: models/networks.py:592-640 (level order), :650-675 (ResidualBlock), feature2face_model.py:225-237."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_problem
+
+pytestmark = pytest.mark.gpu
+
+_BLOBS = {}
+
+
+def _packed(variant, size, max_batch, dtype, norm, tune, dev, ngf=64, num_downs=8):
+    """(packed blob on the device, state-dict seed) -- packed once per configuration; fresh handles bind the same device blob (no re-pack)"""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    from livespeechportraits_amd.topology import build_topology
+    key = (variant, size, max_batch, dtype, norm, json.dumps(tune, sort_keys=True), ngf, num_downs)
+    if key not in _BLOBS:
+        e = Engine(variant, 13, 1, 3, ngf, num_downs, size, max_batch=max_batch, dtype=dtype, norm=norm, tune=tune)
+        topo = build_topology(variant, ngf=ngf, num_downs=num_downs, size=size, norm=norm)
+        sd = synth.make_state_dict(topo, 1234)
+        if norm == "instance":
+            sd = synth.scale_last_conv(sd, topo, 0.25)
+        e.load_state_dict(sd)
+        _BLOBS[key] = e.pack().to(dev)
+        e.close()
+    return _BLOBS[key]
+
+
+def _engine(variant, size, max_batch, dtype="f32", norm="batch", tune=None, dev=None, ngf=64, num_downs=8):
+    from livespeechportraits_amd.engine import Engine
+    e = Engine(variant, 13, 1, 3, ngf, num_downs, size, max_batch=max_batch, dtype=dtype, norm=norm, tune=tune)
+    e.bind(_packed(variant, size, max_batch, dtype, norm, tune, dev, ngf, num_downs))
+    return e
+
+
+def _inputs(batch, size, seed, dev, cand_batch=1):
+    from livespeechportraits_amd import synth
+    feat, cand = synth.make_inputs(batch, size, seed=seed, cand_batch=cand_batch)
+    return torch.from_numpy(feat).to(dev), torch.from_numpy(cand).to(dev)
+
+
+# (variant, frame size, frames, storage, norm, tune): every kernel family of the shipped plans -- Winograd register form and its split-K tickets,
+# up-conv Winograd, full-K (split and unsplit), tiny-M, igemm + reduce, the 16-bit row / band / up kernels, the InstanceNorm statistics routes --
+# plus the two A-B arms of round 5 that change how wino3x3 stores (out_wt) and how far ahead it loads (wino_ureg=2)
+CASES = [
+    ("large", 512, 1, "f32", "batch", None),
+    ("large", 512, 1, "f32", "batch", {"out_wt": 0}),
+    ("large", 512, 1, "f32", "batch", {"wino_ureg": 2}),
+    ("large", 512, 3, "f32", "batch", None),
+    ("normal", 512, 8, "f32", "batch", None),
+    ("normal", 512, 8, "bf16", "batch", None),
+    ("large", 512, 2, "f16", "batch", None),
+    ("normal", 256, 2, "f32", "instance", None),
+    ("large", 512, 1, "f32", "instance", None),
+]
+
+
+@pytest.mark.parametrize("variant,size,batch,dtype,norm,tune", CASES, ids=lambda v: json.dumps(v).replace('"', "") if isinstance(v, dict) else str(v))
+def test_poisoned_workspace_does_not_change_a_bit(variant, size, batch, dtype, norm, tune, gpu_device):
+    e = _engine(variant, size, batch, dtype, norm, tune, gpu_device)
+    feat, cand = _inputs(batch, size, 99, gpu_device)
+    out0 = e.forward(feat, cand).clone()
+    assert torch.isfinite(out0).all()
+    if (variant, size, batch, dtype, norm) == ("large", 512, 1, "f32", "batch"):
+        # the bench workload = the reference golden: what must not change is ALSO the right answer
+        meta, arrays, *_ = golden_problem("large_512")
+        assert float(np.abs(out0.cpu().numpy() - arrays["out"]).max()) <= 5e-5
+    for rep, byte in enumerate((0xFF, 0xFF, 0x00, 0x7F, 0xFF)):
+        assert e.debug_poison(byte) == 0, "a split-K arrival counter was left non-zero by the previous forward"
+        out = e.forward(feat, cand)
+        assert torch.equal(out, out0), "output changed after poisoning the workspace with 0x%02X (repetition %d): max-abs %g, %d NaN" % (
+            byte, rep, float((out - out0).abs().nan_to_num(1e9).max()), int(torch.isnan(out).sum()))
+    # the per-person candidate cache (slot 0) is the one region a forward may rely on across calls: with it set, everything else is still scratch
+    e.set_candidates(cand)
+    ref = e.forward(feat, cand).clone()
+    # (at one frame the cached first-conv contribution rounds in a different order than the 13-channel conv; 16-bit storage and run-time normalisation amplify that)
+    assert (ref - out0).abs().max().item() <= (2e-6 if (dtype, norm) == ("f32", "batch") else 2e-2)
+    for byte in (0xFF, 0x00):
+        assert e.debug_poison(byte) == 0
+        assert torch.equal(e.forward(feat, cand), ref)
+    # the fused uint8 output of the same forward
+    img0 = e.forward_image(feat, cand).clone()
+    assert e.debug_poison(0xFF) == 0
+    assert torch.equal(e.forward_image(feat, cand), img0)
+    assert e.debug_poison(0xFF) == 0
+    e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_alternating_distinct_batches_equal_a_fresh_engine(dtype, gpu_device):
+    """One engine renders A, B, A, B at 1, 3 and 8 frames (A and B share no frame: seeds 99.. and 5000..; per-frame candidates too at 3 frames).  Each result must
+    equal, bit for bit, what a fresh handle -- its own plan and graph, a workspace filled with NaN before its only forward -- renders for that input: nothing a
+    forward reads may come from the forward before it (stale per-frame buffers return plausible numbers for prefix-identical batches, never for these)."""
+    variant, size = "normal", 512
+    e = _engine(variant, size, 8, dtype, dev=gpu_device)
+    for b in (1, 3, 8):
+        cb = b if b == 3 else 1
+        fa, ca = _inputs(b, size, 99, gpu_device, cand_batch=cb)
+        fb, cb_ = _inputs(b, size, 5000, gpu_device, cand_batch=cb)
+        assert not torch.equal(fa[0], fb[0])
+        want = []
+        for f, c in ((fa, ca), (fb, cb_)):
+            fresh = _engine(variant, size, 8, dtype, dev=gpu_device)
+            fresh.debug_poison(0xFF)
+            want.append(fresh.forward(f, c).clone())
+            fresh.close()
+        assert not torch.equal(want[0], want[1])
+        for rep in range(2):
+            for (f, c), w in zip(((fa, ca), (fb, cb_)), want):
+                got = e.forward(f, c)
+                assert torch.equal(got, w), "%s batch %d repetition %d: max-abs %g vs a fresh engine" % (dtype, b, rep, float((got - w).abs().nan_to_num(1e9).max()))
+        assert e.debug_poison(0xFF) == 0
+    e.close()
+
+
+def test_renderer_under_load_is_bit_stable(gpu_device):
+    """The roles of tests/test_gpu_stress.py swapped: the SUBJECT is the renderer (batch 1 large: Winograd register form + in-launch split-K combines on tickets;
+    batch 3 normal: the full-K / igemm + reduce mix) while a second engine keeps every CU busy from another stream, so workgroups of one launch start late, on
+    other CUs and out of order.  20 repetitions each, bit-identical to the quiet run."""
+    load = _engine("normal", 512, 8, "f32", dev=gpu_device)
+    lf, lc = _inputs(8, 512, 7, gpu_device)
+    lo = torch.empty((8, 3, 512, 512), device=gpu_device)
+    side = torch.cuda.Stream(gpu_device)
+    for variant, batch, dtype in (("large", 1, "f32"), ("normal", 3, "f32"), ("normal", 8, "bf16")):
+        e = _engine(variant, 512, batch, dtype, dev=gpu_device)
+        feat, cand = _inputs(batch, 512, 99, gpu_device)
+        quiet = e.forward(feat, cand).clone()
+        torch.cuda.synchronize()
+        for rep in range(20):
+            with torch.cuda.stream(side):                  # ~25 ms of foreign work queued per repetition
+                for _ in range(4):
+                    load.forward(lf, lc, lo)
+            got = e.forward(feat, cand)
+            assert torch.equal(got, quiet), "%s batch %d %s: repetition %d under load differs from the quiet run (max-abs %g)" % (
+                variant, batch, dtype, rep, float((got - quiet).abs().nan_to_num(1e9).max()))
+        torch.cuda.synchronize()
+        assert e.debug_poison(0xFF) == 0
+        e.close()
+    load.close()
+
+
+CHILD = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch
+from conftest import golden_problem
+from livespeechportraits_amd import synth
+from livespeechportraits_amd.engine import Engine
+from livespeechportraits_amd.topology import build_topology
+dev = torch.device("cuda:0")
+meta, arrays, topo, sd, feat, cand = golden_problem("large_512")
+e = Engine("large", size=512)
+e.load_state_dict(sd); e.bind(e.pack(), dev)
+out = e.forward(torch.from_numpy(feat).to(dev), torch.from_numpy(cand).to(dev)).cpu().numpy()
+rec = {"serialize": os.environ.get("AMD_SERIALIZE_KERNEL"), "large_b1_f32": hashlib.sha256(out.tobytes()).hexdigest(), "err": float(np.abs(out - arrays["out"]).max())}
+e.close()
+n = Engine("normal", size=512, max_batch=8, dtype="bf16")
+n.load_state_dict(synth.make_state_dict(build_topology("normal", size=512), 1234)); n.bind(n.pack(), dev)
+f8, c8 = synth.make_inputs(8, 512, seed=99, cand_batch=1)
+o8 = n.forward(torch.from_numpy(f8).to(dev), torch.from_numpy(c8).to(dev)).cpu().numpy()
+rec["normal_b8_bf16"] = hashlib.sha256(o8.tobytes()).hexdigest()
+print(json.dumps(rec))
+"""
+
+
+def test_serialized_kernels_give_the_same_bits():
+    """AMD_SERIALIZE_KERNEL=3: the runtime drains the device before and after every kernel launch.  If the free-running forward (graph replay, launches
+    back to back) depended on an ordering it does not enforce, the serialized run would differ.  Both in child processes (the variable is read when the
+    runtime starts); the golden bound holds in both."""
+    recs = {}
+    for ser in (None, "3"):
+        env = {k: v for k, v in os.environ.items() if k != "AMD_SERIALIZE_KERNEL"}
+        if ser:
+            env["AMD_SERIALIZE_KERNEL"] = ser
+        p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-1500:]
+        recs[ser] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    print(recs)
+    assert recs["3"]["serialize"] == "3" and recs[None]["serialize"] is None
+    assert recs["3"]["err"] <= 5e-5 and recs[None]["err"] <= 5e-5
+    for k in ("large_b1_f32", "normal_b8_bf16"):
+        assert recs["3"][k] == recs[None][k], "%s: serialized and free-running forwards differ" % k
