@@ -941,7 +941,7 @@ __global__ __launch_bounds__(64 * NW) void last_conv_mfma(const LastConvParams p
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) a[tau] = *reinterpret_cast<const float4 *>(sb + abase[tau][t] + (aswz[tau][t] ^ (unsigned)(q << 4)));
         };
-#ifdef LC_ABL_NOMFMA                                         // timing builds of tools/lastconv_ablate.sh: copies only
+#ifdef LC_ABL_NOMFMA                                         // timing builds of tools/sessions/lastconv_ablate.sh: copies only
         return;
 #endif
 #ifdef LC_PF2                                                // operands two iterations ahead (three register sets)

@@ -157,7 +157,7 @@ __device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, con
 #endif
         float4 u[2];
         u[0] = *reinterpret_cast<const float4 *>(up);
-#ifdef WINO_ABL_NOHEAD       // ablation (tools/wino_ablate_job.sh): no raw reads / transform -- whatever the registers hold is multiplied
+#ifdef WINO_ABL_NOHEAD       // ablation (tools/sessions/wino_ablate_job.sh): no raw reads / transform -- whatever the registers hold is multiplied
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void wino4_3x3(const WinoParams p)
         const int y = Y0 - 1 + 4 * hy + pary, x = X0 - 1 + 4 * hx + parx;
         const bool ok = ci < 1224 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         vraw[k] = ok ? ((unsigned)((b * p.H + y) * p.W + x) * (unsigned)p.C + (unsigned)(qd * 4)) * 4u : kOOB4;
-#ifdef W4_ABL_LINEAR_RAW      // ablation (tools/wino4_ablate_job.sh; results are garbage): every raw piece reads 1 KB of CONTIGUOUS memory instead of 64 scattered 16-B chunks
+#ifdef W4_ABL_LINEAR_RAW      // ablation (tools/sessions/wino4_ablate_job.sh; results are garbage): every raw piece reads 1 KB of CONTIGUOUS memory instead of 64 scattered 16-B chunks
         vraw[k] = (unsigned)(((blockIdx.x * 20 + wave * 5 + k) * 1024 + lane * 16) % (p.H * p.W * p.C * 4 - 4096));
 #endif
     }

@@ -26,7 +26,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 // float4 add / subtract as two v_pk_add_f32 (register pairs (x, y), (z, w): where a ds_read_b128 left them).  The input transforms are pure adds, and an
 // fp32 VALU instruction costs the wave ~5 cycles of its MFMA stream: packed, a K-step's transform is 16 instructions instead of 32.
-#ifdef LSPF2F_NO_PK      // A-B builds (tools/gpu_r4_pk.sh): the scalar form
+#ifdef LSPF2F_NO_PK      // A-B builds (tools/sessions/gpu_r4_pk.sh): the scalar form
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 #else

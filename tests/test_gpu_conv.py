@@ -691,7 +691,7 @@ WINO_CASES = [
     (1, 512, 512, 32, 3, 4, True),
 ]
 # tile 4004 ("nb" 4): the register form with FOUR register sets (operands three K-steps ahead; tune key wino_ureg=2) -- an A-B arm prepared at the end of round 4
-# without a GPU left to run it; LSP_TEST_UR4=1 adds its cases (tools/gpu_r5_ur4.sh), they become permanent once they have passed on the hardware
+# without a GPU left to run it; LSP_TEST_UR4=1 adds its cases (tools/sessions/gpu_r5_ur4.sh), they become permanent once they have passed on the hardware
 if os.environ.get("LSP_TEST_UR4"):
     WINO_CASES += [c[:4] + (4,) + c[5:] for c in WINO_CASES if c[4] == 3] + [(1, 24, 32, 16, 4, 1, True), (1, 32, 32, 16, 4, 1, False), (1, 48, 32, 16, 4, 2, True)]   # + three, four K-steps; slices of 3
 

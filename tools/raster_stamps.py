@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the edge-map kernel (GPU; library built with -DLSPRASTER_STAMPS by tools/lastconv_ablate.sh and swapped in by the session script).
+"""Phase stamps of the edge-map kernel (GPU; library built with -DLSPRASTER_STAMPS by tools/sessions/lastconv_ablate.sh and swapped in by the session script).
 Prints, per band workgroup of one frame, the shader cycles spent in: edge setup (points -> quad), planning (outline sides + fill walk), drawing,
 the barrier behind it (waiting for the slowest wave), expansion to the output tensor."""
 import ctypes, os, sys

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Pastes tools/experiments/last_conv_experiments.inc into a scratch copy of csrc/edge_layers.hip (kernels in front of device_cu_count(), launchers behind it)
+# Pastes tools/sessions/experiments/last_conv_experiments.inc into a scratch copy of csrc/edge_layers.hip (kernels in front of device_cu_count(), launchers behind it)
 # and compiles it for gfx950: the archived experiment kernels still build against the library's helpers.  Nothing is written into the tree.
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd); T=$(mktemp -d)
@@ -7,7 +7,7 @@ python3 - "$R" "$T" <<'PY'
 import sys
 R, T = sys.argv[1:3]
 src = open(R + "/livespeechportraits_amd/csrc/edge_layers.hip").read()
-inc = open(R + "/tools/experiments/last_conv_experiments.inc").read()
+inc = open(R + "/tools/sessions/experiments/last_conv_experiments.inc").read()
 marker = "\nstatic int device_cu_count()\n"
 assert marker in src
 head, tail = src.split(marker, 1)

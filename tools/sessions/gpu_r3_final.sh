@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-3 closing session: whole GPU suite, smoke, the profile collection of tools/gpu_r3_prof.sh, then the side tables (InstanceNorm plans, rasteriser, per-layer times)
+# round-3 closing session: whole GPU suite, smoke, the profile collection of tools/sessions/gpu_r3_prof.sh, then the side tables (InstanceNorm plans, rasteriser, per-layer times)
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r3final; mkdir -p $OUT
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -4
-bash tools/gpu_r3_prof.sh
+bash tools/sessions/gpu_r3_prof.sh
 for cfg in "normal 1" "normal 8" "large 1" "large 8"; do
   set -- $cfg
   timeout 300 python tools/in_bench.py $1 $2 2>/dev/null | tail -14

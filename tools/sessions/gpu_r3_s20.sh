@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 GPU session 20: rasteriser with its steps dealt evenly to the threads (bit-exactness, launch time); where the matrix-core last conv's time goes
-# (timing-only builds of tools/lastconv_ablate.sh swapped over the scratch copy's library)
+# (timing-only builds of tools/sessions/lastconv_ablate.sh swapped over the scratch copy's library)
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r3s20; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_raster.py -m gpu -q > $OUT/raster_tests.log 2>&1; echo "raster rc=$?"; tail -4 $OUT/raster_tests.log
 timeout 120 python tools/time_raster.py 2>&1 | grep -v amdgpu.ids | tee $OUT/raster_time.txt

@@ -6,4 +6,4 @@ LSP_HIP_WINO_IL=2 timeout 300 python -m pytest tests/test_gpu_conv.py -k winogra
 timeout 300 tools/ab_switch.sh LSP_HIP_WINO_IL large 1 f32 0
 timeout 300 tools/ab_switch.sh LSP_HIP_WINO_IL large 1 f32 0 2
 timeout 300 tools/ab_switch.sh LSP_HIP_WINO_IL large 8 f32 0
-timeout 600 bash tools/wino_stamps_job.sh 2>&1 | grep -v XCD | tail -60
+timeout 600 bash tools/sessions/wino_stamps_job.sh 2>&1 | grep -v XCD | tail -60

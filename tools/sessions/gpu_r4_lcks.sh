@@ -1,6 +1,6 @@
 #!/bin/bash
 # last conv, K split over the waves (route 6): parity on the goldens (fp32 + uint8 output), then A-B against the shipped eight-wave kernel
-# (record of a session: the K-split kernel `last_conv_ks` / route 6 it drives is not in the library; its source is archived, not built, in tools/experiments/last_conv_experiments.inc -- profiles/r04_lastconv_ab.txt)
+# (record of a session: the K-split kernel `last_conv_ks` / route 6 it drives is not in the library; its source is archived, not built, in tools/sessions/experiments/last_conv_experiments.inc -- profiles/r04_lastconv_ab.txt)
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r4lcks; mkdir -p $OUT
 LSP_HIP_LASTCONV=6 timeout 600 python -m pytest tests/test_gpu_network.py -m gpu -x -q -k "golden and (large_512 or normal_512) or uint8 or batch8" > $OUT/pytest.log 2>&1; echo "tests (route 6) rc=$?"; tail -3 $OUT/pytest.log
 run() { python bench.py --no-cpu-baseline --no-extra --steps 100 --batch $2 2>/dev/null | python -c "

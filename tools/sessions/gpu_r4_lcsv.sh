@@ -1,6 +1,6 @@
 #!/bin/bash
 # last conv on the vector ALU with scalar weights (route 7): parity on the goldens (fp32 + uint8 output, InstanceNorm bias), then A-B against the shipped eight-wave matrix-core kernel
-# (record of a session: the scalar-weight kernel `last_conv_sv` / route 7 it drives is not in the library; its source is archived, not built, in tools/experiments/last_conv_experiments.inc -- profiles/r04_lastconv_ab.txt)
+# (record of a session: the scalar-weight kernel `last_conv_sv` / route 7 it drives is not in the library; its source is archived, not built, in tools/sessions/experiments/last_conv_experiments.inc -- profiles/r04_lastconv_ab.txt)
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r4lcsv; mkdir -p $OUT
 LSP_HIP_LASTCONV=${LC_ROUTE:-7} timeout 600 python -m pytest tests/test_gpu_network.py tests/test_instance_norm.py -m gpu -x -q -k "(golden and (large_512 or normal_512)) or uint8 or batch8" > $OUT/pytest.log 2>&1; echo "tests (route ${LC_ROUTE:-7}) rc=$?"; tail -3 $OUT/pytest.log
 run() { python bench.py --no-cpu-baseline --no-extra --steps 100 --batch $2 2>/dev/null | python -c "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build container: timing-only variants of the matrix-core last conv (results are wrong by construction) into tools/ablate_builds/:
 #   nomfma  copies + barriers + epilogue, no LDS reads / MFMAs        nodma  arithmetic only (two stages copied once)
-# The GPU job (tools/gpu_r3_s20.sh) swaps each over the library of its scratch copy and times the class.
+# The GPU job (tools/sessions/gpu_r3_s20.sh) swaps each over the library of its scratch copy and times the class.
 set -e
 cd "$(dirname "$0")/../livespeechportraits_amd/csrc"
 mkdir -p ../../tools/ablate_builds

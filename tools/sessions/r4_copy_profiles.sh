@@ -1,5 +1,5 @@
 #!/bin/bash
-# build container: gpurun_out/r04_bench_all + gpurun_out/r04_profiles (tools/gpu_r4_prof.sh on the GPU box) -> the tracked profiles/r04_* files
+# build container: gpurun_out/r04_bench_all + gpurun_out/r04_profiles (tools/sessions/gpu_r4_prof.sh on the GPU box) -> the tracked profiles/r04_* files
 cd "$(dirname "$0")/.."
 for f in gpurun_out/r04_bench_all/*.json; do cp $f profiles/r04_bench_$(basename $f); done
 P=gpurun_out/r04_profiles

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the Winograd F(4x4,3x3) kernel (GPU, library built with -DLSPF2F_WINO_STAMPS: tools/wino4_stamps_job.sh):
+"""Phase stamps of the Winograd F(4x4,3x3) kernel (GPU, library built with -DLSPF2F_WINO_STAMPS: tools/sessions/wino4_stamps_job.sh):
   python tools/wino4_stamps.py c h splits [batch]
 Prints, per phase, the median / p90 over all waves of the shader cycles since the wave's kernel entry, and the wall time per launch."""
 import ctypes

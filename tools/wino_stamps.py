@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the Winograd kernel (GPU, library built with -DLSPF2F_WINO_STAMPS: tools/wino_stamps_job.sh):
+"""Phase stamps of the Winograd kernel (GPU, library built with -DLSPF2F_WINO_STAMPS: tools/sessions/wino_stamps_job.sh):
   python tools/wino_stamps.py c h nb splits [batch]
 Prints, per phase, the median / p90 over all waves of the shader cycles since the wave's kernel entry, and the wall time per launch."""
 import ctypes
