@@ -492,7 +492,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.u = bptr(l.wwu_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.C0 = l.c0; p.C1 = l.c1; p.N = l.cout; p.relu = l.inorm ? 0 : l.relu; p.splits = l.splits;
-        p.out_wt = P.out_wt;
+        p.out_wt = P.out_wt; p.prio = P.wino_prio;
         if (l.splits > 1) {
             p.partial = reinterpret_cast<float *>(h->ws + P.partial_offset);
             p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.counters_offset());

@@ -120,8 +120,7 @@ struct WinoParams {
     int nopre, xcd_force, no_il, no_rot;
     int ureg;                   // one channel block per wave: U fragments by plain loads into registers instead of LDS-DMA + ds_read (wino.hip, UR form); 2: four register sets
     int out_wt;                 // tune key `out_wt`: the output leaves through write-through (sc1) stores (wino.hip WT instances; A-B runs)
-    int prio;                   // tune key `wino_prio` (UR form, A-B arm of round 5): wave priority by K-loop progress -- 1 = the wave that is BEHIND gets the matrix pipe (3 - step / 4: the two
-                                // workgroups of a CU advance together), 2 = the wave that is AHEAD (step / 4: the older workgroup runs away and its epilogue overlaps the younger's loop)
+    int prio;                   // tune key `wino_prio`: wave priority by K-loop progress (ProgressPrio, wino_common.h): 1..3 = scheme on the register form only, 4..6 = scheme 1..3 on every Winograd loop
     float *psum, *psq, *pshift; // InstanceNorm plans: per (frame, tile-block, channel) sums of (x - c), (x - c)^2 and the shift c (the tile-block's first pixel) of the
                                 // 128 output pixels a workgroup writes, [B][tile-blocks per frame][N]; nullptr = no statistics (see instnorm.hip)
     // filled by launch_wino
@@ -152,6 +151,7 @@ struct WinoUpParams {
     unsigned *tile_cnt;           // splits > 1: arrival counters, zero between launches
     int B, Hs, Ws, C0, C1, N, relu, splits;
     int out_wt;                   // tune key `out_wt`: write-through output stores (winoup3x3<NB, true>)
+    int prio;                     // tune key `wino_prio` >= 4: wave priority by K-loop progress here too (wino_common.h)
     float *psum, *psq, *pshift;   // InstanceNorm plans: per (frame, tile-block, channel) sums over the 128 output pixels a workgroup writes, as in WinoParams; nullptr = none
     // filled by launch_winoup
     int steps_per_split, ntb, nng, tby, tbx, nmajor;

@@ -104,7 +104,8 @@ struct Plan {
     bool in_wino_stats = true;   // `in_wino_stats`: InstanceNorm plans take a wino3x3 layer's statistics from its epilogue instead of a pass over its output
     int out_wt = 1;              // `out_wt`: wino3x3 / winoup3x3 write their output through (sc1 stores) instead of leaving it dirty in L2 for the end-of-kernel write-back: bit-identical, +0.6 % at batch 1, +0.3 % at batch 8, +1.0 % `normal` batch 1 (A-B-A-B x3, profiles/r05_outwt_ab.txt); 0 = plain stores
     bool fused_splitk16 = false; // `fused_splitk16`: 16-bit plans combine 2..8 K-splits inside the igemm launch like the fp32 plans do (off until measured: round 5)
-    int wino_prio = 0;           // `wino_prio`: wino3x3<1> register form sets its wave priority by K-loop progress (1 = the workgroup behind leads, 2 = the one ahead; A-B arm of round 5)
+    int wino_prio = 1;           // `wino_prio`: wino3x3<1>'s register form sets its wave priority by K-loop progress, the workgroup that is BEHIND leads (ProgressPrio, wino_common.h): bit-identical,
+                                 // +0.7-0.85 % at batch 1 (two boxes, A-B-A-B x3 each), neutral at batch 8; 3 / 4..6 = the variants measured within 0.2 % of it (profiles/r05_wino_prio_ab.txt); 0 = off
     int wino_ureg = 1;           // `wino_ureg`: wino3x3<1> keeps its U fragments in registers (wino.hip UR form: 1 = three register sets, two steps ahead; 2 = four sets, A-B arm)
     bool wino_pre = true, wino_il = true, wino_rot = true;   // tools (`wino_pre` / `wino_il` / `wino_rot` of lspf2f_create_tuned): A-B switches of wino3x3
     int wino_xcd = -1, igemm_xcd = -1;                       // tools: forced block orders (-1 = by operand size)

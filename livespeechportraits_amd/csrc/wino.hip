@@ -109,7 +109,7 @@ struct WinoCopy {
 //   i = 0: d0 - d2     i = 1: d1 + d2     i = 2: d2 - d1     i = 3: d1 - d3
 template <int NB, int NS, bool IL, bool ROT, int ROW, int EPL, class EpiLoads>
 __device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][NB], const char *smem_c, int wave, int lane,
-                                          int ks_begin, int ks_end, unsigned long long *first_landed)
+                                          int ks_begin, int ks_end, unsigned long long *first_landed, int prio_mode)
 {
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
     constexpr int USTAGE = wino_u_stage(NB), RAWB = wino_raw_base(NB, NS);
@@ -144,7 +144,9 @@ __device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, con
     *first_landed = __builtin_amdgcn_s_memtime();
 #endif
     int cur = 0;
+    const ProgressPrio prio(prio_mode, nsteps);
     for (int t = 0; t < nsteps; ++t) {
+        prio.step(t);
         const char *rawp = smem_c + cur * kRawStage;
         const char *up = smem_c + cur * USTAGE + au;
         // raw rows of this step and the first weight fragment: issued straight behind the barrier, their latency rides under the DMA issue below
@@ -228,6 +230,7 @@ __device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, con
 #endif
         if (++cur == NS) cur = 0;
     }
+    prio.done();
 }
 
 
@@ -287,17 +290,12 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, co
 #ifdef LSPF2F_WINO_STAMPS
     *first_landed = __builtin_amdgcn_s_memtime();
 #endif
+    const ProgressPrio prio(prio_mode, nsteps);
     // one K-step on register set S (= ring slot of the raw patch); the loads of step t + NS - 1 go into set (S + NS - 1) % NS, last read in step t - 1
     constexpr int AHEAD = NS - 1;
     auto step = [&](auto Sc, int t) {
         constexpr int S = decltype(Sc)::value, S2 = (S + AHEAD) % NS;
-        // `wino_prio` arm: two workgroups share every SIMD of a CU and the OLDER one wins the matrix pipe at equal priority (it leaves the loop after 28 000 cycles,
-        // the younger after 39 600, profiles/r05_wino_tail_stamps.txt).  Priority outranks age: by progress quarter, 1 = the one behind leads, 2 = the one ahead.
-        // (t and prio_mode are wave-uniform scalars: s_cmp / s_cbranch around one s_setprio)
-        if (prio_mode && (t & 3) == 0) {
-            const int lvl = prio_mode == 1 ? 3 - (t >> 2) : (t >> 2);
-            if (lvl <= 0) __builtin_amdgcn_s_setprio(0); else if (lvl == 1) __builtin_amdgcn_s_setprio(1); else if (lvl == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
-        }
+        prio.step(t);                                          // `wino_prio`: wave priority by K-loop progress (wino_common.h)
         const char *rawp = smem_c + S * kRawStage;
         float4 d[2][4];
 #pragma unroll
@@ -340,7 +338,7 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, co
         if (t + 2 < nsteps) step(IntC<2>{}, t + 2);
         if constexpr (NS == 4) { if (t + 3 < nsteps) step(IntC<3>{}, t + 3); }
     }
-    if (prio_mode) __builtin_amdgcn_s_setprio(0);
+    prio.done();
 }
 
 
@@ -490,17 +488,17 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
     if constexpr (UR) {
         static_assert(NB == 1 && (NS == 3 || NS == 4), "the register form exists for one channel block per wave");
         switch (wave) {
-        case 0: wino_loop_ur<0, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
-        case 1: wino_loop_ur<1, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
-        case 2: wino_loop_ur<2, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
-        default: wino_loop_ur<3, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio); break;
+        case 0: wino_loop_ur<0, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio); break;
+        case 1: wino_loop_ur<1, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio); break;
+        case 2: wino_loop_ur<2, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio); break;
+        default: wino_loop_ur<3, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio); break;
         }
     } else {
         switch (wave) {
-        case 0: wino_loop<NB, NS, IL, ROT, 0, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
-        case 1: wino_loop<NB, NS, IL, ROT, 1, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
-        case 2: wino_loop<NB, NS, IL, ROT, 2, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
-        default: wino_loop<NB, NS, IL, ROT, 3, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl); break;
+        case 0: wino_loop<NB, NS, IL, ROT, 0, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : 0); break;
+        case 1: wino_loop<NB, NS, IL, ROT, 1, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : 0); break;
+        case 2: wino_loop<NB, NS, IL, ROT, 2, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : 0); break;
+        default: wino_loop<NB, NS, IL, ROT, 3, EPL>(cp, epi_loads, acc, smem_c, wave, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : 0); break;
         }
     }
     // (the loop ends on a barrier: every wave is done with the ring slots, the patch below may overwrite them)

@@ -81,7 +81,9 @@ __device__ __forceinline__ void winoup_loop(const WinoUpParams &p, f32x16 (&acc)
     dma_wait<0>();
     __syncthreads();
     int cur = 0;
+    const ProgressPrio prio(p.prio >= 4 ? p.prio - 3 : 0, nsteps);       // `wino_prio` >= 4: the up-conv form too (wino_common.h)
     for (int t = 0; t < nsteps; ++t) {
+        prio.step(t);
         const char *rawp = smem_c + cur * kUpRawStage;
         const char *up = smem_c + cur * USTAGE + au;
         float4 d[NR][3];
@@ -121,6 +123,7 @@ __device__ __forceinline__ void winoup_loop(const WinoUpParams &p, f32x16 (&acc)
         __syncthreads();
         cur ^= 1;
     }
+    prio.done();
     (void)PIECES;
 }
 
