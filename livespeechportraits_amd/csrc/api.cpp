@@ -157,6 +157,8 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "fused_splitk") h->fuse_splitk = v != 0;
         else if (k == "fused_splitk16") P.fused_splitk16 = v != 0;
         else if (k == "out_wt") P.out_wt = v;
+        else if (k == "fullk16") P.fullk16_levels = v;
+        else if (k == "fullk16_min_frames") P.fullk16_min_frames = v;
         else if (k == "wino_prio") P.wino_prio = v;
         else if (k == "prefetch") h->prefetch = v != 0;
         else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
@@ -287,7 +289,7 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
         if (l.wino) return l.wino == 2 ? (l.splits > 1 ? "wino3x3<2> (split-K combined in the launch)" : "wino3x3<2>")
                                        : (l.splits > 1 ? "wino3x3<1> (split-K combined in the launch)" : "wino3x3<1>");
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
-        if (l.fullk) return "conv3x3_fullk";
+        if (l.fullk) return P.dtype ? "conv3x3_fullk16" : "conv3x3_fullk";
         if (l.rowup) return "rowup256";
         if (l.bandconv) return "bandconv512";
         if (l.rowconv) return l.c0 == 64 ? "rowconv64" : "rowconv128";
@@ -572,6 +574,13 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.residual = tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.c0; p.R = l.rowconv; p.relu = l.relu; p.dtype = P.dtype;
         e = launch_rowconv(p, s);
+    } else if (l.fullk && P.dtype != 0) {
+        FullK16Params p{};
+        p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wfk_off); p.wtile = 1; p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.C0 = l.c0; p.C1 = l.c1; p.Cout = l.cout;
+        p.up = l.up; p.relu = l.relu; p.stride = l.stride; p.dtype = P.dtype;
+        e = launch_fullk16(p, l.fullk, s);
     } else if (l.fullk) {
         FullKParams p{};
         p.src0 = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.wfk_off); p.wtile = 1; p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
@@ -1059,6 +1068,16 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the bf16 row kernel does not support this shape");
             e = launch_rowconv(q, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (rowconv) launch");
+            return LSPF2F_OK;
+        }
+        if (dtype != 0 && (tile_m == 16 || tile_m == 32) && tile_n == 16) {      // the 16-bit full-K kernel (fullk16.hip); k_group -1: w_packed in its tile-blocked order
+            FullK16Params q{};
+            q.src0 = src0; q.src1 = c1 ? src1 : nullptr; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
+            q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = ho_; q.Wo = ho_; q.C0 = c0; q.C1 = c1; q.Cout = cout;
+            q.up = upsample == 1; q.relu = relu; q.stride = stride; q.dtype = dtype; q.wtile = k_group == -1 ? 1 : 0;
+            if (upsample == 2 || hs != ws || !fullk16_supported(q, tile_m / 16)) return fail(LSPF2F_ERR_UNSUPPORTED, "the 16-bit full-K kernel does not support this shape");
+            e = launch_fullk16(q, tile_m / 16, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (full-K, 16-bit) launch");
             return LSPF2F_OK;
         }
         int pb = 0;

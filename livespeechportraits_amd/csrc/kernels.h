@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 #include <atomic>
 
 namespace lspf2f {
@@ -206,6 +207,24 @@ struct FullKParams {
 bool fullk_supported(const FullKParams &p, int pb);
 hipError_t launch_fullk(const FullKParams &p, int pb, hipStream_t s);
 void pack_fullk_weights(const float *rows, int c0, int nch, int cout, float *out);   // host: [Cout][9][nch * c0] -> tile-blocked
+
+// The same single-launch full-K structure for the 8x8 / 4x4 / 2x2 levels of the 16-bit plans from 2 frames up (fullk16.hip): bf16 | fp16 storage, one source of
+// 256 | 512 channels or two equal ones, stride 1 | 2 (one source) | nearest x2 upsample in front, Cout % 128 == 0.
+struct FullK16Params {
+    const void *src0, *src1;     // NHWC 16-bit [B][Hs][Ws][C0|C1]; src1 == nullptr when C1 == 0
+    const void *w;               // 16-bit: tile-blocked (pack_fullk16_weights, wtile = 1) or rows [Cout][9][C0 + C1]
+    const float *scale, *shift;  // [Cout] or nullptr
+    const void *residual;        // 16-bit [B][Ho][Wo][Cout] or nullptr
+    void *out;                   // 16-bit [B][Ho][Wo][Cout]
+    int B, Hs, Ws, Ho, Wo, C0, C1, Cout;
+    int up, relu, stride;
+    int dtype;                   // 1 = bf16, 2 = fp16
+    int wtile;
+    int ntm, ntn, tiles_per_img, wo_log2;   // filled by launch_fullk16
+};
+bool fullk16_supported(const FullK16Params &p, int pb);
+hipError_t launch_fullk16(const FullK16Params &p, int pb, hipStream_t s);
+void pack_fullk16_weights(const uint16_t *rows, int c0, int nch, int cout, uint16_t *out);   // host: 16-bit [Cout][9][nch * c0] -> tile-blocked
 
 // Weights-stationary conv for the 64 -> 64 and 128 -> 128 channel layers in bf16 storage (rowconv.hip): stride 1, one source,
 // W % 64 == 0 (64 channels) / W % 32 == 0 (128 channels).

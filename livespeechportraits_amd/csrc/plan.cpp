@@ -349,7 +349,7 @@ unsigned Plan::forms_used(const LayerDesc &l, const Plan &p)
     if (l.rowup) return kFormRowUp;
     if (l.bandconv) return kFormBand;
     if (l.rowconv) return kFormRow;
-    if (l.fullk) return (l.stride == 2 || (l.splits == 2 && !l.c1)) ? kFormFullK2 : kFormFullK;
+    if (l.fullk) return (p.dtype == 0 && (l.stride == 2 || (l.splits == 2 && !l.c1))) ? kFormFullK2 : kFormFullK;      // (16-bit plans: one tile-blocked form, fullk16.hip)
     return kFormRows;
 }
 
@@ -388,6 +388,12 @@ void Plan::assign_offsets(const std::vector<unsigned> *used)
                 l.wfk2_off = (int64_t)off;
                 off += (size_t)l.cout * 9 * l.cin * sizeof(float);
             }
+        }
+        // 16-bit plans: the 8x8 / 4x4 / 2x2 layers in the tile-blocked order of the 16-bit full-K kernel (fullk16.hip)
+        if (l.kind == kIgemm && dtype != 0 && (need & kFormFullK) && fullk16_levels && fullk16_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
+            off = align_up(off, 256);
+            l.wfk_off = (int64_t)off;
+            off += (size_t)l.cout * 9 * l.cin * elt();
         }
         // the stride-2 convs of the small levels on the K-split full-K kernel (tune key `fullk_s2=1`): only carried when that path is switched on
         if (l.kind == kIgemm && (need & kFormFullK2) && use_fullk_s2 && fullk_s2_layer(l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, dtype, l.inorm)) {
@@ -529,6 +535,10 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                                   fullk_s2_choice(batch, l.hs, l.ho, l.c0, l.cout, p.use_fullk_s2) > 0;
             if (fullk_s2) { fullk = 1; bm = 16; bn = 16; splits = 2; group = 1; }
             else if (fullk) { bm = 16 * fullk; bn = 16; splits = fullk_k2 ? 2 : 1; group = 1; }
+            // 16-bit plans: the same single-launch structure, whole K per workgroup, no split (fullk16.hip)
+            const int fullk16 = (p.dtype != 0 && !smallm && l.wfk_off >= 0)
+                                    ? fullk16_choice(batch, l.hs, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype, p.fullk16_levels, p.fullk16_min_frames) : 0;
+            if (fullk16) { fullk = fullk16; bm = 16 * fullk16; bn = 16; splits = 1; group = 1; }
             int wsplits = 1;
             int w4splits = 1;
             const int wino4 = (p.use_wino && p.use_wino4 && l.ww4_off >= 0 && !smallm) ? wino4_choice(batch, l.ho, l.cin, l.cout, &w4splits) : 0;
@@ -543,7 +553,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             int rowup = p.use_rowup && l.wru_off >= 0 ? rowup_rows(batch, l.hs, l.hs) : 0;
             if (rowup < 8) rowup = 0;     // short strips (1 frame: 4 rows + 2 halo steps) do not beat the implicit GEMM: 22.4 vs 22.9 us
             if (rowup) { bm = 32 * rowup; bn = 32; splits = 1; group = 1; }
-            const bool bandconv = p.use_bandconv && l.wbc_off >= 0 && !smallm &&
+            const bool bandconv = p.use_bandconv && l.wbc_off >= 0 && !smallm && !fullk16 &&
                                   (l.ho >= 8 ? (long)batch * (l.ho == 16 ? 4 : 2) * (l.cout / 32) >= p.bandconv_min_blocks
                                              : batch >= p.bandconv_min_frames_small);
             if (bandconv) { bm = l.ho == 16 ? 64 : 32; bn = 32; splits = 1; group = 1; }
@@ -673,7 +683,7 @@ std::string Plan::pack(void *blob, size_t bytes) const
                 for (int ci = 0; ci < cin; ++ci)
                     for (int t = 0; t < 9; ++t)
                         dst[((size_t)co * 9 + t) * cin + ci] = W[((size_t)co * cin + ci) * 9 + t];
-            if (l.wfk_off >= 0) pack_fullk_weights(dst, l.c0, l.c1 ? 2 : 1, cout, reinterpret_cast<float *>(base + l.wfk_off));
+            if (l.wfk_off >= 0 && dtype == 0) pack_fullk_weights(dst, l.c0, l.c1 ? 2 : 1, cout, reinterpret_cast<float *>(base + l.wfk_off));
             if (l.wfk2_off >= 0) pack_fullk_weights(dst, l.c0 / 2, 2, cout, reinterpret_cast<float *>(base + l.wfk2_off));
             if (l.wwg_off >= 0) pack_wino_weights(W, cin, cout, reinterpret_cast<float *>(base + l.wwg_off));
             if (l.ww4_off >= 0) pack_wino4_weights(W, cin, cout, reinterpret_cast<float *>(base + l.ww4_off));
@@ -694,6 +704,8 @@ std::string Plan::pack(void *blob, size_t bytes) const
         }
         if (l.wru_off >= 0)
             pack_rowup_weights(rows16.data(), reinterpret_cast<uint16_t *>(base + l.wru_off));
+        if (l.wfk_off >= 0 && dtype != 0 && l.kind == kIgemm)     // 16-bit plans: the narrowed rows regrouped into the tile-blocked order of conv3x3_fullk16
+            pack_fullk16_weights(rows16.data(), l.c0, l.c1 ? 2 : 1, cout, reinterpret_cast<uint16_t *>(base + l.wfk_off));
         if (l.wbc_off >= 0)
             pack_bandconv_weights(rows16.data(), reinterpret_cast<uint16_t *>(base + l.wbc_off), cout);
         if (l.wrc_off >= 0)     // the same bf16 values, regrouped into the MFMA A-fragments the row kernel keeps in registers

@@ -5,6 +5,7 @@
 // Reference structure restated: models/networks.py:554-572 (large) / 458-476 (normal) build the
 // nest; :592-640 (and :496-544) order each level's nn.Sequential; :650-675 ResidualBlock.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <map>
@@ -84,6 +85,8 @@ struct Plan {
                                // the storage type, so an fp16 plan takes the same kernel per layer as the bf16 plan)
     int norm = 0;              // 0: BatchNorm2d in eval mode (folded, the shipped checkpoints); 1: InstanceNorm2d (norm_layer argument
                                // of the reference constructors, networks.py:555 / :459): conv biases on, statistics at run time, fp32 only
+    int fullk16_levels = 3;    // 16-bit plans: which small levels run on the full-K kernel (fullk16.hip; tune key `fullk16`, bit mask as in fullk16_choice(); 0 = none)
+    int fullk16_min_frames = 2; // ... from this many frames up (tune key `fullk16_min_frames`)
     bool use_bandconv = true;  // bf16 plans: tune key `bandconv=0` puts the 16x16 / 8x8 layers back on the implicit GEMM (A-B runs)
     int bandconv_min_blocks = 128;  // (16x16 / 8x8 levels; the 4x4 / 2x2 levels, one tile per 2 / 8 frames, have their own bound below)
     int bandconv_min_frames_small = 1 << 30;   // 4x4 / 2x2 levels (a tile = 2 / 8 whole frames): never by default -- at 8 frames the 64 / 16
@@ -239,6 +242,31 @@ inline int fullk_choice(int batch, int hs, int ho, int c0, int c1, int cout, int
         if (tiles <= 256 || (pb == (ho == 16 ? 2 : 1) && tiles <= 512)) return pb;
     }
     return 0;
+}
+// The 16-bit twin (fullk16.hip): the 8x8 / 4x4 / 2x2 levels of the bf16 / fp16 plans from 2 frames up -- stride 1, stride 2 (one source) or nearest x2 upsample in
+// front, one source of 256 | 512 channels or two equal ones.  Batch-independent part (who gets the tile-blocked 16-bit weight copy) and the per-batch choice
+// (pixel blocks per tile, or 0).  `levels` (tune key `fullk16`): bit 0 = the 4x4 / 2x2 levels, bit 1 = the stride-2 / upsampling convs that WRITE 8x8
+// (igemm + splitk_reduce otherwise), bit 2 = the stride-1 single-source 8x8 layers (bandconv512 otherwise).
+inline bool fullk16_layer(int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
+{
+    if (dtype == 0 || up4 || inorm) return false;
+    if (ho != 2 && ho != 4 && ho != 8) return false;
+    if (up) { if (stride != 1 || 2 * hs != ho) return false; }
+    else if (stride == 2) { if (hs != 2 * ho || c1 != 0) return false; }
+    else if (stride != 1 || hs != ho) return false;
+    return (c0 == 256 || c0 == 512) && (c1 == 0 || c1 == c0) && cout % 128 == 0;
+}
+inline int fullk16_choice(int batch, int hs, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, int levels = 3, int min_frames = 2)
+{
+    if (!fullk16_layer(hs, ho, c0, c1, cout, stride, up, up4, dtype, false) || batch < min_frames) return 0;
+    const int bit = ho <= 4 ? 1 : (up || stride == 2) ? 2 : 4;
+    if (!(levels & bit)) return 0;
+    const int nr = 16 / ho > 0 ? 16 / ho : 1;                 // output rows per 16-pixel block (a 4x4 / 2x2 frame is one block)
+    const long tiles = (long)batch * ((ho + nr - 1) / nr) * (cout / 16);
+    const int S = (!up && stride == 2) ? 2 : 1;
+    const int rows = std::min(up ? nr / 2 + 2 : S * (nr - 1) + 3, hs);
+    if ((size_t)(c1 ? 2 : 1) * ((size_t)rows * hs + 1) * (c0 * 2 + 16) > 150 * 1024) return 0;
+    return tiles <= 1024 ? 1 : 0;                             // up to four rounds of workgroups (8x8 at 8 frames), like the fp32 kernel
 }
 // Winograd kernel eligibility, batch-independent part (which layers get the G g G^T copy at pack time); the per-batch choice asks
 // wino_supported() itself (kernels.h) through wino_choice() in plan.cpp

@@ -32,6 +32,8 @@ def run_conv(dev, x0, x1, w, scale, shift, res, stride, up, relu, tile=(0, 0), s
         wp = pack_bandconv(w).to(dev).to(tdt)                 # the band kernel's fragment order
     elif k_group == -1 and tile[0] > 1000:
         wp = pack_rowconv(w).to(dev).to(tdt)                  # the row kernel's MFMA-fragment order
+    elif k_group == -1 and dtype != 0:
+        wp = pack_fullk16(w, c0, 2 if c1 else 1).to(dev).to(tdt)   # the 16-bit full-K kernel's tile-blocked layout (fullk16.hip)
     elif k_group == -1:
         wp = pack_fullk(w, c0, 2 if c1 else 1).to(dev)       # the full-K kernel's tile-blocked layout
     elif up == 2:
@@ -67,6 +69,20 @@ def pack_fullk(w, c0, nch):
     c = 4 * (kq * 4 * G + wv * G + g)
     n, src, tap = nt * 16 + li, T // 9, T % 9
     return torch.stack([rows[n, tap, src, c + e] for e in range(4)], -1).contiguous().float()
+
+
+def pack_fullk16(w, c0, nch):
+    """The 16-bit twin (conv3x3_fullk16): [cout/16][source * 9 + tap][wave 4][g][lane 64][8] with G = c0 / 128 groups; lane = li + 16 kq holds channels
+    8 (kq 4G + wave G + g) .. + 7 of source `source`, tap `tap`, output row 16 nt + li (pack_fullk16_weights on the host).  fp32 here; run_conv narrows."""
+    cout = w.shape[0]
+    G = c0 // 128
+    rows = w.permute(0, 2, 3, 1).reshape(cout, 9, nch, c0)                                  # [n][tap][source][c]
+    nt, T, wv, g, lane = torch.meshgrid(torch.arange(cout // 16), torch.arange(nch * 9), torch.arange(4), torch.arange(G),
+                                        torch.arange(64), indexing="ij")
+    li, kq = lane % 16, lane // 16
+    c = 8 * (kq * 4 * G + wv * G + g)
+    n, src, tap = nt * 16 + li, T // 9, T % 9
+    return torch.stack([rows[n, tap, src, c + e] for e in range(8)], -1).contiguous().float()
 
 
 def pack_rowconv(w):
@@ -971,3 +987,60 @@ def test_conv3x3_winograd_upconv_impulse_layout(gpu_device):
         exp = F.conv2d(F.interpolate(torch.cat([x0, x1], 1), scale_factor=2, mode="nearest"), w, None, 1, 1)
         got = run_winoup(gpu_device, x0, x1, w, None, None, False, 1, 1)
         assert torch.equal(got, exp), (ci, y, x_, co, ky, kx)
+
+
+# ---- the 16-bit full-K kernel (csrc/fullk16.hip): the 8x8 / 4x4 / 2x2 levels of the bf16 / fp16 plans from 2 frames up ---------------------------------
+FULLK16_CASES = [
+    # b, c0, c1, cout, hs, stride, up, res, relu, tile_m      (tile_n = 16)
+    (8, 512, 0, 512, 4, 1, False, True, True, 16),        # L6 / L7.u res convs at 8 frames: a tile = one 4x4 frame
+    (8, 512, 0, 512, 2, 1, False, True, True, 16),        # L7 res convs: a tile = one 2x2 frame, 4 of its 16 rows real
+    (8, 512, 0, 512, 8, 2, False, False, True, 16),       # L6.down: 8 -> 4, stride 2, the whole 8x8 source is the band
+    (8, 512, 0, 512, 4, 2, False, False, True, 16),       # L7.down: 4 -> 2 (no BN in the net; scale/shift still exercised here)
+    (8, 512, 0, 512, 2, 1, True, False, True, 16),        # L7.up: 2 -> 4, nearest x2 in front, one source
+    (8, 512, 512, 512, 4, 1, True, False, True, 16),      # L6.up: 4 -> 8 over the concat, two staged sources, 72 weight loads per lane
+    (8, 512, 0, 512, 16, 2, False, False, True, 16),      # L5.down: 16 -> 8, stride 2, 5-row bands
+    (8, 512, 0, 512, 8, 1, False, True, True, 16),        # the 8x8 res convs (bandconv512 in the default plan)
+    (3, 256, 0, 128, 4, 1, False, True, False, 16),       # 256 channels (G = 2: the band goes through registers), 3 frames, no ReLU
+    (2, 256, 256, 256, 2, 1, True, False, True, 16),      # ... two sources, upsampled
+    (5, 256, 0, 128, 16, 1, False, True, True, 32),       # 16x16 in 32-pixel tiles (two pixel blocks per workgroup)
+    (2, 512, 0, 128, 16, 2, False, False, True, 16),      # 32 -> 16, stride 2: 3-row bands of 32 pixels
+]
+
+
+@pytest.mark.parametrize("dtype", [1, 2], ids=["bf16", "f16"])
+@pytest.mark.parametrize("cfg", FULLK16_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_s%d%s_t%d" % (c[0], c[1], c[2], c[3], c[4], c[5], "up" if c[6] else "", c[9]))
+def test_conv3x3_full_k_kernel_16bit(cfg, dtype, gpu_device):
+    """conv3x3_fullk16 against the fp64 convolution of the 16-bit-rounded operands: within one ulp of the 16-bit result (its K order differs from the implicit
+    GEMM's); the tile-blocked weight layout the plans bind gives the same bits as the row layout; repeats are bit-identical (fixed summation order); and the
+    implicit GEMM on the same problem agrees to that ulp."""
+    b, c0, c1, cout, hs, stride, up, res, relu, tm = cfg
+    rt = bf16r if dtype == 1 else (lambda t: t.to(torch.float16).float() if t is not None else None)
+    ulp = 2.0 ** -8 if dtype == 1 else 2.0 ** -11
+    x0 = rt(rnd(b, c0, hs, hs, seed=131))
+    x1 = rt(rnd(b, c1, hs, hs, seed=132)) if c1 else None
+    w = rnd(cout, c0 + c1, 3, 3, seed=133) * 0.02
+    scale, shift = rnd(cout, seed=134) * 0.5 + 1.0, rnd(cout, seed=135) * 0.1
+    ho = 2 * hs if up else hs // stride
+    r = rt(rnd(b, cout, ho, ho, seed=136)) if res else None
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, int(up), relu, (tm, 16), 0, 0, dtype=dtype)
+    ref = ref_conv(x0, x1, rt(w), scale, shift, r, stride, up, relu)
+    assert torch.isfinite(got).all()
+    tol = ref.abs() * ulp + 1e-3
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
+    tiled = run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, int(up), relu, (tm, 16), 0, -1, dtype=dtype)
+    assert torch.equal(tiled, got)                                   # same K order in both weight layouts
+    assert torch.equal(run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, int(up), relu, (tm, 16), 0, -1, dtype=dtype), tiled)
+    gemm = run_conv(gpu_device, x0, x1, w, scale, shift, r, stride, int(up), relu, (64, 64), 0, 0, dtype=dtype)
+    assert ((got - gemm).abs() <= 2 * tol).all(), (got - gemm).abs().max().item()
+
+
+def test_conv3x3_full_k_kernel_16bit_rejects_other_shapes(gpu_device):
+    from livespeechportraits_amd import _native as N
+    x, w = bf16r(rnd(2, 512, 8, 8, seed=1)), rnd(128, 512, 3, 3, seed=2) * 0.02
+    for kw in (dict(x0=bf16r(rnd(2, 128, 8, 8, seed=1)), w=rnd(128, 128, 3, 3, seed=2)),      # 128 channels: not a multiple of the 256 a lane group spans
+               dict(x0=x, w=rnd(64, 512, 3, 3, seed=2)),                                        # Cout not a multiple of 128
+               dict(x0=bf16r(rnd(2, 512, 32, 32, seed=1)), w=w)):                               # 32x32: not a small level
+        with pytest.raises(N.Lspf2fError, match="16-bit full-K"):
+            run_conv(gpu_device, kw["x0"], None, kw["w"], None, None, None, 1, 0, True, (16, 16), 0, 0, dtype=1)
+    with pytest.raises(N.Lspf2fError, match="16-bit full-K"):               # stride 2 over a concat input
+        run_conv(gpu_device, x, x, rnd(128, 1024, 3, 3, seed=2), None, None, None, 2, 0, True, (16, 16), 0, 0, dtype=1)

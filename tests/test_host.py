@@ -335,6 +335,47 @@ def test_bf16_plans_route_small_512_channel_layers_to_the_band_kernel(monkeypatc
     assert checked >= 2
 
 
+def test_16bit_plans_route_the_smallest_levels_to_the_full_k_kernel():
+    """DESIGN.md 4.5 (round 5): from 2 frames up the 16-bit plans run the 4x4 / 2x2 levels and the convs that write 8x8 through a stride or an upsample on
+    conv3x3_fullk16 -- whole K per workgroup, no split-K, no splitk_reduce launch (19 -> 8 of them in configs[2]); the packer's tile-blocked copy equals the
+    numpy restatement the GPU test uses (tests/test_gpu_conv.py pack_fullk16)."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("normal", dtype="bf16", max_batch=8)
+    at8 = e.layers(8)
+    fk = [l["name"] for l in at8 if l["kernel"] == "conv3x3_fullk16"]
+    assert fk == ["L5.down", "L6.down", "L6.d.res0.a", "L6.d.res0.b", "L7.down", "L7.d.res0.a", "L7.d.res0.b", "L7.up", "L7.u.res0.a", "L7.u.res0.b", "L6.up"]
+    assert sum("splitk_reduce" in l["kernel"] for l in at8) == 8                      # VERDICT r4 next #2: <= 8
+    for l in at8:
+        if l["kernel"] == "conv3x3_fullk16":
+            assert l["split_k"] == 1 and l["h_out"] in (2, 4, 8) and l["cout"] == 512
+    assert not any(l["kernel"] == "conv3x3_fullk16" for l in e.layers(1))            # one frame: the tiny-M kernel / the implicit GEMM keep these levels
+    assert len([l for l in e.layers(2) if l["kernel"] == "conv3x3_fullk16"]) >= 6
+    assert not any(l["kernel"] == "conv3x3_fullk16" for l in Engine("normal", max_batch=8).layers(8))          # fp32 plans have conv3x3_fullk
+    assert not any(l["kernel"] == "conv3x3_fullk16" for l in Engine("normal", dtype="bf16", max_batch=8, tune={"fullk16": 0}).layers(8))
+    all8 = [l["name"] for l in Engine("normal", dtype="f16", max_batch=8, tune={"fullk16": 7}).layers(8) if l["kernel"] == "conv3x3_fullk16"]
+    assert len(all8) == 15 and "L5.d.res0.a" in all8                                  # bit 2: the stride-1 8x8 layers too (bandconv512 by default)
+
+    topo, sd = synth.synthetic("normal", ngf=64, num_downs=6, size=128)      # 512 channels at 8x8, 4x4, 2x2
+    s = Engine("normal", ngf=64, num_downs=6, size=128, dtype="bf16", max_batch=4, tune={"all_forms": 1})      # rows AND the tile-blocked copy in the blob
+    s.load_state_dict(sd)
+    blob = s.pack().numpy()
+    checked = 0
+    for i, l in enumerate(s.layers(4)):
+        if l["kernel"] != "conv3x3_fullk16":
+            continue
+        cout, cin = l["cout"], l["cin"]
+        nch, c0 = (2, cin // 2) if l["concat"] else (1, cin)
+        G, nbytes = c0 // 128, cout * 9 * cin * 2
+        fo = s.form_offset(i, "fullk")
+        assert fo >= 0 and l["w_offset"] >= 0 and fo != l["w_offset"]
+        rows = blob[l["w_offset"]: l["w_offset"] + nbytes].view(np.uint16).reshape(cout // 16, 16, 9, nch, 4, 4, G, 8)     # [nt][li][tap][src][kq][wave][g][e]
+        tiled = blob[fo: fo + nbytes].view(np.uint16).reshape(cout // 16, nch, 9, 4, G, 4, 16, 8)                         # [nt][src][tap][wave][g][kq][li][e]
+        assert np.array_equal(tiled, rows.transpose(0, 3, 2, 5, 6, 4, 1, 7)), l["name"]
+        checked += 1
+    assert checked >= 6
+
+
 def test_bf16_plans_route_the_edge_layers_of_the_256_level_to_row_kernels(monkeypatch):
     """in bf16 plans the last conv (GEMM form over two 64-channel sources) runs on rowlast128 and L1.up (two 128-channel
     sources -> 64) on rowup256 from 8-row strips up; the fragment-ordered copy of L1.up's weights equals the numpy restatement of the GPU test."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time ONE conv shape through lspf2f_conv3x3 with a forced tile (GPU): median of hipEvent pairs, eager launches.
-  python tools/time_conv.py c0 c1 cout hs up tile_m tile_n [batch [k_group [dtype(0|1) [residual(0|1) [split_k]]]]]"""
+  python tools/time_conv.py c0 c1 cout hs up tile_m tile_n [batch [k_group [dtype(0|1) [residual(0|1) [split_k [stride]]]]]]"""
 import ctypes, sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,20 +13,21 @@ def main():
     dt = int(sys.argv[10]) if len(sys.argv) > 10 else 0
     with_res = int(sys.argv[11]) if len(sys.argv) > 11 else 0
     split = int(sys.argv[12]) if len(sys.argv) > 12 else 0   # 2 with tile 16 16: the K-split form of the full-K kernel (no stamps then: they share the scratch)
+    stride = int(sys.argv[13]) if len(sys.argv) > 13 else 1
     tdt = torch.bfloat16 if dt else torch.float32
     lib = N.load(); dev = torch.device("cuda:0")
-    ho = 2 * hs if up else hs
+    ho = 2 * hs if up else hs // stride
     d0 = torch.randn(b, hs, hs, c0, device=dev).to(tdt); d1 = torch.randn(b, hs, hs, c1, device=dev).to(tdt) if c1 else None
     w = (torch.randn(cout, 3, 3, c0 + c1, device=dev) * 0.02).to(tdt)     # timing only: any k_group == -1 layout has the same bytes
     sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     out = torch.empty(b, ho, ho, cout, device=dev, dtype=tdt)
     res = torch.randn(b, ho, ho, cout, device=dev).to(tdt) if with_res else None
-    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, 1, up, tm, tn, split, kg, dt)
+    sb = lib.lspf2f_conv3x3_scratch_bytes(b, hs, hs, c0, c1, cout, stride, up, tm, tn, split, kg, dt)
     scratch = torch.zeros(max(sb, 2048 * 4 * 16 * 8), dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run():
-        N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(w), p(sc), p(sh), p(res), p(out), b, hs, hs, c0, c1, cout, 1, up, 1, tm, tn, split, kg, dt, p(scratch), scratch.numel(), st))
+        N.check(lib.lspf2f_conv3x3(p(d0), p(d1), p(w), p(sc), p(sh), p(res), p(out), b, hs, hs, c0, c1, cout, stride, up, 1, tm, tn, split, kg, dt, p(scratch), scratch.numel(), st))
     for _ in range(5): run()
     torch.cuda.synchronize()
     ts = []
@@ -53,7 +54,7 @@ def main():
             t0 = sub[:, :, 0].min(); print("   XCD %d: first wave start -> last wave end %d cycles; spread of starts %d" % (x, sub[:, :, last].max() - t0, sub[:, :, 0].max() - t0))
     gf = 2 * cout * (c0 + c1) * 9 * ho * ho * b / 1e9
     nbytes = (b * hs * hs * (c0 + c1) + b * ho * ho * cout * (2 if with_res else 1)) * (2 if dt else 4) + w.numel() * (2 if dt else 4)
-    print("c%d+%d o%d h%d%s b%d tile %dx%d %s%s: %.1f us per launch (10 back-to-back), %.1f TFLOP/s, %.0f GB/s algorithmic" % (c0, c1, cout, hs, "up" if up else "", b, tm, tn,
+    print("c%d+%d o%d h%d%s%s b%d tile %dx%d %s%s: %.1f us per launch (10 back-to-back), %.1f TFLOP/s, %.0f GB/s algorithmic" % (c0, c1, cout, hs, "up" if up else "", " s2" if stride == 2 else "", b, tm, tn,
           "bf16" if dt else "f32", "+res" if with_res else "", ts[len(ts)//2], gf / ts[len(ts)//2], nbytes / ts[len(ts)//2] / 1e3))
 
 main()
