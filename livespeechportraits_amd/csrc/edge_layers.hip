@@ -126,29 +126,40 @@ __global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             w[ci][t] = *reinterpret_cast<const float4 *>(p.w + (size_t)(ci * 9 + t) * p.Cout + j * 4);
-    const long npix = (long)p.B * Ho * Wo;
+    // A wave owns `ppw` pixel positions and walks the FRAMES inside (round 5): the candidate share `base` (fp32, one frame's worth: 16.8 MB at 512x512) is read once per
+    // position instead of once per frame -- at 8 frames that was 134 of the kernel's 210 MB -- and the tap geometry is computed once.  Per output the operation order is
+    // unchanged (base, then the taps in order), so results are bit-identical to the frame-major walk.
+    const long hw = (long)Ho * Wo;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const size_t plane = (size_t)p.H * p.W;
-    for (long g = wave * ppw + sub; g < npix; g += nwaves * ppw) {
-        const int b = (int)(g / (Ho * Wo));
-        const int r = (int)(g - (long)b * Ho * Wo);
-        const int oy = r / Wo, ox = r - oy * Wo;
-        float4 acc = *reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + j * 4);
+    for (long r = wave * ppw + sub; r < hw; r += nwaves * ppw) {
+        const int oy = (int)(r / Wo), ox = (int)(r - (long)oy * Wo);
+        const float4 base4 = *reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + j * 4);
+        int off[9];                                           // < 0: padding
 #pragma unroll
-        for (int ci = 0; ci < FN; ++ci) {
-            const float *src = p.feat + ((size_t)b * p.feat_nc + ci) * plane;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                const float v = ok ? src[(size_t)iy * p.W + ix] : 0.f;
-                acc.x += v * w[ci][t].x; acc.y += v * w[ci][t].y; acc.z += v * w[ci][t].z; acc.w += v * w[ci][t].w;
-            }
+        for (int t = 0; t < 9; ++t) {
+            const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+            off[t] = (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W)) ? iy * p.W + ix : -1;
         }
-        if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + j * 4); acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
-        if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        store4(static_cast<T *>(p.out) + (size_t)g * p.Cout + j * 4, acc);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + j * 4);
+#pragma unroll 4                                              // four frames' tap loads in flight per wave
+        for (int b = 0; b < p.B; ++b) {
+            float4 acc = base4;
+#pragma unroll
+            for (int ci = 0; ci < FN; ++ci) {
+                const float *src = p.feat + ((size_t)b * p.feat_nc + ci) * plane;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float v = off[t] >= 0 ? src[off[t]] : 0.f;
+                    acc.x += v * w[ci][t].x; acc.y += v * w[ci][t].y; acc.z += v * w[ci][t].z; acc.w += v * w[ci][t].w;
+                }
+            }
+            if (p.bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
+            if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+            store4(static_cast<T *>(p.out) + ((size_t)b * hw + r) * p.Cout + j * 4, acc);
+        }
     }
 }
 
@@ -462,7 +473,7 @@ static hipError_t launch_first_conv_mfma(const FirstConvParams &p, hipStream_t s
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
 {
     if (p.base && p.ci_begin == 0 && p.ci_end == 1 && p.feat_nc == 1 && 64 % (p.Cout / 4) == 0 && p.Cout <= 256) {
-        const long npix = (long)p.B * (p.H / 2) * (p.W / 2);
+        const long npix = (long)(p.H / 2) * (p.W / 2);      // pixel positions of ONE frame: a wave walks the frames inside
         const int ppw = 64 / (p.Cout / 4);
         long blocks = (npix / ppw + 3) / 4;                  // one pixel group per wave ...
         if (blocks > 4096) blocks = 4096;                    // ... up to 16 blocks per CU, then grid-stride
