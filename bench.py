@@ -72,12 +72,22 @@ def self_launch(n):
     sys.exit(rc)
 
 
+RESULT_PRINTED = False      # rank 0 sets it once its JSON line is on stdout
+
+
 def leave_group():
     """Tear the process group down without ever holding the job: the other ranks leave as soon as their part is done (rank 0 goes on alone with the roofline and CPU
     legs for a minute), and a backend teardown that waits for a peer that has already gone must not keep a finished measurement from returning -- a watchdog ends the
-    process (status 0: the result line is out, or this rank has nothing to print) if destroy_process_group() has not returned after 30 s."""
+    process if destroy_process_group() has not returned after 30 s.  A forced exit is never silent: it is reported on stderr, and its status is 0 only when this rank's
+    timed region is complete (every rank reaches leave_group() behind the closing barrier of the timed steps; rank 0 may still owe its JSON line, which it prints
+    AFTER leaving the group) -- a rank that has to be forced out while a peer crashed is still told apart from a clean run by the message and by the peer's own status."""
     import threading
-    t = threading.Timer(30.0, lambda: os._exit(0))
+
+    def forced():
+        sys.stderr.write("bench.py: rank %s: destroy_process_group() did not return within 30 s -- forced exit (timed region complete)\n" % os.environ.get("RANK", "0"))
+        sys.stderr.flush()
+        os._exit(0 if (RESULT_PRINTED or int(os.environ.get("RANK", "0")) != 0) else 3)
+    t = threading.Timer(30.0, forced)
     t.daemon = True
     t.start()
     try:

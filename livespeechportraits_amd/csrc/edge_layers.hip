@@ -108,17 +108,22 @@ __global__ __launch_bounds__(256) void first_conv(const FirstConvParams p)
                                  : make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]));
 }
 
-// Feature-map-only pass of the first layer (the candidate share comes in through `base`): pure streaming,
-// ~1 FLOP/byte.  16 lanes share a pixel and own 4 output channels each, so a wave reads and writes
-// 4 pixels x Cout*4 B contiguously (Cout = 64: exactly 1 KB per instruction); the 9 x feat_nc tap values
-// are broadcast loads, the lane's weights stay in registers.
+// Feature-map-only pass of the first layer (the candidate share comes in through `base`): pure streaming, ~1 FLOP/byte.  16 lanes share a pixel and own 4 output
+// channels each, so a wave reads and writes 4 pixels x Cout*4 B contiguously (Cout = 64: exactly 1 KB per instruction); the lane's weights stay in registers.
+// Round 5: a workgroup owns ONE output row segment of 64 pixels and walks the FRAMES inside.  (a) The 9 tap values come from LDS: the segment's 3 x 130 input
+// window of up to 8 frames is staged with coalesced loads (zeros where the image ends, so no branches later) and read back as 4-address broadcasts -- as global loads
+// every tap was a wave-wide instruction fetching 4 useful dwords, 1.18 M of them at 8 frames, and the kernel sat on the vector-memory ADDRESS path (44.7 us bf16 /
+// 49.5 us fp32 at 8 frames whatever the byte count: profiles/r05_before_kernel_stats_normal_b8_bf16.txt).  (b) The candidate share `base` (fp32, one frame's worth) is
+// read once per pixel, not once per frame.  Per output the operation order is unchanged (base, then the taps in order): bit-identical to the kernel it replaces.
 template <typename T, int FN>
 __global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
 {
+    constexpr int SEG = 64, FB = 8, TW = 2 * SEG + 2;        // pixels per segment, frames per staging round, staged columns (2 ox0 - 1 .. 2 ox0 + 2 SEG)
+    __shared__ float taps[FB][FN][3][TW];
     const int Ho = p.H / 2, Wo = p.W / 2;
     const int lpp = p.Cout / 4;                              // lanes per pixel (16 for ngf 64, 8 for ngf 32)
-    const int ppw = 64 / lpp;                                // pixels per wave
-    const int lane = threadIdx.x & 63;
+    const int ppw = 64 / lpp;                                // pixels per wave and step
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane % lpp, sub = lane / lpp;
     float4 w[FN][9];
 #pragma unroll
@@ -126,39 +131,41 @@ __global__ __launch_bounds__(256) void first_conv_feat(const FirstConvParams p)
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             w[ci][t] = *reinterpret_cast<const float4 *>(p.w + (size_t)(ci * 9 + t) * p.Cout + j * 4);
-    // A wave owns `ppw` pixel positions and walks the FRAMES inside (round 5): the candidate share `base` (fp32, one frame's worth: 16.8 MB at 512x512) is read once per
-    // position instead of once per frame -- at 8 frames that was 134 of the kernel's 210 MB -- and the tap geometry is computed once.  Per output the operation order is
-    // unchanged (base, then the taps in order), so results are bit-identical to the frame-major walk.
-    const long hw = (long)Ho * Wo;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const int segs = (Wo + SEG - 1) / SEG;
+    const int oy = blockIdx.x / segs, ox0 = (blockIdx.x - oy * segs) * SEG;
     const size_t plane = (size_t)p.H * p.W;
-    for (long r = wave * ppw + sub; r < hw; r += nwaves * ppw) {
-        const int oy = (int)(r / Wo), ox = (int)(r - (long)oy * Wo);
-        const float4 base4 = *reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + j * 4);
-        int off[9];                                           // < 0: padding
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-            off[t] = (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W)) ? iy * p.W + ix : -1;
+    const long hw = (long)Ho * Wo;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + j * 4);
+    for (int b0 = 0; b0 < p.B; b0 += FB) {
+        const int nb = p.B - b0 < FB ? p.B - b0 : FB;
+        if (b0) __syncthreads();                              // the previous round's readers are done
+        for (int i = tid; i < nb * FN * 3 * TW; i += 256) {
+            const int col = i % TW, row = (i / TW) % 3, ci = (i / (3 * TW)) % FN, fb = i / (3 * TW * FN);
+            const int iy = 2 * oy + row - 1, ix = 2 * ox0 - 1 + col;
+            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            taps[fb][ci][row][col] = ok ? p.feat[((size_t)(b0 + fb) * p.feat_nc + ci) * plane + (size_t)iy * p.W + ix] : 0.f;
         }
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + j * 4);
-#pragma unroll 4                                              // four frames' tap loads in flight per wave
-        for (int b = 0; b < p.B; ++b) {
-            float4 acc = base4;
+        __syncthreads();
+        for (int px = wave * ppw + sub; px < SEG; px += 4 * ppw) {
+            const int ox = ox0 + px;
+            if (ox >= Wo) break;
+            const long r = (long)oy * Wo + ox;
+            const float4 base4 = *reinterpret_cast<const float4 *>(p.base + (size_t)r * p.Cout + j * 4);
+#pragma unroll 2
+            for (int fb = 0; fb < nb; ++fb) {
+                float4 acc = base4;
 #pragma unroll
-            for (int ci = 0; ci < FN; ++ci) {
-                const float *src = p.feat + ((size_t)b * p.feat_nc + ci) * plane;
+                for (int ci = 0; ci < FN; ++ci)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float v = off[t] >= 0 ? src[off[t]] : 0.f;
-                    acc.x += v * w[ci][t].x; acc.y += v * w[ci][t].y; acc.z += v * w[ci][t].z; acc.w += v * w[ci][t].w;
-                }
+                    for (int t = 0; t < 9; ++t) {
+                        const float v = taps[fb][ci][t / 3][2 * px + t % 3];
+                        acc.x += v * w[ci][t].x; acc.y += v * w[ci][t].y; acc.z += v * w[ci][t].z; acc.w += v * w[ci][t].w;
+                    }
+                if (p.bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
+                if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+                store4(static_cast<T *>(p.out) + ((size_t)(b0 + fb) * hw + r) * p.Cout + j * 4, acc);
             }
-            if (p.bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
-            if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-            store4(static_cast<T *>(p.out) + ((size_t)b * hw + r) * p.Cout + j * 4, acc);
         }
     }
 }
@@ -473,11 +480,8 @@ static hipError_t launch_first_conv_mfma(const FirstConvParams &p, hipStream_t s
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s)
 {
     if (p.base && p.ci_begin == 0 && p.ci_end == 1 && p.feat_nc == 1 && 64 % (p.Cout / 4) == 0 && p.Cout <= 256) {
-        const long npix = (long)(p.H / 2) * (p.W / 2);      // pixel positions of ONE frame: a wave walks the frames inside
-        const int ppw = 64 / (p.Cout / 4);
-        long blocks = (npix / ppw + 3) / 4;                  // one pixel group per wave ...
-        if (blocks > 4096) blocks = 4096;                    // ... up to 16 blocks per CU, then grid-stride
-        if (blocks < 1) blocks = 1;
+        // one workgroup per output row segment of 64 pixels (it walks the frames inside): 1024 workgroups at 512x512
+        const long blocks = (long)(p.H / 2) * ((p.W / 2 + 63) / 64);
         if (p.dtype == 2) hipLaunchKernelGGL((first_conv_feat<f16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else if (p.dtype == 1) hipLaunchKernelGGL((first_conv_feat<bf16_t, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((first_conv_feat<float, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);

@@ -4,7 +4,7 @@
 // 96 v_pk_fma_f32 (384 issue cycles of its SIMD) against 48 wave-uniform ds_read_b128 of weights + 9 lane-distinct ones of activations.  A CU has FOUR SIMDs but ONE
 // LDS pipe, so the question is what a ds_read_b128 costs that pipe when all 64 lanes read the SAME 16 bytes: if it is the full 1 KB return (8 cycles at 128 B/clk)
 // the form is LDS-bound at 4 x 57 x 8 = 1 824 cycles per 384 of arithmetic; if a broadcast returns in ~1-2 cycles it is VALU-bound at 41 us for 8 frames.
-// This program measures it on a stand-in with that instruction mix: every wave loops over batches of 16 ds_read_b128 (uniform address = broadcast, or lane * 16 =
+// This program measures it on a stand-in with that instruction mix: every wave loops over batches of 8 ds_read_b128 (lgkmcnt counts to 15) (uniform address = broadcast, or lane * 16 =
 // distinct) double-buffered against F v_pk_fma_f32 per read (F = 0, 2, 4, 8: pixels per lane P = F / 2), 4 or 8 waves per CU, every CU busy.
 // Printed: shader cycles per ds_read_b128 of one wave, and the same per CU (/ waves per CU) -- the LDS pipe's cost per wave-wide read.
 // Build on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_bcast_probe tools/probes/lds_bcast_probe.hip
@@ -38,16 +38,14 @@ __global__ void probe(float *out, unsigned long long *cycles, int iters)
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = v2f{(float)k, (float)lane};
     v2f x[4] = {v2f{1.0f + lane * 1e-7f, 1.0f}, v2f{0.999f, 1.0f}, v2f{1.001f, 1.0f}, v2f{1.0f, 0.9999f}};
-    v4f w[2][16];
-    auto batch = [&](v4f (&d)[16], unsigned a) {
+    v4f w[2][8];
+    auto batch = [&](v4f (&d)[8], unsigned a) {
         lds_read16<0>(d[0], a); lds_read16<16>(d[1], a); lds_read16<32>(d[2], a); lds_read16<48>(d[3], a);
         lds_read16<1024>(d[4], a); lds_read16<1040>(d[5], a); lds_read16<1056>(d[6], a); lds_read16<1072>(d[7], a);
-        lds_read16<2048>(d[8], a); lds_read16<2064>(d[9], a); lds_read16<2080>(d[10], a); lds_read16<2096>(d[11], a);
-        lds_read16<3072>(d[12], a); lds_read16<3088>(d[13], a); lds_read16<3104>(d[14], a); lds_read16<3120>(d[15], a);
     };
-    auto consume = [&](const v4f (&d)[16]) {
+    auto consume = [&](const v4f (&d)[8]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 8; ++r) {
             const v2f lo = v2f{d[r].x, d[r].y}, hi = v2f{d[r].z, d[r].w};
             if constexpr (F == 0) {
                 if ((r & 3) == 0) acc[r >> 2] += lo + hi;      // one add per four reads: the reads stay live
@@ -65,10 +63,10 @@ __global__ void probe(float *out, unsigned long long *cycles, int iters)
     batch(w[0], addr);
     for (int it = 0; it < iters; it += 2) {
         batch(w[1], addr + 4096u);
-        asm volatile("s_waitcnt lgkmcnt(16)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         consume(w[0]);
         batch(w[0], addr);
-        asm volatile("s_waitcnt lgkmcnt(16)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         consume(w[1]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -91,7 +89,7 @@ static void run(int waves_per_cu, int cus, float *out, unsigned long long *cyc)
     std::vector<unsigned long long> h(blocks * 4);
     CHECK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
     std::sort(h.begin(), h.end());
-    const double reads = (double)(iters + 1) * 16;              // per wave
+    const double reads = (double)(iters + 1) * 8;               // per wave
     const double med = (double)h[h.size() / 2], per_read = med / reads;
     printf("%-9s F=%d v_pk_fma_f32 per read, %d waves/CU: %7.2f cycles per ds_read_b128 of a wave = %5.2f per CU-wide read slot; arithmetic alone would be %5.1f\n",
            BCAST ? "broadcast" : "distinct", F, waves_per_cu, per_read, per_read / waves_per_cu, 4.0 * F);
@@ -101,7 +99,7 @@ int main()
 {
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    printf("%s, %d CUs; per-wave cycles (s_memtime, 100 MHz-independent shader clock) over 8 208 ds_read_b128 per wave, median over all waves\n", prop.gcnArchName, cus);
+    printf("%s, %d CUs; per-wave cycles (s_memtime, 100 MHz-independent shader clock) over 4 104 ds_read_b128 per wave, median over all waves\n", prop.gcnArchName, cus);
     float *out; unsigned long long *cyc;
     CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4)); CHECK(hipMalloc(&cyc, (size_t)cus * 8 * 8 * 8));
     for (int wpc : {4, 8}) {
