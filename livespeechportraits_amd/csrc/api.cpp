@@ -947,6 +947,14 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     if (stride != 1 && stride != 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "stride must be 1 or 2");
     if (upsample && stride != 1) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "upsample requires stride 1");
     if ((scale == nullptr) != (shift == nullptr)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "scale and shift come together");
+    if (k_group == -4) {
+        // The masked 16-of-36 tap operand of a space-to-depth 4x4 / s2 conv ([cout][16][ci]) is an IMPLICIT-GEMM form only: checked here, before any other route
+        // (Winograd, full-K, row / band kernels read w_packed as a dense 9-tap operand) can take the call
+        if (dtype != 0 || stride != 1 || upsample || c1 || c0 % 4 || (c0 / 4) % ktc)
+            return fail(LSPF2F_ERR_UNSUPPORTED, "k_group -4 (space-to-depth 4x4 / s2 taps): fp32, one source of 4 x ci channels, ci a multiple of 32");
+        const bool gemm_tile = (tile_m == 0 && tile_n == 0) || ((tile_m == 32 || tile_m == 64 || tile_m == 128) && (tile_n == 64 || tile_n == 128));
+        if (!gemm_tile) return fail(LSPF2F_ERR_UNSUPPORTED, "k_group -4 runs on the implicit GEMM only: tile 0x0 (planner's choice) or one of its tiles");
+    }
     hipError_t e = hipSuccess;
     {
         // tile 1x1 forces the tiny-M single-launch kernel; tile 0x0 lets the planner's rule pick it
@@ -1059,7 +1067,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (bandconv) launch");
             return LSPF2F_OK;
         }
-        if (tile_m > 1000 && (tile_n == 64 || tile_n == 128)) {   // 1000 + R: the weights-stationary bf16 kernel (tile_n channels in and out) with R output rows per strip
+        if (tile_m > 1000 && (tile_n == 64 || tile_n == 128) && k_group != -4) {   // 1000 + R: the weights-stationary bf16 kernel (tile_n channels in and out) with R output rows per strip
             RowConvParams q{};
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
             q.B = batch; q.H = hs; q.W = ws; q.C = tile_n; q.R = tile_m - 1000; q.relu = relu; q.dtype = dtype;
@@ -1070,7 +1078,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (rowconv) launch");
             return LSPF2F_OK;
         }
-        if (dtype != 0 && (tile_m == 16 || tile_m == 32) && tile_n == 16) {      // the 16-bit full-K kernel (fullk16.hip); k_group -1: w_packed in its tile-blocked order
+        if (dtype != 0 && (tile_m == 16 || tile_m == 32) && tile_n == 16 && k_group != -4) {      // the 16-bit full-K kernel (fullk16.hip); k_group -1: w_packed in its tile-blocked order
             FullK16Params q{};
             q.src0 = src0; q.src1 = c1 ? src1 : nullptr; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
             q.B = batch; q.Hs = hs; q.Ws = ws; q.Ho = ho_; q.Wo = ho_; q.C0 = c0; q.C1 = c1; q.Cout = cout;

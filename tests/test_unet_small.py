@@ -253,3 +253,45 @@ def test_graph_replay_equals_host_sequenced_launches(gpu_device):
     assert len(graph._graphs) == 4                    # (1 | 3 frames) x (float | uint8)
     graph.load_state_dict(sd, "model", gpu_device)
     assert not graph._graphs                          # new weights: the captured launches are dropped
+
+
+@pytest.mark.gpu
+def test_masked_k_form_runs_on_every_implicit_gemm_tile_and_on_nothing_else(gpu_device):
+    """lspf2f_conv3x3 with k_group = -4 (the 16 live (tap, quarter) blocks of a space-to-depth Conv2d(k4, s2, p1); models/networks.py:680-769) against torch's
+    convolution on EVERY implicit-GEMM tile the library instantiates for it (launch_igemm_masked keeps its own instance table: ADVICE r4) -- and refused, before any
+    other route can read the masked operand as a dense 9-tap one, with 16-bit storage, a stride, or a tile that selects the full-K / row kernels."""
+    import ctypes
+    import torch.nn.functional as F
+    from livespeechportraits_amd import _native as N
+    from livespeechportraits_amd.unet_small import pack_down_live
+    lib, dev = N.load(), gpu_device
+    g = torch.Generator().manual_seed(5)
+    b, ci, co, h = 2, 32, 128, 32                              # space-to-depth image: 16 x 16 x (4 * 32)
+    x = torch.rand(b, ci, h, h, generator=g) * 2 - 1
+    w = (torch.rand(co, ci, 4, 4, generator=g) * 2 - 1) * 0.05
+    ref = F.conv2d(x.double(), w.double(), None, 2, 1).float()                 # [b][co][16][16]
+    # space-to-depth with the conv's padding folded in: s2d[y][x][(dy*2+dx)*ci + c] = xpad[2y + dy][2x + dx][c], xpad = x shifted by (+1, +1) so that a 3x3 / p1 conv
+    # on the 17 x 17 -> cropped 16 x 16 grid sees the 4x4 / s2 / p1 taps (the mapping include/lspf2f.h documents next to lspf2f_unet_prepare)
+    s2d = torch.empty(b, h // 2, h // 2, 4 * ci, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd = x.to(dev)
+    N.check(lib.lspf2f_unet_prepare(p(xd), 1, b, h, h, ci, ctypes.c_float(1.0), p(s2d), 4 * ci, None, st()))      # slope 1: no activation
+    wl = torch.from_numpy(pack_down_live(w.numpy())).to(dev)
+
+    def run(tile, dtype=0, stride=1, kg=-4):
+        out = torch.full((b, h // 2, h // 2, co), float("nan"), device=dev)
+        sb = lib.lspf2f_conv3x3_scratch_bytes(b, h // 2, h // 2, 4 * ci, 0, co, stride, 0, tile[0], tile[1], 0, kg, dtype)
+        scratch = torch.zeros(max(sb, 256), dtype=torch.uint8, device=dev)
+        rc = lib.lspf2f_conv3x3(p(s2d), None, p(wl), None, None, None, p(out), b, h // 2, h // 2, 4 * ci, 0, co, stride, 0, 0, tile[0], tile[1], 0, kg, dtype,
+                                p(scratch), scratch.numel(), st())
+        torch.cuda.synchronize()
+        return rc, out.permute(0, 3, 1, 2).cpu()
+
+    for tile in ((0, 0), (128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64)):
+        rc, got = run(tile)
+        assert rc == 0, (tile, lib.lspf2f_last_error())
+        assert (got - ref).abs().max().item() <= 2e-5, (tile, (got - ref).abs().max().item())
+    for bad in (dict(tile=(16, 16)), dict(tile=(1008, 64)), dict(tile=(2000, 32)), dict(tile=(64, 64), dtype=1), dict(tile=(64, 64), stride=2)):
+        rc, _ = run(**bad)
+        assert rc == -2, (bad, rc)                               # LSPF2F_ERR_UNSUPPORTED, never another kernel's launch
