@@ -39,7 +39,7 @@ class NativeLibraryError(RuntimeError):
 # LSP_HIP_<KEY>=<int> environment variables onto those keys HERE, once per Engine; an explicit `tune=` argument wins.
 _PRESENCE_ENV = {   # legacy names whose mere presence is the switch
     "LSP_HIP_LASTCONV_DIRECT": ("lastconv_direct", 1), "LSP_HIP_LASTCONV_STRIP": ("lastconv", 1), "LSP_HIP_LASTCONV_ROWS": ("lastconv", 2),
-    "LSP_HIP_LASTCONV_GENERIC": ("lastconv", 3), "LSP_HIP_LASTCONV_MFMA": ("lastconv", 4), "LSP_HIP_LASTCONV_VALU": ("lastconv", 5), "LSP_HIP_LASTCONV_VL": ("lastconv", 6),
+    "LSP_HIP_LASTCONV_GENERIC": ("lastconv", 3), "LSP_HIP_LASTCONV_MFMA": ("lastconv", 4), "LSP_HIP_LASTCONV_VALU": ("lastconv", 5),
     "LSP_HIP_FIRSTCONV_DIRECT": ("firstconv", 1), "LSP_HIP_FIRSTCONV_REGSTAGE": ("firstconv", 2),
 }
 _RENAMED_ENV = {"LSP_HIP_XCD": "igemm_xcd", "LSP_HIP_FULLK_SPLIT_TILES": "fullk_split_tiles"}

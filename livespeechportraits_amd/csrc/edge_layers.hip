@@ -1071,207 +1071,6 @@ __global__ __launch_bounds__(64 * NW) void last_conv_mfma(const LastConvParams p
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Last layer on the VECTOR ALU with the weights broadcast from LDS (round 5; fp32 plans, C0 == C1 == 64, Cout <= 4).  N = 3 output channels waste matrix-core columns
-// whatever the shape: the v_mfma_f32_4x4x1 stream of last_conv_mfma needs 20.9 / 91.8 us (batch 1 / 8) with no memory traffic at all (profiles/r04_lastconv_ab.txt),
-// while the same 6 144 multiply-adds per source pixel are 3 072 v_pk_fma_f32 = 5 / 41 us of vector time.  What the vector forms of rounds 1-4 died of is operand
-// delivery: one pixel per lane re-reads the 48 weight vectors per 4 input channels for 96 FMAs (LDS-bound), scalar loads were waited for one by one.  Measured this round
-// (tools/probes/lds_bcast_probe.hip, profiles/r05_lds_bcast_probe.txt): a ds_read_b128 costs the CU's LDS pipe 4 cycles, broadcast or not, and 16 v_pk_fma_f32 per
-// read run at 76 % (one wave per SIMD) .. 89 % (two) of the vector peak.  So:
-//   * lane = FOUR source pixels (a column of 4 rows of the 8 x 32 tile): every weight vector read feeds 8 v_pk_fma_f32, the 6 x 3 neighbourhood is 18 reads for 384 FMAs;
-//   * the K loop is SPLIT OVER THE 4 WAVES (wave w owns channel quads 2w, 2w + 1 of every 32-channel stage), so one tile still occupies all four SIMDs at batch 1
-//     (256 tiles = one per CU); the four partial sums of an output meet in the output tile in LDS, added in wave order (bit-reproducible);
-//   * accumulators are v2f pairs over (even, odd) channel of a quad -- v_pk_fma_f32 on (x.xy, w.xy) and (x.zw, w.zw) -- summed at the end;
-//   * staging (LDS-DMA, 32 channels per stage, two buffers, XOR-swizzled quads, zero borders by out-of-range copies), tile walk and output path (NCHW fp32 rows and/or
-//     HWC uint8 rows through LDS, tanh, tensor2im) are those of last_conv_mfma.
-// Reference: Upsample(x2, nearest) + Conv2d(128, 3, 3, 1, 1) + tanh (models/networks.py:610-611, :577); util.tensor2im (util/util.py:19-42) for the uint8 rows.
-template <int CO>
-__global__ __launch_bounds__(256) void last_conv_vl(const LastConvParams p, int ntiles)
-{
-    constexpr int NW = 4;
-    constexpr int NPC = 13;                                   // stage pieces per wave and step (50 real ones)
-    constexpr int WP = 40;                                    // staged pixels per tile row (34 used)
-    constexpr int STG = 10 * WP * 128;                        // one stage buffer
-    constexpr int OTB = 2 * STG;                              // output tile [4][16][68] floats
-    constexpr int WTB = OTB + 4 * 16 * 68 * 4;                // weight table [4 stages][8 quads][(parity, channel, tap)] float4
-    constexpr int WQ = 16 * CO;                               // float4 per (stage, quad)
-    constexpr int DUMP = WTB + 4 * 8 * WQ * 16;
-    constexpr unsigned OOB = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    typedef __attribute__((address_space(3))) float lds_float;
-    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)sm;
-    const char *smc = reinterpret_cast<const char *>(sm);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = p.Ws >> 5, tiles_y = p.Hs >> 3;
-    const size_t frame = (size_t)p.Hs * p.Ws * 64;
-    const int H = 2 * p.Hs, W = 2 * p.Ws;
-
-    // the weights, once per workgroup: row (parity, n, tap) of [4 parities][Cout][4 taps][128] regrouped by (stage, quad), so that a wave's 16 CO vectors of one step are contiguous
-    {
-        const float4 *w4 = reinterpret_cast<const float4 *>(p.w);
-        float4 *wt = reinterpret_cast<float4 *>(sm + WTB / 4);
-        for (int i = tid; i < 4 * 8 * WQ; i += 64 * NW) {
-            const int st = i / (8 * WQ), q = (i / WQ) & 7, r = i % WQ;
-            wt[i] = w4[r * 32 + (st >> 1) * 16 + (st & 1) * 8 + q];
-        }
-    }
-
-    unsigned vst[NPC];
-    i32x4 srd0, srd1;
-    auto tile_origin = [&](int tile, int &b, int &y0, int &x0) {
-        b = tile / (tiles_x * tiles_y);
-        const int r = tile - b * tiles_x * tiles_y;
-        const int ty = r / tiles_x;
-        y0 = ty * 8; x0 = (r - ty * tiles_x) * 32;
-    };
-    auto plan_copies = [&](int tile) {
-        int b, y0, x0;
-        tile_origin(tile, b, y0, x0);
-#pragma unroll
-        for (int j = 0; j < NPC; ++j) {
-            const int I = NW * j + wave;
-            const int row = I / 5, cc = 8 * (I - row * 5) + (lane >> 3);
-            const int pp = row * WP + cc, q = (lane & 7) ^ ((pp >> 1) & 7);
-            const int y = y0 - 1 + row, x = x0 - 1 + cc;
-            const bool ok = I < 50 && cc < 34 && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-            vst[j] = ok ? (unsigned)(((y * p.Ws + x) * 64 + 4 * q) * 4) : OOB;
-        }
-        srd0 = make_srd(static_cast<const float *>(p.src0) + (size_t)b * frame, (unsigned)(frame * 4));
-        srd1 = make_srd(static_cast<const float *>(p.src1) + (size_t)b * frame, (unsigned)(frame * 4));
-    };
-    auto issue = [&](int st, int buf) {
-        const unsigned dst = lds0 + (unsigned)(buf * STG + wave * 1024);
-        const int soff = (st & 1) * 128;
-        const unsigned last = wave < 2 ? dst + 48 * 1024 : lds0 + (unsigned)DUMP;      // pieces 48, 49 exist; the others of that round go to the dump slot
-        const i32x4 srd = st < 2 ? srd0 : srd1;
-        const unsigned v0[4] = {vst[0], vst[1], vst[2], vst[3]}, v1[4] = {vst[4], vst[5], vst[6], vst[7]}, v2[4] = {vst[8], vst[9], vst[10], vst[11]};
-        const unsigned v3[1] = {vst[12]};
-        dma16_group<4, 4096>(dst, v0, srd, soff); dma16_group<4, 4096>(dst + 16384, v1, srd, soff); dma16_group<4, 4096>(dst + 32768, v2, srd, soff);
-        dma16_group<1, 0>(last, v3, srd, soff);
-    };
-
-    // this lane's pixels: rows 4 lh .. 4 lh + 3 of the tile at column lx; staged pixel (row r, column c) of the 10 x 34 halo tile is r * WP + c (r = tile row + 1 - 1 + ty),
-    // whose quad q sits at slot q ^ ((pixel >> 1) & 7): byte address of quad 0 below, quad q = that ^ (q << 4) (the pixel term has no bits below 128)
-    const int lx = lane & 31, lh = lane >> 5;
-    unsigned a0[6][3];
-#pragma unroll
-    for (int ty = 0; ty < 6; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-            const int pp = (4 * lh + ty) * WP + lx + tx;
-            a0[ty][tx] = (unsigned)(pp * 128 + (((pp >> 1) & 7) << 4));
-        }
-    v2f acc[4][4][CO];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int par = 0; par < 4; ++par)
-#pragma unroll
-            for (int n = 0; n < CO; ++n) acc[k][par][n] = v2f{0.f, 0.f};
-
-    auto compute = [&](int st, int buf) {
-        const char *sb = smc + buf * STG;
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const int q = 2 * wave + qq;                       // this wave's quads of the stage (wave-uniform)
-            const unsigned qx = (unsigned)(q << 4);
-            float4 xv[6][3];
-#pragma unroll
-            for (int ty = 0; ty < 6; ++ty)
-#pragma unroll
-                for (int tx = 0; tx < 3; ++tx) xv[ty][tx] = *reinterpret_cast<const float4 *>(sb + (a0[ty][tx] ^ qx));
-            const float4 *wl = reinterpret_cast<const float4 *>(smc + WTB) + (st * 8 + q) * WQ;      // wave-uniform address: broadcast reads
-#pragma unroll
-            for (int par = 0; par < 4; ++par)
-#pragma unroll
-                for (int n = 0; n < CO; ++n)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float4 w4 = wl[(par * CO + n) * 4 + t];
-                        const v2f wlo = v2f{w4.x, w4.y}, whi = v2f{w4.z, w4.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float4 x4 = xv[k + (par >> 1) + (t >> 1)][(par & 1) + (t & 1)];
-                            acc[k][par][n] = __builtin_elementwise_fma(v2f{x4.x, x4.y}, wlo, acc[k][par][n]);
-                            acc[k][par][n] = __builtin_elementwise_fma(v2f{x4.z, x4.w}, whi, acc[k][par][n]);
-                        }
-                    }
-        }
-    };
-
-    float *ot = sm + OTB / 4;
-    const int nmine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // tiles blockIdx.x, + gridDim.x, ...
-    const int nsteps = 4 * nmine;
-    int itile = blockIdx.x;                                   // the copy side's tile
-    plan_copies(itile);
-    issue(0, 0);
-    issue(1, 1);
-    int ist = 2;                                              // next stage the copy side issues
-    int ctile = blockIdx.x;
-    for (int n = 0; n < nsteps; ++n) {
-        const int st = n & 3, buf = n & 1;
-        if (n + 1 < nsteps) dma_wait<NPC>(); else dma_wait<0>();
-        __syncthreads();                                      // (the first one also publishes the weight table)
-        compute(st, buf);
-        if (st == 3) {
-            // the four waves' partial sums meet in the output tile, in wave order: ((w0 + w1) + w2) + w3, then bias and tanh
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                if (wave == w) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int par = 0; par < 4; ++par)
-#pragma unroll
-                            for (int nn = 0; nn < CO; ++nn) {
-                                float *o = ot + (nn * 16 + 2 * (4 * lh + k) + (par >> 1)) * 68 + 2 * lx + (par & 1);
-                                float v = acc[k][par][nn].x + acc[k][par][nn].y;
-                                if (w > 0) v = *o + v;
-                                if (w == NW - 1) {
-                                    if (p.bias) v += p.bias[nn];
-                                    if (p.apply_tanh) v = tanhf(v);
-                                }
-                                *o = v;
-                                acc[k][par][nn] = v2f{0.f, 0.f};
-                            }
-                }
-                __syncthreads();
-            }
-        } else {
-            __syncthreads();                                  // this step's buffer is free
-        }
-        if (st == 3) {
-            int b, y0, x0;
-            tile_origin(ctile, b, y0, x0);
-            if (p.out)
-                for (int i = tid; i < CO * 256; i += 64 * NW) {
-                    const int nn = i >> 8, Y = (i >> 4) & 15, x4 = i & 15;
-                    *reinterpret_cast<float4 *>(p.out + (((size_t)b * CO + nn) * H + 2 * y0 + Y) * W + 2 * x0 + 4 * x4) =
-                        *reinterpret_cast<const float4 *>(ot + (nn * 16 + Y) * 68 + 4 * x4);
-                }
-            if (p.out_u8) {
-                constexpr int wpr = 16 * CO;                 // 4-byte words per tile row (64 pixels x Cout bytes)
-                for (int i = tid; i < 16 * wpr; i += 64 * NW) {
-                    const int Y = i / wpr, wd = i - Y * wpr;
-                    unsigned pk = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int kk = 4 * wd + e, X = kk / CO, nn = kk - X * CO;
-                        pk |= (unsigned)to_u8(ot[(nn * 16 + Y) * 68 + X]) << (8 * e);
-                    }
-                    *reinterpret_cast<unsigned *>(p.out_u8 + (((size_t)b * H + 2 * y0 + Y) * W + 2 * x0) * CO + 4 * wd) = pk;
-                }
-            }
-            ctile += gridDim.x;
-        }
-        if (n + 2 < nsteps) {
-            if (ist == 4) { ist = 0; itile += gridDim.x; plan_copies(itile); }
-            issue(ist, buf);
-            ++ist;
-        }
-    }
-}
-
 static int device_cu_count()
 {
     static int cu_count[64];                                  // per device, filled on first use (racing fills write the same value)
@@ -1307,31 +1106,6 @@ static hipError_t launch_last_conv_mfma_t(const LastConvParams &p, hipStream_t s
     const long grid = tiles < cus ? tiles : cus;
     hipLaunchKernelGGL(last_conv_mfma<NW>, dim3((unsigned)grid), dim3(64 * NW), smem, s, p, (int)tiles);
     return hipGetLastError();
-}
-template <int CO>
-static hipError_t launch_last_conv_vl_t(const LastConvParams &p, hipStream_t s)
-{
-    const size_t smem = 2 * (10 * 40 * 128) + 4 * 16 * 68 * 4 + 4 * 8 * 16 * CO * 16 + 1024;
-    static AttrMask attr_mask;
-    if (attr_needed_on_this_device(attr_mask)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&last_conv_vl<CO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr_done_on_this_device(attr_mask);
-    }
-    const long tiles = (long)p.B * (p.Hs / 8) * (p.Ws / 32);
-    const int cus = device_cu_count();
-    const long grid = tiles < cus ? tiles : cus;
-    hipLaunchKernelGGL(last_conv_vl<CO>, dim3((unsigned)grid), dim3(256), smem, s, p, (int)tiles);
-    return hipGetLastError();
-}
-static hipError_t launch_last_conv_vl(const LastConvParams &p, hipStream_t s)
-{
-    switch (p.Cout) {
-    case 1: return launch_last_conv_vl_t<1>(p, s);
-    case 2: return launch_last_conv_vl_t<2>(p, s);
-    case 3: return launch_last_conv_vl_t<3>(p, s);
-    default: return launch_last_conv_vl_t<4>(p, s);
-    }
 }
 static hipError_t launch_last_conv_mfma(const LastConvParams &p, hipStream_t s)
 {
@@ -1375,8 +1149,9 @@ hipError_t launch_last_conv(const LastConvParams &p, hipStream_t s)
 {
     // route 0 (by shape): the matrix-core kernel in its eight-wave form where it applies; 4 its four-wave form of round 3 "or fail" (A-B runs, tests);
     // 5: the vector-ALU kernels by size.  (A weights-stationary form with both operands in registers was built in round 4, parity-green and slower --
-    // its 400 registers allow one wave per SIMD -- and removed: profiles/r04_lastconv_ab.txt.)
-    if (p.route == 6) return last_conv_mfma_ok(p) ? launch_last_conv_vl(p, s) : hipErrorInvalidValue;      // the vector-ALU form with LDS-broadcast weights (round 5) or fail
+    // its 400 registers allow one wave per SIMD -- and removed: profiles/r04_lastconv_ab.txt.  Round 5: a vector-ALU form with LDS-broadcast weights, four source
+    // pixels per lane and the K loop split over the waves -- parity-green, 25.9 / 139 us against 22.2 / 119 -- likewise: profiles/r05_lastconv_valu_lds.txt; its
+    // source is archived in tools/sessions/experiments/last_conv_experiments.inc.)
     if ((p.route == 0 || p.route == 4) && last_conv_mfma_ok(p)) return launch_last_conv_mfma(p, s);
     if (p.route == 4) return hipErrorInvalidValue;
     if (p.dtype == 2) {

@@ -186,16 +186,15 @@ def test_shared_candidate_paths_agree(gpu_device):
     e.set_candidates(None)
 
 
-@pytest.mark.parametrize("env", ["LSP_HIP_LASTCONV_STRIP", "LSP_HIP_LASTCONV_ROWS", "LSP_HIP_LASTCONV_GENERIC", "LSP_HIP_LASTCONV_VALU", "LSP_HIP_LASTCONV_MFMA", "LSP_HIP_LASTCONV_VL"])
+@pytest.mark.parametrize("env", ["LSP_HIP_LASTCONV_STRIP", "LSP_HIP_LASTCONV_ROWS", "LSP_HIP_LASTCONV_GENERIC", "LSP_HIP_LASTCONV_VALU", "LSP_HIP_LASTCONV_MFMA"])
 def test_every_last_conv_variant_matches_golden(env, gpu_device, monkeypatch):
     """The last layer has a matrix-core kernel (eight waves per workgroup since round 4: the default for the shapes the generators build, so every
     other golden test runs it; _MFMA forces its four-wave form of round 3, which fails loudly on shapes it does not take) and three vector-ALU
     kernels (sliding-window, channel-parallel rows, generic) behind it, picked by size; each is forced once here -- LSP_HIP_LASTCONV_VALU = the
-    by-size rule without the matrix-core kernel -- and checked against the reference golden.  _VL (round 5): the vector-ALU form with LDS-broadcast weights,
-    four source pixels per lane and the K loop split over the waves (last_conv_vl); like _MFMA it takes two 64-channel sources or fails."""
+    by-size rule without the matrix-core kernel -- and checked against the reference golden."""
     monkeypatch.setenv(env, "1")
     # the forced matrix-core routes fail (by design) on shapes they do not take: two 64-channel sources only
-    for case in (("large_512", "normal_512") if env.endswith(("_MFMA", "_VL")) else ("large_s128_b2", "normal_512")):
+    for case in (("large_512", "normal_512") if env.endswith("_MFMA") else ("large_s128_b2", "normal_512")):
         meta, arrays, topo, sd, feat, cand = golden_problem(case)
         e = make_engine(topo, sd, gpu_device, meta["batch"])
         out = e.forward(torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device))

@@ -2,7 +2,7 @@
 # Pastes tools/sessions/experiments/last_conv_experiments.inc into a scratch copy of csrc/edge_layers.hip (kernels in front of device_cu_count(), launchers behind it)
 # and compiles it for gfx950: the archived experiment kernels still build against the library's helpers.  Nothing is written into the tree.
 set -e
-R=$(cd "$(dirname "$0")/../.." && pwd); T=$(mktemp -d)
+R=$(cd "$(dirname "$0")/../../.." && pwd); T=$(mktemp -d)
 python3 - "$R" "$T" <<'PY'
 import sys
 R, T = sys.argv[1:3]
@@ -16,5 +16,5 @@ out = head + "\n" + inc.split("// ---- launchers")[0] + marker + tail[:end] + "\
 open(T + "/edge_layers_exp.hip", "w").write(out)
 PY
 cp "$R"/livespeechportraits_amd/csrc/*.h "$T"/; mkdir -p "$T/../include_dummy"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$R/livespeechportraits_amd/csrc" -I"$R/include" -c "$T/edge_layers_exp.hip" -o "$T/exp.o" -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|last_conv_ks|last_conv_sv" -A4 | grep -E "error|Function Name|VGPRs:|Scratch" | head -12
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$R/livespeechportraits_amd/csrc" -I"$R/include" -c "$T/edge_layers_exp.hip" -o "$T/exp.o" -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|last_conv_ks|last_conv_sv|last_conv_vl" -A4 | grep -E "error|Function Name|VGPRs:|Scratch" | head -12
 echo "compiled: $T/exp.o"; rm -rf "$T"
