@@ -12,7 +12,7 @@ for cfg in large_b1_f32 large_b8_f32 normal_b8_bf16; do
   n=$(python - "$db" <<'PY'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1]).cursor()
-print(c.execute("select count(*) from kernels where name like '%first_conv%'").fetchone()[0])
+print(c.execute("select count(*) from kernels where name like '%first_conv%' and name not like '%first_conv_feat%'").fetchone()[0])   # one per forward (the feature-map pass of a shared-candidate batch is a second kernel)
 PY
 )
   python tools/rocprof_summary.py "$db" > profiles/${R}_kernel_stats_$cfg.txt
@@ -23,7 +23,7 @@ PY
 import csv, glob, sys
 n = 0
 for p in glob.glob(sys.argv[1] + "/**/pmc_counter_collection.csv", recursive=True):
-    n += sum(1 for r in csv.DictReader(open(p)) if "first_conv" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE")
+    n += sum(1 for r in csv.DictReader(open(p)) if "first_conv" in r["Kernel_Name"] and "first_conv_feat" not in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE")
 print(max(n, 1))
 PY
 )
