@@ -148,6 +148,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "bandconv_min_frames") P.bandconv_min_frames_small = v;
         else if (k == "rowup") P.use_rowup = v != 0;
         else if (k == "rowlast") P.use_rowlast = v != 0;
+        else if (k == "rowlast_fused") P.rowlast_fused = v != 0;
         else if (k == "rowconv") P.use_rowconv = v != 0;
         else if (k == "fullk_split") P.use_fullk_split = v != 0;
         else if (k == "fullk_split_tiles") P.fullk_split_max_tiles = v;
@@ -345,7 +346,7 @@ int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout
 {
     if (!g_dev || (!out_f32_dev && !out_u8_dev)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (batch < 1 || hs < 1 || ws < 1 || cout < 1 || cout > 4) return fail(LSPF2F_ERR_SHAPE, "pixel_shuffle: cout must be in 1..4");
-    ShuffleParams sp{g_dev, out_f32_dev, out_u8_dev, batch, hs, ws, cout, apply_tanh ? 1 : 0};
+    ShuffleParams sp{g_dev, out_f32_dev, out_u8_dev, batch, hs, ws, cout, apply_tanh ? 1 : 0, 0};
     const hipError_t e = launch_pixel_shuffle(sp, static_cast<hipStream_t>(hip_stream));
     return e == hipSuccess ? LSPF2F_OK : hipfail(e, "pixel_shuffle launch");
 }
@@ -440,9 +441,12 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             q.src0 = tptr(l.src0); q.src1 = tptr(l.src1); q.w = h->blob + l.wrl_off;
             q.out = reinterpret_cast<float *>(h->ws + P.partial_offset);
             q.B = batch; q.H = l.hs; q.W = l.hs; q.R = rowlast_rows(batch, l.hs, l.hs); q.dtype = P.dtype;
+            // fp32 frames only: shuffle + tanh in the kernel's epilogue (no intermediate, no second launch); uint8 rows (tensor2im) keep the two-launch form
+            const bool fused = P.rowlast_fused && out && !out_u8;
+            if (fused) { q.out_nchw = out; q.cout = l.cout; q.apply_tanh = l.tanh_out ? 1 : 0; }
             e = launch_rowlast(q, s);
-            if (e == hipSuccess) {
-                ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0};
+            if (e == hipSuccess && !fused) {
+                ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0, 1};
                 e = launch_pixel_shuffle(sp, s);
             }
             if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
@@ -457,7 +461,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         g.ktiles_total = 9 * l.cin / P.ktile_channels(); g.splits = 1; g.ktiles_per_split = g.ktiles_total;
         e = launch_igemm(g, 128, 32, 1, s);
         if (e == hipSuccess) {
-            ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0};
+            ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0, 0};
             e = launch_pixel_shuffle(sp, s);
         }
     } else if (l.kind == kLastConv) {

@@ -1194,6 +1194,13 @@ __global__ __launch_bounds__(256) void pixel_shuffle_tanh(ShuffleParams p)
     float v[16];
     for (int i = 0; i < n / 4; ++i) { const float4 t = g4[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
     if (p.apply_tanh) for (int i = 0; i < n; ++i) v[i] = tanhf(v[i]);
+    if (p.paired) {            // rowlast128's column order -> (py * 2 + px) * Cout + co
+        float u[16];
+        for (int i = 0; i < n; ++i) u[i] = v[i];
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int co = 0; co < p.Cout; ++co) v[(py * 2 + px) * p.Cout + co] = u[(py * p.Cout + co) * 2 + px];
+    }
     for (int py = 0; py < 2; ++py) {
         if (p.out)
             for (int co = 0; co < p.Cout; ++co)

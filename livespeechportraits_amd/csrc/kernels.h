@@ -267,7 +267,9 @@ void pack_bandconv_weights(const unsigned short *rows, unsigned short *out, int 
 struct RowLastParams {
     const void *src0, *src1;      // NHWC bf16 [B][H][W][64] each
     const void *w;                // bf16, fragment order of pack_rowlast_weights()
-    float *out;                   // fp32 [B][H][W][12]
+    float *out;                   // fp32 [B][H][W][4 * cout], columns in the PAIRED order n' = ((py * cout + co) * 2 + px) of pack_rowlast_weights (-> pixel_shuffle_tanh with paired = 1)
+    float *out_nchw;              // != nullptr: the fused form -- shuffle + tanh in the epilogue, NCHW fp32 [B][cout][2H][2W] written directly (`out` unused)
+    int cout, apply_tanh;         // fused form only
     int B, H, W, R;
     int dtype;                    // 1 = bf16 (default when 0), 2 = fp16
     int nsx, nsy, nblocks;        // filled by launch_rowlast
@@ -333,6 +335,7 @@ struct ShuffleParams {
     float *out;
     unsigned char *out_u8;
     int B, Hs, Ws, Cout, apply_tanh;
+    int paired;        // columns of g in the order n' = ((py * Cout + co) * 2 + px) (rowlast128's operand order) instead of (py * 2 + px) * Cout + co
 };
 hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s);
 // one wave: {shader cycles, 100-MHz ticks} seen while spinning for duration_us of the constant counter (the clock the chip holds under load)

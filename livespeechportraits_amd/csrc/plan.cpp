@@ -64,7 +64,11 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
             // `normal` 633.5-635.0 -> 638.5-640.9, batch 8 +0.4 %; 1024 is slightly below 768).  Splitting the 512-tile layers of the 128x128 level
             // in two as well (2 -> 4 waves per SIMD) was measured in round 2: the K loop gains what the 8.4-MB slabs cost, 52 -> 55 us per layer.  bf16 keeps 512 (768: batch 8
             // `large` -0.7 %, `normal` no change).  Same session, 3 runs per arm.
-            const int target = dtype == 0 ? 768 : 512;
+            // 16-bit, 64-row tiles, M >= 2048 and a long K (>= 72 K-tiles): L4.down / L5.up of an 8-frame plan, the two 16x16-level layers conv3x3_fullk16 does not take.
+            // 256 tiles x 2 splits measured 46.7 / 29.8 us per layer, x 4 splits 43.1 / 27.3 (tools/sessions/gpu_r5_s7.sh, profiles/r05_bf16_tilings.txt); at 4 frames
+            // (M = 1024) the finer split loses, so the rule stops there
+            const bool long_k16 = dtype != 0 && bm == 64 && M >= 2048 && ktiles >= 72;
+            const int target = dtype == 0 ? 768 : long_k16 ? 1024 : 512;
             splits = (int)((target + tiles - 1) / tiles);
             splits = std::min(splits, std::max(1, ktiles / 4));   // keep >= 4 K-tiles per split
             const int per = (ktiles + splits - 1) / splits;      // make every split non-empty

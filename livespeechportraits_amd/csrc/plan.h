@@ -93,6 +93,7 @@ struct Plan {
                                                // workgroups of such a launch lose to the igemm (normal 4460 -> 4388, large 2881 -> 2840 frames/s,
                                                // A-B-A-B); tune key `bandconv_min_frames` lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_rowup = true;     // bf16 plans: tune key `rowup=0` keeps L1.up on the implicit GEMM (A-B runs)
+    bool rowlast_fused = true; // bf16 plans: rowlast128 applies pixel shuffle + tanh in its epilogue when only fp32 frames are wanted (tune key `rowlast_fused=0`: the two-launch form, A-B runs)
     bool use_rowlast = true;   // bf16 plans: tune key `rowlast=0` keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
     int fullk_split_max_tiles = 128;   // tune key `fullk_split_tiles` (tools): 256 also splits the 16x16 layers at batch 1
     int use_fullk_s2 = 0;          // tune key `fullk_s2`: the stride-2 convs of the small levels at batch 1 on the K-split full-K kernel instead of the implicit

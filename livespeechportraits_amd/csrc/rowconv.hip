@@ -506,13 +506,18 @@ constexpr int RL_TW = 64;                 // low-res pixels per strip row
 constexpr int RL_PITCH = 12288;           // bytes per ring row and source: 96 records of 128 B = 3 passes of the workgroup (66 are real)
 constexpr int RL_NR = 5;
 constexpr int RL_PF = RL_NR - 1;
-constexpr int RL_OPS = 3 + 3 + 1;         // vector-memory operations per step and wave: 3 pieces per source, 1 store
-static_assert((RL_PF - 1) * RL_OPS < 64, "vmcnt is a 6-bit counter");
+constexpr int RL_OPS = 3 + 3 + 1;         // vector-memory operations per step and wave: 3 pieces per source, 1 store (2 in the fused form: + 1)
+static_assert((RL_PF - 1) * (RL_OPS + 1) < 64, "vmcnt is a 6-bit counter");
 }  // namespace
 
-template <bool F16>
+// FUSED (round 5): pixel shuffle + tanh in the epilogue -- the fp32 [B][H][W][12] intermediate (25 MB written and read back at 8 frames) and the pixel_shuffle_tanh
+// launch (13 us) go.  The rows of the weight operand are packed in the order n' = ((py * cout + co) * 2 + px) (pack_rowlast_weights), so a lane's four accumulator registers
+// are two (px = 0, px = 1) pairs of one (output row parity, channel) each: two 8-byte stores per lane, 16 lanes = 128 contiguous bytes of an NCHW output row.  Same tanhf,
+// same fp32 values: bit-identical to the two-launch form, which stays for the uint8 (tensor2im) output.
+template <bool F16, bool FUSED>
 __global__ __launch_bounds__(256) void rowlast128(const RowLastParams p)
 {
+    constexpr int OPS = RL_OPS + (FUSED ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef __attribute__((address_space(3))) float lds_float;
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
@@ -535,7 +540,9 @@ __global__ __launch_bounds__(256) void rowlast128(const RowLastParams p)
     const unsigned imgbytes = (unsigned)(p.H * p.W) * 128u;
     const i32x4 srd0 = make_srd(static_cast<const char *>(p.src0) + (size_t)b * imgbytes, imgbytes);
     const i32x4 srd1 = make_srd(static_cast<const char *>(p.src1) + (size_t)b * imgbytes, imgbytes);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out) + (size_t)b * p.H * p.W * 48, 0, p.H * p.W * 48, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = FUSED
+        ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out_nchw) + (size_t)b * p.cout * p.H * p.W * 16, 0, p.cout * p.H * p.W * 16, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out) + (size_t)b * p.H * p.W * 48, 0, p.H * p.W * 48, 0x00020000);
 
     // DMA roles (both sources alike): pass q moves record slots q*256 + tid, record r = pixel x0 - 1 + r, slot c <- chunk c ^ ((r >> 1) & 7)
     unsigned in_col[3];
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(256) void rowlast128(const RowLastParams p)
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto step = [&](int i, f32x4v &an, f32x4v &am, f32x4v &ao) {
-        if (i < RL_PF) vm_wait<6 * (RL_PF - 1)>(); else vm_wait<(RL_PF - 1) * RL_OPS>();
+        if (i < RL_PF) vm_wait<6 * (RL_PF - 1)>(); else vm_wait<(RL_PF - 1) * OPS>();
         __syncthreads();
         dma_step(i + RL_PF);
         const char *row = reinterpret_cast<const char *>(smem) + (unsigned)(i % RL_NR) * (2 * RL_PITCH);
@@ -617,9 +624,26 @@ __global__ __launch_bounds__(256) void rowlast128(const RowLastParams p)
         }
         // output row j = i - 2 is complete.  D layout: lane = pixel l15, register r = output n = 4*g4 + r: 12 floats per pixel, lanes g4 < 3
         const int j = i - 2;
-        const bool live = j >= 0 && j < p.R && y0 + j < p.H && g4 < 3;
-        const unsigned off = live ? (unsigned)(((y0 + j) * p.W + x0 + wave * 16 + l15) * 48 + g4 * 16) : kOOB;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ao), rs_out, off, 0, 0);
+        if constexpr (FUSED) {
+            // registers (2h, 2h + 1) = output pixels (2x, 2x + 1) of row 2y + py, channel co, with (py, co) = pair 2 g4 + h
+            const bool rowok = j >= 0 && j < p.R && y0 + j < p.H;
+            const int xg = x0 + wave * 16 + l15;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = 2 * g4 + h;
+                const int py = q >= p.cout ? 1 : 0, co = q - py * p.cout;
+                float v0 = ao[2 * h], v1 = ao[2 * h + 1];
+                if (p.apply_tanh) { v0 = tanhf(v0); v1 = tanhf(v1); }
+                const unsigned off = (rowok && q < 2 * p.cout) ? (unsigned)(((co * 2 * p.H + 2 * (y0 + j) + py) * 2 * p.W + 2 * xg) * 4) : kOOB;
+                const v2f pr = {v0, v1};
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pr), rs_out, off, 0, 0);
+            }
+        } else {
+            const bool live = j >= 0 && j < p.R && y0 + j < p.H && g4 < 3;
+            const unsigned off = live ? (unsigned)(((y0 + j) * p.W + x0 + wave * 16 + l15) * 48 + g4 * 16) : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ao), rs_out, off, 0, 0);
+        }
     };
 
 #pragma unroll
@@ -640,8 +664,10 @@ void pack_rowlast_weights(const unsigned short *rows, unsigned short *out, int n
         for (int kc = 0; kc < 4; ++kc)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int n = lane & 15;
-                    out[(((size_t)t * 4 + kc) * 64 + lane) * 8 + e] = n < nout ? rows[((size_t)n * 9 + t) * 128 + kc * 32 + 8 * (lane >> 4) + e] : 0;
+                    // operand row n' = ((py * cout + co) * 2 + px) holds GEMM row (py * 2 + px) * cout + co: a lane's registers are (px 0, px 1) pairs (the fused epilogue)
+                    const int np = lane & 15, cout = nout / 4, q = np >> 1, px = np & 1, py = cout ? q / cout : 0, co = cout ? q % cout : 0;
+                    const int n = (py * 2 + px) * cout + co;
+                    out[(((size_t)t * 4 + kc) * 64 + lane) * 8 + e] = np < nout ? rows[((size_t)n * 9 + t) * 128 + kc * 32 + 8 * (lane >> 4) + e] : 0;
                 }
 }
 
@@ -669,13 +695,21 @@ hipError_t launch_rowlast(const RowLastParams &p_in, hipStream_t s)
     const size_t smem = (size_t)RL_NR * 2 * RL_PITCH;
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rowlast128<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_done_on_this_device(attr_mask);
     }
-    if (p.dtype == 2) hipLaunchKernelGGL(rowlast128<true>, dim3(p.nblocks), dim3(256), smem, s, p);
-    else hipLaunchKernelGGL(rowlast128<false>, dim3(p.nblocks), dim3(256), smem, s, p);
+    if (p.out_nchw) {
+        if (p.cout < 1 || p.cout > 4 || (size_t)p.cout * p.H * p.W * 16 >= 0x7fffffffull) return hipErrorInvalidValue;
+        if (p.dtype == 2) hipLaunchKernelGGL((rowlast128<true, true>), dim3(p.nblocks), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((rowlast128<false, true>), dim3(p.nblocks), dim3(256), smem, s, p);
+        return hipGetLastError();
+    }
+    if (p.dtype == 2) hipLaunchKernelGGL((rowlast128<true, false>), dim3(p.nblocks), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL((rowlast128<false, false>), dim3(p.nblocks), dim3(256), smem, s, p);
     return hipGetLastError();
 }
 

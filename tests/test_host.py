@@ -396,6 +396,18 @@ def test_bf16_plans_route_the_edge_layers_of_the_256_level_to_row_kernels(monkey
     # the blob of `e` (max_batch 8) carries L1.up's rows (one-frame plans: implicit GEMM) and its rowup256 fragments (8-frame plans)
     e.load_state_dict(synth.make_state_dict(__import__("livespeechportraits_amd.topology", fromlist=["build_topology"]).build_topology("normal"), 7))
     blob = e.pack().numpy()
+    # rowlast128's operand: the GEMM form's 12 rows ([4 parities x 3][9][128]) in the PAIRED order n' = ((py * cout + co) * 2 + px), so that a lane's accumulator registers are
+    # (px 0, px 1) pairs and the fused epilogue writes 8-byte runs of an NCHW row (round 5); rows 12..15 of the 16-row MFMA operand are zero
+    il = len(l8) - 1
+    g_off, rl_off = e.form_offset(il, "gemm_last"), e.form_offset(il, "rowlast")
+    assert g_off >= 0 and rl_off >= 0
+    g = blob[g_off: g_off + 12 * 9 * 128 * 2].view(np.uint16).reshape(12, 9, 4, 4, 8)                     # [n][tap][kc][k-group][e]
+    frag = blob[rl_off: rl_off + 9 * 4 * 64 * 8 * 2].view(np.uint16).reshape(9, 4, 4, 16, 8)              # [tap][kc][lane >> 4][lane & 15][e]
+    for npr in range(16):
+        q, px = npr >> 1, npr & 1
+        want = g[(q // 3 * 2 + px) * 3 + q % 3].transpose(0, 1, 2, 3) if npr < 12 else np.zeros((9, 4, 4, 8), np.uint16)
+        assert np.array_equal(frag[:, :, :, npr, :], want), npr
+    assert g.any()
     i, l = [(i, x) for i, x in enumerate(l8) if x["kernel"] == "rowup256"][0]
     nbytes = 16 * 64 * 256 * 2
     fo = e.form_offset(i, "rowup")
