@@ -45,6 +45,17 @@ def test_create_rejects_unsupported_configs():
     e = Engine("normal", ngf=32, num_downs=5, size=64)
     with pytest.raises(N.Lspf2fError):   # forward before weights are bound -> STATE error, not a crash
         N.check(e.lib.lspf2f_forward(e._h, ctypes.c_void_p(8), ctypes.c_void_p(8), 1, ctypes.c_void_p(8), 1, None))
+    # the hazard-test entry point: a null handle and a handle without a workspace are errors with a message, never a crash; the Python wrapper says so before the C call
+    n = ctypes.c_uint32(7)
+    assert e.lib.lspf2f_debug_poison(None, 0xFF, None, ctypes.byref(n)) == -1 and b"null handle" in e.lib.lspf2f_last_error()
+    assert e.lib.lspf2f_debug_poison(e._h, 0xFF, None, ctypes.byref(n)) == -5 and b"workspace not bound" in e.lib.lspf2f_last_error()
+    with pytest.raises(RuntimeError, match="no workspace bound"):
+        e.debug_poison()
+    # unknown tune keys are refused (a typo must not silently run the default)
+    with pytest.raises(N.Lspf2fError):
+        Engine("normal", ngf=32, num_downs=5, size=64, tune={"wino_pri": 1})
+    for k in ("wino_prio", "out_wt", "fullk16", "fullk16_min_frames", "rowlast_fused"):
+        Engine("normal", ngf=64, num_downs=5, size=64, dtype="bf16" if "16" in k or "rowlast" in k else "f32", tune={k: 0}).close()
 
 
 # ---- key map / plan ---------------------------------------------------------------------------
