@@ -58,6 +58,10 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
             const int wn = N >= 128 ? 128 : 64;
             const long tbig = (long)par * ((M + 127) / 128) * ((N + wn - 1) / wn);
             if (tbig >= 256) { bm = 128; bn = wn; tiles = tbig; }
+            // ... except where that tile count needs a K-split (256 .. 511 tiles) although 64 x 128 tiles fill the chip unsplit and K is short (<= 36 K-tiles: L3.down of an
+            // 8-frame plan, 256 -> 512 at stride 2): 36.6 us with 128x128 x 2 splits + splitk_reduce, 32.8 us with 64x128 unsplit (profiles/r05_bf16_tilings.txt); at K = 4608
+            // the 128-row tile keeps its lead (53.4 vs 59.2 us)
+            if (tbig >= 256 && tbig < 512 && ktiles <= 36 && N >= 128 && t128 >= 512) { bm = 64; bn = 128; tiles = t128; }
         }
         if (tiles < (bm == 128 ? 512 : want)) {
             // workgroups to aim for when splitting K.  fp32: 768 beats 512 (batch 1 `large` 388.8-389.5 -> 392.3-393.2 frames/s,

@@ -356,7 +356,7 @@ def test_16bit_plans_route_the_smallest_levels_to_the_full_k_kernel():
     at8 = e.layers(8)
     fk = [l["name"] for l in at8 if l["kernel"] == "conv3x3_fullk16"]
     assert fk == ["L5.down", "L6.down", "L6.d.res0.a", "L6.d.res0.b", "L7.down", "L7.d.res0.a", "L7.d.res0.b", "L7.up", "L7.u.res0.a", "L7.u.res0.b", "L6.up"]
-    assert sum("splitk_reduce" in l["kernel"] for l in at8) == 8                      # <= 8
+    assert sum("splitk_reduce" in l["kernel"] for l in at8) == 7                      # <= 8 (19 in round 4; L3.down runs 64x128 tiles unsplit since the tile sweep of round 5)
     for l in at8:
         if l["kernel"] == "conv3x3_fullk16":
             assert l["split_k"] == 1 and l["h_out"] in (2, 4, 8) and l["cout"] == 512
