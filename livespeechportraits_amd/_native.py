@@ -1,4 +1,4 @@
-"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h, include/lsprnn.h, include/lspraster.h, include/lspmel.h).
+"""ctypes binding of liblspf2f.so (include/lspf2f.h, include/lspa2h.h, include/lsplle.h, include/lsprnn.h, include/lspraster.h, include/lspmel.h, include/lspunet.h).
 
 There is deliberately no fallback: if the shared library is missing or does not
 load, importing the hot path raises -- a GPU box must never silently run
@@ -237,6 +237,36 @@ MEL_SIGNATURES = {
     "lspmel_compute": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
+
+
+class UnetConfig(Structure):
+    """lspunet_config (include/lspunet.h)"""
+    _fields_ = [(n, c_int32) for n in ("abi_version", "input_nc", "feat_nc", "output_nc", "ngf", "num_downs", "size", "max_batch")] + [("flags", c_uint32)]
+
+
+UNET_ABI_VERSION = 1
+UNET_FLAG_NO_GRAPH = 1
+_UNET_FWD = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]
+# every symbol include/lspunet.h declares
+UNET_SIGNATURES = {
+    "lspunet_create": (c_int, [POINTER(UnetConfig), c_char_p, POINTER(c_void_p)]),
+    "lspunet_destroy": (c_int, [c_void_p]),
+    "lspunet_last_error": (c_char_p, []),
+    "lspunet_abi_version": (c_int, []),
+    "lspunet_num_tensors": (c_int, [c_void_p]),
+    "lspunet_tensor_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int64 * 4), POINTER(c_int)]),
+    "lspunet_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "lspunet_packed_bytes": (c_size_t, [c_void_p]),
+    "lspunet_pack_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspunet_bind_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspunet_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "lspunet_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lspunet_forward": (c_int, _UNET_FWD),
+    "lspunet_forward_timed": (c_int, _UNET_FWD + [POINTER(c_float)]),
+    "lspunet_num_launches": (c_int, [c_void_p, c_int]),
+    "lspunet_launch_info": (c_int, [c_void_p, c_int, c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+}
+
 _lib = None
 
 
@@ -254,7 +284,7 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise NativeLibraryError("failed to load %s: %s" % (LIB_PATH, e)) from e
-    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()) + list(RNN_SIGNATURES.items()) + list(RASTER_SIGNATURES.items()) + list(MEL_SIGNATURES.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(A2H_SIGNATURES.items()) + list(LLE_SIGNATURES.items()) + list(RNN_SIGNATURES.items()) + list(RASTER_SIGNATURES.items()) + list(MEL_SIGNATURES.items()) + list(UNET_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
@@ -267,6 +297,8 @@ def load() -> ctypes.CDLL:
     if lib.lspa2h_abi_version() != A2H_ABI_VERSION:
         raise NativeLibraryError("lspa2h ABI version mismatch: library %d, binding %d"
                                  % (lib.lspa2h_abi_version(), A2H_ABI_VERSION))
+    if lib.lspunet_abi_version() != UNET_ABI_VERSION:
+        raise NativeLibraryError("lspunet ABI version mismatch: library %d, binding %d" % (lib.lspunet_abi_version(), UNET_ABI_VERSION))
     _lib = lib
     return lib
 
@@ -335,3 +367,15 @@ def check_mel(rc: int) -> None:
     if rc != OK:
         msg = load().lspmel_last_error()
         raise LspmelError(rc, msg.decode() if msg else "")
+
+
+class LspunetError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lspunet error %d (%s): %s" % (code, ERR_NAMES.get(code, "?"), msg))
+        self.code = code
+
+
+def check_unet(rc: int) -> None:
+    if rc != OK:
+        msg = load().lspunet_last_error()
+        raise LspunetError(rc, msg.decode() if msg else "")

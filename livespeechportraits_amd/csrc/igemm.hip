@@ -45,6 +45,22 @@ static constexpr int LDK = 32;   // LDS row pitch in floats (128 B, unpadded: th
                                  // swizzle instead: 16-B slot s of row r holds k-quad s ^ ((r >> 1) & 7), which
                                  // puts the 16 rows of every ds_read_b128 lane group on 16 distinct bank slots.
 
+// `small` U-Net plans (csrc/unet_plan.cpp, models/networks.py:737-767 of the reference): the stored skip tensor d of a down-conv is only ever read as
+// leaky_relu(d, 0.2) by the next Conv2d(k4, s2, p1) -- through its space-to-depth image -- and as relu(d) by the up-conv (the in-place activations of the
+// reference), so the producer writes those two tensors instead of d (what lspf2f_unet_prepare did in a pass of its own): row `orow` = pixel (b, y, x) of
+// an Ho x Wo frame, channel quad n.  Ho, Wo even.
+__device__ __forceinline__ void unet_dual_store(const IgemmParams &p, unsigned orow, int n, float4 v)
+{
+    const unsigned hw = (unsigned)(p.Ho * p.Wo);
+    const unsigned b = p.div_rhw.div(orow), r = orow - b * hw;
+    const unsigned y = p.div_rw.div(r), x = r - y * (unsigned)p.Wo;
+    *reinterpret_cast<float4 *>(p.relu_out + (size_t)orow * p.Cout + n) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    const size_t opix = ((size_t)b * (unsigned)(p.Ho >> 1) + (y >> 1)) * (unsigned)(p.Wo >> 1) + (x >> 1);
+    const float sl = p.slope;
+    *reinterpret_cast<float4 *>(p.s2d_out + opix * (size_t)(4 * p.Cout) + ((y & 1u) * 2u + (x & 1u)) * (unsigned)p.Cout + n) =
+        make_float4(v.x > 0.f ? v.x : sl * v.x, v.y > 0.f ? v.y : sl * v.y, v.z > 0.f ? v.z : sl * v.z, v.w > 0.f ? v.w : sl * v.w);
+}
+
 // G = K-tiles staged per pipeline step (one barrier per G tiles, G tiles of global loads in
 // flight per thread).  G = 1 for long K loops; G = 4 turns a short split-K range (<= 4 tiles)
 // into a single load -> LDS -> MFMA pass, which is what the latency-bound <= 8x8 levels need.
@@ -431,7 +447,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (ok) {
-                        if (p.out_f32) store4(static_cast<float *>(p.out) + orow * p.Cout + n, v);
+                        if (KM && p.s2d_out) unet_dual_store(p, (unsigned)orow, n, v);       // (masked-K instances only: the `small` U-Net's down-convs)
+                        else if (p.out_f32) store4(static_cast<float *>(p.out) + orow * p.Cout + n, v);
                         else store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
                     }
                     if (p.psum) {                            // wave-uniform
@@ -520,12 +537,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        store4(static_cast<T *>(p.out) + e, v);
+        if (KM && p.s2d_out) unet_dual_store(p, (unsigned)orow, ncol, v);
+        else store4(static_cast<T *>(p.out) + e, v);
     }
 }
 
 // out = epilogue(sum_z partial[z]) -- shared tail of both reduce kernels
-template <typename T>
+template <typename T, bool DUAL = false>      // DUAL: unet_dual_store instead of `out` (its own instances: the reduce launches of the other plans carry none of it)
 __device__ __forceinline__ void reduce_epilogue(const IgemmParams &p, unsigned i, float4 s)
 {
     const unsigned n = (i * 4u) % (unsigned)p.Cout;
@@ -539,6 +557,10 @@ __device__ __forceinline__ void reduce_epilogue(const IgemmParams &p, unsigned i
         const float4 r = load4(static_cast<const T *>(p.residual) + (size_t)i * 4);
         s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
     }
+    if constexpr (DUAL) {
+        unet_dual_store(p, (i * 4u) / (unsigned)p.Cout, (int)n, s);
+        return;
+    }
     if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
     store4(static_cast<T *>(p.out) + (size_t)i * 4, s);
 }
@@ -546,7 +568,7 @@ __device__ __forceinline__ void reduce_epilogue(const IgemmParams &p, unsigned i
 // Many splits (the <= 16x16 levels): block = 64 float4 columns x 4 z-lanes: z-lane y adds partials
 // y, y+4, y+8, ... (ascending), then the four lane sums are added in lane order -- a fixed summation
 // tree, so results are bit-reproducible run to run.
-template <typename T>
+template <typename T, bool DUAL = false>
 __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
 {
     __shared__ float4 red[3][64];
@@ -578,12 +600,12 @@ __global__ __launch_bounds__(256) void splitk_reduce(const IgemmParams p)
         const float4 t = red[k][x];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    reduce_epilogue<T>(p, i, s);
+    reduce_epilogue<T, DUAL>(p, i, s);
 }
 
 // Few splits (2..4: the mid levels, megabytes of partials): one float4 per thread, all partial loads in
 // flight at once, no LDS, no barrier -- a pure streaming pass.  z ascending.
-template <typename T, int NS>
+template <typename T, int NS, bool DUAL = false>
 __global__ __launch_bounds__(256) void splitk_reduce_few(const IgemmParams p)
 {
     const unsigned total4 = (unsigned)(((size_t)p.Mout * p.Cout) >> 2);
@@ -596,7 +618,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_few(const IgemmParams p)
     float4 s = t[0];
 #pragma unroll
     for (int z = 1; z < NS; ++z) { s.x += t[z].x; s.y += t[z].y; s.z += t[z].z; s.w += t[z].w; }
-    reduce_epilogue<T>(p, i, s);
+    reduce_epilogue<T, DUAL>(p, i, s);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int G, bool UP, bool KM = false>
@@ -646,6 +668,7 @@ bool igemm_group_supported(int bm, int bn, int g, bool up)
 static hipError_t launch_igemm_masked(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
 {
     if (p.dtype != 0 || p.up || p.up4) return hipErrorInvalidValue;
+    if (p.s2d_out && (!p.relu_out || p.residual || p.relu || (p.Ho & 1) || (p.Wo & 1) || p.psum)) return hipErrorInvalidValue;   // dual store: see unet_dual_store
     if (g == 4) {
         if (bm == 64 && bn == 64) return launch_igemm_t<float, 64, 64, 2, 2, 4, false, true>(p, s);
         if (bm == 32 && bn == 64) return launch_igemm_t<float, 32, 64, 1, 2, 4, false, true>(p, s);
@@ -715,27 +738,36 @@ hipError_t launch_igemm(const IgemmParams &p_in, int bm, int bn, int g, hipStrea
         if (rule == 1 && p.splits > 1 && p.dtype == 0) rule = 0;
         p.xcd = forced >= 0 ? forced : rule;
     }
+    if (p.s2d_out && !p.kmask) return hipErrorInvalidValue;      // the dual store lives in the masked-K instances only
     if (p.kmask) return launch_igemm_masked(p, bm, bn, g, s);
     if (p.dtype == 2) return launch_igemm_typed<f16_t>(p, bm, bn, g, s);
     return p.dtype == 1 ? launch_igemm_typed<bf16_t>(p, bm, bn, g, s) : launch_igemm_typed<float>(p, bm, bn, g, s);
 }
 
-template <typename T>
+template <typename T, bool DUAL = false>
 static hipError_t launch_splitk_reduce_t(const IgemmParams &p, hipStream_t s)
 {
     const size_t total4 = (size_t)p.Mout * p.Cout / 4;
     const dim3 few((unsigned)((total4 + 255) / 256));
     switch (p.splits) {
-    case 2: hipLaunchKernelGGL((splitk_reduce_few<T, 2>), few, dim3(256), 0, s, p); break;
-    case 3: hipLaunchKernelGGL((splitk_reduce_few<T, 3>), few, dim3(256), 0, s, p); break;
-    case 4: hipLaunchKernelGGL((splitk_reduce_few<T, 4>), few, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL(splitk_reduce<T>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((splitk_reduce_few<T, 2, DUAL>), few, dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((splitk_reduce_few<T, 3, DUAL>), few, dim3(256), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((splitk_reduce_few<T, 4, DUAL>), few, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((splitk_reduce<T, DUAL>), dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, p); break;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_splitk_reduce(const IgemmParams &p, hipStream_t s)
+hipError_t launch_splitk_reduce(const IgemmParams &p_in, hipStream_t s)
 {
+    if (p_in.s2d_out) {                       // the `small` U-Net's split-K down-convs: fp32, the two activated copies instead of `out`
+        if (p_in.dtype != 0 || !p_in.relu_out || (p_in.Ho & 1) || (p_in.Wo & 1) || p_in.up4) return hipErrorInvalidValue;
+        IgemmParams p = p_in;
+        p.div_rhw = FastDiv::make((unsigned)(p.Ho * p.Wo));
+        p.div_rw = FastDiv::make((unsigned)p.Wo);
+        return launch_splitk_reduce_t<float, true>(p, s);
+    }
+    const IgemmParams &p = p_in;
     if (p.dtype == 2) return launch_splitk_reduce_t<f16_t>(p, s);
     return p.dtype == 1 ? launch_splitk_reduce_t<bf16_t>(p, s) : launch_splitk_reduce_t<float>(p, s);
 }

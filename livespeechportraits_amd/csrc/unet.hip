@@ -1,0 +1,778 @@
+// gfx950: the `size == 'small'` generator (Feature2FaceGenerator_Unet, models/networks.py:680-769 of the reference) as a native plan behind include/lspunet.h:
+// state dict -> packed blob, liveness-planned workspace, one launch per convolution, the whole forward replayed from a hipGraph.
+//
+// Effective dataflow (derived and checked bit for bit against the reference module by oracle/unet_small_oracle.py): with the in-place LeakyReLU / ReLU of the
+// reference, the output d_k of down-conv k (after its BatchNorm) is only ever read as leaky_relu(d_k, 0.2) by down-conv k + 1 and as relu(d_k) by up-conv k, so
+//   Y_0            = space-to-depth(cat(feature_map, cand_image))                                  unet_input_s2d (this file)
+//   d_k            = BN_k(Conv2d(k4, s2, p1)(.)) = a 3x3 conv on Y_k walking its 16 live (tap, quarter) K blocks   igemm3x3<.., KM> (igemm.hip)
+//   Y_{k+1}, R_k   = space-to-depth(leaky_relu(d_k)), relu(d_k)                                    written by that launch's epilogue (unet_dual_store)
+//   U_k            = relu(BN(ConvTranspose2d(k4, s2, p1)(cat(R_k, U_{k+1}))))  in sub-pixel form (4 parities x 2x2 taps)   igemm3x3 (up4)
+//   out            = tanh(ConvTranspose2d(cat(R_0, U_1)) + bias): a 3x3 GEMM with N = 4 parities x output_nc on the low-res source + pixel_shuffle_tanh
+#include "../../include/lspunet.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_common.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace lspf2f {
+
+// ---- input pass: two NCHW sources -> the space-to-depth image of their concatenation ---------------------------------------------------------
+// Y[b][i][j][(dy * 2 + dx) * C + c] = X[b][c][2i + dy][2j + dx], channels >= 4C zero (C = 23 -> 92 of 96).  A workgroup owns one output row i and up to 64
+// output columns: it reads the 2 x C source row segments with coalesced loads (a row of an NCHW plane is contiguous), turns them through LDS and writes
+// <= 64 x s2d_c contiguous floats.
+struct UnetInputParams {
+    const float *feat, *cand;      // [B][feat_nc][S][S], [cand_batch][C - feat_nc][S][S]
+    float *out;                    // [B][S/2][S/2][s2d_c]
+    int B, S, C, feat_nc, cand_bcast, s2d_c, cols;   // cols = output columns per workgroup (<= 64)
+};
+
+__global__ __launch_bounds__(256) void unet_input_s2d(const UnetInputParams p)
+{
+    extern __shared__ float lds[];                       // [C][2][pitch]
+    const int cw = 2 * p.cols, pitch = cw + 1;
+    const int S2 = p.S >> 1;
+    const int chunks = S2 / p.cols;
+    const int i = blockIdx.x / chunks, j0 = (blockIdx.x - i * chunks) * p.cols, b = blockIdx.y;
+    const int cand_nc = p.C - p.feat_nc;
+    const size_t plane = (size_t)p.S * p.S;
+    for (int idx = threadIdx.x; idx < p.C * 2 * cw; idx += 256) {
+        const int c = idx / (2 * cw), r = idx - c * 2 * cw;
+        const int dy = r / cw, x = r - dy * cw;
+        const float *src = c < p.feat_nc ? p.feat + ((size_t)b * p.feat_nc + c) * plane
+                                         : p.cand + ((size_t)(p.cand_bcast ? 0 : b) * cand_nc + (c - p.feat_nc)) * plane;
+        lds[(c * 2 + dy) * pitch + x] = src[(size_t)(2 * i + dy) * p.S + 2 * j0 + x];
+    }
+    __syncthreads();
+    const int q4 = p.s2d_c >> 2;
+    float *dst = p.out + (((size_t)b * S2 + i) * S2 + j0) * p.s2d_c;
+    for (int o = threadIdx.x; o < p.cols * q4; o += 256) {
+        const int j = o / q4, ch0 = (o - j * q4) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = ch0 + e;
+            v[e] = 0.f;
+            if (ch < 4 * p.C) {
+                const int q = ch / p.C, c = ch - q * p.C;
+                v[e] = lds[(c * 2 + (q >> 1)) * pitch + 2 * j + (q & 1)];
+            }
+        }
+        *reinterpret_cast<float4 *>(dst + (size_t)j * p.s2d_c + ch0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+static hipError_t launch_unet_input(const UnetInputParams &p, hipStream_t s)
+{
+    const int S2 = p.S / 2;
+    if (p.B < 1 || p.S < 2 || (p.S & 1) || p.C < 1 || p.C > 48 || p.feat_nc < 1 || p.feat_nc > p.C || p.s2d_c < 4 * p.C || (p.s2d_c & 3) || p.cols < 1 || S2 % p.cols)
+        return hipErrorInvalidValue;
+    const size_t smem = (size_t)p.C * 2 * (2 * p.cols + 1) * sizeof(float);
+    hipLaunchKernelGGL(unet_input_s2d, dim3((unsigned)(S2 * (S2 / p.cols)), (unsigned)p.B), dim3(256), smem, s, p);
+    return hipGetLastError();
+}
+
+// ---- the plan -----------------------------------------------------------------------------------------------------------------------------------
+struct UnetParam {
+    std::string key;
+    std::vector<int64_t> dims;
+    std::vector<float> data;
+    bool set = false;
+    size_t numel() const { size_t n = 1; for (auto d : dims) n *= (size_t)d; return n; }
+};
+
+struct UnetLevel {
+    int cin = 0, cout = 0;         // down-conv k: cin -> cout (= chans[k]) at stride 2
+    int s2d = 0;                   // channels of its space-to-depth input (4 cin; block 0: padded to a multiple of 32)
+    int up_cin = 0, up_cout = 0;   // transposed conv of block k: up_cin (cout, or 2 cout with the skip) -> up_cout
+    std::string dc, dbn, uc, ubn;  // state-dict keys (dbn / ubn "" = none)
+    int64_t down_w = -1, down_scale = -1, down_shift = -1, up_w = -1, up_scale = -1, up_shift = -1;   // byte offsets in the blob
+    int64_t up_sub = -1, up_bias = -1;   // block 0 only: its transposed conv in sub-pixel form [4][co][2][2][ci] + the conv bias, for the direct last-layer kernel
+    size_t down_w_bytes = 0, up_w_bytes = 0;
+};
+
+// one launch (or launch + reduce) of the forward
+struct UnetLaunch {
+    std::string name, kernel;
+    int kind = 0;                  // 0 input pass, 1 conv, 2 pixel shuffle, 3 unet_prepare (fused_prepare = 0), 4 the direct last-layer kernel (last_direct = 1)
+    int level = 0;
+    bool down = false, last = false;
+    int bm = 0, bn = 0, splits = 1, group = 1;
+    bool fused_combine = false;
+};
+
+static const unsigned kUnetCounters = 16384;
+
+struct UnetPlan {
+    int input_nc = 23, feat_nc = 23, output_nc = 3, ngf = 64, nd = 8, size = 512;
+    bool fused_prepare = true, input_pass = true;
+    bool fused_splitk = false;                 // 2..8 K splits combined by the last-arriving workgroup instead of a reduce launch: measured SLOWER here (0.903 vs 0.889 ms at one frame,
+                                               // equal at eight; profiles/r05_unet_small_native.txt) -- the split layers of this plan are short launches -- and its 6-split sum runs in another order than splitk_reduce's
+    bool last_direct = true;                   // the outermost transposed conv + tanh (+ tensor2im) on the direct sub-pixel kernel of the other variants' last layer (edge_layers.hip) instead of
+                                               // a 3x3 GEMM with N = 12 of 32 columns live + a pixel-shuffle pass
+    int last_bm = 0, last_bn = 0;              // tune: tile of the last GEMM (0 = the planner's rule)
+    std::vector<int> chans;
+    std::vector<UnetLevel> L;
+    std::vector<UnetParam> params;
+    std::map<std::string, int> index;
+    size_t blob_bytes = 0;
+
+    // per-batch state: the launch list and the workspace layout
+    struct Batch {
+        int B = 0;
+        std::vector<UnetLaunch> launches;
+        size_t y_off[2] = {0, 0}, u_off[2] = {0, 0}, g_off = 0, dtmp_off = 0, part_off = 0, cnt_off = 0, total = 0;
+        std::vector<size_t> r_off;             // R_k, k < nd - 1; r_off[nd - 1] = relu(d_{nd-1}) of the innermost block
+        size_t part_bytes = 0;
+    };
+    Batch cur;
+
+    void add_param(const std::string &k, std::vector<int64_t> d)
+    {
+        index[k] = (int)params.size();
+        UnetParam p; p.key = k; p.dims = std::move(d);
+        params.push_back(std::move(p));
+    }
+    const float *data(const std::string &k) const { return params[index.at(k)].data.data(); }
+
+    std::string build()
+    {
+        if (ngf < 32 || ngf % 32) return "ngf must be a multiple of 32";
+        if (nd < 5 || nd > 12) return "num_downs must be in 5..12";
+        if (output_nc < 1 || output_nc > 4) return "output_nc must be in 1..4";
+        if (input_nc < 1 || input_nc > 48) return "input_nc must be in 1..48";
+        if (feat_nc < 1 || feat_nc > input_nc) return "feat_nc must be in 1..input_nc";
+        if (size < (1 << nd) || size % (1 << nd)) return "frame size must be a multiple of 2**num_downs";
+        chans.clear();
+        for (int i = 0; i < nd; ++i) chans.push_back(ngf * std::min(1 << i, 8));
+        // state-dict keys: the nesting of nn.Sequential indices in UnetSkipConnectionBlock (models/networks.py:737-767)
+        std::string pfx = "model.model";
+        L.assign(nd, UnetLevel());
+        for (int k = 0; k < nd; ++k) {
+            UnetLevel &l = L[k];
+            l.cin = k == 0 ? input_nc : chans[k - 1];
+            l.cout = chans[k];
+            l.s2d = k == 0 ? (4 * input_nc + 31) / 32 * 32 : 4 * l.cin;
+            l.up_cin = k == nd - 1 ? l.cout : 2 * l.cout;
+            l.up_cout = k == 0 ? output_nc : chans[k - 1];
+            if (k == 0) { l.dc = pfx + ".0"; l.uc = pfx + ".3"; pfx += ".1.model"; }
+            else if (k == nd - 1) { l.dc = pfx + ".1"; l.uc = pfx + ".3"; l.ubn = pfx + ".4"; }
+            else { l.dc = pfx + ".1"; l.dbn = pfx + ".2"; l.uc = pfx + ".5"; l.ubn = pfx + ".6"; pfx += ".3.model"; }
+            add_param(l.dc + ".weight", {l.cout, l.cin, 4, 4});
+            if (!l.dbn.empty())
+                for (const char *t : {".weight", ".bias", ".running_mean", ".running_var"}) add_param(l.dbn + t, {l.cout});
+            add_param(l.uc + ".weight", {l.up_cin, l.up_cout, 4, 4});
+            if (k == 0) add_param(l.uc + ".bias", {l.up_cout});
+            if (!l.ubn.empty())
+                for (const char *t : {".weight", ".bias", ".running_mean", ".running_var"}) add_param(l.ubn + t, {l.up_cout});
+        }
+        // blob layout, 256-byte aligned pieces
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return (int64_t)o; };
+        for (int k = 0; k < nd; ++k) {
+            UnetLevel &l = L[k];
+            l.down_w_bytes = k == 0 ? (size_t)l.cout * 9 * l.s2d * 4 : (size_t)l.cout * 16 * l.cin * 4;
+            l.down_w = take(l.down_w_bytes);
+            if (!l.dbn.empty()) { l.down_scale = take((size_t)l.cout * 4); l.down_shift = take((size_t)l.cout * 4); }
+            const int n_up = k == 0 ? 4 * l.up_cout : l.up_cout;
+            l.up_w_bytes = k == 0 ? (size_t)n_up * 9 * l.up_cin * 4 : (size_t)4 * l.up_cout * 4 * l.up_cin * 4;
+            l.up_w = take(l.up_w_bytes);
+            l.up_scale = take((size_t)n_up * 4);
+            l.up_shift = take((size_t)n_up * 4);
+            if (k == 0) { l.up_sub = take((size_t)4 * l.up_cout * 4 * l.up_cin * 4); l.up_bias = take((size_t)l.up_cout * 4); }
+        }
+        blob_bytes = off;
+        cur = Batch();
+        return "";
+    }
+
+    // models/networks.py BatchNorm2d in eval mode, folded in double (eps 1e-5)
+    void fold_bn(const std::string &key, int n, float *scale, float *shift) const
+    {
+        const float *g = data(key + ".weight"), *b = data(key + ".bias"), *m = data(key + ".running_mean"), *v = data(key + ".running_var");
+        for (int i = 0; i < n; ++i) {
+            const double s = (double)g[i] / std::sqrt((double)v[i] + 1e-5);
+            scale[i] = (float)s;
+            shift[i] = (float)((double)b[i] - (double)m[i] * s);
+        }
+    }
+
+    std::string pack(void *blob, size_t bytes) const
+    {
+        if (bytes < blob_bytes) return "packed weight arena too small";
+        for (const auto &p : params)
+            if (!p.set) return "missing state-dict tensor: " + p.key;
+        char *B = static_cast<char *>(blob);
+        std::memset(B, 0, blob_bytes);
+        // 4x4 / s2 tap ky -> (3x3 tap row ty, space-to-depth sub-row dy): input row 2y - 1 + ky = 2 (y + ty - 1) + dy
+        static const int TY[4] = {0, 1, 1, 2}, DY[4] = {1, 0, 1, 0};
+        // transposed conv: kernel row of output parity py, sub-pixel tap a (source row y + py + a - 1)
+        static const int KT[2][2] = {{3, 1}, {2, 0}};
+        for (int k = 0; k < nd; ++k) {
+            const UnetLevel &l = L[k];
+            const float *w = data(l.dc + ".weight");                 // [cout][cin][4][4]
+            float *dw = reinterpret_cast<float *>(B + l.down_w);
+            if (k == 0) {
+                // dense rows [co][ty][tx][s2d] of the 3x3 conv on the space-to-depth image (20 of the 36 (tap, quarter) blocks stay zero; the quarters of 23 channels are
+                // not K-tile aligned, so block 0 cannot drop them)
+                for (int co = 0; co < l.cout; ++co)
+                    for (int ci = 0; ci < l.cin; ++ci)
+                        for (int ky = 0; ky < 4; ++ky)
+                            for (int kx = 0; kx < 4; ++kx)
+                                dw[((size_t)(co * 3 + TY[ky]) * 3 + TY[kx]) * l.s2d + (DY[ky] * 2 + DY[kx]) * l.cin + ci] = w[(((size_t)co * l.cin + ci) * 4 + ky) * 4 + kx];
+            } else {
+                // [co][16 live (tap, quarter) pairs, tap-major / quarter-minor][ci]: the order the masked K cursor walks them
+                int slot[4][4], n = 0;
+                for (int ty = 0; ty < 3; ++ty)
+                    for (int tx = 0; tx < 3; ++tx)
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx)
+                                for (int ky = 0; ky < 4; ++ky)
+                                    for (int kx = 0; kx < 4; ++kx)
+                                        if (TY[ky] == ty && DY[ky] == dy && TY[kx] == tx && DY[kx] == dx) slot[ky][kx] = n++;
+                for (int co = 0; co < l.cout; ++co)
+                    for (int ci = 0; ci < l.cin; ++ci)
+                        for (int ky = 0; ky < 4; ++ky)
+                            for (int kx = 0; kx < 4; ++kx)
+                                dw[((size_t)co * 16 + slot[ky][kx]) * l.cin + ci] = w[(((size_t)co * l.cin + ci) * 4 + ky) * 4 + kx];
+            }
+            if (!l.dbn.empty()) fold_bn(l.dbn, l.cout, reinterpret_cast<float *>(B + l.down_scale), reinterpret_cast<float *>(B + l.down_shift));
+            const float *wt = data(l.uc + ".weight");                // [up_cin][up_cout][4][4]
+            float *uw = reinterpret_cast<float *>(B + l.up_w);
+            float *usc = reinterpret_cast<float *>(B + l.up_scale), *ush = reinterpret_cast<float *>(B + l.up_shift);
+            const int ci_n = l.up_cin, co_n = l.up_cout;
+            if (k == 0) {
+                // GEMM rows [par * co_n + co][3][3][ci]: tap (py + a, px + b) of the 3x3 window on the low-res source carries sub-pixel tap (a, b) of parity (py, px)
+                for (int py = 0; py < 2; ++py)
+                    for (int px = 0; px < 2; ++px)
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b)
+                                for (int co = 0; co < co_n; ++co)
+                                    for (int ci = 0; ci < ci_n; ++ci)
+                                        uw[((((size_t)(py * 2 + px) * co_n + co) * 3 + py + a) * 3 + px + b) * ci_n + ci] =
+                                            wt[(((size_t)ci * co_n + co) * 4 + KT[py][a]) * 4 + KT[px][b]];
+                const float *bias = data(l.uc + ".bias");
+                for (int i = 0; i < 4 * co_n; ++i) { usc[i] = 1.f; ush[i] = bias[i % co_n]; }
+                std::memcpy(B + l.up_bias, bias, (size_t)co_n * 4);
+            }
+            {
+                // sub-pixel form [par][co][a][b][ci] (block 0: a second form of its weights, for the direct last-layer kernel)
+                float *sw = k == 0 ? reinterpret_cast<float *>(B + l.up_sub) : uw;
+                for (int py = 0; py < 2; ++py)
+                    for (int px = 0; px < 2; ++px)
+                        for (int co = 0; co < co_n; ++co)
+                            for (int a = 0; a < 2; ++a)
+                                for (int b = 0; b < 2; ++b)
+                                    for (int ci = 0; ci < ci_n; ++ci)
+                                        sw[((((size_t)(py * 2 + px) * co_n + co) * 2 + a) * 2 + b) * ci_n + ci] =
+                                            wt[(((size_t)ci * co_n + co) * 4 + KT[py][a]) * 4 + KT[px][b]];
+                if (k > 0) fold_bn(l.ubn, co_n, usc, ush);
+            }
+        }
+        return "";
+    }
+
+    // spatial extent of d_k (= of Y_{k+1}'s source, of R_k)
+    int hd(int k) const { return size >> (k + 1); }
+
+    void tile_for(int M, int N, int ktiles, int par, UnetLaunch *u, bool allow_fused, size_t mout_x_cout) const
+    {
+        choose_tiling(M, N, ktiles, par, false, 0, &u->bm, &u->bn, &u->splits, &u->group);
+        const int per = (ktiles + u->splits - 1) / u->splits;
+        u->splits = (ktiles + per - 1) / per;
+        const long tiles = (long)par * ((M + u->bm - 1) / u->bm) * ((N + u->bn - 1) / u->bn);
+        u->fused_combine = allow_fused && fused_splitk && u->splits >= 2 && u->splits <= 8 && tiles <= (long)kUnetCounters &&
+                           (size_t)u->splits * mout_x_cout * sizeof(float) < (size_t)0x7fffffff;
+    }
+
+    void plan_batch(int B) { if (cur.B != B) cur = layout(B); }
+    size_t workspace_bytes(int B) const { return layout(B).total; }
+
+    Batch layout(int B) const
+    {
+        Batch bp;
+        bp.B = B;
+        std::vector<UnetLaunch> &launches = bp.launches;
+        size_t &part_bytes = bp.part_bytes;
+        size_t (&y_off)[2] = bp.y_off, (&u_off)[2] = bp.u_off;
+        size_t &g_off = bp.g_off, &dtmp_off = bp.dtmp_off, &part_off = bp.part_off, &cnt_off = bp.cnt_off, &total = bp.total;
+        std::vector<size_t> &r_off = bp.r_off;
+        auto note_partial = [&](const UnetLaunch &u, size_t mout_x_cout) { if (u.splits > 1) part_bytes = std::max(part_bytes, (size_t)u.splits * mout_x_cout * sizeof(float)); };
+        {
+            UnetLaunch u; u.kind = input_pass ? 0 : 3; u.name = "input"; u.kernel = input_pass ? "unet_input_s2d" : "unet_prepare"; u.level = -1;
+            launches.push_back(u);
+        }
+        for (int k = 0; k < nd; ++k) {
+            const UnetLevel &l = L[k];
+            const int h = hd(k);
+            UnetLaunch u; u.kind = 1; u.level = k; u.down = true; u.name = "L" + std::to_string(k) + ".down";
+            const bool km = k > 0 || (fused_prepare && k < nd - 1);
+            const int ktiles = k == 0 ? 9 * l.s2d / 32 : 16 * l.cin / 32;
+            tile_for(B * h * h, l.cout, ktiles, 1, &u, true, (size_t)B * h * h * l.cout);
+            u.kernel = std::string(km ? "igemm3x3<km>" : "igemm3x3") + (u.splits > 1 ? (u.fused_combine ? " (split-K combined in the launch)" : "+splitk_reduce") : "") +
+                       (fused_prepare && k < nd - 1 ? " -> lrelu s2d + relu" : "");
+            note_partial(u, (size_t)B * h * h * l.cout);
+            launches.push_back(u);
+            if (!fused_prepare && k < nd - 1) {
+                UnetLaunch q; q.kind = 3; q.level = k; q.name = "L" + std::to_string(k) + ".prepare"; q.kernel = "unet_prepare";
+                launches.push_back(q);
+            }
+        }
+        for (int k = nd - 1; k >= 1; --k) {
+            const UnetLevel &l = L[k];
+            const int h = hd(k);                                       // source extent; writes 2h
+            UnetLaunch u; u.kind = 1; u.level = k; u.name = "L" + std::to_string(k) + ".up";
+            tile_for(B * h * h, l.up_cout, 4 * l.up_cin / 32, 4, &u, true, (size_t)B * 4 * h * h * l.up_cout);
+            u.kernel = std::string("igemm3x3 (sub-pixel)") + (u.splits > 1 ? (u.fused_combine ? " (split-K combined in the launch)" : "+splitk_reduce") : "");
+            note_partial(u, (size_t)B * 4 * h * h * l.up_cout);
+            launches.push_back(u);
+        }
+        {
+            const UnetLevel &l = L[0];
+            const int h = hd(0);
+            UnetLaunch u; u.kind = 1; u.level = 0; u.last = true; u.name = "L0.up";
+            if (last_direct) {
+                u.kind = 4; u.kernel = "last_conv (direct sub-pixel kernel: transposed conv + bias + tanh + tensor2im)";
+                launches.push_back(u);
+            } else {
+            tile_for(B * h * h, 4 * l.up_cout, 9 * l.up_cin / 32, 1, &u, false, (size_t)B * h * h * 4 * l.up_cout);
+            // N = 12: the narrowest tile the implicit GEMM has (128 x 32; 64 x 64 by the general rule: 4.47 -> 4.20 ms at eight frames)
+            if (last_bm >= 0) { u.bm = 128; u.bn = 32; u.splits = 1; u.group = 1; }      // last_tile = -1: the general rule above, as the host-sequenced form runs it
+            if (last_bm > 0 && last_bn > 0) { u.bm = last_bm; u.bn = last_bn; }
+            u.kernel = "igemm3x3 (GEMM form, N = 4 parities x output_nc)";
+            note_partial(u, (size_t)B * h * h * 4 * l.up_cout);
+            launches.push_back(u);
+            UnetLaunch q; q.kind = 2; q.level = 0; q.name = "L0.shuffle"; q.kernel = "pixel_shuffle_tanh";
+            launches.push_back(q);
+            }
+        }
+        // workspace: [arrival counters][Y ping-pong][R_k ...][U ping-pong][G][d scratch (fused_prepare = 0)][split-K slabs]
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+        cnt_off = take(kUnetCounters * sizeof(unsigned));
+        size_t ymax[2] = {0, 0}, umax[2] = {0, 0}, dmax = 0;
+        for (int k = 0; k < nd; ++k) {
+            const size_t hy = (size_t)hd(k);                           // Y_k is [B][hd(k)][hd(k)][s2d_k]
+            ymax[k & 1] = std::max(ymax[k & 1], (size_t)B * hy * hy * L[k].s2d * 4);
+            dmax = std::max(dmax, (size_t)B * hy * hy * L[k].cout * 4);
+        }
+        for (int k = nd - 1; k >= 1; --k) {
+            const size_t ho = 2 * (size_t)hd(k);
+            umax[k & 1] = std::max(umax[k & 1], (size_t)B * ho * ho * L[k].up_cout * 4);
+        }
+        y_off[0] = take(ymax[0]); y_off[1] = take(ymax[1]);
+        r_off.assign(nd, 0);
+        for (int k = 0; k < nd; ++k) { const size_t h = (size_t)hd(k); r_off[k] = take((size_t)B * h * h * L[k].cout * 4); }
+        u_off[0] = take(umax[0]); u_off[1] = take(umax[1]);
+        g_off = take((size_t)B * hd(0) * hd(0) * 4 * output_nc * 4);
+        dtmp_off = fused_prepare ? off : take(dmax);
+        part_off = take(part_bytes);
+        total = off;
+        return bp;
+    }
+};
+
+}  // namespace lspf2f
+
+using namespace lspf2f;
+
+namespace {
+
+struct UnetGraphKey {
+    const void *feat, *cand, *out, *out_u8, *ws, *blob;
+    int cand_batch, batch;
+    bool operator==(const UnetGraphKey &o) const
+    {
+        return feat == o.feat && cand == o.cand && out == o.out && out_u8 == o.out_u8 && ws == o.ws && blob == o.blob && cand_batch == o.cand_batch && batch == o.batch;
+    }
+};
+struct UnetGraph {
+    UnetGraphKey key{};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void reset()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr;
+    }
+};
+const size_t kMaxUnetGraphs = 8;
+
+thread_local std::string g_uerr;
+int ufail(int code, const std::string &msg) { g_uerr = msg; return code; }
+int uhipfail(hipError_t e, const std::string &what) { return ufail(LSPUNET_ERR_HIP, what + ": " + hipGetErrorString(e)); }
+
+}  // namespace
+
+struct lspunet_handle {
+    UnetPlan plan;
+    lspunet_config cfg{};
+    const char *blob = nullptr;
+    size_t blob_size = 0;
+    char *ws = nullptr;
+    size_t ws_size = 0;
+    bool use_graph = true, counters_clean = false;
+    hipStream_t cap_stream = nullptr;
+    std::vector<UnetGraph> graphs;
+    size_t next_victim = 0;
+    void drop_graphs()
+    {
+        for (auto &g : graphs) g.reset();
+        graphs.clear();
+    }
+    ~lspunet_handle()
+    {
+        drop_graphs();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    }
+};
+
+// one launch of the planned forward
+static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *feat, const float *cand, int cand_batch, float *out, unsigned char *out_u8, int B, hipStream_t s)
+{
+    const UnetPlan &P = h->plan;
+    auto wsf = [&](size_t off) { return reinterpret_cast<float *>(h->ws + off); };
+    auto bl = [&](int64_t off) { return off < 0 ? nullptr : reinterpret_cast<const float *>(h->blob + off); };
+    hipError_t e = hipSuccess;
+    if (u.kind == 0) {
+        UnetInputParams q{};
+        q.feat = feat; q.cand = cand; q.out = wsf(P.cur.y_off[0]);
+        q.B = B; q.S = P.size; q.C = P.input_nc; q.feat_nc = P.feat_nc; q.cand_bcast = cand_batch == 1 && B > 1; q.s2d_c = P.L[0].s2d;
+        q.cols = 64;
+        while ((P.size / 2) % q.cols) q.cols >>= 1;
+        e = launch_unet_input(q, s);
+    } else if (u.kind == 3) {
+        PrepareParams q{};
+        if (u.level < 0) {          // the input, already concatenated by the caller (input_pass = 0)
+            q.src = feat; q.nchw = 1; q.B = B; q.H = P.size; q.W = P.size; q.C = P.input_nc; q.slope = 1.f;
+            q.s2d = wsf(P.cur.y_off[0]); q.s2d_c = P.L[0].s2d; q.relu = nullptr;
+        } else {
+            const int k = u.level, hh = P.hd(k);
+            q.src = wsf(P.cur.dtmp_off); q.nchw = 0; q.B = B; q.H = hh; q.W = hh; q.C = P.L[k].cout; q.slope = 0.2f;
+            q.s2d = wsf(P.cur.y_off[(k + 1) & 1]); q.s2d_c = 4 * P.L[k].cout; q.relu = wsf(P.cur.r_off[k]);
+        }
+        e = launch_unet_prepare(q, s);
+    } else if (u.kind == 4) {
+        const UnetLevel &l = P.L[0];
+        LastConvParams q{};
+        q.src0 = wsf(P.cur.r_off[0]); q.src1 = wsf(P.cur.u_off[1]); q.dtype = 0; q.w = bl(l.up_sub); q.bias = bl(l.up_bias);
+        q.out = out; q.out_u8 = out_u8; q.B = B; q.Hs = P.hd(0); q.Ws = P.hd(0); q.C0 = l.cout; q.C1 = l.cout; q.Cout = l.up_cout; q.apply_tanh = 1;
+        e = launch_last_conv(q, s);
+    } else if (u.kind == 2) {
+        ShuffleParams q{};
+        q.g = wsf(P.cur.g_off); q.out = out; q.out_u8 = out_u8; q.B = B; q.Hs = P.hd(0); q.Ws = P.hd(0); q.Cout = P.output_nc; q.apply_tanh = 1;
+        e = launch_pixel_shuffle(q, s);
+    } else {
+        const int k = u.level;
+        const UnetLevel &l = P.L[k];
+        const int hh = P.hd(k);
+        IgemmParams p{};
+        p.dtype = 0; p.B = B; p.stride = 1;
+        p.partial = wsf(P.cur.part_off);
+        if (u.down) {
+            // Conv2d(k4, s2, p1) as the 3x3 conv on the space-to-depth image Y_k: [B][hh][hh][s2d]
+            p.src0 = wsf(P.cur.y_off[k & 1]); p.src1 = nullptr; p.w = bl(l.down_w); p.scale = bl(l.down_scale); p.shift = bl(l.down_shift);
+            p.Hs = p.Ws = p.Ho = p.Wo = hh; p.C0 = p.Cin = l.s2d; p.C1 = 0; p.Cout = l.cout;
+            p.Mout = p.M = B * hh * hh;
+            const bool inner = k == P.nd - 1;
+            const bool km = k > 0 || (P.fused_prepare && !inner);
+            if (k > 0) {
+                static const unsigned sub[3] = {2u, 3u, 1u};          // live sub-rows of tap row 0, 1, 2 as a bit set over dy
+                for (int ty = 0; ty < 3; ++ty)
+                    for (int tx = 0; tx < 3; ++tx)
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx)
+                                if (((sub[ty] >> dy) & 1u) && ((sub[tx] >> dx) & 1u)) p.kmask |= 1ull << ((ty * 3 + tx) * 4 + dy * 2 + dx);
+                p.kblk = l.cin;
+                p.ktiles_total = 16 * l.cin / 32;
+            } else {
+                p.ktiles_total = 9 * l.s2d / 32;
+                if (km) {            // block 0 on a masked-K instance with every K-tile live (dense rows): what carries the dual store
+                    p.kblk = 32;
+                    for (int t = 0; t < 9; ++t)
+                        for (int j = 0; j < l.s2d / 32; ++j) p.kmask |= 1ull << (t * 4 + j);
+                }
+            }
+            if (inner) { p.out = wsf(P.cur.r_off[k]); p.relu = 1; }        // only the up-conv reads it, through its ReLU
+            else if (P.fused_prepare) { p.s2d_out = wsf(P.cur.y_off[(k + 1) & 1]); p.relu_out = wsf(P.cur.r_off[k]); p.slope = 0.2f; p.out = nullptr; }
+            else p.out = wsf(P.cur.dtmp_off);
+        } else if (!u.last) {
+            // ConvTranspose2d(k4, s2, p1) over cat(R_k, U_{k+1}) in sub-pixel form; stored ReLU'd (read only through the parent's uprelu)
+            p.src0 = wsf(P.cur.r_off[k]); p.C0 = l.cout;
+            if (k < P.nd - 1) { p.src1 = wsf(P.cur.u_off[(k + 1) & 1]); p.C1 = l.cout; }
+            p.Cin = p.C0 + p.C1; p.Cout = l.up_cout; p.w = bl(l.up_w); p.scale = bl(l.up_scale); p.shift = bl(l.up_shift);
+            p.Hs = p.Ws = hh; p.Ho = p.Wo = 2 * hh; p.up4 = 1; p.relu = 1;
+            p.Mout = B * 4 * hh * hh; p.M = B * hh * hh;
+            p.ktiles_total = 4 * p.Cin / 32;
+            p.out = wsf(P.cur.u_off[k & 1]);
+        } else {
+            // the outermost transposed conv as a 3x3 GEMM on the low-res source, N = 4 parities x output_nc, + bias; tanh in the shuffle pass
+            p.src0 = wsf(P.cur.r_off[0]); p.C0 = l.cout; p.src1 = wsf(P.cur.u_off[1]); p.C1 = l.cout;
+            p.Cin = p.C0 + p.C1; p.Cout = 4 * l.up_cout; p.w = bl(l.up_w); p.scale = bl(l.up_scale); p.shift = bl(l.up_shift);
+            p.Hs = p.Ws = p.Ho = p.Wo = hh;
+            p.Mout = p.M = B * hh * hh;
+            p.ktiles_total = 9 * p.Cin / 32;
+            p.out = wsf(P.cur.g_off);
+        }
+        p.splits = u.splits;
+        p.ktiles_per_split = (p.ktiles_total + u.splits - 1) / u.splits;
+        if (u.fused_combine) {
+            p.tile_cnt = reinterpret_cast<unsigned *>(h->ws + P.cur.cnt_off);
+            p.slab_bytes = (size_t)u.splits * p.Mout * p.Cout * sizeof(float);
+        }
+        e = launch_igemm(p, u.bm, u.bn, u.group, s);
+        if (e == hipSuccess && u.splits > 1 && !u.fused_combine) e = launch_splitk_reduce(p, s);
+    }
+    if (e != hipSuccess) return uhipfail(e, "launch " + u.name);
+    return LSPUNET_OK;
+}
+
+static int check_unet_forward(lspunet_handle *h, const float *feat, const float *cand, int cand_batch, float *out, unsigned char *out_u8, int B)
+{
+    if (!h || !feat) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null argument");
+    if (!out && !out_u8) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "at least one of out_dev / out_u8_dev is required");
+    if (B < 1 || B > h->cfg.max_batch) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "batch out of range (max_batch)");
+    const int cand_nc = h->plan.input_nc - h->plan.feat_nc;
+    if (cand_nc > 0 && !cand) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "cand_image is required (input_nc > feat_nc)");
+    if (cand_nc > 0 && cand_batch != 1 && cand_batch != B) return ufail(LSPUNET_ERR_SHAPE, "cand_batch must be 1 (broadcast) or equal to batch");
+    if (cand_nc > 0 && !h->plan.input_pass) return ufail(LSPUNET_ERR_UNSUPPORTED, "input_pass=0 takes one concatenated tensor (feat_nc == input_nc)");
+    if (!h->blob) return ufail(LSPUNET_ERR_STATE, "weights not bound (lspunet_bind_weights)");
+    if (!h->ws) return ufail(LSPUNET_ERR_STATE, "workspace not bound (lspunet_bind_workspace)");
+    h->plan.plan_batch(B);
+    if (h->ws_size < h->plan.cur.total) return ufail(LSPUNET_ERR_STATE, "workspace too small for this batch (lspunet_workspace_bytes)");
+    return LSPUNET_OK;
+}
+
+extern "C" {
+
+const char *lspunet_last_error(void) { return g_uerr.c_str(); }
+int lspunet_abi_version(void) { return LSPUNET_ABI_VERSION; }
+
+int lspunet_create(const lspunet_config *cfg, const char *tune, lspunet_handle **out)
+{
+    if (!cfg || !out) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null argument");
+    if (cfg->abi_version != LSPUNET_ABI_VERSION) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "ABI version mismatch");
+    if (cfg->max_batch < 1) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "max_batch must be >= 1");
+    lspunet_handle *h = new (std::nothrow) lspunet_handle();
+    if (!h) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "out of host memory");
+    h->cfg = *cfg;
+    h->use_graph = (cfg->flags & LSPUNET_FLAG_NO_GRAPH) == 0;
+    UnetPlan &P = h->plan;
+    P.input_nc = cfg->input_nc; P.feat_nc = cfg->feat_nc; P.output_nc = cfg->output_nc; P.ngf = cfg->ngf; P.nd = cfg->num_downs; P.size = cfg->size;
+    // "key=value,key=value": applied once, before the plan is built; the library reads no environment
+    std::string t = tune ? tune : "";
+    size_t i = 0;
+    while (i < t.size()) {
+        size_t j = t.find(',', i);
+        if (j == std::string::npos) j = t.size();
+        std::string tok = t.substr(i, j - i);
+        i = j + 1;
+        const size_t a = tok.find_first_not_of(" \t"), b = tok.find_last_not_of(" \t");
+        if (a == std::string::npos) continue;
+        tok = tok.substr(a, b - a + 1);
+        const size_t eq = tok.find('=');
+        char *endp = nullptr;
+        const long v = eq == std::string::npos || eq == 0 || eq + 1 >= tok.size() ? 0 : std::strtol(tok.c_str() + eq + 1, &endp, 10);
+        if (!endp || *endp) { delete h; return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "tune: expected key=integer, got '" + tok + "'"); }
+        const std::string k = tok.substr(0, eq);
+        if (k == "graph") h->use_graph = h->use_graph && v != 0;
+        else if (k == "fused_prepare") P.fused_prepare = v != 0;
+        else if (k == "input_pass") P.input_pass = v != 0;
+        else if (k == "fused_splitk") P.fused_splitk = v != 0;
+        else if (k == "last_direct") P.last_direct = v != 0;
+        else if (k == "last_tile") { P.last_bm = v < 0 ? -1 : (int)(v / 1000); P.last_bn = v < 0 ? -1 : (int)(v % 1000); }      // e.g. 128032 = 128 x 32; -1 = the general tiling rule
+        else { delete h; return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "tune: unknown key '" + k + "'"); }
+    }
+    if (P.last_bm > 0 && !igemm_group_supported(P.last_bm, P.last_bn, 1, false)) { delete h; return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "tune: last_tile is not an implicit-GEMM tile"); }
+    const std::string e = P.build();
+    if (!e.empty()) { delete h; return ufail(LSPUNET_ERR_UNSUPPORTED, e); }
+    P.plan_batch(cfg->max_batch);
+    *out = h;
+    return LSPUNET_OK;
+}
+
+int lspunet_destroy(lspunet_handle *h)
+{
+    delete h;
+    return LSPUNET_OK;
+}
+
+int lspunet_num_tensors(const lspunet_handle *h) { return h ? (int)h->plan.params.size() : ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null handle"); }
+
+int lspunet_tensor_info(const lspunet_handle *h, int i, const char **key, int64_t dims[4], int *ndim)
+{
+    if (!h || i < 0 || i >= (int)h->plan.params.size()) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "bad tensor index");
+    const UnetParam &p = h->plan.params[i];
+    if (key) *key = p.key.c_str();
+    if (ndim) *ndim = (int)p.dims.size();
+    if (dims) for (size_t d = 0; d < p.dims.size() && d < 4; ++d) dims[d] = p.dims[d];
+    return LSPUNET_OK;
+}
+
+int lspunet_set_tensor(lspunet_handle *h, const char *key, const float *host, size_t numel)
+{
+    if (!h || !key || !host) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null argument");
+    auto it = h->plan.index.find(key);
+    if (it == h->plan.index.end()) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, std::string("unexpected state-dict key: ") + key);
+    UnetParam &p = h->plan.params[it->second];
+    if (numel != p.numel())
+        return ufail(LSPUNET_ERR_SHAPE, std::string("size mismatch for ") + key + ": got " + std::to_string(numel) + ", expected " + std::to_string(p.numel()));
+    p.data.assign(host, host + numel);
+    p.set = true;
+    return LSPUNET_OK;
+}
+
+size_t lspunet_packed_bytes(const lspunet_handle *h) { return h ? h->plan.blob_bytes : 0; }
+
+int lspunet_pack_weights(lspunet_handle *h, void *host_blob, size_t bytes)
+{
+    if (!h || !host_blob) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null argument");
+    const std::string e = h->plan.pack(host_blob, bytes);
+    if (!e.empty()) return ufail(e.rfind("missing", 0) == 0 ? LSPUNET_ERR_MISSING_TENSOR : LSPUNET_ERR_INVALID_ARGUMENT, e);
+    for (auto &p : h->plan.params) { std::vector<float>().swap(p.data); p.set = false; }     // the fp32 copies are no longer needed
+    return LSPUNET_OK;
+}
+
+int lspunet_bind_weights(lspunet_handle *h, const void *dev_blob, size_t bytes)
+{
+    if (!h || !dev_blob) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null argument");
+    if (bytes < h->plan.blob_bytes) return ufail(LSPUNET_ERR_SHAPE, "packed weight arena too small");
+    if ((uintptr_t)dev_blob % 256) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "weight arena must be 256-byte aligned");
+    h->drop_graphs();
+    h->blob = static_cast<const char *>(dev_blob);
+    h->blob_size = bytes;
+    return LSPUNET_OK;
+}
+
+size_t lspunet_workspace_bytes(const lspunet_handle *h, int batch)
+{
+    if (!h || batch < 1) return 0;
+    size_t need = 0;
+    for (int b = 1; b <= batch; ++b) need = std::max(need, h->plan.workspace_bytes(b));     // split-K slabs come and go with the batch: not monotonic
+    return need;
+}
+
+int lspunet_bind_workspace(lspunet_handle *h, void *dev_workspace, size_t bytes)
+{
+    if (!h || !dev_workspace) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null argument");
+    if ((uintptr_t)dev_workspace % 256) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    h->drop_graphs();
+    h->counters_clean = false;
+    h->ws = static_cast<char *>(dev_workspace);
+    h->ws_size = bytes;
+    return LSPUNET_OK;
+}
+
+int lspunet_forward(lspunet_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch, float *out_dev, unsigned char *out_u8_dev, int batch,
+                    void *hip_stream)
+{
+    int rc = check_unet_forward(h, feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (!h->counters_clean) {      // arrival counters of the in-launch split-K combines: zero once per binding, every last arriver resets its own
+        const hipError_t e = hipMemsetAsync(h->ws + h->plan.cur.cnt_off, 0, kUnetCounters * sizeof(unsigned), s);
+        if (e != hipSuccess) return uhipfail(e, "hipMemsetAsync (split-K arrival counters)");
+        h->counters_clean = true;
+    }
+    bool eager = !h->use_graph;
+    if (!eager) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s != nullptr && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) eager = true;
+    }
+    if (eager) {
+        for (const auto &u : h->plan.cur.launches) {
+            rc = run_unet_launch(h, u, feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch, s);
+            if (rc) return rc;
+        }
+        return LSPUNET_OK;
+    }
+    UnetGraphKey key{feat_dev, cand_dev, out_dev, out_u8_dev, h->ws, h->blob, cand_batch, batch};
+    UnetGraph *g = nullptr;
+    for (auto &c : h->graphs)
+        if (c.exec && c.key == key) { g = &c; break; }
+    if (!g) {
+        if (!h->cap_stream) {
+            const hipError_t e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return uhipfail(e, "hipStreamCreateWithFlags");
+        }
+        if (h->graphs.size() < kMaxUnetGraphs) h->graphs.emplace_back();
+        g = &h->graphs[h->next_victim++ % h->graphs.size()];
+        g->reset();
+        hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return uhipfail(e, "hipStreamBeginCapture");
+        for (const auto &u : h->plan.cur.launches) {
+            rc = run_unet_launch(h, u, feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch, h->cap_stream);
+            if (rc) break;
+        }
+        e = hipStreamEndCapture(h->cap_stream, &g->graph);
+        if (rc) { g->reset(); return rc; }
+        if (e != hipSuccess) { g->reset(); return uhipfail(e, "hipStreamEndCapture"); }
+        e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { g->reset(); return uhipfail(e, "hipGraphInstantiate"); }
+        g->key = key;
+    }
+    const hipError_t e = hipGraphLaunch(g->exec, s);
+    if (e != hipSuccess) return uhipfail(e, "hipGraphLaunch");
+    return LSPUNET_OK;
+}
+
+int lspunet_forward_timed(lspunet_handle *h, const float *feat_dev, const float *cand_dev, int cand_batch, float *out_dev, unsigned char *out_u8_dev, int batch,
+                          void *hip_stream, float *ms_per_launch)
+{
+    int rc = check_unet_forward(h, feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch);
+    if (rc) return rc;
+    if (!ms_per_launch) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (!h->counters_clean) {
+        const hipError_t e = hipMemsetAsync(h->ws + h->plan.cur.cnt_off, 0, kUnetCounters * sizeof(unsigned), s);
+        if (e != hipSuccess) return uhipfail(e, "hipMemsetAsync (split-K arrival counters)");
+        h->counters_clean = true;
+    }
+    const size_t n = h->plan.cur.launches.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return ufail(LSPUNET_ERR_HIP, "hipEventCreate");
+    (void)hipEventRecord(ev[0], s);
+    for (size_t i = 0; i < n && !rc; ++i) {
+        rc = run_unet_launch(h, h->plan.cur.launches[i], feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch, s);
+        (void)hipEventRecord(ev[i + 1], s);
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) rc = uhipfail(e, "hipStreamSynchronize");
+    for (size_t i = 0; i < n && !rc; ++i) (void)hipEventElapsedTime(&ms_per_launch[i], ev[i], ev[i + 1]);
+    for (auto &x : ev) (void)hipEventDestroy(x);
+    return rc;
+}
+
+int lspunet_num_launches(lspunet_handle *h, int batch)
+{
+    if (!h || batch < 1 || batch > h->cfg.max_batch) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "batch out of range");
+    h->plan.plan_batch(batch);
+    return (int)h->plan.cur.launches.size();
+}
+
+int lspunet_launch_info(lspunet_handle *h, int batch, int index, const char **name, const char **kernel, int *tile_m, int *tile_n, int *split_k)
+{
+    if (!h || batch < 1 || batch > h->cfg.max_batch) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "batch out of range");
+    h->plan.plan_batch(batch);
+    if (index < 0 || index >= (int)h->plan.cur.launches.size()) return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "bad launch index");
+    const UnetLaunch &u = h->plan.cur.launches[index];
+    if (name) *name = u.name.c_str();
+    if (kernel) *kernel = u.kernel.c_str();
+    if (tile_m) *tile_m = u.bm;
+    if (tile_n) *tile_n = u.bn;
+    if (split_k) *split_k = u.splits;
+    return LSPUNET_OK;
+}
+
+}  // extern "C"

@@ -48,10 +48,8 @@ class Feature2FaceModel(BaseModel):
             g = self._g().netG
             if feature_map.device.type != "cuda":
                 raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
-            if isinstance(g, Feature2FaceGenerator_Unet):        # size == 'small': its own engine, same fused uint8 output
-                x = feature_map if cand_image is None else torch.cat(
-                    [feature_map, cand_image.expand(feature_map.shape[0], -1, -1, -1)], 1)
-                return g._get_engine(x.device).forward(x.float(), out_u8=True)
+            if isinstance(g, Feature2FaceGenerator_Unet):        # size == 'small': its own native plan (include/lspunet.h), same fused uint8 output
+                return g.render(feature_map, cand_image, out_u8=True)
             net = self.Feature2Face_G
             if isinstance(net, networks.MultiDeviceParallel):    # several gpu_ids: sliced over all of them like inference(), uint8 fused on every device
                 return net.render_image(feature_map, cand_image)

@@ -1,5 +1,12 @@
 """The reference's `size == 'small'` generator (Feature2FaceGenerator_Unet, models/networks.py:680-769; selected at
-models/feature2face_G.py:16-17 with a 23-channel input) on the MI355X, built from the library's existing kernels:
+models/feature2face_G.py:16-17 with a 23-channel input) on the MI355X.
+
+SmallUnetEngine is the thin ctypes host of the NATIVE plan behind include/lspunet.h (csrc/unet.hip): state dict in, packed blob,
+caller-owned workspace, one launch per convolution -- the down-convs write leaky_relu / relu copies of their output from their own epilogue, the torch.cat
+of feature map and candidates is two base pointers of the input pass -- replayed from a hipGraph.
+
+HostSequencedUnetEngine is the round-3/4 form the native plan replaced, kept as the independent second route the tests compare it with bit for bit: one C
+call per launch from Python, out of the library's building blocks,
 
   Conv2d(k4, s2, p1)           -> lspf2f_unet_prepare (space-to-depth + the in-place LeakyReLU) + lspf2f_conv3x3 on 4x the
                                   channels with the 16 real taps scattered into a 3x3 pattern; 20 of its 36 (tap, channel quarter)
@@ -8,12 +15,8 @@ models/feature2face_G.py:16-17 with a 23-channel input) on the MI355X, built fro
   ConvTranspose2d(k4, s2, p1)  -> lspf2f_conv3x3 in sub-pixel form (upsample = 2): 4 output parities x 2x2 taps
   last ConvTranspose + Tanh    -> 3x3 GEMM with N = 4 parities x 3 on the low-res source + lspf2f_pixel_shuffle (tanh)
 
-No shipped configuration selects this variant, so it is sequenced from the host, one C call per launch, rather than
-planned and fused like 'normal' / 'large'.  SmallUnetEngine(graph=True) captures the ~40 launches into a hipGraph per (batch, frame
-size, output kind) through torch.cuda.graphs and replays them (inputs copied into the graph's static buffer, outputs out of it); it is
-bit-identical and NOT faster (512x512: 1.04 vs 1.01 ms at one frame, 5.77 vs 5.72 ms at eight -- the launches are asynchronous and
-the device is the limiter, tools/unet_small_time.py), so it is off by default.  All arithmetic is in the HIP kernels (no CPU path).
-The mappings are documented in include/lspf2f.h next to lspf2f_unet_prepare."""
+(graph=True captures those ~40 launches through torch.cuda.graphs; bit-identical and not faster: the device is the limiter, tools/unet_small_time.py.)
+All arithmetic is in the HIP kernels (no CPU path).  The mappings are documented in include/lspf2f.h next to lspf2f_unet_prepare."""
 from __future__ import annotations
 
 import ctypes
@@ -104,7 +107,7 @@ def block_keys(num_downs: int, prefix: str = "model"):
     return out
 
 
-class SmallUnetEngine:
+class HostSequencedUnetEngine:
     def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, graph: bool = False, live_taps: bool = True):
         if ngf % 32 or num_downs < 5 or not (1 <= output_nc <= 4):
             raise ValueError("ngf must be a multiple of 32, num_downs >= 5, output_nc <= 4")
@@ -170,7 +173,7 @@ class SmallUnetEngine:
     def forward(self, x: torch.Tensor, out_u8: bool = False) -> torch.Tensor:
         """x [B, input_nc, S, S] fp32 on the device -> [B, output_nc, S, S] fp32 (or uint8 HWC frames)."""
         if self.layers is None:
-            raise RuntimeError("SmallUnetEngine.load_state_dict first")
+            raise RuntimeError("HostSequencedUnetEngine.load_state_dict first")
         if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != self.input_nc:
             raise ValueError("x must be a float32 device tensor [B, %d, S, S] (there is no CPU path)" % self.input_nc)
         x = x.contiguous()
@@ -240,6 +243,124 @@ class SmallUnetEngine:
         return out
 
 
+class SmallUnetEngine:
+    """Host of one native plan per (frame size, feat_nc): include/lspunet.h.  forward(x) takes the concatenated [B, input_nc, S, S] tensor
+    (Feature2FaceGenerator_Unet.forward, models/networks.py:694-697); render(feat, cand) takes the two tensors of Feature2FaceModel.inference()
+    (models/feature2face_model.py:225-237) and never concatenates them."""
+
+    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, max_batch: int = 8, graph: bool = True, tune=None):
+        if ngf % 32 or num_downs < 5 or not (1 <= output_nc <= 4):
+            raise ValueError("ngf must be a multiple of 32, num_downs >= 5, output_nc <= 4")
+        self.lib = N.load()
+        self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
+        self.max_batch, self.use_graph = max_batch, graph
+        self.tune = tune if isinstance(tune, (str, type(None))) else ",".join("%s=%d" % kv for kv in sorted(tune.items()))
+        self.sd: Optional[Dict[str, np.ndarray]] = None
+        self.device = None
+        self._plans: Dict[tuple, dict] = {}        # (S, feat_nc) -> {handle, blob, ws, max_batch}
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray], prefix: str = "model", device="cuda:0") -> None:
+        self.close()
+        cut = len(prefix) - len("model")            # keys reach the library relative to netG: "model.model.0.weight", ...
+        self.sd = {k[cut:]: np.ascontiguousarray(v.detach().float().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32))
+                   for k, v in sd.items() if k.startswith(prefix + ".") and not k.endswith("num_batches_tracked")}
+        self.device = torch.device(device)
+
+    def close(self) -> None:
+        for p in self._plans.values():
+            self.lib.lspunet_destroy(p["handle"])
+        self._plans = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _plan(self, S: int, feat_nc: int, batch: int) -> dict:
+        if self.sd is None:
+            raise RuntimeError("SmallUnetEngine.load_state_dict first")
+        key = (S, feat_nc)
+        p = self._plans.get(key)
+        if p is not None and batch <= p["max_batch"]:
+            return p
+        if p is not None:
+            self.lib.lspunet_destroy(p["handle"])
+            del self._plans[key]
+        mb = max(batch, self.max_batch)
+        cfg = N.UnetConfig(N.UNET_ABI_VERSION, self.input_nc, feat_nc, self.output_nc, self.ngf, self.num_downs, S, mb, 0 if self.use_graph else N.UNET_FLAG_NO_GRAPH)
+        h = ctypes.c_void_p()
+        N.check_unet(self.lib.lspunet_create(ctypes.byref(cfg), self.tune.encode() if self.tune else None, ctypes.byref(h)))
+        try:
+            name, dims, nd = ctypes.c_char_p(), (ctypes.c_int64 * 4)(), ctypes.c_int()
+            for i in range(self.lib.lspunet_num_tensors(h)):
+                N.check_unet(self.lib.lspunet_tensor_info(h, i, ctypes.byref(name), ctypes.byref(dims), ctypes.byref(nd)))
+                k = name.value.decode()
+                if k not in self.sd:
+                    raise KeyError("state dict lacks %s" % k)
+                a = self.sd[k]
+                if list(a.shape) != [dims[j] for j in range(nd.value)]:
+                    raise ValueError("%s: shape %s, expected %s" % (k, list(a.shape), [dims[j] for j in range(nd.value)]))
+                N.check_unet(self.lib.lspunet_set_tensor(h, name.value, a.ctypes.data_as(ctypes.c_void_p), a.size))
+            nb = self.lib.lspunet_packed_bytes(h)
+            host = torch.empty(nb, dtype=torch.uint8)
+            N.check_unet(self.lib.lspunet_pack_weights(h, ctypes.c_void_p(host.data_ptr()), nb))
+            blob = host.to(self.device)
+            N.check_unet(self.lib.lspunet_bind_weights(h, ctypes.c_void_p(blob.data_ptr()), nb))
+            wb = self.lib.lspunet_workspace_bytes(h, mb)
+            ws = torch.empty(wb, dtype=torch.uint8, device=self.device)
+            N.check_unet(self.lib.lspunet_bind_workspace(h, ctypes.c_void_p(ws.data_ptr()), wb))
+        except Exception:
+            self.lib.lspunet_destroy(h)
+            raise
+        p = {"handle": h, "blob": blob, "ws": ws, "max_batch": mb}
+        self._plans[key] = p
+        return p
+
+    def _check(self, t: torch.Tensor, c: int, what: str) -> torch.Tensor:
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.shape[1] != c or t.shape[2] != t.shape[3]:
+            raise ValueError("%s must be a float32 device tensor [B, %d, S, S] (there is no CPU path)" % (what, c))
+        return t.contiguous()
+
+    def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: bool = False, timed: Optional[list] = None) -> torch.Tensor:
+        """feat [B, feat_nc, S, S], cand [1 | B, input_nc - feat_nc, S, S] (None: feat carries every channel) -> [B, output_nc, S, S] fp32 or uint8 HWC frames"""
+        feat_nc = self.input_nc if cand is None else self.input_nc - cand.shape[1]
+        feat = self._check(feat, feat_nc, "feature_map")
+        B, _, S, _ = feat.shape
+        if cand is not None:
+            cand = self._check(cand, self.input_nc - feat_nc, "cand_image")
+            if cand.shape[2] != S or cand.shape[0] not in (1, B):
+                raise ValueError("cand_image must be [1 | B, %d, %d, %d]" % (self.input_nc - feat_nc, S, S))
+        if S % (1 << self.num_downs):
+            raise ValueError("frame size must be a multiple of 2**num_downs")
+        p = self._plan(S, feat_nc, B)
+        with torch.cuda.device(self.device):
+            out = torch.empty((B, S, S, self.output_nc), dtype=torch.uint8, device=self.device) if out_u8 else \
+                torch.empty((B, self.output_nc, S, S), dtype=torch.float32, device=self.device)
+            ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+            args = (p["handle"], ptr(feat), ptr(cand), 0 if cand is None else cand.shape[0], None if out_u8 else ptr(out), ptr(out) if out_u8 else None, B,
+                    ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            if timed is None:
+                N.check_unet(self.lib.lspunet_forward(*args))
+            else:
+                ms = (ctypes.c_float * self.lib.lspunet_num_launches(p["handle"], B))()
+                N.check_unet(self.lib.lspunet_forward_timed(*args, ms))
+                timed[:] = list(ms)
+        return out
+
+    def forward(self, x: torch.Tensor, out_u8: bool = False) -> torch.Tensor:
+        """x [B, input_nc, S, S] fp32 on the device -> [B, output_nc, S, S] fp32 (or uint8 HWC frames)."""
+        return self.render(x, None, out_u8)
+
+    def launches(self, S: int, batch: int, feat_nc: Optional[int] = None) -> List[dict]:
+        p = self._plan(S, self.input_nc if feat_nc is None else feat_nc, batch)
+        out, name, kern, tm, tn, sk = [], ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        for i in range(self.lib.lspunet_num_launches(p["handle"], batch)):
+            N.check_unet(self.lib.lspunet_launch_info(p["handle"], batch, i, ctypes.byref(name), ctypes.byref(kern), ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sk)))
+            out.append({"name": name.value.decode(), "kernel": kern.value.decode(), "tile": (tm.value, tn.value), "split_k": sk.value})
+        return out
+
+
 # ---- parameter container with the reference's keys ---------------------------------------------------
 class _Slot(nn.Identity):
     """occupies an index of the reference's nn.Sequential that holds no parameters (activations, Tanh)"""
@@ -282,6 +403,8 @@ class Feature2FaceGenerator_Unet(nn.Module):
     def _get_engine(self, device) -> SmallUnetEngine:
         version = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
         if self._engine is None or self._version != version or self._engine.device != device:
+            if self._engine is not None:
+                self._engine.close()
             e = SmallUnetEngine(self.input_nc, self.output_nc, self.num_downs, self.ngf)
             e.load_state_dict({k: v for k, v in self.state_dict().items() if not k.endswith("num_batches_tracked")}, "model", device)
             self._engine, self._version = e, version
@@ -292,8 +415,9 @@ class Feature2FaceGenerator_Unet(nn.Module):
             raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
         return self._get_engine(x.device).forward(x.float())
 
-    def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor]) -> torch.Tensor:
-        """feature2face_model.py:229-231: cat([feature_map, cand_image], 1) unless cand_image is None"""
-        if cand is not None and cand.shape[0] != feat.shape[0]:
-            cand = cand.expand(feat.shape[0], -1, -1, -1)          # shared candidate stack (batch 1) with a batch of feature maps
-        return self.forward(feat if cand is None else torch.cat([feat, cand], 1))
+    def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: bool = False) -> torch.Tensor:
+        """feature2face_model.py:229-231: cat([feature_map, cand_image], 1) unless cand_image is None -- here two base pointers of the input pass; a shared
+        candidate stack (batch 1) is broadcast over a batch of feature maps"""
+        if feat.device.type != "cuda":
+            raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
+        return self._get_engine(feat.device).render(feat.float(), None if cand is None else cand.float(), out_u8)

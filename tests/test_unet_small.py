@@ -142,16 +142,140 @@ def test_masked_k_cursor_walks_exactly_the_live_tiles(ci, bke):
         assert seq == full, splits
 
 
+# ---- the native plan (include/lspunet.h, csrc/unet.hip): host side, no device ---------------------------------
+def _unet_handle(input_nc=23, feat_nc=None, output_nc=3, ngf=64, num_downs=8, size=512, max_batch=2, tune=None, flags=0):
+    import ctypes
+    from livespeechportraits_amd import _native as N
+    lib = N.load()
+    cfg = N.UnetConfig(N.UNET_ABI_VERSION, input_nc, input_nc if feat_nc is None else feat_nc, output_nc, ngf, num_downs, size, max_batch, flags)
+    h = ctypes.c_void_p()
+    rc = lib.lspunet_create(ctypes.byref(cfg), tune.encode() if tune else None, ctypes.byref(h))
+    return lib, h, rc
+
+
+def test_lspunet_header_binding_and_library_agree():
+    import re
+    from livespeechportraits_amd import _native as N
+    lib = N.load()
+    text = open(os.path.join(ROOT, "include", "lspunet.h")).read()
+    declared = set(re.findall(r"\b(lspunet_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(N.UNET_SIGNATURES), declared ^ set(N.UNET_SIGNATURES)
+    assert all(hasattr(lib, n) for n in declared)
+    assert lib.lspunet_abi_version() == N.UNET_ABI_VERSION
+
+
+def test_native_plan_expects_the_reference_keys_and_packs_like_the_numpy_packers():
+    """lspunet_pack_weights against the numpy restatements this file checks against torch's own convolutions (pack_down / pack_down_live / pack_up / pack_last)
+    and a float64 BatchNorm fold; the expected tensors are exactly the reference module's state-dict entries (golden `keys`)."""
+    import ctypes
+    from livespeechportraits_amd import synth, _native as N
+    from livespeechportraits_amd.unet_small import _fold_bn, block_keys, pack_down, pack_down_live, pack_last, pack_up
+    nd, ngf, inc = 6, 32, 23
+    lib, h, rc = _unet_handle(inc, None, 3, ngf, nd, 128, 2)
+    assert rc == 0, lib.lspunet_last_error()
+    sd = synth.make_unet_small_state_dict(inc, 3, nd, ngf, seed=11)
+    name, dims, ndim = ctypes.c_char_p(), (ctypes.c_int64 * 4)(), ctypes.c_int()
+    keys = {}
+    for i in range(lib.lspunet_num_tensors(h)):
+        assert lib.lspunet_tensor_info(h, i, ctypes.byref(name), ctypes.byref(dims), ctypes.byref(ndim)) == 0
+        keys[name.value.decode()] = [dims[j] for j in range(ndim.value)]
+    assert keys == {k: list(v.shape) for k, v in sd.items()}
+    meta = json.load(open(os.path.join(GOLD, "unet_small_512.json")))
+    lib8, h8, _ = _unet_handle()
+    k8 = {}
+    for i in range(lib8.lspunet_num_tensors(h8)):
+        lib8.lspunet_tensor_info(h8, i, ctypes.byref(name), ctypes.byref(dims), ctypes.byref(ndim))
+        k8[name.value.decode()] = [dims[j] for j in range(ndim.value)]
+    assert k8 == {k: v for k, v in meta["keys"].items() if not k.endswith("num_batches_tracked")}       # the reference module's own keys and shapes
+    lib8.lspunet_destroy(h8)
+    nb = lib.lspunet_packed_bytes(h)
+    blob = np.zeros(nb, np.uint8)
+    assert lib.lspunet_pack_weights(h, blob.ctypes.data_as(ctypes.c_void_p), nb) == -3                 # nothing supplied yet: MISSING_TENSOR
+    assert b"missing" in lib.lspunet_last_error()
+    assert lib.lspunet_set_tensor(h, b"model.model.9.weight", sd["model.model.0.weight"].ctypes.data_as(ctypes.c_void_p), 1) == -1      # unknown key
+    assert lib.lspunet_set_tensor(h, b"model.model.0.weight", sd["model.model.0.weight"].ctypes.data_as(ctypes.c_void_p), 7) == -4      # wrong size
+    for k, v in sd.items():
+        a = np.ascontiguousarray(v, np.float32)
+        assert lib.lspunet_set_tensor(h, k.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size) == 0, k
+    assert lib.lspunet_pack_weights(h, blob.ctypes.data_as(ctypes.c_void_p), nb - 1) == -1             # arena too small
+    assert lib.lspunet_pack_weights(h, blob.ctypes.data_as(ctypes.c_void_p), nb) == 0
+    f = blob.view(np.float32)
+    off = 0
+
+    def take(n):
+        nonlocal off
+        a = f[off // 4: off // 4 + n].copy()
+        off += (4 * n + 255) // 256 * 256
+        return a
+    chans = [ngf * min(2 ** i, 8) for i in range(nd)]
+    for k, (dc, dbn, uc, ubn) in enumerate(block_keys(nd, "model")):
+        cin, cout = (inc if k == 0 else chans[k - 1]), chans[k]
+        w = sd[dc + ".weight"]
+        want = pack_down(w, (4 * inc + 31) // 32 * 32) if k == 0 else pack_down_live(w)
+        assert np.array_equal(take(want.size), want.ravel()), "down %d" % k
+        if dbn:
+            sc, sh = _fold_bn(sd, dbn)
+            assert np.array_equal(take(cout), sc) and np.array_equal(take(cout), sh)
+        wt = sd[uc + ".weight"]
+        want = pack_last(wt) if k == 0 else pack_up(wt)
+        assert np.array_equal(take(want.size), want.ravel()), "up %d" % k
+        if k == 0:
+            assert np.array_equal(take(12), np.ones(12, np.float32)) and np.array_equal(take(12), np.tile(sd[uc + ".bias"], 4))
+            sub = pack_up(wt)                                                  # second form: sub-pixel rows + the bias, for the direct last-layer kernel
+            assert np.array_equal(take(sub.size), sub.ravel()) and np.array_equal(take(3), sd[uc + ".bias"])
+        else:
+            sc, sh = _fold_bn(sd, ubn)
+            assert np.array_equal(take(wt.shape[1]), sc) and np.array_equal(take(wt.shape[1]), sh)
+    assert off == nb
+    # a second pack of the same handle needs the tensors again
+    assert lib.lspunet_pack_weights(h, blob.ctypes.data_as(ctypes.c_void_p), nb) == -3
+    lib.lspunet_destroy(h)
+
+
+def test_native_plan_launch_list_workspace_and_errors():
+    import ctypes
+    lib, h, rc = _unet_handle(max_batch=8)
+    assert rc == 0
+    name, kern, tm, tn, sk = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for b in (1, 8):
+        n = lib.lspunet_num_launches(h, b)
+        assert n == 1 + 8 + 7 + 1                                            # input pass, 8 down-convs, 7 transposed convs, the direct last layer (+ tanh)
+        rows = []
+        for i in range(n):
+            assert lib.lspunet_launch_info(h, b, i, ctypes.byref(name), ctypes.byref(kern), ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sk)) == 0
+            rows.append((name.value.decode(), kern.value.decode(), tm.value, tn.value, sk.value))
+        assert [r[0] for r in rows] == ["input"] + ["L%d.down" % k for k in range(8)] + ["L%d.up" % k for k in range(7, -1, -1)]
+        assert all("lrelu s2d + relu" in r[1] for r in rows[1:8]) and "lrelu" not in rows[8][1]     # every down-conv but the innermost writes the two activated copies
+        assert all("<km>" in r[1] for r in rows[1:9])
+    w1, w8 = lib.lspunet_workspace_bytes(h, 1), lib.lspunet_workspace_bytes(h, 8)
+    assert 0 < w1 < w8 < 2 << 30
+    assert lib.lspunet_num_launches(h, 9) < 0                                 # beyond max_batch
+    lib.lspunet_destroy(h)
+    lib, h, rc = _unet_handle(max_batch=1, tune="fused_prepare=0,input_pass=0,graph=0,last_direct=0")
+    assert rc == 0 and lib.lspunet_num_launches(h, 1) == 1 + 8 + 7 + 7 + 2   # + one unet_prepare per level but the innermost; GEMM-form last layer + pixel shuffle
+    lib.lspunet_destroy(h)
+    for bad in (dict(tune="nonsense=1"), dict(tune="graph"), dict(tune="last_tile=7007"), dict(ngf=48), dict(num_downs=4), dict(size=384, num_downs=8),
+                dict(output_nc=5), dict(input_nc=64), dict(feat_nc=0), dict(max_batch=0)):
+        lib, h, rc = _unet_handle(**bad)
+        assert rc < 0 and lib.lspunet_last_error(), bad
+    import ctypes as C
+    from livespeechportraits_amd import _native as N
+    cfg = N.UnetConfig(99, 23, 23, 3, 64, 8, 512, 1, 0)
+    h = C.c_void_p()
+    assert lib.lspunet_create(C.byref(cfg), None, C.byref(h)) == -1           # ABI version mismatch
+
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_live_tap_down_convs_agree_with_the_dense_form(gpu_device):
     """the down-convs with only their 16 live K blocks (default) against the dense 3x3 / space-to-depth form (live_taps=False): the same products in the same order,
     minus exact zeros -- equal up to the split-K boundaries the shorter K moves; both on the reference golden"""
-    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    from livespeechportraits_amd.unet_small import HostSequencedUnetEngine
     meta, sd, x, ref = load_case("small_512")
     outs = []
     for live in (True, False):
-        e = SmallUnetEngine(23, 3, meta["num_downs"], meta["ngf"], live_taps=live)
+        e = HostSequencedUnetEngine(23, 3, meta["num_downs"], meta["ngf"], live_taps=live)
         e.load_state_dict(sd, "model", gpu_device)
         assert any(l["down_live"] for l in e.layers) == live
         outs.append(e.forward(torch.from_numpy(x).to(gpu_device)).cpu().numpy())
@@ -239,12 +363,12 @@ def test_prepare_and_shuffle_entry_points():
 
 @pytest.mark.gpu
 def test_graph_replay_equals_host_sequenced_launches(gpu_device):
-    """SmallUnetEngine(graph=True) captures its ~40 launches once per (batch, size, output kind) and replays them: same bits as the
+    """HostSequencedUnetEngine(graph=True) captures its ~40 launches once per (batch, size, output kind) and replays them: same bits as the
     host-sequenced engine, for new inputs, another batch size in between (a larger split-K scratch), and the uint8 output."""
     from livespeechportraits_amd import synth
-    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    from livespeechportraits_amd.unet_small import HostSequencedUnetEngine
     sd = synth.make_unet_small_state_dict(input_nc=5, num_downs=5, ngf=32)
-    eager, graph = SmallUnetEngine(5, 3, 5, 32), SmallUnetEngine(5, 3, 5, 32, graph=True)
+    eager, graph = HostSequencedUnetEngine(5, 3, 5, 32), HostSequencedUnetEngine(5, 3, 5, 32, graph=True)
     eager.load_state_dict(sd, "model", gpu_device); graph.load_state_dict(sd, "model", gpu_device)
     xs = [torch.from_numpy(synth.symmetric(b * 5 * 64 * 64, 0.6, 10 + i).reshape(b, 5, 64, 64)).to(gpu_device) for i, b in enumerate((1, 3, 1, 3))]
     for x in xs:
@@ -295,3 +419,73 @@ def test_masked_k_form_runs_on_every_implicit_gemm_tile_and_on_nothing_else(gpu_
     for bad in (dict(tile=(16, 16)), dict(tile=(1008, 64)), dict(tile=(2000, 32)), dict(tile=(64, 64), dtype=1), dict(tile=(64, 64), stride=2)):
         rc, _ = run(**bad)
         assert rc == -2, (bad, rc)                               # LSPF2F_ERR_UNSUPPORTED, never another kernel's launch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_s64_b2", "small_512"])
+def test_native_plan_equals_the_host_sequenced_launches_bit_for_bit(name, gpu_device):
+    """The native plan (fused activated copies, two-source input pass, in-launch split-K combines, hipGraph) against the round-3/4 form sequenced from Python out of
+    lspf2f_conv3x3 / lspf2f_unet_prepare: the same products summed in the same order -> the same bits; and every A-B arm of the plan against its default."""
+    from livespeechportraits_amd.unet_small import HostSequencedUnetEngine, SmallUnetEngine
+    meta, sd, x, ref = load_case(name)
+    xd = torch.from_numpy(x).to(gpu_device)
+    host = HostSequencedUnetEngine(23, 3, meta["num_downs"], meta["ngf"])
+    host.load_state_dict(sd, "model", gpu_device)
+    want = host.forward(xd)
+    # with the last layer in its GEMM form on the host-sequenced form's tile, every arm of the plan repeats its bits; the defaults (direct last-layer kernel) and the
+    # in-launch split-K combine (another summation order at 6 splits) are held to the reference golden
+    same = "last_direct=0,last_tile=-1"
+    for tune, exact in ((same, True), (same + ",fused_prepare=0", True), (same + ",input_pass=0", True), (same + ",graph=0", True),
+                        (same + ",fused_prepare=0,input_pass=0,graph=0", True), (None, False), ("last_direct=0", False), ("fused_splitk=1", False), ("graph=0", False)):
+        e = SmallUnetEngine(23, 3, meta["num_downs"], meta["ngf"], tune=tune)
+        e.load_state_dict(sd, "model", gpu_device)
+        got = e.forward(xd)
+        err = np.abs(got.cpu().numpy() - ref).max()
+        print("[%s] %-60s max-abs vs reference %.2e, vs the host-sequenced form %.2e" % (name, tune, err, (got - want).abs().max().item()))
+        assert err <= TOL, tune
+        if exact:
+            assert torch.equal(got, want), (tune, (got - want).abs().max().item())
+            assert torch.equal(e.forward(xd, out_u8=True), host.forward(xd, out_u8=True))
+        assert torch.equal(e.forward(xd), got)                                 # graph replay
+        u8 = e.forward(xd, out_u8=True).cpu().numpy().astype(np.int32)
+        assert np.abs(u8 - np.clip((ref.transpose(0, 2, 3, 1) + 1.0) / 2.0 * 255.0, 0, 255).astype(np.uint8).astype(np.int32)).max() <= 1      # util.tensor2im
+        e.close()
+
+
+@pytest.mark.gpu
+def test_native_plan_two_sources_broadcast_candidates_and_hazards(gpu_device):
+    """(feature_map, cand_image) as two base pointers == the concatenated tensor; a batch-1 candidate stack broadcast over 3 feature maps; alternating distinct
+    batches through ONE engine == fresh engines; a workspace poisoned with NaN bytes between forwards changes no bit."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    nd, ngf, S = 6, 32, 128
+    sd = synth.make_unet_small_state_dict(23, 3, nd, ngf, seed=5)
+    mk = lambda b, seed: torch.from_numpy(synth.symmetric(b * 23 * S * S, 0.6, seed).reshape(b, 23, S, S)).to(gpu_device)
+    e = SmallUnetEngine(23, 3, nd, ngf)
+    e.load_state_dict(sd, "model", gpu_device)
+    x3 = mk(3, 21)
+    full = e.forward(x3)
+    assert torch.equal(e.render(x3[:, :1].contiguous(), x3[:, 1:].contiguous()), full)
+    xb = torch.cat([x3[:, :1], x3[:1, 1:].expand(3, -1, -1, -1)], 1).contiguous()
+    assert torch.equal(e.render(x3[:, :1].contiguous(), x3[:1, 1:].contiguous()), e.forward(xb))                  # cand batch 1: broadcast
+    assert torch.equal(e.render(x3[:, :5].contiguous(), x3[:, 5:].contiguous(), out_u8=True), e.forward(x3, out_u8=True))
+    # alternate distinct batches through one engine; each against a fresh engine
+    seq = [(1, 31), (3, 32), (2, 33), (1, 34), (3, 35)]
+    for b, seed in seq:
+        x = mk(b, seed)
+        got = e.forward(x)
+        fresh = SmallUnetEngine(23, 3, nd, ngf, max_batch=b)
+        fresh.load_state_dict(sd, "model", gpu_device)
+        assert torch.equal(got, fresh.forward(x)), (b, seed)
+        fresh.close()
+    # poison: everything behind the arrival counters (16384 x 4 bytes at the head of the workspace) is scratch
+    plan = e._plan(S, 23, 3)
+    before = e.forward(x3).clone()
+    plan["ws"][16384 * 4:].fill_(0xFF)
+    torch.cuda.synchronize()
+    assert torch.equal(e.forward(x3), before) and not torch.isnan(before).any()
+    assert int(plan["ws"][:16384 * 4].view(torch.int32).ne(0).sum()) == 0      # every last arriver left its counter at zero
+    with pytest.raises(ValueError):
+        e.forward(x3.cpu())
+    with pytest.raises(ValueError):
+        e.render(x3[:, :1].contiguous(), x3[:2, 1:].contiguous())               # cand batch neither 1 nor B
