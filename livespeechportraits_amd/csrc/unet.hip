@@ -81,6 +81,202 @@ static hipError_t launch_unet_input(const UnetInputParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- the <= 16-position levels: one weight-streaming launch per layer --------------------------------------------------------------------------
+// The deepest levels at one frame (4x4 and 2x2 tensors, 512 channels) are pure weight streaming -- 16.8 / 33.5 MB of weights for <= 0.3 GFLOP -- and ran as a 64-way
+// split-K implicit GEMM + a reduce launch (40-47 us each for 3-5 us of HBM time, profiles/r05_unet_small_native_first.txt).  Same structure as conv3x3_smallm
+// (small_layers.hip): every workgroup owns NC weight rows over the FULL K (no cross-workgroup reduction), requests them first, stages the whole input tensor in LDS,
+// multiplies on the vector ALU and reduces through LDS in a fixed order.  Two gathers:
+//   down  Conv2d(k4, s2, p1) on the space-to-depth image: row n = [16 live (tap, quarter) slots][ci]; position m = output pixel; slot -> (s2d pixel, quarter)
+//   up    ConvTranspose2d(k4, s2, p1) in sub-pixel form: row (parity, n) = [2][2][C0 + C1]; position m = SOURCE pixel, written to output pixel (2y + py, 2x + px)
+// "vector" = the V contiguous floats one (tap, position) pair multiplies: V = ci (a quarter of an s2d pixel) or C0 + C1 (a pixel of the concatenation).
+struct UnetTinyParams {
+    const float *src0, *src1;      // down: the s2d image [B][Hs][Ws][4 ci]; up: [B][Hs][Ws][C0], [B][Hs][Ws][C1] (or nullptr, C1 = 0)
+    const float *w, *scale, *shift;
+    float *out;                    // down: [B][Hs][Ws][Cout] (innermost block, ReLU'd); up: [B][2Hs][2Ws][Cout]
+    float *s2d_out, *relu_out;     // down: the two activated copies instead of `out` (unet_dual_store)
+    float slope;
+    int B, Hs, Ws, C0, C1, Cout, up, relu, M;
+};
+
+template <int NJ, int MM>
+__global__ __launch_bounds__(256) void unet_tiny(const UnetTinyParams p)
+{
+    constexpr int NC = 2, RS = 264;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    int *tab = reinterpret_cast<int *>(sm);                // [ntap][MM] vector index of (tap, position); padding / rows past M -> the zero vector
+    float *act = sm + 256;                                 // [NV + 1][V]; later red[MM * NC][RS]
+    const int tid = threadIdx.x;
+    asm volatile("" :: "s"(p.src0), "s"(p.src1), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.out), "s"(p.s2d_out), "s"(p.relu_out), "s"(p.B), "s"(p.Hs), "s"(p.Ws),
+                       "s"(p.C0), "s"(p.C1), "s"(p.Cout), "s"(p.up), "s"(p.relu), "s"(p.M));
+    const int V = p.up ? p.C0 + p.C1 : p.C0 >> 2, V4 = V >> 2;
+    const int ntap = p.up ? 4 : 16, K4 = ntap * V4;
+    const int rows_per_par = p.Cout / NC;
+    const int par = p.up ? blockIdx.x / rows_per_par : 0;
+    const int n0 = (blockIdx.x - par * rows_per_par) * NC;
+    const int py = par >> 1, px = par & 1;
+    // 1. this workgroup's weight rows: asked for first
+    float4 wv[NC][NJ];
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k4 = tid + 256 * j;
+            wv[nc][j] = k4 < K4 ? *reinterpret_cast<const float4 *>(p.w + ((size_t)par * p.Cout + n0 + nc) * (size_t)(K4 * 4) + (size_t)k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    // 2. the input tensor(s) -> LDS as [vector][V]; the gather table; the epilogue's operands
+    const int npix = p.B * p.Hs * p.Ws;
+    const int nvec = p.up ? npix : npix * 4;
+    const int eo = tid >> 3, em = eo / NC, en = n0 + eo % NC;
+    const bool ewrite = tid < MM * NC * 8 && (tid & 7) == 0 && em < p.M;
+    float e_sc = 1.f, e_sh = 0.f;
+    if (ewrite && p.scale) { e_sc = p.scale[en]; e_sh = p.shift[en]; }
+    // LDS-DMA, 1 KB per wave and instruction (no staging registers, no dependent load -> ds_write chain: the first version copied through registers and spent 10+ us
+    // of a 128-KB tensor's staging on it); a vector of the concatenation is C0 floats of src0 then C1 of src1, both multiples of 256
+    {
+        typedef __attribute__((address_space(3))) float lds_float;
+        const unsigned lds_act = (unsigned)(unsigned long long)(lds_float *)act;
+        const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6), lane16 = ((unsigned)tid & 63u) * 16u;      // (wave-uniform: the LDS base of a copy is a scalar)
+        if (!p.up || p.C1 == 0) {
+            const unsigned total = (unsigned)nvec * (unsigned)V * 4u;
+            const i32x4 srd = make_srd(p.src0, total);
+            for (unsigned o = wave * 1024u; o < total; o += 4096u) dma16(lds_act + o, o + lane16, srd, 0);
+        } else {
+            const unsigned ppv = (unsigned)V >> 8, pp0 = (unsigned)p.C0 >> 8;          // 1-KB pieces per vector, of which from src0
+            const i32x4 srd0 = make_srd(p.src0, (unsigned)nvec * (unsigned)p.C0 * 4u), srd1 = make_srd(p.src1, (unsigned)nvec * (unsigned)p.C1 * 4u);
+            for (unsigned piece = wave; piece < (unsigned)nvec * ppv; piece += 4u) {
+                const unsigned v = piece / ppv, q = piece - v * ppv;
+                if (q < pp0) dma16(lds_act + piece * 1024u, (v * pp0 + q) * 1024u + lane16, srd0, 0);
+                else dma16(lds_act + piece * 1024u, (v * (ppv - pp0) + q - pp0) * 1024u + lane16, srd1, 0);
+            }
+        }
+    }
+    for (int i = tid; i < V4; i += 256) reinterpret_cast<float4 *>(act)[nvec * V4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < ntap * MM) {
+        const int t = tid / MM, m = tid - t * MM;
+        int vec = nvec;
+        if (m < p.M) {
+            const int hw = p.Hs * p.Ws, b = m / hw, r = m - b * hw, y = r / p.Ws, x = r - y * p.Ws;
+            if (p.up) {
+                const int sy = y + py + (t >> 1) - 1, sx = x + px + (t & 1) - 1;
+                if (sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws) vec = (b * p.Hs + sy) * p.Ws + sx;
+            } else {
+                // slot t of the live (tap, quarter) pairs in tap-major / quarter-minor order: tap row ty carries sub-rows {1}, {0, 1}, {0} for ty = 0, 1, 2 (columns alike)
+                int ty = 0, tx = 0, dy = 0, dx = 0, n = 0;
+                for (int a = 0; a < 3; ++a)
+                    for (int c = 0; c < 3; ++c)
+                        for (int d = 0; d < 2; ++d)
+                            for (int e = 0; e < 2; ++e) {
+                                const bool live = (a == 0 ? d == 1 : a == 2 ? d == 0 : true) && (c == 0 ? e == 1 : c == 2 ? e == 0 : true);
+                                if (live) { if (n == t) { ty = a; tx = c; dy = d; dx = e; } ++n; }
+                            }
+                const int sy = y + ty - 1, sx = x + tx - 1;
+                if (sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws) vec = ((b * p.Hs + sy) * p.Ws + sx) * 4 + dy * 2 + dx;
+            }
+        }
+        tab[tid] = vec;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies have landed (and its weight rows)
+    __syncthreads();
+    // 3. this thread's K-slice times every position.  k4 = tid + 256 j; a wave's 64 consecutive float4 stay inside one tap (V % 256 == 0): the table reads are wave-uniform
+    float acc[MM][NC];
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc) acc[m][nc] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int k4 = tid + 256 * j;
+        if (k4 >= K4) continue;
+        const int tap = k4 / V4, c4 = k4 - tap * V4;
+        int vec[MM];
+#pragma unroll
+        for (int q = 0; q < MM / 4; ++q) {
+            const int4 t4 = reinterpret_cast<const int4 *>(tab + tap * MM)[q];
+            vec[4 * q] = t4.x; vec[4 * q + 1] = t4.y; vec[4 * q + 2] = t4.z; vec[4 * q + 3] = t4.w;
+        }
+        float4 a[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) a[m] = reinterpret_cast<const float4 *>(act)[vec[m] * V4 + c4];
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) {
+                const float4 w4 = wv[nc][j];
+                acc[m][nc] += a[m].x * w4.x + a[m].y * w4.y + a[m].z * w4.z + a[m].w * w4.w;
+            }
+    }
+    __syncthreads();                                       // everyone is done with act
+    // 4. block reduction in a fixed order: red[o][tid], then 8 threads per output sum 32 interleaved values each
+    float *red = act;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc) red[(m * NC + nc) * RS + tid] = acc[m][nc];
+    __syncthreads();
+    if (tid < MM * NC * 8) {
+        const int o = tid >> 3, part = tid & 7;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) sum += red[o * RS + i * 8 + part];
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        if (part == 0 && ewrite) {
+            const float v = sum * e_sc + e_sh;
+            const int hw = p.Hs * p.Ws, b = em / hw, r = em - b * hw, y = r / p.Ws, x = r - y * p.Ws;
+            if (p.up) {
+                p.out[(((size_t)b * 2 * p.Hs + 2 * y + py) * (2 * p.Ws) + 2 * x + px) * p.Cout + en] = p.relu ? fmaxf(v, 0.f) : v;
+            } else if (p.s2d_out) {
+                p.relu_out[(size_t)em * p.Cout + en] = fmaxf(v, 0.f);
+                const size_t opix = ((size_t)b * (p.Hs >> 1) + (y >> 1)) * (p.Ws >> 1) + (x >> 1);
+                p.s2d_out[opix * (size_t)(4 * p.Cout) + ((y & 1) * 2 + (x & 1)) * p.Cout + en] = v > 0.f ? v : p.slope * v;
+            } else {
+                p.out[(size_t)em * p.Cout + en] = p.relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
+
+static size_t unet_tiny_lds(const UnetTinyParams &p)
+{
+    const size_t V = p.up ? p.C0 + p.C1 : p.C0 / 4, nvec = (size_t)p.B * p.Hs * p.Ws * (p.up ? 1 : 4);
+    const size_t act = (nvec + 1) * V * 4, red = (size_t)16 * 2 * 264 * 4;
+    return 256 * 4 + (act > red ? act : red);
+}
+
+static bool unet_tiny_supported(const UnetTinyParams &p)
+{
+    const int V = p.up ? p.C0 + p.C1 : p.C0 / 4, ntap = p.up ? 4 : 16;
+    if (p.M < 1 || p.M > 16 || p.M != p.B * p.Hs * p.Ws || V % 256 || ntap * (V / 4) > 8 * 256 || p.Cout % 2) return false;
+    if (p.up ? (p.C0 % 256 || p.C1 % 256) : (p.C1 != 0 || p.C0 % 16)) return false;      // (the staging copies move 1-KB pieces of either source)
+    if (p.s2d_out && (p.up || !p.relu_out || (p.Hs & 1) || (p.Ws & 1))) return false;
+    return unet_tiny_lds(p) <= 150 * 1024;
+}
+
+template <int NJ, int MM>
+static hipError_t launch_unet_tiny_t(const UnetTinyParams &p, hipStream_t s)
+{
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&unet_tiny<NJ, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    const unsigned grid = (unsigned)((p.up ? 4 : 1) * (p.Cout / 2));
+    hipLaunchKernelGGL((unet_tiny<NJ, MM>), dim3(grid), dim3(256), unet_tiny_lds(p), s, p);
+    return hipGetLastError();
+}
+
+static hipError_t launch_unet_tiny(const UnetTinyParams &p, hipStream_t s)
+{
+    if (!unet_tiny_supported(p)) return hipErrorInvalidValue;
+    const int V = p.up ? p.C0 + p.C1 : p.C0 / 4, nj = ((p.up ? 4 : 16) * (V / 4) + 255) / 256;
+    const bool four = p.M <= 4;
+    if (nj <= 2) return four ? launch_unet_tiny_t<2, 4>(p, s) : launch_unet_tiny_t<2, 16>(p, s);
+    if (nj <= 4) return four ? launch_unet_tiny_t<4, 4>(p, s) : launch_unet_tiny_t<4, 16>(p, s);
+    return four ? launch_unet_tiny_t<8, 4>(p, s) : launch_unet_tiny_t<8, 16>(p, s);
+}
+
 // ---- the plan -----------------------------------------------------------------------------------------------------------------------------------
 struct UnetParam {
     std::string key;
@@ -108,6 +304,7 @@ struct UnetLaunch {
     bool down = false, last = false;
     int bm = 0, bn = 0, splits = 1, group = 1;
     bool fused_combine = false;
+    bool tiny = false;             // the weight-streaming kernel of the <= 16-position levels (unet_tiny) instead of the implicit GEMM + reduce
 };
 
 static const unsigned kUnetCounters = 16384;
@@ -117,6 +314,7 @@ struct UnetPlan {
     bool fused_prepare = true, input_pass = true;
     bool fused_splitk = false;                 // 2..8 K splits combined by the last-arriving workgroup instead of a reduce launch: measured SLOWER here (0.903 vs 0.889 ms at one frame,
                                                // equal at eight; profiles/r05_unet_small_native.txt) -- the split layers of this plan are short launches -- and its 6-split sum runs in another order than splitk_reduce's
+    bool use_tiny = true;                      // tune key `tiny`
     bool last_direct = true;                   // the outermost transposed conv + tanh (+ tensor2im) on the direct sub-pixel kernel of the other variants' last layer (edge_layers.hip) instead of
                                                // a 3x3 GEMM with N = 12 of 32 columns live + a pixel-shuffle pass
     int last_bm = 0, last_bn = 0;              // tune: tile of the last GEMM (0 = the planner's rule)
@@ -281,6 +479,14 @@ struct UnetPlan {
         return "";
     }
 
+    // unet_tiny_supported() for a level of this plan (host mirror): <= 16 positions, vectors of a multiple of 256 floats, <= 8 float4 of K per thread, the input in 150 KB of LDS
+    bool tiny_ok(int B, int h, int V, int ntap, int nvec_per_pix, int cout) const
+    {
+        const long M = (long)B * h * h;
+        if (!use_tiny || M > 16 || V % 256 || (ntap == 4 && V >= 512 && (V / 2) % 256) || ntap * (V / 4) > 8 * 256 || cout % 2) return false;
+        return 256 * 4 + ((size_t)M * nvec_per_pix + 1) * V * 4 <= 150 * 1024;
+    }
+
     // spatial extent of d_k (= of Y_{k+1}'s source, of R_k)
     int hd(int k) const { return size >> (k + 1); }
 
@@ -318,6 +524,10 @@ struct UnetPlan {
             const bool km = k > 0 || (fused_prepare && k < nd - 1);
             const int ktiles = k == 0 ? 9 * l.s2d / 32 : 16 * l.cin / 32;
             tile_for(B * h * h, l.cout, ktiles, 1, &u, true, (size_t)B * h * h * l.cout);
+            if (k > 0 && (fused_prepare || k == nd - 1) && tiny_ok(B, h, l.cin, 16, 4, l.cout)) {
+                u.tiny = true; u.bm = u.bn = 1; u.splits = 1; u.group = 1; u.fused_combine = false;
+                u.kernel = std::string("unet_tiny (down)") + (k < nd - 1 ? " -> lrelu s2d + relu" : "");
+            } else
             u.kernel = std::string(km ? "igemm3x3<km>" : "igemm3x3") + (u.splits > 1 ? (u.fused_combine ? " (split-K combined in the launch)" : "+splitk_reduce") : "") +
                        (fused_prepare && k < nd - 1 ? " -> lrelu s2d + relu" : "");
             note_partial(u, (size_t)B * h * h * l.cout);
@@ -332,6 +542,10 @@ struct UnetPlan {
             const int h = hd(k);                                       // source extent; writes 2h
             UnetLaunch u; u.kind = 1; u.level = k; u.name = "L" + std::to_string(k) + ".up";
             tile_for(B * h * h, l.up_cout, 4 * l.up_cin / 32, 4, &u, true, (size_t)B * 4 * h * h * l.up_cout);
+            if (tiny_ok(B, h, l.up_cin, 4, 1, l.up_cout)) {
+                u.tiny = true; u.bm = u.bn = 1; u.splits = 1; u.group = 1; u.fused_combine = false;
+                u.kernel = "unet_tiny (sub-pixel up)";
+            } else
             u.kernel = std::string("igemm3x3 (sub-pixel)") + (u.splits > 1 ? (u.fused_combine ? " (split-K combined in the launch)" : "+splitk_reduce") : "");
             note_partial(u, (size_t)B * 4 * h * h * l.up_cout);
             launches.push_back(u);
@@ -476,6 +690,23 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
         const int k = u.level;
         const UnetLevel &l = P.L[k];
         const int hh = P.hd(k);
+        if (u.tiny) {
+            UnetTinyParams q{};
+            q.B = B; q.Hs = q.Ws = hh; q.M = B * hh * hh; q.slope = 0.2f;
+            if (u.down) {
+                q.src0 = wsf(P.cur.y_off[k & 1]); q.C0 = l.s2d; q.Cout = l.cout; q.w = bl(l.down_w); q.scale = bl(l.down_scale); q.shift = bl(l.down_shift);
+                if (k == P.nd - 1) { q.out = wsf(P.cur.r_off[k]); q.relu = 1; }
+                else { q.s2d_out = wsf(P.cur.y_off[(k + 1) & 1]); q.relu_out = wsf(P.cur.r_off[k]); }
+            } else {
+                q.up = 1; q.src0 = wsf(P.cur.r_off[k]); q.C0 = l.cout;
+                if (k < P.nd - 1) { q.src1 = wsf(P.cur.u_off[(k + 1) & 1]); q.C1 = l.cout; }
+                q.Cout = l.up_cout; q.w = bl(l.up_w); q.scale = bl(l.up_scale); q.shift = bl(l.up_shift); q.relu = 1;
+                q.out = wsf(P.cur.u_off[k & 1]);
+            }
+            const hipError_t e2 = launch_unet_tiny(q, s);
+            if (e2 != hipSuccess) return uhipfail(e2, "launch " + u.name);
+            return LSPUNET_OK;
+        }
         IgemmParams p{};
         p.dtype = 0; p.B = B; p.stride = 1;
         p.partial = wsf(P.cur.part_off);
@@ -590,6 +821,7 @@ int lspunet_create(const lspunet_config *cfg, const char *tune, lspunet_handle *
         else if (k == "input_pass") P.input_pass = v != 0;
         else if (k == "fused_splitk") P.fused_splitk = v != 0;
         else if (k == "last_direct") P.last_direct = v != 0;
+        else if (k == "tiny") P.use_tiny = v != 0;
         else if (k == "last_tile") { P.last_bm = v < 0 ? -1 : (int)(v / 1000); P.last_bn = v < 0 ? -1 : (int)(v % 1000); }      // e.g. 128032 = 128 x 32; -1 = the general tiling rule
         else { delete h; return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "tune: unknown key '" + k + "'"); }
     }

@@ -246,7 +246,9 @@ def test_native_plan_launch_list_workspace_and_errors():
             rows.append((name.value.decode(), kern.value.decode(), tm.value, tn.value, sk.value))
         assert [r[0] for r in rows] == ["input"] + ["L%d.down" % k for k in range(8)] + ["L%d.up" % k for k in range(7, -1, -1)]
         assert all("lrelu s2d + relu" in r[1] for r in rows[1:8]) and "lrelu" not in rows[8][1]     # every down-conv but the innermost writes the two activated copies
-        assert all("<km>" in r[1] for r in rows[1:9])
+        tiny = [r[0] for r in rows if r[1].startswith("unet_tiny")]
+        assert tiny == (["L6.down", "L7.down", "L7.up", "L6.up"] if b == 1 else [])                # <= 16 positions: the weight-streaming kernel
+        assert all("<km>" in r[1] for r in rows[1:9] if r[0] not in tiny)
     w1, w8 = lib.lspunet_workspace_bytes(h, 1), lib.lspunet_workspace_bytes(h, 8)
     assert 0 < w1 < w8 < 2 << 30
     assert lib.lspunet_num_launches(h, 9) < 0                                 # beyond max_batch
@@ -434,9 +436,9 @@ def test_native_plan_equals_the_host_sequenced_launches_bit_for_bit(name, gpu_de
     want = host.forward(xd)
     # with the last layer in its GEMM form on the host-sequenced form's tile, every arm of the plan repeats its bits; the defaults (direct last-layer kernel) and the
     # in-launch split-K combine (another summation order at 6 splits) are held to the reference golden
-    same = "last_direct=0,last_tile=-1"
+    same = "last_direct=0,last_tile=-1,tiny=0"
     for tune, exact in ((same, True), (same + ",fused_prepare=0", True), (same + ",input_pass=0", True), (same + ",graph=0", True),
-                        (same + ",fused_prepare=0,input_pass=0,graph=0", True), (None, False), ("last_direct=0", False), ("fused_splitk=1", False), ("graph=0", False)):
+                        (same + ",fused_prepare=0,input_pass=0,graph=0", True), (None, False), ("last_direct=0", False), ("fused_splitk=1", False), ("graph=0", False), ("tiny=0", False)):
         e = SmallUnetEngine(23, 3, meta["num_downs"], meta["ngf"], tune=tune)
         e.load_state_dict(sd, "model", gpu_device)
         got = e.forward(xd)
