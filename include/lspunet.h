@@ -18,7 +18,7 @@
  *
  * Conventions as lspf2f.h: 0 / negative status (the LSPF2F_* values), lspunet_last_error() for the message, nothing throws, the library allocates no
  * device memory (weights arena and workspace are the caller's, sizes are queried), lspunet_forward() enqueues on the given hipStream_t and returns.
- * fp32 only (the reference's opt.fp16 autocast is not offered for this variant).  There is no CPU path.
+ * fp32, or fp16 storage for the reference's opt.fp16 (lspunet_config.dtype).  There is no CPU path.
  */
 #ifndef LSPUNET_H
 #define LSPUNET_H
@@ -55,6 +55,8 @@ typedef struct lspunet_config {
     int32_t num_downs;   /* 8 (>= 5) */
     int32_t size;        /* 512: square frames, a multiple of 2^num_downs */
     int32_t max_batch;
+    int32_t dtype;       /* 0: fp32 (the parity configuration); 2: fp16 storage of activations and conv weights, fp32 accumulate and epilogue, API tensors fp32 -- the
+                            reference's opt.fp16, torch.cuda.amp.autocast around netG (models/feature2face_G.py:28-30); values as lspf2f_dtype (bf16 is not offered here) */
     uint32_t flags;      /* LSPUNET_FLAG_* */
 } lspunet_config;
 
@@ -62,10 +64,11 @@ typedef struct lspunet_handle lspunet_handle;
 
 /* Feature2FaceGenerator_Unet.__init__ (models/networks.py:681-692).  Builds the static plan; touches no device.
  * `tune` = "key=value,..." (integers; NULL / "" = none; an unknown key is an error) -- the A-B switches of tests and measurements:
- *   graph (1) | fused_splitk (1: 2..8 K splits combined inside the launch by the last-arriving workgroup) | last_tile (0 = by rule; bm * 1000 + bn forces the tile of the
- *   last GEMM, e.g. 128032) | fused_prepare (1: the down-convs write leaky_relu / relu copies themselves; 0: a separate elementwise launch per level, the round-3 form)
- *   | live_taps (1: 16 of 36 K blocks; 0: the dense space-to-depth form -- the blob then carries the zero blocks) | input_pass (1: the two-source input kernel;
- *   0: lspf2f_unet_prepare on a concatenated tensor, feat_nc == input_nc only). */
+ *   graph (1) | fused_splitk (0; 1: 2..8 K splits combined inside the launch by the last-arriving workgroup instead of a reduce launch) | last_tile (0 = by rule; bm * 1000 + bn forces the tile of the
+ *   last GEMM, e.g. 128032; -1 = the general tiling rule) | last_direct (1: the outermost transposed conv + tanh + tensor2im on the direct sub-pixel kernel of the other variants'
+ *   last layer; 0: a 3x3 GEMM with N = 4 x output_nc + a pixel-shuffle pass) | tiny (1: the <= 16-position levels on the weight-streaming kernel unet_tiny) | fused_prepare (1: the
+ *   down-convs write leaky_relu / relu copies themselves; 0: a separate elementwise launch per level, the round-3 form) | input_pass (1: the two-source input kernel;
+ *   0: lspf2f_unet_prepare on a concatenated tensor, feat_nc == input_nc only).  With fp16 storage only `graph` has an effect (the other arms are fp32 launches). */
 int lspunet_create(const lspunet_config *cfg, const char *tune, lspunet_handle **out);
 int lspunet_destroy(lspunet_handle *h);
 const char *lspunet_last_error(void);

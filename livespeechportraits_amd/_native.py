@@ -241,7 +241,7 @@ MEL_SIGNATURES = {
 
 class UnetConfig(Structure):
     """lspunet_config (include/lspunet.h)"""
-    _fields_ = [(n, c_int32) for n in ("abi_version", "input_nc", "feat_nc", "output_nc", "ngf", "num_downs", "size", "max_batch")] + [("flags", c_uint32)]
+    _fields_ = [(n, c_int32) for n in ("abi_version", "input_nc", "feat_nc", "output_nc", "ngf", "num_downs", "size", "max_batch", "dtype")] + [("flags", c_uint32)]
 
 
 UNET_ABI_VERSION = 1

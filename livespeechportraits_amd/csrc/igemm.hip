@@ -49,16 +49,17 @@ static constexpr int LDK = 32;   // LDS row pitch in floats (128 B, unpadded: th
 // leaky_relu(d, 0.2) by the next Conv2d(k4, s2, p1) -- through its space-to-depth image -- and as relu(d) by the up-conv (the in-place activations of the
 // reference), so the producer writes those two tensors instead of d (what lspf2f_unet_prepare did in a pass of its own): row `orow` = pixel (b, y, x) of
 // an Ho x Wo frame, channel quad n.  Ho, Wo even.
+template <typename T>
 __device__ __forceinline__ void unet_dual_store(const IgemmParams &p, unsigned orow, int n, float4 v)
 {
     const unsigned hw = (unsigned)(p.Ho * p.Wo);
     const unsigned b = p.div_rhw.div(orow), r = orow - b * hw;
     const unsigned y = p.div_rw.div(r), x = r - y * (unsigned)p.Wo;
-    *reinterpret_cast<float4 *>(p.relu_out + (size_t)orow * p.Cout + n) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    store4(static_cast<T *>(p.relu_out) + (size_t)orow * p.Cout + n, make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)));
     const size_t opix = ((size_t)b * (unsigned)(p.Ho >> 1) + (y >> 1)) * (unsigned)(p.Wo >> 1) + (x >> 1);
     const float sl = p.slope;
-    *reinterpret_cast<float4 *>(p.s2d_out + opix * (size_t)(4 * p.Cout) + ((y & 1u) * 2u + (x & 1u)) * (unsigned)p.Cout + n) =
-        make_float4(v.x > 0.f ? v.x : sl * v.x, v.y > 0.f ? v.y : sl * v.y, v.z > 0.f ? v.z : sl * v.z, v.w > 0.f ? v.w : sl * v.w);
+    store4(static_cast<T *>(p.s2d_out) + opix * (size_t)(4 * p.Cout) + ((y & 1u) * 2u + (x & 1u)) * (unsigned)p.Cout + n,
+           make_float4(v.x > 0.f ? v.x : sl * v.x, v.y > 0.f ? v.y : sl * v.y, v.z > 0.f ? v.z : sl * v.z, v.w > 0.f ? v.w : sl * v.w));
 }
 
 // G = K-tiles staged per pipeline step (one barrier per G tiles, G tiles of global loads in
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (ok) {
-                        if (KM && p.s2d_out) unet_dual_store(p, (unsigned)orow, n, v);       // (masked-K instances only: the `small` U-Net's down-convs)
+                        if (KM && p.s2d_out) unet_dual_store<T>(p, (unsigned)orow, n, v);       // (masked-K instances only: the `small` U-Net's down-convs)
                         else if (p.out_f32) store4(static_cast<float *>(p.out) + orow * p.Cout + n, v);
                         else store4(static_cast<T *>(p.out) + orow * p.Cout + n, v);
                     }
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm3x3(const IgemmParams p)
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (KM && p.s2d_out) unet_dual_store(p, (unsigned)orow, ncol, v);
+        if (KM && p.s2d_out) unet_dual_store<T>(p, (unsigned)orow, ncol, v);
         else store4(static_cast<T *>(p.out) + e, v);
     }
 }
@@ -558,7 +559,7 @@ __device__ __forceinline__ void reduce_epilogue(const IgemmParams &p, unsigned i
         s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
     }
     if constexpr (DUAL) {
-        unet_dual_store(p, (i * 4u) / (unsigned)p.Cout, (int)n, s);
+        unet_dual_store<T>(p, (i * 4u) / (unsigned)p.Cout, (int)n, s);
         return;
     }
     if (p.relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
@@ -664,28 +665,34 @@ bool igemm_group_supported(int bm, int bn, int g, bool up)
     return false;
 }
 
-// masked K (the space-to-depth form of a 4x4 / stride-2 conv, lspf2f_conv3x3 with k_group -4): fp32, no upsample; its own instances of the kernel
-static hipError_t launch_igemm_masked(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
+// masked K (the space-to-depth form of a 4x4 / stride-2 conv, lspf2f_conv3x3 with k_group -4; the `small` U-Net's down-convs): no upsample; its own instances of the kernel,
+// fp32 and -- for the opt.fp16 plan of that variant (include/lspunet.h) -- fp16 storage
+template <typename T>
+static hipError_t launch_igemm_masked_t(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
 {
-    if (p.dtype != 0 || p.up || p.up4) return hipErrorInvalidValue;
-    if (p.s2d_out && (!p.relu_out || p.residual || p.relu || (p.Ho & 1) || (p.Wo & 1) || p.psum)) return hipErrorInvalidValue;   // dual store: see unet_dual_store
     if (g == 4) {
-        if (bm == 64 && bn == 64) return launch_igemm_t<float, 64, 64, 2, 2, 4, false, true>(p, s);
-        if (bm == 32 && bn == 64) return launch_igemm_t<float, 32, 64, 1, 2, 4, false, true>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 4, false, true>(p, s);
+        if (bm == 32 && bn == 64) return launch_igemm_t<T, 32, 64, 1, 2, 4, false, true>(p, s);
         return hipErrorInvalidValue;
     }
     if (g == 2) {
-        if (bm == 128 && bn == 64) return launch_igemm_t<float, 128, 64, 2, 2, 2, false, true>(p, s);
-        if (bm == 64 && bn == 64) return launch_igemm_t<float, 64, 64, 2, 2, 2, false, true>(p, s);
+        if (bm == 128 && bn == 64) return launch_igemm_t<T, 128, 64, 2, 2, 2, false, true>(p, s);
+        if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 2, false, true>(p, s);
         return hipErrorInvalidValue;
     }
-    if (bm == 128 && bn == 128) return launch_igemm_t<float, 128, 128, 2, 2, 1, false, true>(p, s);
-    if (bm == 128 && bn == 64) return launch_igemm_t<float, 128, 64, 2, 2, 1, false, true>(p, s);
-    if (bm == 64 && bn == 128) return launch_igemm_t<float, 64, 128, 2, 2, 1, false, true>(p, s);
-    if (bm == 64 && bn == 64) return launch_igemm_t<float, 64, 64, 2, 2, 1, false, true>(p, s);
-    if (bm == 32 && bn == 128) return launch_igemm_t<float, 32, 128, 1, 4, 1, false, true>(p, s);
-    if (bm == 32 && bn == 64) return launch_igemm_t<float, 32, 64, 1, 2, 1, false, true>(p, s);
+    if (bm == 128 && bn == 128) return launch_igemm_t<T, 128, 128, 2, 2, 1, false, true>(p, s);
+    if (bm == 128 && bn == 64) return launch_igemm_t<T, 128, 64, 2, 2, 1, false, true>(p, s);
+    if (bm == 64 && bn == 128) return launch_igemm_t<T, 64, 128, 2, 2, 1, false, true>(p, s);
+    if (bm == 64 && bn == 64) return launch_igemm_t<T, 64, 64, 2, 2, 1, false, true>(p, s);
+    if (bm == 32 && bn == 128) return launch_igemm_t<T, 32, 128, 1, 4, 1, false, true>(p, s);
+    if (bm == 32 && bn == 64) return launch_igemm_t<T, 32, 64, 1, 2, 1, false, true>(p, s);
     return hipErrorInvalidValue;
+}
+static hipError_t launch_igemm_masked(const IgemmParams &p, int bm, int bn, int g, hipStream_t s)
+{
+    if ((p.dtype != 0 && p.dtype != 2) || p.up || p.up4) return hipErrorInvalidValue;
+    if (p.s2d_out && (!p.relu_out || p.residual || p.relu || (p.Ho & 1) || (p.Wo & 1) || p.psum)) return hipErrorInvalidValue;   // dual store: see unet_dual_store
+    return p.dtype == 2 ? launch_igemm_masked_t<f16_t>(p, bm, bn, g, s) : launch_igemm_masked_t<float>(p, bm, bn, g, s);
 }
 
 template <typename T>
@@ -760,12 +767,12 @@ static hipError_t launch_splitk_reduce_t(const IgemmParams &p, hipStream_t s)
 
 hipError_t launch_splitk_reduce(const IgemmParams &p_in, hipStream_t s)
 {
-    if (p_in.s2d_out) {                       // the `small` U-Net's split-K down-convs: fp32, the two activated copies instead of `out`
-        if (p_in.dtype != 0 || !p_in.relu_out || (p_in.Ho & 1) || (p_in.Wo & 1) || p_in.up4) return hipErrorInvalidValue;
+    if (p_in.s2d_out) {                       // the `small` U-Net's split-K down-convs (fp32 or fp16 storage): the two activated copies instead of `out`
+        if ((p_in.dtype != 0 && p_in.dtype != 2) || !p_in.relu_out || (p_in.Ho & 1) || (p_in.Wo & 1) || p_in.up4) return hipErrorInvalidValue;
         IgemmParams p = p_in;
         p.div_rhw = FastDiv::make((unsigned)(p.Ho * p.Wo));
         p.div_rw = FastDiv::make((unsigned)p.Wo);
-        return launch_splitk_reduce_t<float, true>(p, s);
+        return p.dtype == 2 ? launch_splitk_reduce_t<f16_t, true>(p, s) : launch_splitk_reduce_t<float, true>(p, s);
     }
     const IgemmParams &p = p_in;
     if (p.dtype == 2) return launch_splitk_reduce_t<f16_t>(p, s);

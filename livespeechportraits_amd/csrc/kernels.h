@@ -70,8 +70,8 @@ struct IgemmParams {
     int dbg;                    // ablation bits, honoured only by builds with -DLSPF2F_ABLATE (tools/ablate.sh): 1 no refetch,
                                 // 4 no barrier, 8 no buffer flip, 16 no epilogue, 32 no K loop
     // `small` U-Net plans (masked-K instances and their reduce launches only; last so that every other field keeps its kernarg offset): instead of `out`, write
-    float *s2d_out;             //   leaky_relu(v, slope) into the space-to-depth image [B][Ho/2][Wo/2][4 * Cout] (channel (dy * 2 + dx) * Cout + c) the next Conv2d(k4, s2, p1) reads
-    float *relu_out;            //   and relu(v) into the NHWC skip tensor [B][Ho][Wo][Cout] the up-conv reads; nullptr / nullptr = the plain `out`
+    void *s2d_out;              //   leaky_relu(v, slope) into the space-to-depth image [B][Ho/2][Wo/2][4 * Cout] (channel (dy * 2 + dx) * Cout + c) the next Conv2d(k4, s2, p1) reads
+    void *relu_out;             //   and relu(v) into the NHWC skip tensor [B][Ho][Wo][Cout] the up-conv reads (both in the storage type); nullptr / nullptr = the plain `out`
     float slope;
 };
 

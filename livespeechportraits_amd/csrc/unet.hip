@@ -32,10 +32,11 @@ namespace lspf2f {
 // <= 64 x s2d_c contiguous floats.
 struct UnetInputParams {
     const float *feat, *cand;      // [B][feat_nc][S][S], [cand_batch][C - feat_nc][S][S]
-    float *out;                    // [B][S/2][S/2][s2d_c]
+    void *out;                     // [B][S/2][S/2][s2d_c] in the plan's storage type
     int B, S, C, feat_nc, cand_bcast, s2d_c, cols;   // cols = output columns per workgroup (<= 64)
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void unet_input_s2d(const UnetInputParams p)
 {
     extern __shared__ float lds[];                       // [C][2][pitch]
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void unet_input_s2d(const UnetInputParams p)
     }
     __syncthreads();
     const int q4 = p.s2d_c >> 2;
-    float *dst = p.out + (((size_t)b * S2 + i) * S2 + j0) * p.s2d_c;
+    T *dst = static_cast<T *>(p.out) + (((size_t)b * S2 + i) * S2 + j0) * p.s2d_c;
     for (int o = threadIdx.x; o < p.cols * q4; o += 256) {
         const int j = o / q4, ch0 = (o - j * q4) * 4;
         float v[4];
@@ -67,17 +68,19 @@ __global__ __launch_bounds__(256) void unet_input_s2d(const UnetInputParams p)
                 v[e] = lds[(c * 2 + (q >> 1)) * pitch + 2 * j + (q & 1)];
             }
         }
-        *reinterpret_cast<float4 *>(dst + (size_t)j * p.s2d_c + ch0) = make_float4(v[0], v[1], v[2], v[3]);
+        store4(dst + (size_t)j * p.s2d_c + ch0, make_float4(v[0], v[1], v[2], v[3]));
     }
 }
 
-static hipError_t launch_unet_input(const UnetInputParams &p, hipStream_t s)
+static hipError_t launch_unet_input(const UnetInputParams &p, int dtype, hipStream_t s)
 {
     const int S2 = p.S / 2;
     if (p.B < 1 || p.S < 2 || (p.S & 1) || p.C < 1 || p.C > 48 || p.feat_nc < 1 || p.feat_nc > p.C || p.s2d_c < 4 * p.C || (p.s2d_c & 3) || p.cols < 1 || S2 % p.cols)
         return hipErrorInvalidValue;
     const size_t smem = (size_t)p.C * 2 * (2 * p.cols + 1) * sizeof(float);
-    hipLaunchKernelGGL(unet_input_s2d, dim3((unsigned)(S2 * (S2 / p.cols)), (unsigned)p.B), dim3(256), smem, s, p);
+    const dim3 grid((unsigned)(S2 * (S2 / p.cols)), (unsigned)p.B);
+    if (dtype == 2) hipLaunchKernelGGL(unet_input_s2d<f16_t>, grid, dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(unet_input_s2d<float>, grid, dim3(256), smem, s, p);
     return hipGetLastError();
 }
 
@@ -311,6 +314,10 @@ static const unsigned kUnetCounters = 16384;
 
 struct UnetPlan {
     int input_nc = 23, feat_nc = 23, output_nc = 3, ngf = 64, nd = 8, size = 512;
+    int dtype = 0;                             // 0: fp32; 2: fp16 storage of activations and conv weights, fp32 accumulate / epilogue (the reference's opt.fp16: autocast around netG,
+                                               // models/feature2face_G.py:28-30) -- the same launches on v_mfma_f32_32x32x16_f16 minus the fp32-only ones (unet_tiny, the A-B arms)
+    size_t elt() const { return dtype ? 2 : 4; }
+    int ktc() const { return dtype ? 64 : 32; }   // channels per K-tile (128 B)
     bool fused_prepare = true, input_pass = true;
     bool fused_splitk = false;                 // 2..8 K splits combined by the last-arriving workgroup instead of a reduce launch: measured SLOWER here (0.903 vs 0.889 ms at one frame,
                                                // equal at eight; profiles/r05_unet_small_native.txt) -- the split layers of this plan are short launches -- and its 6-split sum runs in another order than splitk_reduce's
@@ -350,6 +357,9 @@ struct UnetPlan {
         if (input_nc < 1 || input_nc > 48) return "input_nc must be in 1..48";
         if (feat_nc < 1 || feat_nc > input_nc) return "feat_nc must be in 1..input_nc";
         if (size < (1 << nd) || size % (1 << nd)) return "frame size must be a multiple of 2**num_downs";
+        if (dtype != 0 && dtype != 2) return "dtype must be 0 (fp32) or 2 (fp16 storage)";
+        if (dtype && ngf % 64) return "fp16 storage needs ngf % 64 == 0";
+        if (dtype) { fused_prepare = true; input_pass = true; last_direct = true; use_tiny = false; fused_splitk = false; }     // (the other arms are fp32 launches)
         chans.clear();
         for (int i = 0; i < nd; ++i) chans.push_back(ngf * std::min(1 << i, 8));
         // state-dict keys: the nesting of nn.Sequential indices in UnetSkipConnectionBlock (models/networks.py:737-767)
@@ -359,7 +369,7 @@ struct UnetPlan {
             UnetLevel &l = L[k];
             l.cin = k == 0 ? input_nc : chans[k - 1];
             l.cout = chans[k];
-            l.s2d = k == 0 ? (4 * input_nc + 31) / 32 * 32 : 4 * l.cin;
+            l.s2d = k == 0 ? (4 * input_nc + ktc() - 1) / ktc() * ktc() : 4 * l.cin;
             l.up_cin = k == nd - 1 ? l.cout : 2 * l.cout;
             l.up_cout = k == 0 ? output_nc : chans[k - 1];
             if (k == 0) { l.dc = pfx + ".0"; l.uc = pfx + ".3"; pfx += ".1.model"; }
@@ -378,11 +388,11 @@ struct UnetPlan {
         auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return (int64_t)o; };
         for (int k = 0; k < nd; ++k) {
             UnetLevel &l = L[k];
-            l.down_w_bytes = k == 0 ? (size_t)l.cout * 9 * l.s2d * 4 : (size_t)l.cout * 16 * l.cin * 4;
+            l.down_w_bytes = (k == 0 ? (size_t)l.cout * 9 * l.s2d : (size_t)l.cout * 16 * l.cin) * elt();
             l.down_w = take(l.down_w_bytes);
             if (!l.dbn.empty()) { l.down_scale = take((size_t)l.cout * 4); l.down_shift = take((size_t)l.cout * 4); }
             const int n_up = k == 0 ? 4 * l.up_cout : l.up_cout;
-            l.up_w_bytes = k == 0 ? (size_t)n_up * 9 * l.up_cin * 4 : (size_t)4 * l.up_cout * 4 * l.up_cin * 4;
+            l.up_w_bytes = k == 0 ? (size_t)n_up * 9 * l.up_cin * 4 : (size_t)4 * l.up_cout * 4 * l.up_cin * elt();      // (block 0: the fp32 GEMM rows of the last_direct = 0 arm)
             l.up_w = take(l.up_w_bytes);
             l.up_scale = take((size_t)n_up * 4);
             l.up_shift = take((size_t)n_up * 4);
@@ -404,6 +414,15 @@ struct UnetPlan {
         }
     }
 
+    // fp32 -> IEEE binary16, round to nearest even (the storage type of dtype 2)
+    static void narrow(const std::vector<float> &src, char *dst)
+    {
+        for (size_t i = 0; i < src.size(); ++i) {
+            const _Float16 h = (_Float16)src[i];
+            std::memcpy(dst + 2 * i, &h, 2);
+        }
+    }
+
     std::string pack(void *blob, size_t bytes) const
     {
         if (bytes < blob_bytes) return "packed weight arena too small";
@@ -418,7 +437,9 @@ struct UnetPlan {
         for (int k = 0; k < nd; ++k) {
             const UnetLevel &l = L[k];
             const float *w = data(l.dc + ".weight");                 // [cout][cin][4][4]
+            std::vector<float> stage;                                   // 16-bit plans: conv weights are packed in fp32 here, then narrowed (RNE) into the blob
             float *dw = reinterpret_cast<float *>(B + l.down_w);
+            if (dtype) { stage.assign(l.down_w_bytes / 2, 0.f); dw = stage.data(); }
             if (k == 0) {
                 // dense rows [co][ty][tx][s2d] of the 3x3 conv on the space-to-depth image (20 of the 36 (tap, quarter) blocks stay zero; the quarters of 23 channels are
                 // not K-tile aligned, so block 0 cannot drop them)
@@ -443,6 +464,7 @@ struct UnetPlan {
                             for (int kx = 0; kx < 4; ++kx)
                                 dw[((size_t)co * 16 + slot[ky][kx]) * l.cin + ci] = w[(((size_t)co * l.cin + ci) * 4 + ky) * 4 + kx];
             }
+            if (dtype) narrow(stage, B + l.down_w);
             if (!l.dbn.empty()) fold_bn(l.dbn, l.cout, reinterpret_cast<float *>(B + l.down_scale), reinterpret_cast<float *>(B + l.down_shift));
             const float *wt = data(l.uc + ".weight");                // [up_cin][up_cout][4][4]
             float *uw = reinterpret_cast<float *>(B + l.up_w);
@@ -465,6 +487,7 @@ struct UnetPlan {
             {
                 // sub-pixel form [par][co][a][b][ci] (block 0: a second form of its weights, for the direct last-layer kernel)
                 float *sw = k == 0 ? reinterpret_cast<float *>(B + l.up_sub) : uw;
+                if (dtype && k > 0) { stage.assign(l.up_w_bytes / 2, 0.f); sw = stage.data(); }
                 for (int py = 0; py < 2; ++py)
                     for (int px = 0; px < 2; ++px)
                         for (int co = 0; co < co_n; ++co)
@@ -473,6 +496,7 @@ struct UnetPlan {
                                     for (int ci = 0; ci < ci_n; ++ci)
                                         sw[((((size_t)(py * 2 + px) * co_n + co) * 2 + a) * 2 + b) * ci_n + ci] =
                                             wt[(((size_t)ci * co_n + co) * 4 + KT[py][a]) * 4 + KT[px][b]];
+                if (dtype && k > 0) narrow(stage, B + l.up_w);
                 if (k > 0) fold_bn(l.ubn, co_n, usc, ush);
             }
         }
@@ -492,7 +516,7 @@ struct UnetPlan {
 
     void tile_for(int M, int N, int ktiles, int par, UnetLaunch *u, bool allow_fused, size_t mout_x_cout) const
     {
-        choose_tiling(M, N, ktiles, par, false, 0, &u->bm, &u->bn, &u->splits, &u->group);
+        choose_tiling(M, N, ktiles, par, false, dtype, &u->bm, &u->bn, &u->splits, &u->group);
         const int per = (ktiles + u->splits - 1) / u->splits;
         u->splits = (ktiles + per - 1) / per;
         const long tiles = (long)par * ((M + u->bm - 1) / u->bm) * ((N + u->bn - 1) / u->bn);
@@ -522,7 +546,7 @@ struct UnetPlan {
             const int h = hd(k);
             UnetLaunch u; u.kind = 1; u.level = k; u.down = true; u.name = "L" + std::to_string(k) + ".down";
             const bool km = k > 0 || (fused_prepare && k < nd - 1);
-            const int ktiles = k == 0 ? 9 * l.s2d / 32 : 16 * l.cin / 32;
+            const int ktiles = k == 0 ? 9 * l.s2d / ktc() : 16 * l.cin / ktc();
             tile_for(B * h * h, l.cout, ktiles, 1, &u, true, (size_t)B * h * h * l.cout);
             if (k > 0 && (fused_prepare || k == nd - 1) && tiny_ok(B, h, l.cin, 16, 4, l.cout)) {
                 u.tiny = true; u.bm = u.bn = 1; u.splits = 1; u.group = 1; u.fused_combine = false;
@@ -541,7 +565,7 @@ struct UnetPlan {
             const UnetLevel &l = L[k];
             const int h = hd(k);                                       // source extent; writes 2h
             UnetLaunch u; u.kind = 1; u.level = k; u.name = "L" + std::to_string(k) + ".up";
-            tile_for(B * h * h, l.up_cout, 4 * l.up_cin / 32, 4, &u, true, (size_t)B * 4 * h * h * l.up_cout);
+            tile_for(B * h * h, l.up_cout, 4 * l.up_cin / ktc(), 4, &u, true, (size_t)B * 4 * h * h * l.up_cout);
             if (tiny_ok(B, h, l.up_cin, 4, 1, l.up_cout)) {
                 u.tiny = true; u.bm = u.bn = 1; u.splits = 1; u.group = 1; u.fused_combine = false;
                 u.kernel = "unet_tiny (sub-pixel up)";
@@ -576,16 +600,16 @@ struct UnetPlan {
         size_t ymax[2] = {0, 0}, umax[2] = {0, 0}, dmax = 0;
         for (int k = 0; k < nd; ++k) {
             const size_t hy = (size_t)hd(k);                           // Y_k is [B][hd(k)][hd(k)][s2d_k]
-            ymax[k & 1] = std::max(ymax[k & 1], (size_t)B * hy * hy * L[k].s2d * 4);
+            ymax[k & 1] = std::max(ymax[k & 1], (size_t)B * hy * hy * L[k].s2d * elt());
             dmax = std::max(dmax, (size_t)B * hy * hy * L[k].cout * 4);
         }
         for (int k = nd - 1; k >= 1; --k) {
             const size_t ho = 2 * (size_t)hd(k);
-            umax[k & 1] = std::max(umax[k & 1], (size_t)B * ho * ho * L[k].up_cout * 4);
+            umax[k & 1] = std::max(umax[k & 1], (size_t)B * ho * ho * L[k].up_cout * elt());
         }
         y_off[0] = take(ymax[0]); y_off[1] = take(ymax[1]);
         r_off.assign(nd, 0);
-        for (int k = 0; k < nd; ++k) { const size_t h = (size_t)hd(k); r_off[k] = take((size_t)B * h * h * L[k].cout * 4); }
+        for (int k = 0; k < nd; ++k) { const size_t h = (size_t)hd(k); r_off[k] = take((size_t)B * h * h * L[k].cout * elt()); }
         u_off[0] = take(umax[0]); u_off[1] = take(umax[1]);
         g_off = take((size_t)B * hd(0) * hd(0) * 4 * output_nc * 4);
         dtmp_off = fused_prepare ? off : take(dmax);
@@ -655,7 +679,7 @@ struct lspunet_handle {
 static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *feat, const float *cand, int cand_batch, float *out, unsigned char *out_u8, int B, hipStream_t s)
 {
     const UnetPlan &P = h->plan;
-    auto wsf = [&](size_t off) { return reinterpret_cast<float *>(h->ws + off); };
+    auto wsf = [&](size_t off) { return reinterpret_cast<float *>(h->ws + off); };      // (typed by the kernels: the plan's storage type for Y / R / U, fp32 for G and the slabs)
     auto bl = [&](int64_t off) { return off < 0 ? nullptr : reinterpret_cast<const float *>(h->blob + off); };
     hipError_t e = hipSuccess;
     if (u.kind == 0) {
@@ -664,7 +688,7 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
         q.B = B; q.S = P.size; q.C = P.input_nc; q.feat_nc = P.feat_nc; q.cand_bcast = cand_batch == 1 && B > 1; q.s2d_c = P.L[0].s2d;
         q.cols = 64;
         while ((P.size / 2) % q.cols) q.cols >>= 1;
-        e = launch_unet_input(q, s);
+        e = launch_unet_input(q, P.dtype, s);
     } else if (u.kind == 3) {
         PrepareParams q{};
         if (u.level < 0) {          // the input, already concatenated by the caller (input_pass = 0)
@@ -679,7 +703,7 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
     } else if (u.kind == 4) {
         const UnetLevel &l = P.L[0];
         LastConvParams q{};
-        q.src0 = wsf(P.cur.r_off[0]); q.src1 = wsf(P.cur.u_off[1]); q.dtype = 0; q.w = bl(l.up_sub); q.bias = bl(l.up_bias);
+        q.src0 = wsf(P.cur.r_off[0]); q.src1 = wsf(P.cur.u_off[1]); q.dtype = P.dtype; q.w = bl(l.up_sub); q.bias = bl(l.up_bias);
         q.out = out; q.out_u8 = out_u8; q.B = B; q.Hs = P.hd(0); q.Ws = P.hd(0); q.C0 = l.cout; q.C1 = l.cout; q.Cout = l.up_cout; q.apply_tanh = 1;
         e = launch_last_conv(q, s);
     } else if (u.kind == 2) {
@@ -708,7 +732,8 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
             return LSPUNET_OK;
         }
         IgemmParams p{};
-        p.dtype = 0; p.B = B; p.stride = 1;
+        p.dtype = P.dtype; p.B = B; p.stride = 1;
+        const int ktc = P.ktc();
         p.partial = wsf(P.cur.part_off);
         if (u.down) {
             // Conv2d(k4, s2, p1) as the 3x3 conv on the space-to-depth image Y_k: [B][hh][hh][s2d]
@@ -725,13 +750,13 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
                             for (int dx = 0; dx < 2; ++dx)
                                 if (((sub[ty] >> dy) & 1u) && ((sub[tx] >> dx) & 1u)) p.kmask |= 1ull << ((ty * 3 + tx) * 4 + dy * 2 + dx);
                 p.kblk = l.cin;
-                p.ktiles_total = 16 * l.cin / 32;
+                p.ktiles_total = 16 * l.cin / ktc;
             } else {
-                p.ktiles_total = 9 * l.s2d / 32;
+                p.ktiles_total = 9 * l.s2d / ktc;
                 if (km) {            // block 0 on a masked-K instance with every K-tile live (dense rows): what carries the dual store
-                    p.kblk = 32;
+                    p.kblk = ktc;
                     for (int t = 0; t < 9; ++t)
-                        for (int j = 0; j < l.s2d / 32; ++j) p.kmask |= 1ull << (t * 4 + j);
+                        for (int j = 0; j < l.s2d / ktc; ++j) p.kmask |= 1ull << (t * 4 + j);
                 }
             }
             if (inner) { p.out = wsf(P.cur.r_off[k]); p.relu = 1; }        // only the up-conv reads it, through its ReLU
@@ -744,7 +769,7 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
             p.Cin = p.C0 + p.C1; p.Cout = l.up_cout; p.w = bl(l.up_w); p.scale = bl(l.up_scale); p.shift = bl(l.up_shift);
             p.Hs = p.Ws = hh; p.Ho = p.Wo = 2 * hh; p.up4 = 1; p.relu = 1;
             p.Mout = B * 4 * hh * hh; p.M = B * hh * hh;
-            p.ktiles_total = 4 * p.Cin / 32;
+            p.ktiles_total = 4 * p.Cin / ktc;
             p.out = wsf(P.cur.u_off[k & 1]);
         } else {
             // the outermost transposed conv as a 3x3 GEMM on the low-res source, N = 4 parities x output_nc, + bias; tanh in the shuffle pass
@@ -799,6 +824,7 @@ int lspunet_create(const lspunet_config *cfg, const char *tune, lspunet_handle *
     h->cfg = *cfg;
     h->use_graph = (cfg->flags & LSPUNET_FLAG_NO_GRAPH) == 0;
     UnetPlan &P = h->plan;
+    P.dtype = cfg->dtype;
     P.input_nc = cfg->input_nc; P.feat_nc = cfg->feat_nc; P.output_nc = cfg->output_nc; P.ngf = cfg->ngf; P.nd = cfg->num_downs; P.size = cfg->size;
     // "key=value,key=value": applied once, before the plan is built; the library reads no environment
     std::string t = tune ? tune : "";

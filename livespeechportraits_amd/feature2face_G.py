@@ -24,7 +24,12 @@ class Feature2Face_G(nn.Module):
             raise ValueError("opt.size must be 'small', 'normal' or 'large' (feature2face_G.py:16-21), got %r" % (size,))
         if size == "small":
             # feature2face_G.py:17: the pix2pix U-Net on a 23-channel input; no shipped config selects it
-            self.netG = Feature2FaceGenerator_Unet(input_nc=23, output_nc=3, num_downs=opt.n_downsample_G, ngf=opt.ngf)
+            # opt.fp16 (feature2face_G.py:28-30 wraps whichever netG in autocast): the fp16 storage plan of include/lspunet.h
+            fp16 = bool(getattr(opt, "fp16", 0))
+            if fp16 and opt.ngf % 64 != 0:
+                warnings.warn("opt.fp16 needs ngf %% 64 == 0 (got %d): running fp32" % opt.ngf)
+                fp16 = False
+            self.netG = Feature2FaceGenerator_Unet(input_nc=23, output_nc=3, num_downs=opt.n_downsample_G, ngf=opt.ngf, dtype="f16" if fp16 else "f32")
         else:
             # feature2face_G.py:19-21 hard-codes input_nc=13, output_nc=3
             # opt.fp16 (base_options_feature2face.py:59; feature2face_G.py:28-30 wraps netG in torch.cuda.amp.autocast): fp16 storage path of
@@ -35,8 +40,6 @@ class Feature2Face_G(nn.Module):
                 fp16 = False
             self.netG = Feature2FaceGenerator(size, input_nc=13, output_nc=3,
                                               num_downs=opt.n_downsample_G, ngf=opt.ngf, feat_nc=1, dtype="f16" if fp16 else "f32")
-        if size == "small" and getattr(opt, "fp16", 0):
-            warnings.warn("opt.fp16 is ignored for size == 'small': that variant runs fp32")
 
     def forward(self, input):
         return self.netG(input)

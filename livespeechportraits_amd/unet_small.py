@@ -248,9 +248,12 @@ class SmallUnetEngine:
     (Feature2FaceGenerator_Unet.forward, models/networks.py:694-697); render(feat, cand) takes the two tensors of Feature2FaceModel.inference()
     (models/feature2face_model.py:225-237) and never concatenates them."""
 
-    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, max_batch: int = 8, graph: bool = True, tune=None):
+    def __init__(self, input_nc: int = 23, output_nc: int = 3, num_downs: int = 8, ngf: int = 64, max_batch: int = 8, graph: bool = True, tune=None, dtype: str = "f32"):
         if ngf % 32 or num_downs < 5 or not (1 <= output_nc <= 4):
             raise ValueError("ngf must be a multiple of 32, num_downs >= 5, output_nc <= 4")
+        if dtype not in ("f32", "f16") or (dtype == "f16" and ngf % 64):
+            raise ValueError("dtype must be 'f32' or 'f16' (fp16 storage -- the reference's opt.fp16 -- needs ngf % 64 == 0)")
+        self.dtype = dtype
         self.lib = N.load()
         self.input_nc, self.output_nc, self.num_downs, self.ngf = input_nc, output_nc, num_downs, ngf
         self.max_batch, self.use_graph = max_batch, graph
@@ -288,7 +291,8 @@ class SmallUnetEngine:
             self.lib.lspunet_destroy(p["handle"])
             del self._plans[key]
         mb = max(batch, self.max_batch)
-        cfg = N.UnetConfig(N.UNET_ABI_VERSION, self.input_nc, feat_nc, self.output_nc, self.ngf, self.num_downs, S, mb, 0 if self.use_graph else N.UNET_FLAG_NO_GRAPH)
+        cfg = N.UnetConfig(N.UNET_ABI_VERSION, self.input_nc, feat_nc, self.output_nc, self.ngf, self.num_downs, S, mb, N.DTYPE_IDS[self.dtype],
+                           0 if self.use_graph else N.UNET_FLAG_NO_GRAPH)
         h = ctypes.c_void_p()
         N.check_unet(self.lib.lspunet_create(ctypes.byref(cfg), self.tune.encode() if self.tune else None, ctypes.byref(h)))
         try:
@@ -384,8 +388,9 @@ class UnetSkipConnectionBlock(nn.Module):
 class Feature2FaceGenerator_Unet(nn.Module):
     """Weights container + device evaluation; same constructor and state-dict keys as the reference class."""
 
-    def __init__(self, input_nc=4, output_nc=3, num_downs=8, ngf=64):
+    def __init__(self, input_nc=4, output_nc=3, num_downs=8, ngf=64, dtype="f32"):
         super().__init__()
+        self.dtype = dtype                        # 'f32', or 'f16' for the reference's opt.fp16 (autocast around netG, models/feature2face_G.py:28-30)
         blk = UnetSkipConnectionBlock(ngf * 8, ngf * 8, innermost=True)
         for _ in range(num_downs - 5):
             blk = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=blk)
@@ -405,7 +410,7 @@ class Feature2FaceGenerator_Unet(nn.Module):
         if self._engine is None or self._version != version or self._engine.device != device:
             if self._engine is not None:
                 self._engine.close()
-            e = SmallUnetEngine(self.input_nc, self.output_nc, self.num_downs, self.ngf)
+            e = SmallUnetEngine(self.input_nc, self.output_nc, self.num_downs, self.ngf, dtype=self.dtype)
             e.load_state_dict({k: v for k, v in self.state_dict().items() if not k.endswith("num_batches_tracked")}, "model", device)
             self._engine, self._version = e, version
         return self._engine
@@ -413,11 +418,13 @@ class Feature2FaceGenerator_Unet(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.device.type != "cuda":
             raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
-        return self._get_engine(x.device).forward(x.float())
+        out = self._get_engine(x.device).forward(x.float())
+        return out.half() if self.dtype == "f16" else out      # under autocast the reference's generator returns a float16 tensor
 
     def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: bool = False) -> torch.Tensor:
         """feature2face_model.py:229-231: cat([feature_map, cand_image], 1) unless cand_image is None -- here two base pointers of the input pass; a shared
         candidate stack (batch 1) is broadcast over a batch of feature maps"""
         if feat.device.type != "cuda":
             raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
-        return self._get_engine(feat.device).render(feat.float(), None if cand is None else cand.float(), out_u8)
+        out = self._get_engine(feat.device).render(feat.float(), None if cand is None else cand.float(), out_u8)
+        return out.half() if (self.dtype == "f16" and not out_u8) else out

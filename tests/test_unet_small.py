@@ -143,11 +143,11 @@ def test_masked_k_cursor_walks_exactly_the_live_tiles(ci, bke):
 
 
 # ---- the native plan (include/lspunet.h, csrc/unet.hip): host side, no device ---------------------------------
-def _unet_handle(input_nc=23, feat_nc=None, output_nc=3, ngf=64, num_downs=8, size=512, max_batch=2, tune=None, flags=0):
+def _unet_handle(input_nc=23, feat_nc=None, output_nc=3, ngf=64, num_downs=8, size=512, max_batch=2, tune=None, flags=0, dtype=0):
     import ctypes
     from livespeechportraits_amd import _native as N
     lib = N.load()
-    cfg = N.UnetConfig(N.UNET_ABI_VERSION, input_nc, input_nc if feat_nc is None else feat_nc, output_nc, ngf, num_downs, size, max_batch, flags)
+    cfg = N.UnetConfig(N.UNET_ABI_VERSION, input_nc, input_nc if feat_nc is None else feat_nc, output_nc, ngf, num_downs, size, max_batch, dtype, flags)
     h = ctypes.c_void_p()
     rc = lib.lspunet_create(ctypes.byref(cfg), tune.encode() if tune else None, ctypes.byref(h))
     return lib, h, rc
@@ -232,6 +232,60 @@ def test_native_plan_expects_the_reference_keys_and_packs_like_the_numpy_packers
     lib.lspunet_destroy(h)
 
 
+def test_native_fp16_plan_packs_the_rounded_fp32_rows():
+    """dtype 2 (the reference's opt.fp16): conv weights in IEEE binary16, round to nearest even, of exactly the fp32 rows (block 0 padded to 128 channels: a K-tile is 64
+    of them); BatchNorm scale / shift and the last layer's sub-pixel weights stay fp32; the plan keeps the masked-K implicit GEMM on every level and needs half the arena."""
+    import ctypes
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.unet_small import _fold_bn, block_keys, pack_down, pack_down_live, pack_last, pack_up
+    nd, ngf, inc = 5, 64, 23
+    sd = synth.make_unet_small_state_dict(inc, 3, nd, ngf, seed=12)
+    lib, h, rc = _unet_handle(inc, None, 3, ngf, nd, 64, 2, dtype=2)
+    assert rc == 0, lib.lspunet_last_error()
+    lib32, h32, _ = _unet_handle(inc, None, 3, ngf, nd, 64, 2)
+    assert lib.lspunet_workspace_bytes(h, 2) < lib32.lspunet_workspace_bytes(h32, 2)
+    nb = lib.lspunet_packed_bytes(h)
+    assert nb < 0.56 * lib32.lspunet_packed_bytes(h32)
+    lib32.lspunet_destroy(h32)
+    for k, v in sd.items():
+        a = np.ascontiguousarray(v, np.float32)
+        assert lib.lspunet_set_tensor(h, k.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size) == 0, k
+    blob = np.zeros(nb, np.uint8)
+    assert lib.lspunet_pack_weights(h, blob.ctypes.data_as(ctypes.c_void_p), nb) == 0
+    off = 0
+
+    def take(n, dt):
+        nonlocal off
+        a = blob[off: off + n * np.dtype(dt).itemsize].view(dt).copy()
+        off += (n * np.dtype(dt).itemsize + 255) // 256 * 256
+        return a
+    chans = [ngf * min(2 ** i, 8) for i in range(nd)]
+    for k, (dc, dbn, uc, ubn) in enumerate(block_keys(nd, "model")):
+        w = sd[dc + ".weight"]
+        want = pack_down(w, 128) if k == 0 else pack_down_live(w)
+        assert np.array_equal(take(want.size, np.float16), want.ravel().astype(np.float16)), "down %d" % k
+        if dbn:
+            sc, sh = _fold_bn(sd, dbn)
+            assert np.array_equal(take(chans[k], np.float32), sc) and np.array_equal(take(chans[k], np.float32), sh)
+        wt = sd[uc + ".weight"]
+        if k == 0:
+            assert np.array_equal(take(12 * 9 * 128, np.float32), pack_last(wt).ravel())
+            take(12, np.float32); take(12, np.float32)
+            assert np.array_equal(take(pack_up(wt).size, np.float32), pack_up(wt).ravel()) and np.array_equal(take(3, np.float32), sd[uc + ".bias"])
+        else:
+            assert np.array_equal(take(pack_up(wt).size, np.float16), pack_up(wt).ravel().astype(np.float16)), "up %d" % k
+            sc, sh = _fold_bn(sd, ubn)
+            assert np.array_equal(take(wt.shape[1], np.float32), sc) and np.array_equal(take(wt.shape[1], np.float32), sh)
+    assert off == nb
+    name, kern = ctypes.c_char_p(), ctypes.c_char_p()
+    kerns = []
+    for i in range(lib.lspunet_num_launches(h, 1)):
+        lib.lspunet_launch_info(h, 1, i, ctypes.byref(name), ctypes.byref(kern), None, None, None)
+        kerns.append(kern.value.decode())
+    assert not any("unet_tiny" in k or "unet_prepare" in k for k in kerns) and sum("<km>" in k for k in kerns) == nd
+    lib.lspunet_destroy(h)
+
+
 def test_native_plan_launch_list_workspace_and_errors():
     import ctypes
     lib, h, rc = _unet_handle(max_batch=8)
@@ -257,12 +311,12 @@ def test_native_plan_launch_list_workspace_and_errors():
     assert rc == 0 and lib.lspunet_num_launches(h, 1) == 1 + 8 + 7 + 7 + 2   # + one unet_prepare per level but the innermost; GEMM-form last layer + pixel shuffle
     lib.lspunet_destroy(h)
     for bad in (dict(tune="nonsense=1"), dict(tune="graph"), dict(tune="last_tile=7007"), dict(ngf=48), dict(num_downs=4), dict(size=384, num_downs=8),
-                dict(output_nc=5), dict(input_nc=64), dict(feat_nc=0), dict(max_batch=0)):
+                dict(output_nc=5), dict(input_nc=64), dict(feat_nc=0), dict(max_batch=0), dict(dtype=1), dict(dtype=3), dict(dtype=2, ngf=32)):
         lib, h, rc = _unet_handle(**bad)
         assert rc < 0 and lib.lspunet_last_error(), bad
     import ctypes as C
     from livespeechportraits_amd import _native as N
-    cfg = N.UnetConfig(99, 23, 23, 3, 64, 8, 512, 1, 0)
+    cfg = N.UnetConfig(99, 23, 23, 3, 64, 8, 512, 1, 0, 0)
     h = C.c_void_p()
     assert lib.lspunet_create(C.byref(cfg), None, C.byref(h)) == -1           # ABI version mismatch
 
@@ -491,3 +545,74 @@ def test_native_plan_two_sources_broadcast_candidates_and_hazards(gpu_device):
         e.forward(x3.cpu())
     with pytest.raises(ValueError):
         e.render(x3[:, :1].contiguous(), x3[:2, 1:].contiguous())               # cand batch neither 1 nor B
+
+
+@pytest.mark.gpu
+def test_fp16_plan_of_the_small_generator_against_the_autocast_oracle(gpu_device):
+    """opt.fp16 with size == 'small' (models/feature2face_G.py:28-30 wraps WHICHEVER netG in torch.cuda.amp.autocast): the pin is the oracle's op sequence -- bit-identical
+    to the reference module in fp32 (oracle/make_golden_unet.py) -- under torch.autocast(float16) on this device.  Its distance from the fp32 reference output is the error
+    the reference accepts when a user sets fp16; the HIP fp16 plan (fp16 storage, fp32 accumulate and epilogue: one rounding per layer) must stay inside it, max and mean,
+    per frame, and close to the autocast output itself."""
+    from oracle import unet_small_oracle
+    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    meta, sd, x, ref32 = load_case("small_512")
+    sd_d = {k: torch.from_numpy(v).to(gpu_device) for k, v in sd.items()}
+    xd = torch.from_numpy(x).to(gpu_device)
+    with torch.autocast("cuda", dtype=torch.float16):
+        ref16 = unet_small_oracle.generator_forward(sd_d, xd, meta["num_downs"])
+    assert ref16.dtype == torch.float16            # what the reference's inference() returns under opt.fp16
+    ref16 = ref16.float().cpu().numpy()
+    e = SmallUnetEngine(23, 3, meta["num_downs"], meta["ngf"], dtype="f16")
+    e.load_state_dict(sd, "model", gpu_device)
+    out_t = e.forward(xd)
+    assert torch.equal(e.forward(xd), out_t)       # deterministic, graph replay
+    out = out_t.cpu().numpy()
+    names = [r["kernel"] for r in e.launches(512, xd.shape[0])]
+    assert not any("unet_tiny" in n for n in names) and sum("<km>" in n for n in names) == 8        # the fp16 plan: masked-K implicit GEMMs on every level
+    B = x.shape[0]
+    d_ref, d_got, d_16 = (np.abs(a - b).reshape(B, -1) for a, b in ((ref16, ref32), (out, ref32), (out, ref16)))
+    fmt = lambda a: " ".join("%.1e" % v for v in a)
+    print("\nsmall generator fp16, per frame:\n  autocast oracle vs fp32 reference  max %s | mean %s\n  HIP fp16 vs fp32 reference         max %s | mean %s\n"
+          "  HIP fp16 vs autocast oracle        max %s | mean %s" % (fmt(d_ref.max(1)), fmt(d_ref.mean(1)), fmt(d_got.max(1)), fmt(d_got.mean(1)), fmt(d_16.max(1)), fmt(d_16.mean(1))))
+    assert (d_got.max(1) <= 1.25 * d_ref.max(1) + 1e-4).all() and (d_got.mean(1) <= 1.25 * d_ref.mean(1) + 1e-5).all()
+    assert (d_16.max(1) <= 2.0 * d_ref.max(1) + 1e-4).all() and (d_16.mean(1) <= 2.0 * d_ref.mean(1) + 1e-5).all()
+    assert d_got.max() > 1e-5                      # really the fp16 plan
+    # two sources, broadcast candidates, three frames, uint8: the same plan through render()
+    x3 = torch.cat([xd, xd.flip(0)[:1] * 0.5, xd[:1] * -0.7])[:3].contiguous() if B < 3 else xd[:3]
+    xb = torch.cat([x3[:, :1], x3[:1, 1:].expand(3, -1, -1, -1)], 1).contiguous()
+    assert torch.equal(e.render(x3[:, :1].contiguous(), x3[:1, 1:].contiguous()), e.forward(xb))
+    u8 = e.forward(xd, out_u8=True).cpu().numpy().astype(np.int32)
+    assert np.abs(u8 - np.clip((out.transpose(0, 2, 3, 1) + 1.0) / 2.0 * 255.0, 0, 255).astype(np.uint8).astype(np.int32)).max() <= 1
+    e.close()
+
+
+@pytest.mark.gpu
+def test_opt_fp16_with_size_small_selects_the_fp16_plan_and_returns_half(tmp_path):
+    """create_model(opt) with size='small', fp16=1 (ngf 64): the fp16 plan, a float16 tensor out like autocast returns; fp16=0 stays fp32; ngf 32 warns and runs fp32."""
+    import warnings
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.models import create_model
+    outs = {}
+    for ngf, fp16 in ((64, 0), (64, 1), (32, 1)):
+        sd = synth.make_unet_small_state_dict(23, 3, 6, ngf, seed=9)
+        ckpt = os.path.join(tmp_path, "Feature2Face_%d_%d.pkl" % (ngf, fp16))
+        torch.save({"module.netG." + k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
+        opt = argparse.Namespace(model="feature2face", gpu_ids=[0], isTrain=False, size="small", ngf=ngf, n_downsample_G=6, fp16=fp16,
+                                 checkpoints_dir=str(tmp_path), name="x", load_epoch=ckpt, verbose=False)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            m = create_model(opt)
+        m.setup(opt)
+        m.eval()
+        g = m._g().netG
+        want16 = bool(fp16) and ngf % 64 == 0
+        assert g.dtype == ("f16" if want16 else "f32")
+        assert any("fp16" in str(x.message) for x in w) == (bool(fp16) and not want16)
+        x = torch.from_numpy(synth.symmetric(2 * 23 * 128 * 128, 0.6, 77).reshape(2, 23, 128, 128)).cuda()
+        y = m.inference(x[:, :1], x[:, 1:])
+        assert y.dtype == (torch.float16 if want16 else torch.float32) and tuple(y.shape) == (2, 3, 128, 128)
+        assert m.inference_image(x[:, :1], x[:, 1:]).dtype == torch.uint8
+        outs[(ngf, fp16)] = y.float().cpu().numpy()
+    d = np.abs(outs[(64, 1)] - outs[(64, 0)])
+    print("\nsize small, opt.fp16 = 1 at 128x128: max-abs %.2e mean-abs %.2e vs the fp32 plan" % (d.max(), d.mean()))
+    assert 1e-6 < d.max() <= 5e-3

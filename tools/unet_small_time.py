@@ -40,21 +40,24 @@ for label, mk in (("host-sequenced (round 4)", lambda: HostSequencedUnetEngine()
                   ("native, input_pass=0", lambda: SmallUnetEngine(tune="input_pass=0")),
                   ("native, fused_splitk=1", lambda: SmallUnetEngine(tune="fused_splitk=1")),
                   ("native, graph=0", lambda: SmallUnetEngine(tune="graph=0")),
-                  ("native plan (again)", lambda: SmallUnetEngine())):
+                  ("native plan (again)", lambda: SmallUnetEngine()),
+                  ("native plan, fp16 storage", lambda: SmallUnetEngine(dtype="f16"))):
     e = mk(); e.load_state_dict(sd, "model", dev)
     for B in (1, 8):
         x = xs[B]
         out = e.forward(x)
         same = ""
-        if B in ref: same = " bit-identical to the host-sequenced form" if torch.equal(out, ref[B]) else " DIFFERS from the host-sequenced form by %.2e" % (out - ref[B]).abs().max().item()
+        if B in ref and "fp16" in label: same = " max-abs %.2e vs the fp32 host-sequenced form" % (out - ref[B]).abs().max().item()
+        elif B in ref: same = " bit-identical to the host-sequenced form" if torch.equal(out, ref[B]) else " DIFFERS from the host-sequenced form by %.2e" % (out - ref[B]).abs().max().item()
         ref.setdefault(B, out.clone())
         med, mn = clock(lambda: e.forward(x))
         dv = burst(lambda: e.forward(x))
         print("small generator, %-26s batch %d: %.3f ms per forward with a sync each (min %.3f), %.3f ms back to back = %.0f frames/s;%s" % (label + ",", B, 1e3 * med, 1e3 * mn, dv, B / dv * 1e3, same), flush=True)
     if hasattr(e, "close"): e.close()
 
-e = SmallUnetEngine(); e.load_state_dict(sd, "model", dev)
-for B in (1, 8):
+for dt in ("f32", "f16"):
+  e = SmallUnetEngine(dtype=dt); e.load_state_dict(sd, "model", dev)
+  for B in (1, 8):
     rows = e.launches(512, B)
     acc = np.zeros(len(rows))
     for _ in range(5):
@@ -62,9 +65,10 @@ for B in (1, 8):
         e.render(xs[B], None, timed=ms)
         acc += np.array(ms)
     acc /= 5
-    print("\nper launch (eager, one event pair each), batch %d: sum %.3f ms" % (B, acc.sum()))
+    print("\nper launch (eager, one event pair each), %s, batch %d: sum %.3f ms" % (dt, B, acc.sum()))
     for r, t in zip(rows, acc):
         print("  %-12s %-72s tile %3dx%-3d splits %-3d %8.1f us" % (r["name"], r["kernel"], r["tile"][0], r["tile"][1], r["split_k"], 1e3 * t))
+  e.close()
 
 if "--no-oracle" not in sys.argv:
     from oracle import unet_small_oracle
