@@ -346,7 +346,7 @@ int lspf2f_pixel_shuffle(const float *g_dev, int batch, int hs, int ws, int cout
 {
     if (!g_dev || (!out_f32_dev && !out_u8_dev)) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
     if (batch < 1 || hs < 1 || ws < 1 || cout < 1 || cout > 4) return fail(LSPF2F_ERR_SHAPE, "pixel_shuffle: cout must be in 1..4");
-    ShuffleParams sp{g_dev, out_f32_dev, out_u8_dev, batch, hs, ws, cout, apply_tanh ? 1 : 0, 0};
+    ShuffleParams sp{g_dev, out_f32_dev, out_u8_dev, batch, hs, ws, cout, apply_tanh ? 1 : 0, 0, nullptr};
     const hipError_t e = launch_pixel_shuffle(sp, static_cast<hipStream_t>(hip_stream));
     return e == hipSuccess ? LSPF2F_OK : hipfail(e, "pixel_shuffle launch");
 }
@@ -446,7 +446,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             if (fused) { q.out_nchw = out; q.cout = l.cout; q.apply_tanh = l.tanh_out ? 1 : 0; }
             e = launch_rowlast(q, s);
             if (e == hipSuccess && !fused) {
-                ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0, 1};
+                ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0, 1, nullptr};
                 e = launch_pixel_shuffle(sp, s);
             }
             if (e != hipSuccess) return hipfail(e, ("launch " + l.name).c_str());
@@ -461,7 +461,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         g.ktiles_total = 9 * l.cin / P.ktile_channels(); g.splits = 1; g.ktiles_per_split = g.ktiles_total;
         e = launch_igemm(g, 128, 32, 1, s);
         if (e == hipSuccess) {
-            ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0, 0};
+            ShuffleParams sp{reinterpret_cast<const float *>(h->ws + P.partial_offset), out, out_u8, batch, l.hs, l.hs, l.cout, l.tanh_out ? 1 : 0, 0, nullptr};
             e = launch_pixel_shuffle(sp, s);
         }
     } else if (l.kind == kLastConv) {

@@ -1193,6 +1193,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle_tanh(ShuffleParams p)
     const float4 *g4 = reinterpret_cast<const float4 *>(p.g + gid * n);
     float v[16];
     for (int i = 0; i < n / 4; ++i) { const float4 t = g4[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+    if (p.bias)                // (column -> output channel in either order)
+        for (int i = 0; i < n; ++i) v[i] += p.bias[p.paired ? (i >> 1) % p.Cout : i % p.Cout];
     if (p.apply_tanh) for (int i = 0; i < n; ++i) v[i] = tanhf(v[i]);
     if (p.paired) {            // rowlast128's column order -> (py * 2 + px) * Cout + co
         float u[16];

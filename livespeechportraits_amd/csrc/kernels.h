@@ -340,6 +340,7 @@ struct ShuffleParams {
     unsigned char *out_u8;
     int B, Hs, Ws, Cout, apply_tanh;
     int paired;        // columns of g in the order n' = ((py * Cout + co) * 2 + px) (rowlast128's operand order) instead of (py * 2 + px) * Cout + co
+    const float *bias; // [Cout] added before the tanh, or nullptr (the `small` U-Net's outermost ConvTranspose2d carries a bias; the other variants' last conv has none)
 };
 hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s);
 // one wave: {shader cycles, 100-MHz ticks} seen while spinning for duration_us of the constant counter (the clock the chip holds under load)

@@ -34,6 +34,7 @@ struct UnetInputParams {
     const float *feat, *cand;      // [B][feat_nc][S][S], [cand_batch][C - feat_nc][S][S]
     void *out;                     // [B][S/2][S/2][s2d_c] in the plan's storage type
     int B, S, C, feat_nc, cand_bcast, s2d_c, cols;   // cols = output columns per workgroup (<= 64)
+    int qc;                        // channels per quarter in the output: C (dense: quarter q at q * C, the tail zero) or C rounded up to a K-tile (quarter q at q * qc, its tail zero)
 };
 
 template <typename T>
@@ -46,12 +47,15 @@ __global__ __launch_bounds__(256) void unet_input_s2d(const UnetInputParams p)
     const int i = blockIdx.x / chunks, j0 = (blockIdx.x - i * chunks) * p.cols, b = blockIdx.y;
     const int cand_nc = p.C - p.feat_nc;
     const size_t plane = (size_t)p.S * p.S;
-    for (int idx = threadIdx.x; idx < p.C * 2 * cw; idx += 256) {
-        const int c = idx / (2 * cw), r = idx - c * 2 * cw;
-        const int dy = r / cw, x = r - dy * cw;
+    const int cw4 = cw >> 2;                                // 16-byte loads: a row segment starts at a multiple of 2 * cols >= 4 floats (cols even)
+    for (int idx = threadIdx.x; idx < p.C * 2 * cw4; idx += 256) {
+        const int c = idx / (2 * cw4), r = idx - c * 2 * cw4;
+        const int dy = r / cw4, x = (r - dy * cw4) * 4;
         const float *src = c < p.feat_nc ? p.feat + ((size_t)b * p.feat_nc + c) * plane
                                          : p.cand + ((size_t)(p.cand_bcast ? 0 : b) * cand_nc + (c - p.feat_nc)) * plane;
-        lds[(c * 2 + dy) * pitch + x] = src[(size_t)(2 * i + dy) * p.S + 2 * j0 + x];
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)(2 * i + dy) * p.S + 2 * j0 + x);
+        float *d = lds + (c * 2 + dy) * pitch + x;          // (odd pitch: the column gather below stays two-way conflicted at worst; four scalar stores)
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
     const int q4 = p.s2d_c >> 2;
@@ -63,10 +67,8 @@ __global__ __launch_bounds__(256) void unet_input_s2d(const UnetInputParams p)
         for (int e = 0; e < 4; ++e) {
             const int ch = ch0 + e;
             v[e] = 0.f;
-            if (ch < 4 * p.C) {
-                const int q = ch / p.C, c = ch - q * p.C;
-                v[e] = lds[(c * 2 + (q >> 1)) * pitch + 2 * j + (q & 1)];
-            }
+            const int q = ch / p.qc, c = ch - q * p.qc;
+            if (q < 4 && c < p.C) v[e] = lds[(c * 2 + (q >> 1)) * pitch + 2 * j + (q & 1)];
         }
         store4(dst + (size_t)j * p.s2d_c + ch0, make_float4(v[0], v[1], v[2], v[3]));
     }
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void unet_input_s2d(const UnetInputParams p)
 static hipError_t launch_unet_input(const UnetInputParams &p, int dtype, hipStream_t s)
 {
     const int S2 = p.S / 2;
-    if (p.B < 1 || p.S < 2 || (p.S & 1) || p.C < 1 || p.C > 48 || p.feat_nc < 1 || p.feat_nc > p.C || p.s2d_c < 4 * p.C || (p.s2d_c & 3) || p.cols < 1 || S2 % p.cols)
+    if (p.B < 1 || p.S < 4 || (p.S & 3) || p.C < 1 || p.C > 48 || p.feat_nc < 1 || p.feat_nc > p.C || p.qc < p.C || p.s2d_c < 4 * p.qc || (p.s2d_c & 3) || p.cols < 2 || (p.cols & 1) || S2 % p.cols)
         return hipErrorInvalidValue;
     const size_t smem = (size_t)p.C * 2 * (2 * p.cols + 1) * sizeof(float);
     const dim3 grid((unsigned)(S2 * (S2 / p.cols)), (unsigned)p.B);
@@ -291,10 +293,13 @@ struct UnetParam {
 
 struct UnetLevel {
     int cin = 0, cout = 0;         // down-conv k: cin -> cout (= chans[k]) at stride 2
-    int s2d = 0;                   // channels of its space-to-depth input (4 cin; block 0: padded to a multiple of 32)
+    int s2d = 0;                   // channels of its space-to-depth input: 4 cin_p (block 0 in its dense form: 4 cin padded to a K-tile)
+    int cin_p = 0;                 // channels per quarter of that image: cin (block 0 in its live form: cin rounded up to a K-tile, the tail zero)
+    bool live = true;              // weights = the 16 live (tap, quarter) pairs [co][16][cin_p]; false (block 0, dense form): the 3x3 rows [co][9][s2d]
     int up_cin = 0, up_cout = 0;   // transposed conv of block k: up_cin (cout, or 2 cout with the skip) -> up_cout
     std::string dc, dbn, uc, ubn;  // state-dict keys (dbn / ubn "" = none)
     int64_t down_w = -1, down_scale = -1, down_shift = -1, up_w = -1, up_scale = -1, up_shift = -1;   // byte offsets in the blob
+    int64_t up_rl = -1;                  // block 0, 16-bit plans with two 64-channel sources: its GEMM rows in the fragment order of rowlast128 (rowconv.hip)
     int64_t up_sub = -1, up_bias = -1;   // block 0 only: its transposed conv in sub-pixel form [4][co][2][2][ci] + the conv bias, for the direct last-layer kernel
     size_t down_w_bytes = 0, up_w_bytes = 0;
 };
@@ -302,7 +307,7 @@ struct UnetLevel {
 // one launch (or launch + reduce) of the forward
 struct UnetLaunch {
     std::string name, kernel;
-    int kind = 0;                  // 0 input pass, 1 conv, 2 pixel shuffle, 3 unet_prepare (fused_prepare = 0), 4 the direct last-layer kernel (last_direct = 1)
+    int kind = 0;                  // 0 input pass, 1 conv, 2 pixel shuffle, 3 unet_prepare (fused_prepare = 0), 4 the direct last-layer kernel (last_direct = 1), 5 rowlast128 (16-bit plans)
     int level = 0;
     bool down = false, last = false;
     int bm = 0, bn = 0, splits = 1, group = 1;
@@ -321,6 +326,9 @@ struct UnetPlan {
     bool fused_prepare = true, input_pass = true;
     bool fused_splitk = false;                 // 2..8 K splits combined by the last-arriving workgroup instead of a reduce launch: measured SLOWER here (0.903 vs 0.889 ms at one frame,
                                                // equal at eight; profiles/r05_unet_small_native.txt) -- the split layers of this plan are short launches -- and its 6-split sum runs in another order than splitk_reduce's
+    bool dense0 = false;                       // tune key `dense0`: block 0 (23 input channels) as dense 3x3 rows on 4 x 23 -> 96 channels, 27 K-tiles of which 15 multiply zeros (the host-sequenced
+                                               // form's block 0); default: its quarters padded to 32 channels each and only the 16 live (tap, quarter) pairs walked (16 K-tiles).
+                                               // 16-bit plans keep the dense form (a K-tile is 64 channels: 16 x 64 = 1024 of K against 9 x 128 = 1152, on a larger input)
     bool use_tiny = true;                      // tune key `tiny`
     bool last_direct = true;                   // the outermost transposed conv + tanh (+ tensor2im) on the direct sub-pixel kernel of the other variants' last layer (edge_layers.hip) instead of
                                                // a 3x3 GEMM with N = 12 of 32 columns live + a pixel-shuffle pass
@@ -359,7 +367,8 @@ struct UnetPlan {
         if (size < (1 << nd) || size % (1 << nd)) return "frame size must be a multiple of 2**num_downs";
         if (dtype != 0 && dtype != 2) return "dtype must be 0 (fp32) or 2 (fp16 storage)";
         if (dtype && ngf % 64) return "fp16 storage needs ngf % 64 == 0";
-        if (dtype) { fused_prepare = true; input_pass = true; last_direct = true; use_tiny = false; fused_splitk = false; }     // (the other arms are fp32 launches)
+        if (dtype) { fused_prepare = true; input_pass = true; last_direct = true; use_tiny = false; fused_splitk = false; dense0 = true; }     // (the other arms are fp32 launches)
+        if (!input_pass) dense0 = true;             // (lspf2f_unet_prepare writes the dense quarter layout)
         chans.clear();
         for (int i = 0; i < nd; ++i) chans.push_back(ngf * std::min(1 << i, 8));
         // state-dict keys: the nesting of nn.Sequential indices in UnetSkipConnectionBlock (models/networks.py:737-767)
@@ -369,7 +378,9 @@ struct UnetPlan {
             UnetLevel &l = L[k];
             l.cin = k == 0 ? input_nc : chans[k - 1];
             l.cout = chans[k];
-            l.s2d = k == 0 ? (4 * input_nc + ktc() - 1) / ktc() * ktc() : 4 * l.cin;
+            l.live = k > 0 || !dense0;
+            l.cin_p = l.live ? (l.cin + ktc() - 1) / ktc() * ktc() : l.cin;
+            l.s2d = l.live ? 4 * l.cin_p : (4 * l.cin + ktc() - 1) / ktc() * ktc();
             l.up_cin = k == nd - 1 ? l.cout : 2 * l.cout;
             l.up_cout = k == 0 ? output_nc : chans[k - 1];
             if (k == 0) { l.dc = pfx + ".0"; l.uc = pfx + ".3"; pfx += ".1.model"; }
@@ -388,7 +399,7 @@ struct UnetPlan {
         auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return (int64_t)o; };
         for (int k = 0; k < nd; ++k) {
             UnetLevel &l = L[k];
-            l.down_w_bytes = (k == 0 ? (size_t)l.cout * 9 * l.s2d : (size_t)l.cout * 16 * l.cin) * elt();
+            l.down_w_bytes = (l.live ? (size_t)l.cout * 16 * l.cin_p : (size_t)l.cout * 9 * l.s2d) * elt();
             l.down_w = take(l.down_w_bytes);
             if (!l.dbn.empty()) { l.down_scale = take((size_t)l.cout * 4); l.down_shift = take((size_t)l.cout * 4); }
             const int n_up = k == 0 ? 4 * l.up_cout : l.up_cout;
@@ -397,6 +408,7 @@ struct UnetPlan {
             l.up_scale = take((size_t)n_up * 4);
             l.up_shift = take((size_t)n_up * 4);
             if (k == 0) { l.up_sub = take((size_t)4 * l.up_cout * 4 * l.up_cin * 4); l.up_bias = take((size_t)l.up_cout * 4); }
+            if (k == 0 && rowlast_ok()) l.up_rl = take((size_t)9 * 4 * 64 * 8 * 2);
         }
         blob_bytes = off;
         cur = Batch();
@@ -440,7 +452,7 @@ struct UnetPlan {
             std::vector<float> stage;                                   // 16-bit plans: conv weights are packed in fp32 here, then narrowed (RNE) into the blob
             float *dw = reinterpret_cast<float *>(B + l.down_w);
             if (dtype) { stage.assign(l.down_w_bytes / 2, 0.f); dw = stage.data(); }
-            if (k == 0) {
+            if (!l.live) {
                 // dense rows [co][ty][tx][s2d] of the 3x3 conv on the space-to-depth image (20 of the 36 (tap, quarter) blocks stay zero; the quarters of 23 channels are
                 // not K-tile aligned, so block 0 cannot drop them)
                 for (int co = 0; co < l.cout; ++co)
@@ -462,7 +474,7 @@ struct UnetPlan {
                     for (int ci = 0; ci < l.cin; ++ci)
                         for (int ky = 0; ky < 4; ++ky)
                             for (int kx = 0; kx < 4; ++kx)
-                                dw[((size_t)co * 16 + slot[ky][kx]) * l.cin + ci] = w[(((size_t)co * l.cin + ci) * 4 + ky) * 4 + kx];
+                                dw[((size_t)co * 16 + slot[ky][kx]) * l.cin_p + ci] = w[(((size_t)co * l.cin + ci) * 4 + ky) * 4 + kx];     // (block 0: channels cin .. cin_p - 1 stay zero)
             }
             if (dtype) narrow(stage, B + l.down_w);
             if (!l.dbn.empty()) fold_bn(l.dbn, l.cout, reinterpret_cast<float *>(B + l.down_scale), reinterpret_cast<float *>(B + l.down_shift));
@@ -483,6 +495,11 @@ struct UnetPlan {
                 const float *bias = data(l.uc + ".bias");
                 for (int i = 0; i < 4 * co_n; ++i) { usc[i] = 1.f; ush[i] = bias[i % co_n]; }
                 std::memcpy(B + l.up_bias, bias, (size_t)co_n * 4);
+                if (l.up_rl >= 0) {
+                    std::vector<unsigned short> g16((size_t)4 * co_n * 9 * ci_n);
+                    for (size_t i = 0; i < g16.size(); ++i) { const _Float16 hv = (_Float16)uw[i]; std::memcpy(&g16[i], &hv, 2); }
+                    pack_rowlast_weights(g16.data(), reinterpret_cast<unsigned short *>(B + l.up_rl), 4 * co_n);
+                }
             }
             {
                 // sub-pixel form [par][co][a][b][ci] (block 0: a second form of its weights, for the direct last-layer kernel)
@@ -510,6 +527,10 @@ struct UnetPlan {
         if (!use_tiny || M > 16 || V % 256 || (ntap == 4 && V >= 512 && (V / 2) % 256) || ntap * (V / 4) > 8 * 256 || cout % 2) return false;
         return 256 * 4 + ((size_t)M * nvec_per_pix + 1) * V * 4 <= 150 * 1024;
     }
+
+    // 16-bit plans whose last layer reads two 64-channel sources: the row kernel of the other variants' 16-bit last conv (rowlast128, rowconv.hip) on the GEMM rows
+    // + the pixel-shuffle pass (which adds the bias): 62 / 294 us -> see profiles/r05_unet_small_native.txt for the direct kernel's vector-ALU route it replaces
+    bool rowlast_ok() const { return dtype != 0 && ngf == 64 && (size / 2) % 64 == 0; }
 
     // spatial extent of d_k (= of Y_{k+1}'s source, of R_k)
     int hd(int k) const { return size >> (k + 1); }
@@ -545,10 +566,10 @@ struct UnetPlan {
             const UnetLevel &l = L[k];
             const int h = hd(k);
             UnetLaunch u; u.kind = 1; u.level = k; u.down = true; u.name = "L" + std::to_string(k) + ".down";
-            const bool km = k > 0 || (fused_prepare && k < nd - 1);
-            const int ktiles = k == 0 ? 9 * l.s2d / ktc() : 16 * l.cin / ktc();
+            const bool km = l.live || (fused_prepare && k < nd - 1);
+            const int ktiles = l.live ? 16 * l.cin_p / ktc() : 9 * l.s2d / ktc();
             tile_for(B * h * h, l.cout, ktiles, 1, &u, true, (size_t)B * h * h * l.cout);
-            if (k > 0 && (fused_prepare || k == nd - 1) && tiny_ok(B, h, l.cin, 16, 4, l.cout)) {
+            if (l.live && (fused_prepare || k == nd - 1) && tiny_ok(B, h, l.cin_p, 16, 4, l.cout)) {
                 u.tiny = true; u.bm = u.bn = 1; u.splits = 1; u.group = 1; u.fused_combine = false;
                 u.kernel = std::string("unet_tiny (down)") + (k < nd - 1 ? " -> lrelu s2d + relu" : "");
             } else
@@ -578,7 +599,12 @@ struct UnetPlan {
             const UnetLevel &l = L[0];
             const int h = hd(0);
             UnetLaunch u; u.kind = 1; u.level = 0; u.last = true; u.name = "L0.up";
-            if (last_direct) {
+            if (L[0].up_rl >= 0) {
+                u.kind = 5; u.kernel = "rowlast128 (GEMM form on the row kernel, fp32 [B][H][W][4 x output_nc] out)";
+                launches.push_back(u);
+                UnetLaunch q; q.kind = 2; q.level = 0; q.name = "L0.shuffle"; q.kernel = "pixel_shuffle_tanh (+ bias)";
+                launches.push_back(q);
+            } else if (last_direct) {
                 u.kind = 4; u.kernel = "last_conv (direct sub-pixel kernel: transposed conv + bias + tanh + tensor2im)";
                 launches.push_back(u);
             } else {
@@ -685,7 +711,7 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
     if (u.kind == 0) {
         UnetInputParams q{};
         q.feat = feat; q.cand = cand; q.out = wsf(P.cur.y_off[0]);
-        q.B = B; q.S = P.size; q.C = P.input_nc; q.feat_nc = P.feat_nc; q.cand_bcast = cand_batch == 1 && B > 1; q.s2d_c = P.L[0].s2d;
+        q.B = B; q.S = P.size; q.C = P.input_nc; q.feat_nc = P.feat_nc; q.cand_bcast = cand_batch == 1 && B > 1; q.s2d_c = P.L[0].s2d; q.qc = P.L[0].cin_p;
         q.cols = 64;
         while ((P.size / 2) % q.cols) q.cols >>= 1;
         e = launch_unet_input(q, P.dtype, s);
@@ -706,9 +732,16 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
         q.src0 = wsf(P.cur.r_off[0]); q.src1 = wsf(P.cur.u_off[1]); q.dtype = P.dtype; q.w = bl(l.up_sub); q.bias = bl(l.up_bias);
         q.out = out; q.out_u8 = out_u8; q.B = B; q.Hs = P.hd(0); q.Ws = P.hd(0); q.C0 = l.cout; q.C1 = l.cout; q.Cout = l.up_cout; q.apply_tanh = 1;
         e = launch_last_conv(q, s);
+    } else if (u.kind == 5) {
+        const UnetLevel &l = P.L[0];
+        RowLastParams q{};
+        q.src0 = wsf(P.cur.r_off[0]); q.src1 = wsf(P.cur.u_off[1]); q.w = h->blob + l.up_rl; q.out = wsf(P.cur.g_off);
+        q.B = B; q.H = P.hd(0); q.W = P.hd(0); q.R = rowlast_rows(B, P.hd(0), P.hd(0)); q.dtype = P.dtype;
+        e = launch_rowlast(q, s);
     } else if (u.kind == 2) {
         ShuffleParams q{};
         q.g = wsf(P.cur.g_off); q.out = out; q.out_u8 = out_u8; q.B = B; q.Hs = P.hd(0); q.Ws = P.hd(0); q.Cout = P.output_nc; q.apply_tanh = 1;
+        if (P.L[0].up_rl >= 0) { q.paired = 1; q.bias = bl(P.L[0].up_bias); }      // rowlast128's column order; its GEMM has no epilogue: the bias is added here
         e = launch_pixel_shuffle(q, s);
     } else {
         const int k = u.level;
@@ -741,16 +774,16 @@ static int run_unet_launch(lspunet_handle *h, const UnetLaunch &u, const float *
             p.Hs = p.Ws = p.Ho = p.Wo = hh; p.C0 = p.Cin = l.s2d; p.C1 = 0; p.Cout = l.cout;
             p.Mout = p.M = B * hh * hh;
             const bool inner = k == P.nd - 1;
-            const bool km = k > 0 || (P.fused_prepare && !inner);
-            if (k > 0) {
+            const bool km = l.live || (P.fused_prepare && !inner);
+            if (l.live) {
                 static const unsigned sub[3] = {2u, 3u, 1u};          // live sub-rows of tap row 0, 1, 2 as a bit set over dy
                 for (int ty = 0; ty < 3; ++ty)
                     for (int tx = 0; tx < 3; ++tx)
                         for (int dy = 0; dy < 2; ++dy)
                             for (int dx = 0; dx < 2; ++dx)
                                 if (((sub[ty] >> dy) & 1u) && ((sub[tx] >> dx) & 1u)) p.kmask |= 1ull << ((ty * 3 + tx) * 4 + dy * 2 + dx);
-                p.kblk = l.cin;
-                p.ktiles_total = 16 * l.cin / ktc;
+                p.kblk = l.cin_p;
+                p.ktiles_total = 16 * l.cin_p / ktc;
             } else {
                 p.ktiles_total = 9 * l.s2d / ktc;
                 if (km) {            // block 0 on a masked-K instance with every K-tile live (dense rows): what carries the dual store
@@ -848,6 +881,7 @@ int lspunet_create(const lspunet_config *cfg, const char *tune, lspunet_handle *
         else if (k == "fused_splitk") P.fused_splitk = v != 0;
         else if (k == "last_direct") P.last_direct = v != 0;
         else if (k == "tiny") P.use_tiny = v != 0;
+        else if (k == "dense0") P.dense0 = v != 0;
         else if (k == "last_tile") { P.last_bm = v < 0 ? -1 : (int)(v / 1000); P.last_bn = v < 0 ? -1 : (int)(v % 1000); }      // e.g. 128032 = 128 x 32; -1 = the general tiling rule
         else { delete h; return ufail(LSPUNET_ERR_INVALID_ARGUMENT, "tune: unknown key '" + k + "'"); }
     }

@@ -211,7 +211,11 @@ def test_native_plan_expects_the_reference_keys_and_packs_like_the_numpy_packers
     for k, (dc, dbn, uc, ubn) in enumerate(block_keys(nd, "model")):
         cin, cout = (inc if k == 0 else chans[k - 1]), chans[k]
         w = sd[dc + ".weight"]
-        want = pack_down(w, (4 * inc + 31) // 32 * 32) if k == 0 else pack_down_live(w)
+        if k == 0:                                                             # block 0: quarters padded to a K-tile (23 -> 32 channels), live pairs only
+            wp = np.zeros((w.shape[0], 32, 4, 4), np.float32)
+            wp[:, :inc] = w
+            w = wp
+        want = pack_down_live(w)
         assert np.array_equal(take(want.size), want.ravel()), "down %d" % k
         if dbn:
             sc, sh = _fold_bn(sd, dbn)
@@ -283,6 +287,15 @@ def test_native_fp16_plan_packs_the_rounded_fp32_rows():
         lib.lspunet_launch_info(h, 1, i, ctypes.byref(name), ctypes.byref(kern), None, None, None)
         kerns.append(kern.value.decode())
     assert not any("unet_tiny" in k or "unet_prepare" in k for k in kerns) and sum("<km>" in k for k in kerns) == nd
+    assert any(k.startswith("last_conv") for k in kerns)                      # 32 low-res columns: not a multiple of the row kernel's 64-pixel strips
+    lib.lspunet_destroy(h)
+    lib, h, rc = _unet_handle(dtype=2)                                        # 512 x 512, ngf 64: the last layer on rowlast128 + the shuffle pass (which adds the bias)
+    assert rc == 0
+    kerns = []
+    for i in range(lib.lspunet_num_launches(h, 1)):
+        lib.lspunet_launch_info(h, 1, i, ctypes.byref(name), ctypes.byref(kern), None, None, None)
+        kerns.append(kern.value.decode())
+    assert kerns[-2].startswith("rowlast128") and kerns[-1].startswith("pixel_shuffle_tanh")
     lib.lspunet_destroy(h)
 
 
@@ -490,9 +503,9 @@ def test_native_plan_equals_the_host_sequenced_launches_bit_for_bit(name, gpu_de
     want = host.forward(xd)
     # with the last layer in its GEMM form on the host-sequenced form's tile, every arm of the plan repeats its bits; the defaults (direct last-layer kernel) and the
     # in-launch split-K combine (another summation order at 6 splits) are held to the reference golden
-    same = "last_direct=0,last_tile=-1,tiny=0"
+    same = "last_direct=0,last_tile=-1,tiny=0,dense0=1"
     for tune, exact in ((same, True), (same + ",fused_prepare=0", True), (same + ",input_pass=0", True), (same + ",graph=0", True),
-                        (same + ",fused_prepare=0,input_pass=0,graph=0", True), (None, False), ("last_direct=0", False), ("fused_splitk=1", False), ("graph=0", False), ("tiny=0", False)):
+                        (same + ",fused_prepare=0,input_pass=0,graph=0", True), (None, False), ("last_direct=0", False), ("fused_splitk=1", False), ("graph=0", False), ("tiny=0", False), ("dense0=1", False)):
         e = SmallUnetEngine(23, 3, meta["num_downs"], meta["ngf"], tune=tune)
         e.load_state_dict(sd, "model", gpu_device)
         got = e.forward(xd)

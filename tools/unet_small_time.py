@@ -35,6 +35,7 @@ for label, mk in (("host-sequenced (round 4)", lambda: HostSequencedUnetEngine()
                   ("native plan", lambda: SmallUnetEngine()),
                   ("native, last_direct=0", lambda: SmallUnetEngine(tune="last_direct=0")),
                   ("native, last_direct=0 64x64", lambda: SmallUnetEngine(tune="last_direct=0,last_tile=-1")),
+                  ("native, dense0=1", lambda: SmallUnetEngine(tune="dense0=1")),
                   ("native, tiny=0", lambda: SmallUnetEngine(tune="tiny=0")),
                   ("native, fused_prepare=0", lambda: SmallUnetEngine(tune="fused_prepare=0")),
                   ("native, input_pass=0", lambda: SmallUnetEngine(tune="input_pass=0")),
