@@ -36,7 +36,7 @@ extern "C" {
 typedef enum lspf2f_status {
     LSPF2F_OK = 0,
     LSPF2F_ERR_INVALID_ARGUMENT = -1,
-    LSPF2F_ERR_UNSUPPORTED = -2,     /* e.g. size == 'small' (networks.py:680-769), ngf % 32 != 0 */
+    LSPF2F_ERR_UNSUPPORTED = -2,     /* e.g. ngf % 32 != 0 (size == 'small', networks.py:680-769, has its own handle: lspunet.h) */
     LSPF2F_ERR_MISSING_TENSOR = -3,  /* a state-dict key the network needs was never supplied */
     LSPF2F_ERR_SHAPE = -4,
     LSPF2F_ERR_STATE = -5,           /* call order violated (e.g. forward before bind) */
