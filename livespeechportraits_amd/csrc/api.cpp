@@ -50,6 +50,7 @@ struct lspf2f_handle {
     // (the next four: `tune` keys of lspf2f_create_tuned -- tools, tests, A-B runs)
     bool last_direct = false;     // lastconv_direct=1: 16-bit plans run the direct last-conv kernel instead of the GEMM form
     bool prefetch = true;         // prefetch=0: weight-streaming layers do not request the next launch's weights
+    bool smallm_dma = true;       // smallm_dma=0: conv3x3_smallm stages its input tensor through registers (the form of rounds 2-4) instead of LDS-DMA pieces
     bool fuse_splitk = true;      // fused_splitk=0: always combine split-K slabs with a separate launch
     bool counters_clean = false;  // the arrival counters at the head of the workspace were zeroed since it was bound
     int first_direct = 0;         // firstconv=1: vector-ALU first conv; 2: register-staged matrix-core kernel
@@ -162,6 +163,8 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "fullk16_min_frames") P.fullk16_min_frames = v;
         else if (k == "wino_prio") P.wino_prio = v;
         else if (k == "prefetch") h->prefetch = v != 0;
+        else if (k == "smallm_dma") h->smallm_dma = v != 0;
+        else if (k == "smallm_kb") P.smallm_kb = v;
         else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
         else if (k == "lastconv") h->last_route = v;                   // LastConvParams::route (0 = by shape)
         else if (k == "firstconv") h->first_direct = v;                // FirstConvParams::force_direct (0 = by shape)
@@ -477,6 +480,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.Cin = l.cin; p.Cout = l.cout;
         p.stride = l.stride; p.up = l.up; p.relu = l.inorm ? 0 : l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
+        p.stage_regs = h->smallm_dma ? 0 : 1;
         if (h->prefetch && P.dtype == 0 && !l.inorm) {
             // the next launch, if it is another weight-streaming layer: its weights are requested from inside this one
             const size_t li = (size_t)(&l - P.layers.data());

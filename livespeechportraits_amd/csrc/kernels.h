@@ -182,6 +182,8 @@ struct SmallMParams {
     const void *pf;
     unsigned pf_bytes;
     unsigned pf_dump;            // filled by launch_smallm: LDS byte offset of the dump slot
+    int stage_regs;              // 1: stage the input tensor through registers (the form of rounds 2-4: pairs of loads, each pair waited for before the next -- four dependent round trips
+                                 // for a 4x4x512 tensor); 0 (default): LDS-DMA pieces, all in flight at once (fp32 storage; 16-bit inputs are widened on the way and keep the registers)
 };
 bool smallm_supported(const SmallMParams &p);
 hipError_t launch_smallm(const SmallMParams &p, hipStream_t s);

@@ -527,7 +527,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             const int Mout = batch * l.ho * l.ho;
             const int M = l.up4 ? batch * l.hs * l.hs : Mout;
             choose_tiling(M, l.cout, (l.up4 ? 4 : 9) * l.cin / p.ktile_channels(), l.up4 ? 4 : 1, l.up, p.dtype, &bm, &bn, &splits, &group);
-            const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4);
+            const bool smallm = !l.up4 && smallm_eligible(M, l.cin, l.c1, l.cout, (size_t)batch * l.hs * l.hs * l.cin * 4, p.dtype == 0 ? p.smallm_kb : 64);
             if (smallm) { bm = bn = 1; splits = 1; group = 1; }
             // (every kernel choice below looks only at the offset of the weight form IT reads: the blob of a handle carries just the forms its
             // batch range uses, Plan::build)

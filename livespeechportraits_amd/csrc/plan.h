@@ -106,6 +106,8 @@ struct Plan {
     bool use_wino4 = false;    // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSPF2F_FLAG_WINO4; measured slower at batch 1 and
                                // equal at batch 8, DESIGN.md 4.11, so off by default); decides whether the blob carries the 6x6 transformed weights
     bool in_wino_stats = true;   // `in_wino_stats`: InstanceNorm plans take a wino3x3 layer's statistics from its epilogue instead of a pass over its output
+    int smallm_kb = 64;          // `smallm_kb`: largest input tensor (KB, fp32 in LDS) the tiny-M kernel takes.  64 until round 5; with LDS-DMA staging a 128-KB tensor (one workgroup per CU) is
+                                 // one round of copies: L6.down (512 -> 512 at stride 2, 8x8 -> 4x4) leaves the 36-way split-K implicit GEMM + reduce launch at one frame
     int out_wt = 1;              // `out_wt`: wino3x3 / winoup3x3 write their output through (sc1 stores) instead of leaving it dirty in L2 for the end-of-kernel write-back: bit-identical, +0.6 % at batch 1, +0.3 % at batch 8, +1.0 % `normal` batch 1 (A-B-A-B x3, profiles/r05_outwt_ab.txt); 0 = plain stores
     bool fused_splitk16 = false; // `fused_splitk16`: 16-bit plans combine 2..8 K-splits inside the igemm launch like the fp32 plans do (off until measured: round 5)
     int wino_prio = 1;           // `wino_prio`: wino3x3<1>'s register form sets its wave priority by K-loop progress, the workgroup that is BEHIND leads (ProgressPrio, wino_common.h): bit-identical,
@@ -165,9 +167,9 @@ struct Plan {
 // tile / split-K heuristic shared by the planner and lspf2f_conv3x3
 void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *bm, int *bn, int *splits, int *group);
 // tiny-M kernel eligibility (mirrors smallm_supported() in small_layers.hip)
-inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes)
+inline bool smallm_eligible(int M, int cin, int c1, int cout, size_t in_bytes, int max_kb = 64)
 {
-    return M <= 16 && c1 == 0 && cin % 256 == 0 && 9 * (cin / 4) <= 5 * 256 && in_bytes <= 64 * 1024 && cout % 2 == 0;
+    return M <= 16 && c1 == 0 && cin % 256 == 0 && 9 * (cin / 4) <= 5 * 256 && in_bytes <= (size_t)max_kb * 1024 && cout % 2 == 0;
 }
 // weights-stationary kernel eligibility (mirrors rowconv_supported() in rowconv.hip): bf16 storage, one source of 64 or 128 channels,
 // as many out, stride 1, no upsample, BatchNorm (folded) plans

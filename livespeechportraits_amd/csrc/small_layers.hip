@@ -72,8 +72,23 @@ __global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMPar
         if (p.scale) { e_sc = p.scale[en]; e_sh = p.shift[en]; }
         if (p.residual) e_res = ld1(static_cast<const T *>(p.residual) + (size_t)em * p.Cout + en);
     }
-    for (int i = tid; i < nin4; i += 256)
-        reinterpret_cast<float4 *>(act)[i] = load4(static_cast<const T *>(p.src) + (size_t)i * 4);   // LDS copy is fp32
+    bool dma = false;
+    if constexpr (sizeof(T) == 4) {
+        // fp32: LDS-DMA, 1 KB per wave and instruction, every piece in flight at once.  The register form below compiles to pairs of loads each waited for before the
+        // next pair is issued (the ds_write needs the data): four dependent L2 round trips for the 32-KB tensor of a 4x4 level, inside a 6.6-us launch (round 5)
+        if (!p.stage_regs) {
+            dma = true;
+            typedef __attribute__((address_space(3))) float lds_float;
+            const unsigned lds_act = (unsigned)(unsigned long long)(lds_float *)act;
+            const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6), lane16 = ((unsigned)tid & 63u) * 16u;
+            const unsigned total = (unsigned)nin4 * 16u;                // Cin % 256 == 0: whole 1-KB pieces
+            const i32x4 srd = make_srd(p.src, total);
+            for (unsigned o = wave * 1024u; o < total; o += 4096u) dma16(lds_act + o, o + lane16, srd, 0);
+        }
+    }
+    if (!dma)
+        for (int i = tid; i < nin4; i += 256)
+            reinterpret_cast<float4 *>(act)[i] = load4(static_cast<const T *>(p.src) + (size_t)i * 4);   // LDS copy is fp32
     for (int i = tid; i < C4; i += 256) reinterpret_cast<float4 *>(act)[nin4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < MM * 9) {
         const int t = tid / MM, m = tid - t * MM;
@@ -89,6 +104,7 @@ __global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMPar
         }
         pixtab[tid] = pix;
     }
+    if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's copies have landed (its weight rows too: needed next)
     __syncthreads();
 
     // 3. this thread's K-slice times every pixel.  k4 = tid + 256 j; a wave's 64 consecutive float4 stay
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMPar
 bool smallm_supported(const SmallMParams &p)
 {
     const size_t act_bytes = (size_t)p.B * p.Hs * p.Ws * p.Cin * 4;
-    return p.M <= 16 && p.Cin % 256 == 0 && 9 * (p.Cin / 4) <= 5 * 256 && act_bytes <= 64 * 1024 && p.Cout % 2 == 0;
+    return p.M <= 16 && p.Cin % 256 == 0 && 9 * (p.Cin / 4) <= 5 * 256 && act_bytes <= (p.dtype == 0 ? 128 : 64) * 1024 && p.Cout % 2 == 0;      // (fp32: staged by LDS-DMA, one workgroup per CU above 64 KB)
 }
 
 hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
@@ -160,7 +176,7 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     size_t smem = 160 * 4 + (act_bytes > red_bytes ? act_bytes : red_bytes);
     static AttrMask attr_mask;
     if (attr_needed_on_this_device(attr_mask)) {
-        const int cap = 160 * 4 + 67 * 1024;
+        const int cap = 160 * 4 + 133 * 1024;       // 128 KB of input + the zero pixel + the prefetch wave's dump slot
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
