@@ -404,6 +404,7 @@ def main():
                                         "note": "lspraster_edge_maps: 88 thick edges per frame -> fp32 [8,1,512,512]; parity unpinned vs cv2 (bit-exact to oracle/raster_oracle.c)"}
         extra["torch_rocm_baseline"] = torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a)
         extra["config2_normal_b8_bf16"] = config2_extra(dev, a)
+        extra["small_unet_native_plan"] = small_unet_extra(dev, a)
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
@@ -473,6 +474,33 @@ def torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a):
 def synth_inputs(b, size):
     from livespeechportraits_amd import synth
     return synth.make_inputs(b, size, seed=99, cand_batch=1)
+
+
+def small_unet_extra(dev, a):
+    """opt.size == 'small' (Feature2FaceGenerator_Unet, models/networks.py:680-769): the native plan behind include/lspunet.h, fp32 at one and
+    eight frames and the fp16 storage plan of opt.fp16, forwards enqueued back to back between two events; no shipped configuration selects the variant."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    sd = synth.make_unet_small_state_dict()
+    r = {"workload": "pix2pix U-Net, 23-channel input, ngf 64, 8 levels, %dx%d, synthetic weights+inputs" % (a.size, a.size)}
+    for dt in ("f32", "f16"):
+        e = SmallUnetEngine(dtype=dt)
+        e.load_state_dict(sd, "model", dev)
+        for B in (1, 8):
+            x = torch.from_numpy(synth.symmetric(B * 23 * a.size * a.size, 0.6, 3).reshape(B, 23, a.size, a.size)).to(dev)
+            for _ in range(3):
+                e.forward(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            n = 40 if B == 1 else 12
+            for _ in range(n):
+                e.forward(x)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            r["%s_batch%d" % (dt, B)] = {"ms_per_forward": round(ms, 4), "frames_per_s": round(B / ms * 1e3, 1)}
+        e.close()
+    r["note"] = "parity: tests/test_unet_small.py (fp32 vs the reference module's frozen output <= 1e-4, measured 1.4e-6; fp16 pinned on the autocast oracle); host-sequenced form of round 4: 0.90 / 4.61 ms"
+    return r
 
 
 def config2_extra(dev, a):
