@@ -278,7 +278,7 @@ class MultiDeviceParallel(nn.Module):
         b = feature_map.shape[0]
         spans = self.spans(b, len(self.device_ids))
         if not isinstance(g, Feature2FaceGenerator):
-            # the 'small' U-Net (its own host-sequenced engine): the module's device does it all.  (The uint8 route of that generator is
+            # the 'small' U-Net (its own native plan, include/lspunet.h): the module's device does it all.  (The uint8 route of that generator is
             # Feature2FaceModel.inference_image's own branch; it never reaches this class.)
             if image:
                 raise RuntimeError("render_image over several devices serves the normal / large generators")
