@@ -326,8 +326,10 @@ class SmallUnetEngine:
             raise ValueError("%s must be a float32 device tensor [B, %d, S, S] (there is no CPU path)" % (what, c))
         return t.contiguous()
 
-    def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: bool = False, timed: Optional[list] = None) -> torch.Tensor:
-        """feat [B, feat_nc, S, S], cand [1 | B, input_nc - feat_nc, S, S] (None: feat carries every channel) -> [B, output_nc, S, S] fp32 or uint8 HWC frames"""
+    def render(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out_u8: bool = False, timed: Optional[list] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feat [B, feat_nc, S, S], cand [1 | B, input_nc - feat_nc, S, S] (None: feat carries every channel) -> [B, output_nc, S, S] fp32 or uint8 HWC frames.
+        `out`: a caller-owned result tensor (the library caches one hipGraph per set of pointers: a render loop that reuses its buffers replays, one that hands in fresh
+        ones re-captures -- eight graphs are kept)"""
         feat_nc = self.input_nc if cand is None else self.input_nc - cand.shape[1]
         feat = self._check(feat, feat_nc, "feature_map")
         B, _, S, _ = feat.shape
@@ -339,8 +341,11 @@ class SmallUnetEngine:
             raise ValueError("frame size must be a multiple of 2**num_downs")
         p = self._plan(S, feat_nc, B)
         with torch.cuda.device(self.device):
-            out = torch.empty((B, S, S, self.output_nc), dtype=torch.uint8, device=self.device) if out_u8 else \
-                torch.empty((B, self.output_nc, S, S), dtype=torch.float32, device=self.device)
+            want = ((B, S, S, self.output_nc), torch.uint8) if out_u8 else ((B, self.output_nc, S, S), torch.float32)
+            if out is None:
+                out = torch.empty(want[0], dtype=want[1], device=self.device)
+            elif tuple(out.shape) != want[0] or out.dtype != want[1] or out.device != self.device or not out.is_contiguous():
+                raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (want[1], want[0], self.device))
             ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
             args = (p["handle"], ptr(feat), ptr(cand), 0 if cand is None else cand.shape[0], None if out_u8 else ptr(out), ptr(out) if out_u8 else None, B,
                     ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
@@ -352,9 +357,9 @@ class SmallUnetEngine:
                 timed[:] = list(ms)
         return out
 
-    def forward(self, x: torch.Tensor, out_u8: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out_u8: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [B, input_nc, S, S] fp32 on the device -> [B, output_nc, S, S] fp32 (or uint8 HWC frames)."""
-        return self.render(x, None, out_u8)
+        return self.render(x, None, out_u8, out=out)
 
     def launches(self, S: int, batch: int, feat_nc: Optional[int] = None) -> List[dict]:
         p = self._plan(S, self.input_nc if feat_nc is None else feat_nc, batch)

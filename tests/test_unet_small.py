@@ -554,6 +554,10 @@ def test_native_plan_two_sources_broadcast_candidates_and_hazards(gpu_device):
     torch.cuda.synchronize()
     assert torch.equal(e.forward(x3), before) and not torch.isnan(before).any()
     assert int(plan["ws"][:16384 * 4].view(torch.int32).ne(0).sum()) == 0      # every last arriver left its counter at zero
+    buf = torch.empty_like(before)
+    assert e.forward(x3, out=buf) is buf and torch.equal(buf, before)           # caller-owned result tensor
+    with pytest.raises(ValueError):
+        e.forward(x3, out=torch.empty(1, 3, S, S, device=gpu_device))
     with pytest.raises(ValueError):
         e.forward(x3.cpu())
     with pytest.raises(ValueError):
