@@ -108,7 +108,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
 /* The same with the A-B switches of tools, tests and measurements: `tune` = "key=value,key=value" (integers; NULL or "" = none; an unknown
  * key is LSPF2F_ERR_INVALID_ARGUMENT).  The library never reads the process environment -- every switch arrives here, once per handle,
  * before the plan is built.  Keys (default): graph (1) | wino (1), wino4 (flag), winoup (1): the Winograd kernels | wino_ureg (1:
- * U fragments of wino3x3<1> in registers; 2: four register sets), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), wino_prio (wave priority by K-loop progress: 1 = the workgroup that is behind leads, 2 = the one ahead, 3 = 1 with the older half of the grid kept at level 1 through its last quarter -- on wino3x3<1>'s register form; 4..6 = the same three schemes on every Winograd loop; 0 = off; default 1), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
+ * U fragments of wino3x3<1> in registers; 2: four register sets), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), in_small_regs (1: the one-launch InstanceNorm pass keeps its rows in registers -- one read of the slab instead of three), in_smallm_fused (1: the tiny-M kernel normalises in its own epilogue under InstanceNorm plans), wino_prio (wave priority by K-loop progress: 1 = the workgroup that is behind leads, 2 = the one ahead, 3 = 1 with the older half of the grid kept at level 1 through its last quarter -- on wino3x3<1>'s register form; 4..6 = the same three schemes on every Winograd loop; 0 = off; default 1), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
  * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, rowup (1), rowlast (1), rowlast_fused (1: rowlast128 shuffles + applies tanh in its epilogue when only fp32 frames are wanted), rowconv (1): kernels of the 16-bit plans |
  * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), fused_splitk16 (0: the 16-bit plans combine 2..8 K-splits in the launch too), out_wt (1: the Winograd kernels write their output through to memory, sc1 stores; 0: plain stores, left dirty in L2), prefetch (1), smallm_dma (1: the tiny-M kernel stages its input tensor by LDS-DMA, every piece in flight at once; 0: through registers), smallm_kb (128: largest input tensor, in KB, the tiny-M kernel takes; 64 = rounds 2-4) |
  * lastconv (0 = by shape; 1..5 force a last-conv kernel), lastconv_direct (0), firstconv (0 = by shape; 1, 2 force a first-conv kernel). */

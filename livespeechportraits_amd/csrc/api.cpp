@@ -50,6 +50,7 @@ struct lspf2f_handle {
     // (the next four: `tune` keys of lspf2f_create_tuned -- tools, tests, A-B runs)
     bool last_direct = false;     // lastconv_direct=1: 16-bit plans run the direct last-conv kernel instead of the GEMM form
     bool prefetch = true;         // prefetch=0: weight-streaming layers do not request the next launch's weights
+    bool in_small_regs = true;    // in_small_regs=0: InstanceNorm plans run in_small in its three-pass form (re-reads the slab for the variance and the normalisation)
     bool smallm_dma = true;       // smallm_dma=0: conv3x3_smallm stages its input tensor through registers (the form of rounds 2-4) instead of LDS-DMA pieces
     bool fuse_splitk = true;      // fused_splitk=0: always combine split-K slabs with a separate launch
     bool counters_clean = false;  // the arrival counters at the head of the workspace were zeroed since it was bound
@@ -165,6 +166,9 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "prefetch") h->prefetch = v != 0;
         else if (k == "smallm_dma") h->smallm_dma = v != 0;
         else if (k == "smallm_kb") P.smallm_kb = v;
+        else if (k == "in_small_regs") h->in_small_regs = v != 0;
+        else if (k == "in_smallm_fused") P.in_smallm_fused = v != 0;
+        else if (k == "in_small_max_hw") P.in_small_max_hw = v;
         else if (k == "lastconv_direct") h->last_direct = v != 0;      // 16-bit plans: the direct last-conv kernel instead of the GEMM form
         else if (k == "lastconv") h->last_route = v;                   // LastConvParams::route (0 = by shape)
         else if (k == "firstconv") h->first_direct = v;                // FirstConvParams::force_direct (0 = by shape)
@@ -297,7 +301,7 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
         if (l.rowup) return "rowup256";
         if (l.bandconv) return "bandconv512";
         if (l.rowconv) return l.c0 == 64 ? "rowconv64" : "rowconv128";
-        if (l.inorm) return l.smallm ? "conv3x3_smallm+in_small" : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
+        if (l.inorm) return l.smallm ? (P.in_smallm_fused ? "conv3x3_smallm(in)" : "conv3x3_smallm+in_small") : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
                           : l.in_route == kInSmall ? "igemm3x3+in_small" : "igemm3x3+in_reduce_stats+in_finalize+in_apply";
         return l.smallm ? "conv3x3_smallm" : (l.splits > 1 ? (l.fused_splitk ? "igemm3x3 (split-K combined in the launch)" : "igemm3x3+splitk_reduce") : "igemm3x3");
     }
@@ -397,6 +401,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
         const size_t slab = (size_t)batch * P.stats_groups_max;
         InstNormParams q{};
+            q.three_pass = h->in_small_regs ? 0 : 1;
         q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu; q.partial = nullptr; q.splits = 1; q.bias = nullptr;
         q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
         if (l.in_route == kInSmall) return launch_in_small(q, s);
@@ -477,9 +482,11 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
     } else if (l.smallm) {
         SmallMParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
-        p.residual = l.inorm ? nullptr : tptr(l.res); p.out = tptr(l.out);
+        const bool in_fused = l.inorm && P.in_smallm_fused;      // InstanceNorm plans: the workgroup holds every pixel of its channels -> normalisation in the epilogue
+        p.residual = (l.inorm && !in_fused) ? nullptr : tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.Hs = l.hs; p.Ws = l.hs; p.Ho = l.ho; p.Wo = l.ho; p.Cin = l.cin; p.Cout = l.cout;
-        p.stride = l.stride; p.up = l.up; p.relu = l.inorm ? 0 : l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
+        p.stride = l.stride; p.up = l.up; p.relu = (l.inorm && !in_fused) ? 0 : l.relu; p.M = batch * l.ho * l.ho; p.dtype = P.dtype;
+        p.in_fused = in_fused ? 1 : 0;
         p.stage_regs = h->smallm_dma ? 0 : 1;
         if (h->prefetch && P.dtype == 0 && !l.inorm) {
             // the next launch, if it is another weight-streaming layer: its weights are requested from inside this one
@@ -491,8 +498,9 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             }
         }
         e = launch_smallm(p, s);
-        if (e == hipSuccess && l.inorm) {          // raw conv output (+ bias) -> statistics + normalisation (+ residual, ReLU) in one launch
+        if (e == hipSuccess && l.inorm && !in_fused) {          // raw conv output (+ bias) -> statistics + normalisation (+ residual, ReLU) in one launch
             InstNormParams q{};
+            q.three_pass = h->in_small_regs ? 0 : 1;
             q.x = tptr(l.out); q.partial = nullptr; q.splits = 1; q.bias = nullptr; q.residual = tptr(l.res); q.relu = l.relu;
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             e = launch_in_small(q, s);
@@ -512,6 +520,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
             const size_t slab = (size_t)batch * P.stats_groups_max;
             InstNormParams q{};
+            q.three_pass = h->in_small_regs ? 0 : 1;
             q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu; q.partial = nullptr; q.splits = 1; q.bias = nullptr;
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             q.psum = st; q.psq = st + slab * l.cout; q.pshift = st + 2 * slab * l.cout;
@@ -551,6 +560,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
             const size_t slab = (size_t)batch * P.stats_groups_max;
             InstNormParams q{};
+            q.three_pass = h->in_small_regs ? 0 : 1;
             q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu; q.partial = nullptr; q.splits = 1; q.bias = nullptr;
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             q.psum = st; q.psq = st + slab * l.cout; q.pshift = st + 2 * slab * l.cout;
@@ -604,6 +614,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         e = launch_fullk(p, l.fullk, s);
         if (e == hipSuccess && l.inorm) {          // InstanceNorm plans: H*W <= 256 here, the one-launch statistics route
             InstNormParams q{};
+            q.three_pass = h->in_small_regs ? 0 : 1;
             q.x = tptr(l.out); q.partial = nullptr; q.splits = 1; q.bias = nullptr; q.residual = tptr(l.res); q.relu = l.relu;
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             e = launch_in_small(q, s);
@@ -629,6 +640,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
             float *st = reinterpret_cast<float *>(h->ws + P.stats_offset);
             const size_t slab = (size_t)batch * P.stats_groups_max;            // [B][groups][C] with C <= the plan's widest layer
             InstNormParams q{};
+            q.three_pass = h->in_small_regs ? 0 : 1;
             q.x = tptr(l.out); q.residual = tptr(l.res); q.relu = l.relu;
             q.B = batch; q.hw = l.ho * l.ho; q.C = l.cout;
             q.psum = st; q.psq = st + slab * l.cout; q.pshift = st + 2 * slab * l.cout;

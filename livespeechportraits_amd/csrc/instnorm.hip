@@ -141,15 +141,18 @@ __global__ __launch_bounds__(256) void in_finalize(const InstNormParams p)
     }
 }
 
-__device__ __forceinline__ float4 normalise(float4 v, float4 m, float4 r, const float *res, int relu)
+__device__ __forceinline__ float4 normalise_v(float4 v, float4 m, float4 r, bool has_res, float4 t, int relu)
 {
     v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
-    if (res) {
-        const float4 t = *reinterpret_cast<const float4 *>(res);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
+    if (has_res) { v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
+}
+__device__ __forceinline__ float4 normalise(float4 v, float4 m, float4 r, const float *res, int relu)
+{
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) t = *reinterpret_cast<const float4 *>(res);
+    return normalise_v(v, m, r, res != nullptr, t, relu);
 }
 
 // streaming pass: one channel quad per thread, in place
@@ -167,7 +170,11 @@ __global__ __launch_bounds__(256) void in_apply(const InstNormParams p)
     *px = normalise(*px, m, r, p.residual ? p.residual + i * 4 : nullptr, p.relu);
 }
 
-// grid (C / 32, B), 256 threads = 32 row lanes x 8 channel quads: fold, statistics and normalisation of one 32-channel slab
+// grid (C / 32, B), 256 threads = 32 row lanes x 8 channel quads: fold, statistics and normalisation of one 32-channel slab.
+// R = rows per thread the instance holds in REGISTERS (hw <= 32 R; R = 0: the three-pass form of rounds 2-4, which re-reads the slab from memory for the variance and again
+// for the normalisation).  With the rows resident the two-pass variance and the normalisation cost no further memory round trip: one read (+ the residual, requested together
+// with it where the registers allow), one write -- same operations in the same order, so the same bits (round 5; `in_small_regs`).
+template <int R>
 __global__ __launch_bounds__(256) void in_small(const InstNormParams p)
 {
     __shared__ float4 red[1][4][8];
@@ -188,39 +195,86 @@ __global__ __launch_bounds__(256) void in_small(const InstNormParams p)
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const float4 a = red[0][w][q]; out[0] += a.x; out[1] += a.y; out[2] += a.z; out[3] += a.w; }
     };
-    // pass 1: fold the split-K partials (+ bias) into x, mean
+    constexpr int RR = R > 0 ? R : 1;
+    constexpr bool PRE_RES = R > 0 && R <= 8;                  // the residual rows are requested with the tensor's own (registers allow it up to 8 rows per thread)
+    float4 row[RR], resv[PRE_RES ? RR : 1];
+    // pass 1: fold the split-K partials (+ bias), mean
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live)
-        for (int r = rl; r < p.hw; r += 32) {
-            const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
-            float4 v = fold_row(p, e);
-            if (p.splits > 1) {
-                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-                *reinterpret_cast<float4 *>(p.x + e) = v;      // re-read below by the SAME thread
+    if (live) {
+        if constexpr (R > 0) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = rl + 32 * i;
+                row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < p.hw) {
+                    const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
+                    row[i] = fold_row(p, e);
+                    if constexpr (PRE_RES) resv[i] = p.residual ? *reinterpret_cast<const float4 *>(p.residual + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                if (rl + 32 * i < p.hw) {
+                    float4 &v = row[i];
+                    if (p.splits > 1) { v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w; }
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                }
+        } else {
+            for (int r = rl; r < p.hw; r += 32) {
+                const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
+                float4 v = fold_row(p, e);
+                if (p.splits > 1) {
+                    v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                    *reinterpret_cast<float4 *>(p.x + e) = v;      // re-read below by the SAME thread
+                }
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            }
         }
+    }
     double sum[4];
     block_sum(s1, sum);
     const float4 m4 = make_float4((float)(sum[0] / p.hw), (float)(sum[1] / p.hw), (float)(sum[2] / p.hw), (float)(sum[3] / p.hw));
     // pass 2: sum of squared deviations from that mean (two-pass variance: no cancellation)
     float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live)
-        for (int r = rl; r < p.hw; r += 32) {
-            const float4 v = *reinterpret_cast<const float4 *>(p.x + ((size_t)b * p.hw + r) * p.C + c0);
-            const float4 d = make_float4(v.x - m4.x, v.y - m4.y, v.z - m4.z, v.w - m4.w);
-            s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+    if (live) {
+        if constexpr (R > 0) {
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                if (rl + 32 * i < p.hw) {
+                    const float4 v = row[i];
+                    const float4 d = make_float4(v.x - m4.x, v.y - m4.y, v.z - m4.z, v.w - m4.w);
+                    s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+                }
+        } else {
+            for (int r = rl; r < p.hw; r += 32) {
+                const float4 v = *reinterpret_cast<const float4 *>(p.x + ((size_t)b * p.hw + r) * p.C + c0);
+                const float4 d = make_float4(v.x - m4.x, v.y - m4.y, v.z - m4.z, v.w - m4.w);
+                s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+            }
         }
+    }
     double ssq[4];
     block_sum(s2, ssq);
     if (!live) return;
     const float4 r4 = make_float4((float)(1.0 / sqrt(ssq[0] / p.hw + kInEps)), (float)(1.0 / sqrt(ssq[1] / p.hw + kInEps)),
                                   (float)(1.0 / sqrt(ssq[2] / p.hw + kInEps)), (float)(1.0 / sqrt(ssq[3] / p.hw + kInEps)));
     // pass 3: normalise (+ residual) (+ ReLU) in place
-    for (int r = rl; r < p.hw; r += 32) {
-        const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
-        float4 *px = reinterpret_cast<float4 *>(p.x + e);
-        *px = normalise(*px, m4, r4, p.residual ? p.residual + e : nullptr, p.relu);
+    if constexpr (R > 0) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = rl + 32 * i;
+            if (r >= p.hw) continue;
+            const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.residual) { if constexpr (PRE_RES) t = resv[i]; else t = *reinterpret_cast<const float4 *>(p.residual + e); }
+            *reinterpret_cast<float4 *>(p.x + e) = normalise_v(row[i], m4, r4, p.residual != nullptr, t, p.relu);      // (the same helper as the three-pass form: the same roundings)
+        }
+    } else {
+        for (int r = rl; r < p.hw; r += 32) {
+            const size_t e = ((size_t)b * p.hw + r) * p.C + c0;
+            float4 *px = reinterpret_cast<float4 *>(p.x + e);
+            *px = normalise(*px, m4, r4, p.residual ? p.residual + e : nullptr, p.relu);
+        }
     }
 }
 
@@ -252,7 +306,13 @@ hipError_t launch_in_apply(const InstNormParams &p, hipStream_t s)
 hipError_t launch_in_small(const InstNormParams &p, hipStream_t s)
 {
     if (!in_shape_ok(p)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(in_small, dim3((unsigned)((p.C + 31) / 32), (unsigned)p.B), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)((p.C + 31) / 32), (unsigned)p.B);
+    // rows per thread held in registers (32 row lanes): the smallest instance that covers hw; beyond 1024 rows (never planned) or with in_small_regs = 0: the three-pass form
+    if (p.three_pass || p.hw > 1024) hipLaunchKernelGGL(in_small<0>, grid, dim3(256), 0, s, p);
+    else if (p.hw <= 32) hipLaunchKernelGGL(in_small<1>, grid, dim3(256), 0, s, p);
+    else if (p.hw <= 64) hipLaunchKernelGGL(in_small<2>, grid, dim3(256), 0, s, p);
+    else if (p.hw <= 256) hipLaunchKernelGGL(in_small<8>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(in_small<32>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

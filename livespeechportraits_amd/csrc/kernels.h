@@ -182,6 +182,7 @@ struct SmallMParams {
     const void *pf;
     unsigned pf_bytes;
     unsigned pf_dump;            // filled by launch_smallm: LDS byte offset of the dump slot
+    int in_fused;                // InstanceNorm plans: InstanceNorm2d(affine=False, eps=1e-5) over each frame's pixels in the epilogue, then residual / ReLU (instead of an in_small launch)
     int stage_regs;              // 1: stage the input tensor through registers (the form of rounds 2-4: pairs of loads, each pair waited for before the next -- four dependent round trips
                                  // for a 4x4x512 tensor); 0 (default): LDS-DMA pieces, all in flight at once (fp32 storage; 16-bit inputs are widened on the way and keep the registers)
 };
@@ -361,6 +362,7 @@ struct InstNormParams {
     float *mean, *rstd;        // [B][C]
     int B, hw, C, groups;
     int rows_per_group;        // rows behind one group's sums (the last group of a frame may hold fewer: hw - g * rows_per_group)
+    int three_pass;            // in_small: 1 = the three-pass form of rounds 2-4 (tune key in_small_regs = 0; A-B runs), 0 = rows resident in registers
 };
 hipError_t launch_in_reduce_stats(const InstNormParams &p, hipStream_t s);   // fold partials, write raw x, 64-row partial sums
 hipError_t launch_in_finalize(const InstNormParams &p, hipStream_t s);       // partial sums -> mean, rstd (double)

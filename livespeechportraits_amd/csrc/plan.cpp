@@ -579,7 +579,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                     // (57.9 -> 33 us per layer at 32 x 32, batch 1)
                     route = kInWino;
                     groups_max = std::max(groups_max, hw / 128);
-                } else if (hw <= 1024) {
+                } else if (hw <= p.in_small_max_hw) {
                     route = kInSmall;
                 } else {
                     route = kInReduce;

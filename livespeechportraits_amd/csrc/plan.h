@@ -105,6 +105,9 @@ struct Plan {
     bool use_wino = true;      // fp32 plans: stride-1 convs at >= 32x32 on the Winograd kernel (tune key `wino=0`: the implicit GEMM, A-B runs)
     bool use_wino4 = false;    // fp32 plans: ... and of those the layers wino4_choice() takes on the F(4x4,3x3) kernel (LSPF2F_FLAG_WINO4; measured slower at batch 1 and
                                // equal at batch 8, DESIGN.md 4.11, so off by default); decides whether the blob carries the 6x6 transformed weights
+    int in_small_max_hw = 1024;  // `in_small_max_hw`: InstanceNorm plans take the one-launch route (in_small: one workgroup per (frame, 32 channels)) up to this many pixels per frame; above it
+                                 // in_reduce_stats + in_finalize + in_apply spread the frame over the chip
+    bool in_smallm_fused = true; // `in_smallm_fused`: InstanceNorm plans normalise in conv3x3_smallm's epilogue (a workgroup holds every pixel of its channels) instead of an in_small launch behind it
     bool in_wino_stats = true;   // `in_wino_stats`: InstanceNorm plans take a wino3x3 layer's statistics from its epilogue instead of a pass over its output
     int smallm_kb = 64;          // `smallm_kb`: largest input tensor (KB, fp32 in LDS) the tiny-M kernel takes.  64 until round 5; with LDS-DMA staging a 128-KB tensor (one workgroup per CU) is
                                  // one round of copies: L6.down (512 -> 512 at stride 2, 8x8 -> 4x4) leaves the 36-way split-K implicit GEMM + reduce launch at one frame

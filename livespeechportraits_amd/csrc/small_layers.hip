@@ -20,7 +20,10 @@ namespace lspf2f {
 // 2b, 2b+1 in both), in the memory-side cache otherwise.  The wave takes part in the barriers and leaves once its requests have landed.
 // MM = output pixels the instance is built for (batch folded in): 16, or 4 for the 2x2 level at batch 1, whose threads then do a quarter of the
 // multiply-adds and LDS reads of the 16-pixel form.
-template <typename T, int NC, bool PF, int MM>
+// INF (InstanceNorm plans, fp32): the workgroup holds EVERY pixel of its channels, i.e. the whole population of InstanceNorm2d(affine=False, eps=1e-5) per (frame, channel) -- the
+// normalisation (+ residual, ReLU; models/networks.py:587-590, 650-675) runs in the epilogue instead of a launch of its own (in_small): two-pass variance in double over the <= 16
+// values of a frame, in pixel order.  Its own instances: the BatchNorm plans' kernel carries none of it.
+template <typename T, int NC, bool PF, int MM, bool INF = false>
 __global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMParams p)
 {
     constexpr int NJ = 5;                                  // K/4 <= 5*256 float4 per weight row (Cin <= 512... 568)
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMPar
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc) red[(m * NC + nc) * RS + tid] = acc[m][nc];
     __syncthreads();
+    float xraw = 0.f;
     if (tid < MM * NC * 8) {
         const int o = tid >> 3, part = tid & 7;
         float sum = 0.f;
@@ -153,8 +157,28 @@ __global__ __launch_bounds__(PF ? 320 : 256) void conv3x3_smallm(const SmallMPar
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
         sum += __shfl_xor(sum, 4);
-        if (part == 0 && ewrite) {
+        if constexpr (INF) {
+            // raw conv output (+ bias) of every (pixel, channel) of this workgroup -> LDS (the gather table's words are free since the barrier behind step 3)
+            xraw = sum * e_sc + e_sh;
+            if (part == 0) sm[o] = xraw;                      // xs[MM * NC]
+        } else if (part == 0 && ewrite) {
             float v = sum * e_sc + e_sh + e_res;             // scale 1 / shift 0 / residual 0 where the layer has none: the same roundings as before
+            if (p.relu) v = fmaxf(v, 0.f);
+            st1(static_cast<T *>(p.out) + (size_t)em * p.Cout + en, v);
+        }
+    }
+    if constexpr (INF) {
+        __syncthreads();
+        if (ewrite) {                                        // (tid < MM * NC * 8, part 0, a live output)
+            const float *xs = sm;
+            const int hw = p.Ho * p.Wo, f0 = (em / hw) * hw, nc = eo % NC;
+            double s1 = 0.0;
+            for (int r = 0; r < hw; ++r) s1 += (double)xs[(f0 + r) * NC + nc];
+            const float m = (float)(s1 / hw);
+            double s2 = 0.0;
+            for (int r = 0; r < hw; ++r) { const float d = xs[(f0 + r) * NC + nc] - m; s2 += (double)(d * d); }
+            const float rs = (float)(1.0 / sqrt(s2 / hw + 1e-5));
+            float v = (xraw - m) * rs + e_res;
             if (p.relu) v = fmaxf(v, 0.f);
             st1(static_cast<T *>(p.out) + (size_t)em * p.Cout + en, v);
         }
@@ -188,6 +212,20 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     }
     const unsigned grid = (unsigned)((p.Cout + NC - 1) / NC);
     const bool four = p.M <= 4;                               // fp32 plans: the 2x2 level at batch 1
+    if (p.in_fused) {                                         // InstanceNorm plans: normalisation in the epilogue (fp32; whole frames: M = B * Ho * Wo)
+        if (p.dtype != 0 || p.M != p.B * p.Ho * p.Wo) return hipErrorInvalidValue;
+        static AttrMask attr_in;
+        if (attr_needed_on_this_device(attr_in)) {
+            const int cap = 160 * 4 + 133 * 1024;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_smallm<float, NC, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e != hipSuccess) return e;
+            attr_done_on_this_device(attr_in);
+        }
+        if (four) hipLaunchKernelGGL((conv3x3_smallm<float, NC, false, 4, true>), dim3(grid), dim3(256), smem, s, p);
+        else hipLaunchKernelGGL((conv3x3_smallm<float, NC, false, 16, true>), dim3(grid), dim3(256), smem, s, p);
+        return hipGetLastError();
+    }
     if (p.dtype == 2) hipLaunchKernelGGL((conv3x3_smallm<f16_t, NC, false, 16>), dim3(grid), dim3(256), smem, s, p);
     else if (p.dtype == 1) hipLaunchKernelGGL((conv3x3_smallm<bf16_t, NC, false, 16>), dim3(grid), dim3(256), smem, s, p);
     else if (p.pf != nullptr && p.pf_bytes >= 1024u * grid) {

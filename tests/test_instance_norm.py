@@ -148,3 +148,30 @@ def test_batch8_and_the_parameter_container(gpu_device):
         err = np.abs(out[i:i + 1] - want).max()
         print("frame %d: %.2e" % (i, err))
         assert err <= TOL, i            # other inputs than the fixture's: the contract itself (the `normal` nets leave room for it)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["in_large_s128_b2", "in_large_512"])
+def test_round5_arms_of_the_one_launch_route(case, gpu_device):
+    """in_small with its rows resident in registers (one read of the slab instead of three) performs the same operations in the same order as the three-pass form: the same
+    bits.  conv3x3_smallm normalising in its own epilogue (a workgroup holds every pixel of its channels) sums a frame's <= 16 values in another order than in_small's
+    shuffle tree: held to the golden like the default, and to a hair of the unfused arm."""
+    from livespeechportraits_amd.engine import Engine
+    meta, ref, topo, sd, feat, cand = problem(case)
+    f, c = torch.from_numpy(feat).to(gpu_device), torch.from_numpy(cand).to(gpu_device)
+    outs = {}
+    for name, tune in (("default", None), ("three_pass", {"in_small_regs": 0}), ("unfused", {"in_smallm_fused": 0}), ("unfused_three_pass", {"in_smallm_fused": 0, "in_small_regs": 0}),
+                       ("reduce_above_256", {"in_small_max_hw": 256})):
+        e = Engine(meta["variant"], 13, 1, 3, meta["ngf"], meta["num_downs"], meta["size"], max_batch=meta["batch"], norm="instance", tune=tune)
+        e.load_state_dict(sd)
+        e.bind(e.pack(), gpu_device)
+        outs[name] = e.forward(f, c).clone()
+        kern = sorted({l["kernel"] for l in e.layers(meta["batch"]) if l["kernel"].startswith("conv3x3_smallm")})
+        assert kern and all(("(in)" in k) == (name in ("default", "three_pass", "reduce_above_256")) for k in kern if k != "conv3x3_smallm"), (name, kern)
+        e.close()
+    assert torch.equal(outs["default"], outs["three_pass"]) and torch.equal(outs["unfused"], outs["unfused_three_pass"])
+    self_d = meta["reference_self_distance"]
+    for name, o in outs.items():
+        err = np.abs(o.cpu().numpy() - ref)
+        print("%s %-20s max-abs vs the reference module %.2e (mean %.2e); vs the default arm %.2e" % (case, name, err.max(), err.mean(), (o - outs["default"]).abs().max().item()))
+        assert err.max() <= 1.5 * self_d["onednn_off_max"] and err.mean() <= 1.5 * self_d["onednn_off_mean"]

@@ -1,6 +1,6 @@
 """A-B of any tune key of lspf2f_create_tuned on a whole forward (GPU): two engines on the same weights and inputs, outputs compared, time per forward of both arms
 interleaved (A-B-A-B, graph replays between two events).
-  python tools/ab_tune.py key=value[,key=value] [variant] [batch] [dtype] [reps]
+  python tools/ab_tune.py key=value[,key=value] [variant] [batch] [dtype] [reps] [norm: batch | instance]
 e.g.  python tools/ab_tune.py out_wt=1 large 1 f32"""
 import os
 import sys
@@ -18,14 +18,15 @@ def main():
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"
     reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    norm = sys.argv[6] if len(sys.argv) > 6 else "batch"
     dev = torch.device("cuda:0")
-    topo = build_topology(variant)
+    topo = build_topology(variant, norm=norm)
     sd = synth.make_state_dict(topo, 1234)
     feat, cand = synth.make_inputs(batch, 512, 99, 1)
     f, c = torch.from_numpy(feat).to(dev), torch.from_numpy(cand).to(dev)
     arms = {}
     for name, t in (("default", None), (sys.argv[1], tune)):
-        e = Engine(variant, dtype=dtype, max_batch=batch, tune=t)
+        e = Engine(variant, dtype=dtype, max_batch=batch, tune=t, norm=norm)
         e.load_state_dict(sd)                                       # returns the ignored num_batches_tracked keys
         e.bind(e.pack(), dev)
         arms[name] = (e, e.forward(f, c).clone())
