@@ -405,6 +405,7 @@ def main():
         extra["torch_rocm_baseline"] = torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a)
         extra["config2_normal_b8_bf16"] = config2_extra(dev, a)
         extra["small_unet_native_plan"] = small_unet_extra(dev, a)
+        extra["concurrent_batch1_forwards"] = concurrent_extra(dev, eng, a)
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
@@ -474,6 +475,40 @@ def torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a):
 def synth_inputs(b, size):
     from livespeechportraits_amd import synth
     return synth.make_inputs(b, size, seed=99, cand_batch=1)
+
+
+def concurrent_extra(dev, eng, a):
+    """NOT the headline: N independent batch-1 forwards in flight at once (N handles on ONE packed blob, one stream each) against the single stream `value` is
+    measured on.  A batch-1 forward is a chain of dependent launches, each a single round of workgroups, so prologues, tails and kernel boundaries overlap nothing;
+    independent frames on other streams fill those holes.  What it says about the kernels: the single-stream loss is dependency latency, not throughput.  A caller
+    with frames in hand batches them instead (the batch-8 rows are faster still); this is the number for frames that arrive one by one."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.engine import Engine
+    blob = eng._blob_dev
+    engines, streams, ins, outs = [eng], [torch.cuda.Stream(dev)], [], []
+    for i in range(1, 4):
+        e = Engine(a.variant, size=a.size, max_batch=eng.max_batch, dtype=a.dtype)
+        e.bind(blob, dev)
+        engines.append(e); streams.append(torch.cuda.Stream(dev))
+    for i in range(4):
+        f, c = synth.make_inputs(1, a.size, 99 + i, 1)
+        ins.append((torch.from_numpy(f).to(dev), torch.from_numpy(c).to(dev)))
+        outs.append(torch.empty((1, 3, a.size, a.size), device=dev))
+    torch.cuda.synchronize()
+    r = {"note": "N handles on one packed blob, one stream each, batch 1 per forward; outputs bit-identical to the single-stream run; `value` above is the 1-stream number"}
+    for n in (1, 2, 4):
+        def run(reps):
+            for _ in range(reps):
+                for i in range(n):
+                    with torch.cuda.stream(streams[i]):
+                        engines[i].forward(ins[i][0], ins[i][1], outs[i])
+        run(5); torch.cuda.synchronize()
+        reps = max(20, a.steps)
+        t0 = time.perf_counter(); run(reps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        r["streams_%d" % n] = {"frames_per_s": round(n * reps / dt, 1), "ms_per_frame": round(1e3 * dt / (n * reps), 4)}
+    for e in engines[1:]:
+        e.close()
+    return r
 
 
 def small_unet_extra(dev, a):
