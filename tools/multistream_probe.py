@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of N CONCURRENT batch-1 forwards (N engines on one packed blob, one stream each) against one stream (GPU).  A batch-1 forward is a chain of 79 dependent launches,
 every one a single round of workgroups: its prologues, tails and kernel boundaries overlap nothing.  Independent frames on separate streams can fill those holes.
-  python tools/multistream_probe.py [variant] [dtype] [max_streams]"""
+  python tools/multistream_probe.py [variant] [dtype] [max_streams] [batch]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,20 +12,21 @@ from livespeechportraits_amd.topology import build_topology
 variant = sys.argv[1] if len(sys.argv) > 1 else "large"
 dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
 nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device("cuda:0")
 topo = build_topology(variant)
 sd = synth.make_state_dict(topo, 1234)
-first = Engine(variant, dtype=dtype, max_batch=1)
+first = Engine(variant, dtype=dtype, max_batch=B)
 first.load_state_dict(sd)
 blob = first.pack().to(dev)
 engines, streams, ins, outs = [], [], [], []
 for i in range(nmax):
-    e = first if i == 0 else Engine(variant, dtype=dtype, max_batch=1)
+    e = first if i == 0 else Engine(variant, dtype=dtype, max_batch=B)
     e.bind(blob, dev)                                               # one copy of the weights for all of them
-    f, c = synth.make_inputs(1, 512, 99 + i, 1)
+    f, c = synth.make_inputs(B, 512, 99 + i, 1)
     engines.append(e); streams.append(torch.cuda.Stream(dev))
     ins.append((torch.from_numpy(f).to(dev), torch.from_numpy(c).to(dev)))
-    outs.append(torch.empty((1, 3, 512, 512), device=dev))
+    outs.append(torch.empty((B, 3, 512, 512), device=dev))
 torch.cuda.synchronize()
 ref = [engines[i].forward(*ins[i]).clone() for i in range(nmax)]
 torch.cuda.synchronize()
@@ -36,7 +37,7 @@ for n in range(1, nmax + 1):
                 with torch.cuda.stream(streams[i]):
                     engines[i].forward(ins[i][0], ins[i][1], outs[i])
     run(10); torch.cuda.synchronize()
-    reps = 200
+    reps = 200 if B == 1 else 40
     t0 = time.perf_counter(); run(reps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     same = all(torch.equal(outs[i], ref[i]) for i in range(n))
-    print("%s %s batch 1, %d concurrent stream(s): %.1f frames/s (%.4f ms per frame); outputs bit-identical to the single-stream run: %s" % (variant, dtype, n, n * reps / dt, 1e3 * dt / (n * reps), same), flush=True)
+    print("%s %s batch %d, %d concurrent stream(s): %.1f frames/s (%.4f ms per frame); outputs bit-identical to the single-stream run: %s" % (variant, dtype, B, n, B * n * reps / dt, 1e3 * dt / (B * n * reps), same), flush=True)
