@@ -66,7 +66,8 @@ typedef struct lspunet_handle lspunet_handle;
  * `tune` = "key=value,..." (integers; NULL / "" = none; an unknown key is an error) -- the A-B switches of tests and measurements:
  *   graph (1) | fused_splitk (0; 1: 2..8 K splits combined inside the launch by the last-arriving workgroup instead of a reduce launch) | last_tile (0 = by rule; bm * 1000 + bn forces the tile of the
  *   last GEMM, e.g. 128032; -1 = the general tiling rule) | last_direct (1: the outermost transposed conv + tanh + tensor2im on the direct sub-pixel kernel of the other variants'
- *   last layer; 0: a 3x3 GEMM with N = 4 x output_nc + a pixel-shuffle pass) | tiny (1: the <= 16-position levels on the weight-streaming kernel unet_tiny) | fused_prepare (1: the
+ *   last layer; 0: a 3x3 GEMM with N = 4 x output_nc + a pixel-shuffle pass) | tiny (1: the <= 16-position levels on the weight-streaming kernel unet_tiny) | dense0 (0: block 0's space-to-depth quarters are padded
+ *   to a K-tile and only its 16 live (tap, quarter) pairs walked; 1: the dense 3x3 rows on 4 x 23 -> 96 channels, the host-sequenced form's block 0) | fused_prepare (1: the
  *   down-convs write leaky_relu / relu copies themselves; 0: a separate elementwise launch per level, the round-3 form) | input_pass (1: the two-source input kernel;
  *   0: lspf2f_unet_prepare on a concatenated tensor, feat_nc == input_nc only).  With fp16 storage only `graph` has an effect (the other arms are fp32 launches). */
 int lspunet_create(const lspunet_config *cfg, const char *tune, lspunet_handle **out);

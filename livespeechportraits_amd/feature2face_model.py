@@ -41,9 +41,11 @@ class Feature2FaceModel(BaseModel):
                 return net.render(feature_map, cand_image)
             return self._g().render(feature_map, cand_image)
 
-    def inference_image(self, feature_map, cand_image):
+    def inference_image(self, feature_map, cand_image, replica: int = 0):
         """inference() followed by util.tensor2im, fused on the device: uint8 [B,H,W,3] frames
-        (``util.tensor2im(pred_fake[0])`` of demo.py:268 is ``inference_image(...)[0].cpu().numpy()``)."""
+        (``util.tensor2im(pred_fake[0])`` of demo.py:268 is ``inference_image(...)[0].cpu().numpy()``).
+        ``replica`` > 0 renders through a further handle on the same device and packed weights (single-device normal / large generators): calls with
+        different replicas on different streams overlap (render_loop.render_frames(streams=2))."""
         with torch.no_grad():
             g = self._g().netG
             if feature_map.device.type != "cuda":
@@ -54,7 +56,13 @@ class Feature2FaceModel(BaseModel):
             if isinstance(net, networks.MultiDeviceParallel):    # several gpu_ids: sliced over all of them like inference(), uint8 fused on every device
                 return net.render_image(feature_map, cand_image)
             e = g._engine_for(feature_map.shape[-1], feature_map.shape[0], feature_map.device)
+            if replica:
+                e = g._twin_engine(replica, e)
             return e.forward_image(feature_map.float(), cand_image.float() if cand_image is not None else None)
+
+    def supports_replicas(self) -> bool:
+        """whether inference_image(replica=k) means another handle (else the argument is ignored: the small U-Net, several gpu_ids)"""
+        return not isinstance(self._g().netG, Feature2FaceGenerator_Unet) and not isinstance(self.Feature2Face_G, networks.MultiDeviceParallel)
 
     # the reference's abstract training hooks (base_model.py:70-86); kept so callers that probe
     # for them get a clear message instead of an AttributeError

@@ -96,6 +96,7 @@ class Feature2FaceGenerator(nn.Module):
         self._dirty = True
         self._adopted = False                          # the bound blob arrived packed (adopt_packed): this module's own parameters are NOT its source
         self._blob_version = 0                         # bumped whenever the packed blob is rebuilt (replicas on other devices copy it again)
+        self._twins = {}                               # replica index -> (blob version, primary engine, Engine): further handles on the SAME device and blob (render_loop streams)
         self.register_load_state_dict_post_hook(lambda *_: self.mark_dirty())
 
     # -- weight ingress ------------------------------------------------------------
@@ -138,6 +139,21 @@ class Feature2FaceGenerator(nn.Module):
             self._dirty = False
             self._blob_version += 1
         return e
+
+    def _twin_engine(self, index: int, primary: Engine) -> Engine:
+        """A further handle on the primary's device AND packed blob (no second copy of the weights; its own workspace and hipGraphs): what lets two forwards be in flight at
+        once on two streams -- a batch's kernel tails, prologues and boundaries are filled by the other's work (render_loop.render_frames(streams=2); profiles/r05_concurrent_streams.txt)."""
+        if index == 0:
+            return primary
+        t = self._twins.get(index)
+        if t is None or t[0] != self._blob_version or t[1] is not primary:
+            if t is not None:
+                t[2].close()
+            e = Engine(self.variant, self.input_nc, self.feat_nc, self.output_nc, self.ngf, self.num_downs, primary.size, primary.max_batch, norm=self.norm, dtype=self.dtype)
+            e.bind(primary._blob_dev)
+            e.auto_cand_cache = primary.auto_cand_cache
+            self._twins[index] = t = (self._blob_version, primary, e)
+        return t[2]
 
     def adopt_packed(self, engine: Engine) -> None:
         """Use an engine whose weights were bound elsewhere (multi-GPU: the blob arrived by

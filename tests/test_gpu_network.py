@@ -436,6 +436,18 @@ def test_batched_render_loop_on_gpu(gpu_device, tmp_path):
         one = model.inference_image(torch.from_numpy(feats[i:i + 1]).to(gpu_device), c)[0].cpu().numpy()
         d = np.abs(one.astype(np.int16) - frames[i].astype(np.int16))
         assert d.max() <= 1            # batch-1 and batch-3 tilings sum in a different order: <= 1 grey level
+    # several batches in flight (one HIP stream and one handle on the same packed weights per lane): the same frames, bit for bit, in order, with a ragged last batch;
+    # a second pass replays the lanes' graphs; on_frame sees every index once
+    assert model.supports_replicas()
+    for lanes in (2, 3):
+        again = render_frames(model, (torch.from_numpy(f) for f in feats), c, batch=3, streams=lanes)
+        assert len(again) == 7 and all(np.array_equal(a, b) for a, b in zip(again, frames)), lanes
+    seen = []
+    render_frames(model, (torch.from_numpy(f).to(gpu_device) for f in feats), c, batch=2, streams=2, on_frame=lambda i, a: seen.append((i, a.copy())))
+    assert [i for i, _ in seen] == list(range(7))
+    assert all(np.abs(a.astype(np.int16) - frames[i].astype(np.int16)).max() <= 1 for i, a in seen)       # (batch 2: another tiling)
+    g = model._g().netG
+    assert len(g._twins) == 2 and all(t[2]._blob_dev.data_ptr() == g._engine._blob_dev.data_ptr() for t in g._twins.values())      # one copy of the weights
 
 
 def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
