@@ -32,51 +32,68 @@ def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch
     ``img_candidates`` ([1,12,H,W], already on the device).  Returns (or streams to ``on_frame``) uint8 HWC
     frames, i.e. exactly what ``util.tensor2im(pred_fake[0])`` produced per frame in the reference loop.
     ``model`` is a Feature2FaceModel (anything with ``inference_image``).
+
+    The loop owns ``streams + 1`` sets of buffers (a pinned staging tensor for the maps, their device tensor, a pinned tensor for the frames) and cycles through them: the maps of
+    batch i + 1 are gathered into pinned memory and uploaded while batch i renders, and nothing is allocated per batch (a pageable ``torch.stack(...).to(device)`` and a fresh pinned
+    result tensor per batch kept this loop at 160-290 frames/s on a generator that renders 1019: round 5).
     ``streams`` > 1: that many batches in flight at once, each on its own HIP stream and its own handle on the same packed weights -- one batch's kernel tails and boundaries are
-    filled by the next one's work (+5 % at 8 fp32 frames, +16 % on the 16-bit plans; same frames, bit for bit).  Ignored where the model cannot give a second handle."""
+    filled by the next one's work (generator alone: +5 % at 8 fp32 frames, +16 % on the 16-bit plans; same frames, bit for bit).  Ignored where the model cannot give a second handle."""
     device = device or cand_image.device
     frames: List[np.ndarray] = []
-    pending: List = []                  # (first index, pinned host tensor, event), oldest first
+    pending: List = []                  # (first index, frames in the batch, buffer set, event), oldest first
     idx = 0
-    nstream = max(1, int(streams)) if device.type == "cuda" and getattr(model, "supports_replicas", lambda: False)() else 1
+    on_gpu = device.type == "cuda"
+    nstream = max(1, int(streams)) if on_gpu and getattr(model, "supports_replicas", lambda: False)() else 1
     lanes = [torch.cuda.Stream(device) for _ in range(nstream)] if nstream > 1 else [None]
-    if nstream > 1:
-        cur = torch.cuda.current_stream(device)
-        for s in lanes:
-            s.wait_stream(cur)                                 # cand_image (and whatever produced the maps so far) was enqueued there
+    sets: List[dict] = []               # nstream + 1 buffer sets, made at the first batch (shapes come from the data)
+
+    def emit(i0, host, n):
+        for k in range(n):
+            arr = host[k].numpy().copy()
+            if on_frame is not None:
+                on_frame(i0 + k, arr)
+            else:
+                frames.append(arr)
 
     def flush(keep: int):
         while len(pending) > keep:
-            i0, host, ev = pending.pop(0)
+            i0, n, bs, ev = pending.pop(0)
             ev.synchronize()
-            for k in range(host.shape[0]):
-                arr = host[k].numpy().copy()
-                if on_frame is not None:
-                    on_frame(i0 + k, arr)
-                else:
-                    frames.append(arr)
+            emit(i0, bs["host"], n)
 
     for n, chunk in enumerate(batched(feature_maps, batch)):
+        chunk = [m if m.dim() == 3 else m.unsqueeze(0) for m in chunk]
+        b = len(chunk)
+        if not on_gpu:                                          # (stand-in models on the host: tests)
+            emit(idx, model.inference_image(torch.stack(chunk).to(device, torch.float32), cand_image), b)
+            idx += b
+            continue
+        flush(nstream)                                          # the batch that used this buffer set nstream + 1 batches ago is out of it
+        if not sets:
+            shape = (batch,) + tuple(chunk[0].shape)
+            for _ in range(nstream + 1):
+                sets.append({"stage": torch.empty(shape, dtype=torch.float32, pin_memory=True), "dev": torch.empty(shape, dtype=torch.float32, device=device), "host": None})
+        bs = sets[n % (nstream + 1)]
         lane = lanes[n % nstream]
-        ctx = torch.cuda.stream(lane) if lane is not None else _null()
-        with ctx:
-            maps = torch.stack([m if m.dim() == 3 else m.unsqueeze(0) for m in chunk]).to(device, torch.float32, non_blocking=True)
-            if lane is not None:
-                u8 = model.inference_image(maps, cand_image, replica=n % nstream)
+        cpu_rows = [k for k, m in enumerate(chunk) if m.device.type != "cuda"]
+        for k in cpu_rows:
+            bs["stage"][k].copy_(chunk[k])                      # host memcpy into pinned memory (overlaps the batches in flight)
+        if lane is not None:
+            lane.wait_stream(torch.cuda.current_stream(device))  # cand_image, and maps that live on the device, were produced there
+        with (torch.cuda.stream(lane) if lane is not None else _null()):
+            if len(cpu_rows) == b:
+                bs["dev"][:b].copy_(bs["stage"][:b], non_blocking=True)
             else:
-                u8 = model.inference_image(maps, cand_image)   # [b,H,W,3] uint8 on the device
-            host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=device.type == "cuda")
-            host.copy_(u8, non_blocking=True)
-            ev = torch.cuda.Event() if device.type == "cuda" else None
-            if ev is not None:
-                ev.record()
-        if ev is None:
-            for k in range(host.shape[0]):
-                (on_frame(idx + k, host[k].numpy().copy()) if on_frame else frames.append(host[k].numpy().copy()))
-        else:
-            pending.append((idx, host, ev))
-            flush(nstream)                                      # the batches of the other lanes stay in flight; older ones are certainly done soon
-        idx += len(chunk)
+                for k, m in enumerate(chunk):
+                    bs["dev"][k].copy_(bs["stage"][k] if m.device.type != "cuda" else m, non_blocking=True)
+            u8 = model.inference_image(bs["dev"][:b], cand_image, replica=n % nstream) if lane is not None else model.inference_image(bs["dev"][:b], cand_image)
+            if bs["host"] is None:
+                bs["host"] = torch.empty((batch,) + tuple(u8.shape[1:]), dtype=torch.uint8, pin_memory=True)
+            bs["host"][:b].copy_(u8, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        pending.append((idx, b, bs, ev))
+        idx += b
     flush(0)
     if nstream > 1:
         for s in lanes:
@@ -115,22 +132,27 @@ def render_frames_from_landmarks(model, landmarks: Iterable, shoulders: Iterable
     frames: List[np.ndarray] = []
     pending = None
     idx = 0
-    for maps in chunks():
+    hosts: List[Optional[torch.Tensor]] = [None, None]         # two pinned result tensors, alternating (none allocated per batch)
+
+    def drain():
+        nonlocal pending
+        if pending is not None:
+            i0, n0, h0, e0 = pending
+            e0.synchronize()
+            for k in range(n0):
+                (on_frame(i0 + k, h0[k].numpy().copy()) if on_frame else frames.append(h0[k].numpy().copy()))
+            pending = None
+
+    for n, maps in enumerate(chunks()):
         u8 = model.inference_image(maps, cand_image)
-        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
-        host.copy_(u8, non_blocking=True)
+        if hosts[n & 1] is None:
+            hosts[n & 1] = torch.empty((batch,) + tuple(u8.shape[1:]), dtype=torch.uint8, pin_memory=True)
+        host = hosts[n & 1]                                     # (its previous user, batch n - 2, was drained before batch n - 1 was issued)
+        host[:u8.shape[0]].copy_(u8, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        if pending is not None:
-            i0, h0, e0 = pending
-            e0.synchronize()
-            for k in range(h0.shape[0]):
-                (on_frame(i0 + k, h0[k].numpy().copy()) if on_frame else frames.append(h0[k].numpy().copy()))
-        pending = (idx, host, ev)
+        drain()
+        pending = (idx, u8.shape[0], host, ev)
         idx += u8.shape[0]
-    if pending is not None:
-        i0, h0, e0 = pending
-        e0.synchronize()
-        for k in range(h0.shape[0]):
-            (on_frame(i0 + k, h0[k].numpy().copy()) if on_frame else frames.append(h0[k].numpy().copy()))
+    drain()
     return frames
