@@ -41,24 +41,27 @@ class Feature2FaceModel(BaseModel):
                 return net.render(feature_map, cand_image)
             return self._g().render(feature_map, cand_image)
 
-    def inference_image(self, feature_map, cand_image, replica: int = 0):
+    def inference_image(self, feature_map, cand_image, replica: int = 0, out=None):
         """inference() followed by util.tensor2im, fused on the device: uint8 [B,H,W,3] frames
         (``util.tensor2im(pred_fake[0])`` of demo.py:268 is ``inference_image(...)[0].cpu().numpy()``).
         ``replica`` > 0 renders through a further handle on the same device and packed weights (single-device normal / large generators): calls with
-        different replicas on different streams overlap (render_loop.render_frames(streams=2))."""
+        different replicas on different streams overlap (render_loop.render_frames(streams=2)).  ``out``: a caller-owned uint8 [B,H,W,3] device tensor for the frames -- the
+        library replays one cached hipGraph per set of pointers (eight are kept), so a loop that reuses its buffers replays, one that lets the allocator hand out fresh result
+        tensors re-captures (~15 ms per call); render_loop.render_frames passes its own."""
         with torch.no_grad():
             g = self._g().netG
             if feature_map.device.type != "cuda":
                 raise RuntimeError("the feature2face HIP renderer needs ROCm tensors; there is no CPU fallback")
             if isinstance(g, Feature2FaceGenerator_Unet):        # size == 'small': its own native plan (include/lspunet.h), same fused uint8 output
-                return g.render(feature_map, cand_image, out_u8=True)
+                return g.render(feature_map, cand_image, out_u8=True) if out is None else g._get_engine(feature_map.device).render(
+                    feature_map.float(), None if cand_image is None else cand_image.float(), True, out=out)
             net = self.Feature2Face_G
             if isinstance(net, networks.MultiDeviceParallel):    # several gpu_ids: sliced over all of them like inference(), uint8 fused on every device
                 return net.render_image(feature_map, cand_image)
             e = g._engine_for(feature_map.shape[-1], feature_map.shape[0], feature_map.device)
             if replica:
                 e = g._twin_engine(replica, e)
-            return e.forward_image(feature_map.float(), cand_image.float() if cand_image is not None else None)
+            return e.forward_image(feature_map.float(), cand_image.float() if cand_image is not None else None, out_u8=out)
 
     def supports_replicas(self) -> bool:
         """whether inference_image(replica=k) means another handle (else the argument is ignored: the small U-Net, several gpu_ids)"""
