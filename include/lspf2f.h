@@ -293,6 +293,12 @@ int64_t lspf2f_layer_form_offset(const lspf2f_handle *h, int layer, int form);
  * the next forward replays the same hipGraph on the poisoned workspace. */
 int lspf2f_debug_poison(lspf2f_handle *h, unsigned char byte, void *hip_stream, unsigned *nonzero_counters);
 
+/* A copy executed by a KERNEL on `hip_stream` (16-byte aligned pointers and size).  Replaces, in the frame loop, the transfers either side of the generator -- the feature map going up
+ * (`feature_map.to(device)`, demo.py:262-265) and the frame coming down (`util.tensor2im(...)` reads it on the host, demo.py:268) -- when the host side is PINNED memory: a pinned host
+ * pointer is an ordinary address to a kernel, and a kernel is the next packet of the stream's own queue, whereas hipMemcpyAsync between two launches hands the stream to the copy engine
+ * and back (two cross-queue waits the runtime resolves from a host thread: milliseconds on a busy host).  Either pointer may be device or pinned host memory. */
+int lspf2f_memcpy(void *dst, const void *src, size_t bytes, void *hip_stream);
+
 /* Measurement aid (bench.py `roofline.clock_ghz_observed`): ONE wave spins for about `duration_us` microseconds of the constant 100 MHz
  * counter (s_memrealtime) and writes {shader cycles (s_memtime), 100-MHz ticks} it saw to out_dev[0..1].  Launched on a side stream while
  * the timed region runs, cycles / ticks x 0.1 is the shader clock in GHz the chip held under that load.  duration_us <= 2 000 000. */

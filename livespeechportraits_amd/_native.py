@@ -141,6 +141,7 @@ SIGNATURES = {
     "lspf2f_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "lspf2f_pixel_shuffle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lspf2f_clock_probe": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "lspf2f_memcpy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "lspf2f_layer_form_offset": (c_int64, [c_void_p, c_int, c_int]),
     "lspf2f_debug_poison": (c_int, [c_void_p, ctypes.c_ubyte, c_void_p, POINTER(c_uint32)]),
 }

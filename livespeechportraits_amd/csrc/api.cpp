@@ -378,6 +378,14 @@ int64_t lspf2f_layer_form_offset(const lspf2f_handle *h, int layer, int form)
     }
 }
 
+int lspf2f_memcpy(void *dst, const void *src, size_t bytes, void *hip_stream)
+{
+    if (!dst || !src) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    const hipError_t e = launch_copy16(dst, src, bytes, static_cast<hipStream_t>(hip_stream));
+    if (e == hipErrorInvalidValue) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "lspf2f_memcpy: pointers and size must be multiples of 16 bytes");
+    return e == hipSuccess ? LSPF2F_OK : hipfail(e, "lspf2f_memcpy launch");
+}
+
 int lspf2f_clock_probe(unsigned long long *out_dev, unsigned duration_us, void *hip_stream)
 {
     if (!out_dev || duration_us == 0 || duration_us > 2000000u) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "clock_probe: null output or duration outside 1..2 000 000 us");

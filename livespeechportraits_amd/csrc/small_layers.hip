@@ -240,6 +240,25 @@ hipError_t launch_smallm(const SmallMParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
+// Copy on the COMPUTE queue (lspf2f_memcpy): 16 bytes per lane, grid-stride.  For the render loop's transfers between pinned host memory and HBM (both are plain pointers to a
+// kernel): a hipMemcpyAsync between two launches of one stream goes to the copy engine and back, two cross-queue hand-offs that the runtime resolves from a host thread -- 4-6 ms each on
+// a busy host (tools/render_loop_profile.py) -- where a kernel is just the next packet of the same queue.
+__global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+hipError_t launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return hipErrorInvalidValue;
+    const size_t n16 = bytes >> 4;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(copy16, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16);
+    return hipGetLastError();
+}
+
 // bench.py's clock probe: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz reference
 __global__ __launch_bounds__(64) void clock_probe(unsigned long long *out, unsigned long long ticks)
 {

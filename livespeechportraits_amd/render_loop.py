@@ -27,30 +27,30 @@ def batched(it: Iterable, n: int) -> Iterator[List]:
 
 def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch.Tensor, batch: int = 8,
                   device: Optional[torch.device] = None,
-                  on_frame: Optional[Callable[[int, np.ndarray], None]] = None, streams: int = 1) -> List[np.ndarray]:
+                  on_frame: Optional[Callable[[int, np.ndarray], None]] = None, streams: int = 2) -> List[np.ndarray]:
     """``feature_maps`` yields [1,H,W] (or [C,H,W]) CPU/GPU tensors as
     ``facedataset.dataset.get_data_test_mode`` does (demo.py:262); ``cand_image`` is demo.py's
     ``img_candidates`` ([1,12,H,W], already on the device).  Returns (or streams to ``on_frame``) uint8 HWC
     frames, i.e. exactly what ``util.tensor2im(pred_fake[0])`` produced per frame in the reference loop.
     ``model`` is a Feature2FaceModel (anything with ``inference_image``).
 
-    The loop owns ``streams + 1`` sets of buffers (a pinned staging tensor for the maps, their device tensor, a pinned tensor for the frames) and cycles through them: the maps of
-    batch i + 1 are gathered into pinned memory and uploaded while batch i renders, and nothing is allocated per batch (a pageable ``torch.stack(...).to(device)`` and a fresh pinned
-    result tensor per batch kept this loop at 160-290 frames/s on a generator that renders 1019: round 5).
-    ``streams`` > 1: that many batches in flight at once, each on its own HIP stream and its own handle on the same packed weights -- one batch's kernel tails and boundaries are
-    filled by the next one's work (generator alone: +5 % at 8 fp32 frames, +16 % on the 16-bit plans; same frames, bit for bit).  Ignored where the model cannot give a second handle."""
+    ``streams`` lanes, each a HIP stream, a handle on the same packed weights (``inference_image(replica=k)``) and its own buffers (pinned staging tensor for the maps, their
+    device tensor, the frames' device tensor, a pinned tensor for the frames): batch n runs on lane n % streams; before a lane is reused the host waits for THAT STREAM to drain
+    and hands out its frames.  Nothing is allocated per batch, the pointers a handle sees never change (it replays one cached hipGraph), the maps of the next batch are gathered
+    into pinned memory while the lanes render, and two batches in flight fill each other's kernel tails (generator alone: +5 % at 8 fp32 frames, +16 % on the 16-bit plans).
+    Measured, round 5 (tools/render_loop_profile.py): waiting on an EVENT in the middle of a busy stream returns late on this runtime (the loop of rounds 2-4 -- one stream,
+    event per batch, fresh tensors per batch -- ran at 70-290 frames/s on a generator that renders 665-1019); a stream's own tail is signalled promptly.
+    A model that cannot give a second handle (the `small` U-Net, several gpu_ids, stand-ins) gets one lane on the current stream: enqueue, wait, hand out."""
     device = device or cand_image.device
     frames: List[np.ndarray] = []
-    pending: List = []                  # (first index, frames in the batch, buffer set, event), oldest first
     idx = 0
     on_gpu = device.type == "cuda"
-    nstream = max(1, int(streams)) if on_gpu and getattr(model, "supports_replicas", lambda: False)() else 1
-    lanes = [torch.cuda.Stream(device) for _ in range(nstream)] if nstream > 1 else [None]
-    sets: List[dict] = []               # nstream + 1 buffer sets, made at the first batch (shapes come from the data)
+    nlane = max(1, int(streams)) if on_gpu and getattr(model, "supports_replicas", lambda: False)() else 1
     try:
         takes_out = "out" in inspect.signature(model.inference_image).parameters      # (stand-in models of the tests do not)
     except (TypeError, ValueError):
         takes_out = False
+    lanes: List[dict] = []              # made at the first batch (shapes come from the data)
 
     def emit(i0, host, n):
         for k in range(n):
@@ -60,11 +60,12 @@ def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch
             else:
                 frames.append(arr)
 
-    def flush(keep: int):
-        while len(pending) > keep:
-            i0, n, bs, ev = pending.pop(0)
-            ev.synchronize()
-            emit(i0, bs["host"], n)
+    def drain(lane):
+        if lane["busy"] is not None:
+            i0, n = lane["busy"]
+            (lane["stream"] if lane["stream"] is not None else torch.cuda.current_stream(device)).synchronize()
+            emit(i0, lane["host"], n)
+            lane["busy"] = None
 
     for n, chunk in enumerate(batched(feature_maps, batch)):
         chunk = [m if m.dim() == 3 else m.unsqueeze(0) for m in chunk]
@@ -73,44 +74,45 @@ def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch
             emit(idx, model.inference_image(torch.stack(chunk).to(device, torch.float32), cand_image), b)
             idx += b
             continue
-        flush(nstream)                                          # the batch that used this buffer set nstream + 1 batches ago is out of it
-        if not sets:
+        if not lanes:
             shape = (batch,) + tuple(chunk[0].shape)
-            for _ in range(nstream + 1):
-                sets.append({"stage": torch.empty(shape, dtype=torch.float32, pin_memory=True), "dev": torch.empty(shape, dtype=torch.float32, device=device), "host": None, "u8": None})
-        bs = sets[n % (nstream + 1)]
-        lane = lanes[n % nstream]
+            cur = torch.cuda.current_stream(device)
+            for k in range(nlane):
+                st = torch.cuda.Stream(device) if nlane > 1 else None
+                if st is not None:
+                    st.wait_stream(cur)                          # cand_image was produced there
+                lanes.append({"stream": st, "busy": None, "host": None, "u8": None,
+                              "stage": torch.empty(shape, dtype=torch.float32, pin_memory=True), "dev": torch.empty(shape, dtype=torch.float32, device=device)})
+        lane = lanes[n % nlane]
+        drain(lane)                                             # its previous batch: frames handed out, buffers free
         cpu_rows = [k for k, m in enumerate(chunk) if m.device.type != "cuda"]
         for k in cpu_rows:
-            bs["stage"][k].copy_(chunk[k])                      # host memcpy into pinned memory (overlaps the batches in flight)
-        if lane is not None:
-            lane.wait_stream(torch.cuda.current_stream(device))  # cand_image, and maps that live on the device, were produced there
-        with (torch.cuda.stream(lane) if lane is not None else _null()):
+            lane["stage"][k].copy_(chunk[k])                    # host memcpy into pinned memory (the other lanes keep rendering)
+        if lane["stream"] is not None and len(cpu_rows) < b:
+            lane["stream"].wait_stream(torch.cuda.current_stream(device))      # maps that live on the device were produced there
+        with (torch.cuda.stream(lane["stream"]) if lane["stream"] is not None else _null()):
             if len(cpu_rows) == b:
-                bs["dev"][:b].copy_(bs["stage"][:b], non_blocking=True)
+                lane["dev"][:b].copy_(lane["stage"][:b], non_blocking=True)
             else:
                 for k, m in enumerate(chunk):
-                    bs["dev"][k].copy_(bs["stage"][k] if m.device.type != "cuda" else m, non_blocking=True)
-            # the frames land in this buffer set's own device tensor: stable pointers -> the handle replays its cached hipGraph (a fresh result tensor per call made it re-capture,
-            # ~15 ms per batch).  A model that does not take `out` (stand-ins) allocates its own.
-            kw = {"replica": n % nstream} if lane is not None else {}
+                    lane["dev"][k].copy_(lane["stage"][k] if m.device.type != "cuda" else m, non_blocking=True)
+            kw = {"replica": n % nlane} if nlane > 1 else {}
             if takes_out:
-                if bs["u8"] is None:
+                if lane["u8"] is None:
                     H = chunk[0].shape[-1]
-                    bs["u8"] = torch.empty((batch, H, H, 3), dtype=torch.uint8, device=device)
-                kw["out"] = bs["u8"][:b]
-            u8 = model.inference_image(bs["dev"][:b], cand_image, **kw)
-            if bs["host"] is None:
-                bs["host"] = torch.empty((batch,) + tuple(u8.shape[1:]), dtype=torch.uint8, pin_memory=True)
-            bs["host"][:b].copy_(u8, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        pending.append((idx, b, bs, ev))
+                    lane["u8"] = torch.empty((batch, H, H, 3), dtype=torch.uint8, device=device)
+                kw["out"] = lane["u8"][:b]
+            u8 = model.inference_image(lane["dev"][:b], cand_image, **kw)
+            if lane["host"] is None:
+                lane["host"] = torch.empty((batch,) + tuple(u8.shape[1:]), dtype=torch.uint8, pin_memory=True)
+            lane["host"][:b].copy_(u8, non_blocking=True)
+        lane["busy"] = (idx, b)
         idx += b
-    flush(0)
-    if nstream > 1:
-        for s in lanes:
-            torch.cuda.current_stream(device).wait_stream(s)
+        if nlane == 1:
+            drain(lane)                                         # one lane: nothing to overlap with -- wait now (prompt) rather than behind the next batch's enqueue
+    # hand out what is still in flight, oldest first
+    for lane in sorted((l for l in lanes if l["busy"] is not None), key=lambda l: l["busy"][0]):
+        drain(lane)
     return frames
 
 
@@ -143,29 +145,16 @@ def render_frames_from_landmarks(model, landmarks: Iterable, shoulders: Iterable
             yield rast.rasterise(lm_a, sh_a, pad, out=maps_buf[:lm_a.shape[0]])
 
     frames: List[np.ndarray] = []
-    pending = None
     idx = 0
-    hosts: List[Optional[torch.Tensor]] = [None, None]         # two pinned result tensors, alternating (none allocated per batch)
-
-    def drain():
-        nonlocal pending
-        if pending is not None:
-            i0, n0, h0, e0 = pending
-            e0.synchronize()
-            for k in range(n0):
-                (on_frame(i0 + k, h0[k].numpy().copy()) if on_frame else frames.append(h0[k].numpy().copy()))
-            pending = None
-
-    for n, maps in enumerate(chunks()):
+    host = None                                                 # one pinned result tensor, reused
+    for maps in chunks():
         u8 = model.inference_image(maps, cand_image)
-        if hosts[n & 1] is None:
-            hosts[n & 1] = torch.empty((batch,) + tuple(u8.shape[1:]), dtype=torch.uint8, pin_memory=True)
-        host = hosts[n & 1]                                     # (its previous user, batch n - 2, was drained before batch n - 1 was issued)
+        if host is None:
+            host = torch.empty((batch,) + tuple(u8.shape[1:]), dtype=torch.uint8, pin_memory=True)
         host[:u8.shape[0]].copy_(u8, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        drain()
-        pending = (idx, u8.shape[0], host, ev)
+        # wait on the stream's own tail (prompt); an event waited for behind the next batch's enqueue returns late on this runtime (render_frames above)
+        torch.cuda.current_stream(device).synchronize()
+        for k in range(u8.shape[0]):
+            (on_frame(idx + k, host[k].numpy().copy()) if on_frame else frames.append(host[k].numpy().copy()))
         idx += u8.shape[0]
-    drain()
     return frames
