@@ -83,11 +83,19 @@ def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch
                     st.wait_stream(cur)                          # cand_image was produced there
                 lanes.append({"stream": st, "busy": None, "host": None, "u8": None,
                               "stage": torch.empty(shape, dtype=torch.float32, pin_memory=True), "dev": torch.empty(shape, dtype=torch.float32, device=device)})
+                lanes[-1]["stage_np"] = lanes[-1]["stage"].numpy()
         lane = lanes[n % nlane]
         drain(lane)                                             # its previous batch: frames handed out, buffers free
         cpu_rows = [k for k, m in enumerate(chunk) if m.device.type != "cuda"]
         for k in cpu_rows:
-            lane["stage"][k].copy_(chunk[k])                    # host memcpy into pinned memory (the other lanes keep rendering)
+            # host memcpy into pinned memory (the other lanes keep rendering).  Through numpy, i.e. on THIS thread: torch's CPU copy_ fans a 1-MiB tensor out over its
+            # intra-op pool (128 threads on the GPU boxes, under a 16-CPU container quota), whose spinning workers get the whole process throttled for milliseconds at a time
+            # -- measured as 4-6 ms per MiB "copied" and 8-13 ms waits for a 1.5-ms forward (tools/render_loop_profile.py, tools/host_probe.py)
+            m = chunk[k]
+            if m.dtype == torch.float32 and m.is_contiguous():
+                np.copyto(lane["stage_np"][k], m.numpy())
+            else:
+                lane["stage"][k].copy_(m)
         if lane["stream"] is not None and len(cpu_rows) < b:
             lane["stream"].wait_stream(torch.cuda.current_stream(device))      # maps that live on the device were produced there
         with (torch.cuda.stream(lane["stream"]) if lane["stream"] is not None else _null()):
