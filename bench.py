@@ -406,6 +406,7 @@ def main():
         extra["config2_normal_b8_bf16"] = config2_extra(dev, a)
         extra["small_unet_native_plan"] = small_unet_extra(dev, a)
         extra["concurrent_batch1_forwards"] = concurrent_extra(dev, eng, a)
+        extra["render_loop_end_to_end"] = render_loop_extra(dev, sd, a)
         extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
         extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
@@ -475,6 +476,33 @@ def torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a):
 def synth_inputs(b, size):
     from livespeechportraits_amd import synth
     return synth.make_inputs(b, size, seed=99, cand_batch=1)
+
+
+def render_loop_extra(dev, sd, a):
+    """The product's frame loop (render_loop.render_frames = demo.py:260-272 batched): pinned host feature maps in, uint8 HWC frames out on the host -- gather, H2D, generator +
+    tensor2im, D2H, hand-out -- through the drop-in model object, 8 frames per batch, two lanes (stream + handle each).  PCIe-inclusive: never `value`."""
+    import argparse as _ap
+    import livespeechportraits_amd as L
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.render_loop import render_frames
+    opt = _ap.Namespace(model="feature2face", gpu_ids=[0], isTrain=False, size=a.variant, ngf=64, n_downsample_G=8, fp16=0, checkpoints_dir="/tmp", name="bench",
+                        load_epoch="none", verbose=False)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):                  # (the reference's constructor prints)
+        model = L.create_model(opt)
+    model._g().load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    model.eval()
+    feats, cand = synth.make_inputs(8, a.size, seed=5, cand_batch=1)
+    c = torch.from_numpy(cand).to(dev)
+    maps = [torch.from_numpy(feats[i % 8]).pin_memory() for i in range(256)]
+    r = {}
+    for lanes in (1, 2):
+        render_frames(model, iter(maps[:32]), c, batch=8, streams=lanes)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = render_frames(model, iter(maps), c, batch=8, streams=lanes)
+        r["lanes_%d_frames_per_s" % lanes] = round(len(out) / (time.perf_counter() - t0), 1)
+    r["note"] = "256 frames, batch 8, host feature maps (1 MiB each, pinned) -> uint8 frames on the host; round 4's loop (one stream, event waits, torch CPU copies): 160-290 on the same boxes"
+    return r
 
 
 def concurrent_extra(dev, eng, a):
