@@ -508,8 +508,9 @@ def render_loop_extra(dev, sd, a):
 def concurrent_extra(dev, eng, a):
     """NOT the headline: N independent batch-1 forwards in flight at once (N handles on ONE packed blob, one stream each) against the single stream `value` is
     measured on.  A batch-1 forward is a chain of dependent launches, each a single round of workgroups, so prologues, tails and kernel boundaries overlap nothing;
-    independent frames on other streams fill those holes.  What it says about the kernels: the single-stream loss is dependency latency, not throughput.  A caller
-    with frames in hand batches them instead (the batch-8 rows are faster still); this is the number for frames that arrive one by one."""
+    independent frames on other streams fill those holes: +7 % with four streams on a normal box of the pool, +40 % on its slow-boundary boxes (where they hide the box's
+    extra ~2.7 us per kernel boundary; profiles/r05_concurrent_streams.txt) -- the size of what a cross-layer overlap inside one forward could win.  A caller with
+    frames in hand batches them instead (the batch-8 rows are faster still); this is the number for frames that arrive one by one."""
     from livespeechportraits_amd import synth
     from livespeechportraits_amd.engine import Engine
     blob = eng._blob_dev
