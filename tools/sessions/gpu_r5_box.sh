@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-5: which kind of box + the default bench line (with extra.concurrent_batch1_forwards) + the concurrent-streams probe
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r5box_$(date +%H%M%S); mkdir -p $OUT
-bash tools/box_info.sh > $OUT/box.txt 2>&1; head -40 $OUT/box.txt
+bash tools/sessions/box_info.sh > $OUT/box.txt 2>&1; head -40 $OUT/box.txt
 timeout 400 python bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench_default.json
 python - $OUT/bench_default.json <<'P'
 import json, sys

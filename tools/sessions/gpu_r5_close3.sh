@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-5 closing session #3: whole GPU suite + smoke at HEAD, the default bench line (with the new extras), box info
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r5close3; mkdir -p $OUT
-bash tools/box_info.sh > $OUT/box.txt 2>&1
+bash tools/sessions/box_info.sh > $OUT/box.txt 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee $OUT/pytest.rc; tail -6 $OUT/pytest.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -4 $OUT/smoke.log
 T0=$(date +%s); timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench.err; echo "bench rc=$? in $(( $(date +%s) - T0 )) s"; tail -3 $OUT/bench.err
