@@ -538,6 +538,18 @@ def concurrent_extra(dev, eng, a):
         r["streams_%d" % n] = {"frames_per_s": round(n * reps / dt, 1), "ms_per_frame": round(1e3 * dt / (n * reps), 4)}
     for e in engines[1:]:
         e.close()
+    # the same measurement in a process of its own (tools/multistream_probe.py): the figure that is not distorted by this process's stream history
+    try:
+        import re, subprocess
+        root = os.path.dirname(os.path.abspath(__file__))
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "multistream_probe.py"), a.variant, a.dtype, "4", "1"], capture_output=True, text=True, timeout=180)
+        fresh = {}
+        for m in re.finditer(r"(\d+) concurrent stream\(s\): ([0-9.]+) frames/s .*bit-identical to the single-stream run: (True|False)", p.stdout):
+            fresh["streams_%s" % m.group(1)] = {"frames_per_s": float(m.group(2)), "bit_identical": m.group(3) == "True"}
+        if fresh:
+            r["fresh_process"] = fresh
+    except Exception as ex:      # the probe is an extra: never fail the bench line over it
+        r["fresh_process_error"] = str(ex)[:200]
     return r
 
 
