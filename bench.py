@@ -509,8 +509,8 @@ def concurrent_extra(dev, eng, a):
     """NOT the headline: N independent batch-1 forwards in flight at once (N handles on ONE packed blob, one stream each) against the single stream `value` is
     measured on.  A batch-1 forward is a chain of dependent launches, each a single round of workgroups, so prologues, tails and kernel boundaries overlap nothing;
     independent frames on other streams fill those holes.  In a FRESH process four streams add 26 % (667 -> 838 frames/s, tools/multistream_probe.py,
-    profiles/r05_concurrent_streams.txt): the size of what a cross-layer overlap inside one forward could win.  In THIS process the figure is lower -- it has created a dozen
-    streams by now and the runtime maps streams onto four hardware queues, so the lanes share queues.  A caller with frames in hand batches them instead (the batch-8 rows
+    profiles/r05_concurrent_streams.txt): the size of what a cross-layer overlap inside one forward could win.  In THIS process, late in its life, the figure reads lower (why is not established; streams
+    created earlier are ruled out), so the probe is also run in a process of its own (`fresh_process`).  A caller with frames in hand batches them instead (the batch-8 rows
     are faster still); this is the number for frames that arrive one by one."""
     from livespeechportraits_amd import synth
     from livespeechportraits_amd.engine import Engine
