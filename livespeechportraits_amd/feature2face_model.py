@@ -45,9 +45,9 @@ class Feature2FaceModel(BaseModel):
         """inference() followed by util.tensor2im, fused on the device: uint8 [B,H,W,3] frames
         (``util.tensor2im(pred_fake[0])`` of demo.py:268 is ``inference_image(...)[0].cpu().numpy()``).
         ``replica`` > 0 renders through a further handle on the same device and packed weights (single-device normal / large generators): calls with
-        different replicas on different streams overlap (render_loop.render_frames(streams=2)).  ``out``: a caller-owned uint8 [B,H,W,3] device tensor for the frames -- the
-        library replays one cached hipGraph per set of pointers (eight are kept), so a loop that reuses its buffers replays, one that lets the allocator hand out fresh result
-        tensors re-captures (~15 ms per call); render_loop.render_frames passes its own."""
+        different replicas on different streams overlap (render_loop.render_frames(streams=2)).  ``out``: a caller-owned uint8 [B,H,W,3] device tensor for the frames (the library replays one cached hipGraph per set of pointers and keeps eight; a miss re-captures, which
+        costs the host ~nothing next to the forward -- measured equal with 12 buffer pairs in rotation, tools/graph_recapture_probe.py -- so this is about not allocating per call);
+        render_loop.render_frames passes its own."""
         with torch.no_grad():
             g = self._g().netG
             if feature_map.device.type != "cuda":

@@ -36,10 +36,11 @@ def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch
 
     ``streams`` lanes, each a HIP stream, a handle on the same packed weights (``inference_image(replica=k)``) and its own buffers (pinned staging tensor for the maps, their
     device tensor, the frames' device tensor, a pinned tensor for the frames): batch n runs on lane n % streams; before a lane is reused the host waits for THAT STREAM to drain
-    and hands out its frames.  Nothing is allocated per batch, the pointers a handle sees never change (it replays one cached hipGraph), the maps of the next batch are gathered
+    and hands out its frames.  Nothing is allocated per batch, the maps of the next batch are gathered
     into pinned memory while the lanes render, and two batches in flight fill each other's kernel tails (generator alone: +5 % at 8 fp32 frames, +16 % on the 16-bit plans).
-    Measured, round 5 (tools/render_loop_profile.py): waiting on an EVENT in the middle of a busy stream returns late on this runtime (the loop of rounds 2-4 -- one stream,
-    event per batch, fresh tensors per batch -- ran at 70-290 frames/s on a generator that renders 665-1019); a stream's own tail is signalled promptly.
+    Measured, round 5 (tools/render_loop_profile.py, tools/host_probe.py): the loop of rounds 2-4 ran at 70-290 frames/s on a generator that renders 665-1019 -- because of the
+    host-side copy described at the gather below, not because of how it waited or allocated (a hipGraph cache miss costs nothing next to a forward; the late event waits seen in the
+    first measurements were not separated from that throttling).
     A model that cannot give a second handle (the `small` U-Net, several gpu_ids, stand-ins) gets one lane on the current stream: enqueue, wait, hand out."""
     device = device or cand_image.device
     frames: List[np.ndarray] = []
@@ -160,7 +161,7 @@ def render_frames_from_landmarks(model, landmarks: Iterable, shoulders: Iterable
         if host is None:
             host = torch.empty((batch,) + tuple(u8.shape[1:]), dtype=torch.uint8, pin_memory=True)
         host[:u8.shape[0]].copy_(u8, non_blocking=True)
-        # wait on the stream's own tail (prompt); an event waited for behind the next batch's enqueue returns late on this runtime (render_frames above)
+        # one batch at a time: the rasteriser's output tensor is reused, and the wait is on the stream's own tail
         torch.cuda.current_stream(device).synchronize()
         for k in range(u8.shape[0]):
             (on_frame(idx + k, host[k].numpy().copy()) if on_frame else frames.append(host[k].numpy().copy()))
