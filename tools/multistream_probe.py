@@ -15,6 +15,7 @@ nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device("cuda:0")
 pre = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+MB = int(sys.argv[6]) if len(sys.argv) > 6 else 0            # handles planned for up to this many frames (0: the batch itself) -- bench.py's are planned for 8
 dummies = [torch.cuda.Stream(dev) for _ in range(pre)]          # does a process's stream history change what the lanes get?  (bench.py measures this late in its life)
 for d in dummies:
     with torch.cuda.stream(d):
@@ -22,12 +23,12 @@ for d in dummies:
 torch.cuda.synchronize()
 topo = build_topology(variant)
 sd = synth.make_state_dict(topo, 1234)
-first = Engine(variant, dtype=dtype, max_batch=B)
+first = Engine(variant, dtype=dtype, max_batch=max(B, MB))
 first.load_state_dict(sd)
 blob = first.pack().to(dev)
 engines, streams, ins, outs = [], [], [], []
 for i in range(nmax):
-    e = first if i == 0 else Engine(variant, dtype=dtype, max_batch=B)
+    e = first if i == 0 else Engine(variant, dtype=dtype, max_batch=max(B, MB))
     e.bind(blob, dev)                                               # one copy of the weights for all of them
     f, c = synth.make_inputs(B, 512, 99 + i, 1)
     engines.append(e); streams.append(torch.cuda.Stream(dev))
@@ -46,4 +47,4 @@ for n in range(1, nmax + 1):
     reps = 200 if B == 1 else 40
     t0 = time.perf_counter(); run(reps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     same = all(torch.equal(outs[i], ref[i]) for i in range(n))
-    print(("[%d streams created before] " % pre if pre else "") + "%s %s batch %d, %d concurrent stream(s): %.1f frames/s (%.4f ms per frame); outputs bit-identical to the single-stream run: %s" % (variant, dtype, B, n, B * n * reps / dt, 1e3 * dt / (B * n * reps), same), flush=True)
+    print(("[%d streams created before] " % pre if pre else "") + ("[handles planned for %d frames] " % MB if MB else "") + "%s %s batch %d, %d concurrent stream(s): %.1f frames/s (%.4f ms per frame); outputs bit-identical to the single-stream run: %s" % (variant, dtype, B, n, B * n * reps / dt, 1e3 * dt / (B * n * reps), same), flush=True)
