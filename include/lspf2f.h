@@ -111,6 +111,9 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
  * U fragments of wino3x3<1> in registers; 2: four register sets), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), in_small_regs (1: the one-launch InstanceNorm pass keeps its rows in registers -- one read of the slab instead of three), in_smallm_fused (1: the tiny-M kernel normalises in its own epilogue under InstanceNorm plans), wino_prio (wave priority by K-loop progress: 1 = the workgroup that is behind leads, 2 = the one ahead, 3 = 1 with the older half of the grid kept at level 1 through its last quarter -- on wino3x3<1>'s register form; 4..6 = the same three schemes on every Winograd loop; 0 = off; default 1), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
  * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, rowup (1), rowlast (1), rowlast_fused (1: rowlast128 shuffles + applies tanh in its epilogue when only fp32 frames are wanted), rowconv (1): kernels of the 16-bit plans |
  * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), fused_splitk16 (0: the 16-bit plans combine 2..8 K-splits in the launch too), out_wt (1: the Winograd kernels write their output through to memory, sc1 stores; 0: plain stores, left dirty in L2), prefetch (1), smallm_dma (1: the tiny-M kernel stages its input tensor by LDS-DMA, every piece in flight at once; 0: through registers), smallm_kb (128: largest input tensor, in KB, the tiny-M kernel takes; 64 = rounds 2-4) |
+ * fullk16 (3: which small levels of a 16-bit plan run on conv3x3_fullk16 -- bit 0 the 4x4 / 2x2 levels, bit 1 the stride-2 / upsampling convs that write 8x8, bit 2 the stride-1 8x8 layers; 0 = none), fullk16_min_frames (2) |
+ * wino_chain (0: one launch per layer; N = 2..4: up to N consecutive wino3x3<1> layers of one shape -- the convs of one or two ResidualBlocks -- run as ONE launch whose workgroups are gated on
+ * per-tile-block arrival counters, wino3x3_chain; bit-identical) |
  * lastconv (0 = by shape; 1..5 force a last-conv kernel), lastconv_direct (0), firstconv (0 = by shape; 1, 2 force a first-conv kernel). */
 int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handle **out);
 int lspf2f_destroy(lspf2f_handle *h);
@@ -254,6 +257,18 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                    int c0, int c1, int cout, int stride, int upsample, int relu, int tile_m,
                    int tile_n, int split_k, int k_group, int dtype, void *scratch, size_t scratch_bytes,
                    void *hip_stream);
+
+/* Round 6 (tools/probes/wino_pair_probe.py, tests/test_gpu_conv.py): `nlayers` (1..4) consecutive Winograd convs of ONE shape (batch x hs x hs x c -> c, fp32: the convs of one
+ * or two ResidualBlocks, models/networks.py:650-675), layer k reading src[k] (= out[k - 1] for k > 0), weights u_packed[k] in the fragment order of tile 4001, optional
+ * scale[k] / shift[k] / residual[k] (NULL entries allowed), relu[k].  mode 0: one launch of wino3x3<1> per layer, exactly as the plans run them; mode 1: ONE launch of
+ * nlayers x (workgroups of a layer) workgroups, a layer's workgroups gated on the arrival counters of the tile-blocks they read (wino.hip, wino3x3_chain) -- same
+ * arithmetic in the same order, bit-identical; mode 2: the chain kernel launched once per layer (what its own prologue costs).  The outputs must be distinct buffers
+ * that are no input of an earlier layer.  scratch: lspf2f_wino_chain_scratch_bytes() bytes, ZERO on entry, left zero -- except its LAST 32-bit word, which a launch
+ * sets to 1 if a gate gave up waiting (the results are then garbage; it never happens while the dispatcher hands out workgroups in order). */
+size_t lspf2f_wino_chain_scratch_bytes(int nlayers, int batch, int hs, int c, int split_k);
+int lspf2f_wino_chain(int nlayers, const float *const *src, const float *const *u_packed, const float *const *scale, const float *const *shift,
+                      const float *const *residual, float *const *out, const int *relu, int batch, int hs, int c, int split_k, int mode,
+                      void *scratch, size_t scratch_bytes, void *hip_stream);
 
 /* ---- building blocks of the `size == 'small'` generator (Feature2FaceGenerator_Unet, models/networks.py:680-769) ----
  * That U-Net is made of 4x4 stride-2 convs and 4x4 stride-2 transposed convs.  Both map onto lspf2f_conv3x3:

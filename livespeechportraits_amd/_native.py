@@ -48,7 +48,7 @@ _RENAMED_ENV = {"LSP_HIP_XCD": "igemm_xcd", "LSP_HIP_FULLK_SPLIT_TILES": "fullk_
 TUNE_KEYS = frozenset((
     "graph", "wino", "wino4", "wino_pre", "wino_ureg", "wino_prio", "in_wino_stats", "wino_xcd", "wino_il", "wino_rot", "winoup", "winoup_nb", "winoup_target", "igemm_xcd",
     "bandconv", "bandconv_min_blocks", "bandconv_min_frames", "rowup", "rowlast", "rowlast_fused", "rowconv", "fullk_split", "fullk_split_tiles", "fullk_s2",
-    "all_forms", "blob_pad_kb", "fused_splitk", "fused_splitk16", "out_wt", "prefetch", "smallm_dma", "smallm_kb", "in_small_regs", "in_smallm_fused", "in_small_max_hw", "lastconv_direct", "lastconv", "firstconv"))
+    "all_forms", "blob_pad_kb", "fused_splitk", "fused_splitk16", "fullk16", "fullk16_min_frames", "out_wt", "wino_chain", "prefetch", "smallm_dma", "smallm_kb", "in_small_regs", "in_smallm_fused", "in_small_max_hw", "lastconv_direct", "lastconv", "firstconv"))
 _HOST_ENV = frozenset(("LSP_HIP_CAND_CACHE", "LSP_HIP_TUNE"))
 
 
@@ -138,6 +138,8 @@ SIGNATURES = {
                                     POINTER(c_float), POINTER(c_int)]),
     "lspf2f_conv3x3_scratch_bytes": (c_size_t, [c_int] * 13),
     "lspf2f_conv3x3": (c_int, [c_void_p] * 7 + [c_int] * 14 + [c_void_p, c_size_t, c_void_p]),
+    "lspf2f_wino_chain_scratch_bytes": (c_size_t, [c_int] * 5),
+    "lspf2f_wino_chain": (c_int, [c_int] + [POINTER(c_void_p)] * 6 + [POINTER(c_int)] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "lspf2f_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "lspf2f_pixel_shuffle": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lspf2f_clock_probe": (c_int, [c_void_p, c_uint32, c_void_p]),

@@ -1206,4 +1206,70 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
     return LSPF2F_OK;
 }
 
+
+// scratch of lspf2f_wino_chain: [split-K slabs][one arrival counter per (tile-block, channel group)][(nlayers - 1) x tile-blocks gate counters][1 give-up word]
+static void wino_chain_scratch_layout(int nlayers, int batch, int hs, int c, int sp, size_t *slab, size_t *ncnt, size_t *narr)
+{
+    *slab = sp > 1 ? (size_t)sp * batch * hs * hs * c * sizeof(float) : 0;
+    *ncnt = sp > 1 ? (size_t)batch * (hs / 8) * (hs / 16) * (c / 32) : 0;
+    *narr = (size_t)(nlayers > 1 ? nlayers - 1 : 0) * batch * (hs / 8) * (hs / 16) * kWinoArriveStride;
+}
+
+size_t lspf2f_wino_chain_scratch_bytes(int nlayers, int batch, int hs, int c, int split_k)
+{
+    if (nlayers < 1 || batch < 1 || hs < 16 || c < 32) return 0;
+    size_t slab, ncnt, narr;
+    wino_chain_scratch_layout(nlayers, batch, hs, c, split_k > 0 ? split_k : 1, &slab, &ncnt, &narr);
+    return slab + (ncnt + narr + 1) * sizeof(unsigned);
+}
+
+int lspf2f_wino_chain(int nlayers, const float *const *src, const float *const *u_packed, const float *const *scale, const float *const *shift,
+                      const float *const *residual, float *const *out, const int *relu, int batch, int hs, int c, int split_k, int mode,
+                      void *scratch, size_t scratch_bytes, void *hip_stream)
+{
+    if (nlayers < 1 || nlayers > kWinoChainMax) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "wino_chain: 1..4 layers");
+    if (!src || !u_packed || !scale || !shift || !residual || !out || !relu) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
+    if (mode < 0 || mode > 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "wino_chain: mode 0 (one launch per layer), 1 (one launch), 2 (one one-layer chain launch per layer)");
+    const int sp = split_k > 0 ? split_k : 1;
+    size_t slab, ncnt, narr;
+    wino_chain_scratch_layout(nlayers, batch, hs, c, sp, &slab, &ncnt, &narr);
+    if (!scratch || scratch_bytes < slab + (ncnt + narr + 1) * sizeof(unsigned)) return fail(LSPF2F_ERR_STATE, "wino_chain: scratch missing or too small (lspf2f_wino_chain_scratch_bytes)");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    WinoParams q{};
+    q.B = batch; q.H = hs; q.W = hs; q.C = c; q.N = c; q.splits = sp; q.ureg = 1; q.out_wt = 1; q.prio = 1;
+    if (sp > 1) {
+        q.partial = static_cast<float *>(scratch);
+        q.tile_cnt = reinterpret_cast<unsigned *>(static_cast<char *>(scratch) + slab);
+    }
+    unsigned *arrive = reinterpret_cast<unsigned *>(static_cast<char *>(scratch) + slab) + ncnt;
+    if (!wino_supported(q, 1)) return fail(LSPF2F_ERR_UNSUPPORTED, "the Winograd kernel does not support this shape");
+    hipError_t e = hipSuccess;
+    if (mode == 0) {
+        for (int k = 0; k < nlayers && e == hipSuccess; ++k) {
+            WinoParams p = q;
+            p.src = src[k]; p.u = u_packed[k]; p.scale = scale[k]; p.shift = shift[k]; p.residual = residual[k]; p.out = out[k]; p.relu = relu[k];
+            e = launch_wino(p, 1, s);
+        }
+    } else {
+        WinoChainParams pc{};
+        pc.c = q;
+        pc.arrive = arrive; pc.fail = arrive + narr;
+        auto fill = [&](int slot, int k) {
+            WinoChainLayer &l = pc.L[slot];
+            l.src = src[k]; l.u = u_packed[k]; l.scale = scale[k]; l.shift = shift[k]; l.residual = residual[k]; l.out = out[k]; l.relu = relu[k];
+        };
+        if (mode == 1) {
+            pc.nlayers = nlayers;
+            for (int k = 0; k < nlayers; ++k) fill(k, k);
+            if (!wino_chain_supported(pc)) return fail(LSPF2F_ERR_UNSUPPORTED, "wino_chain: layer k must read layer k - 1's output, and no output may alias another tensor of the chain");
+            e = launch_wino_chain(pc, s);
+        } else {
+            pc.nlayers = 1;
+            for (int k = 0; k < nlayers && e == hipSuccess; ++k) { fill(0, k); e = launch_wino_chain(pc, s); }
+        }
+    }
+    if (e != hipSuccess) return hipfail(e, "lspf2f_wino_chain launch");
+    return LSPF2F_OK;
+}
+
 }  // extern "C"

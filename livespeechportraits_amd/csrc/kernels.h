@@ -136,6 +136,33 @@ struct WinoParams {
 };
 bool wino_supported(const WinoParams &p, int nb);
 hipError_t launch_wino(const WinoParams &p, int nb, hipStream_t s);
+
+// Round 6: 2..4 consecutive wino3x3<1> layers of ONE shape (the convs of one or two ResidualBlocks, models/networks.py:650-675) as ONE launch of
+// nlayers x (workgroups of a layer) workgroups: blockIdx / wgs = the layer.  A workgroup of layer k > 0 requests its weights, then waits on the arrival
+// counters of the <= 9 tile-blocks of layer k - 1 its raw patch reads (wino.hip, wino3x3_chain).  Same arithmetic in the same order as nlayers launches
+// of wino3x3<1>: bit-identical.  The layers must not alias each other's outputs (a buffer is written once per launch).
+static const int kWinoChainMax = 4;
+static const int kWinoArriveStride = 32;      // 32-bit words between two gate counters (one per 128-byte line)
+struct WinoChainLayer {
+    const float *src, *u, *scale, *shift, *residual;
+    float *out;
+    int relu;
+    int res_fresh;                // the residual was written by an earlier layer of THIS launch (read behind the gate, past the L1)
+};
+struct WinoChainParams {
+    WinoParams c;                 // the shared shape: B, H, W, C, N, splits, partial, tile_cnt, prio (src / u / scale / shift / residual / out / relu unused)
+    WinoChainLayer L[kWinoChainMax];
+    int nlayers;
+    unsigned *arrive;             // [nlayers - 1][ntb][kWinoArriveStride] arrival counters (word 0 of each line), zero between launches: += 1 per finished (tile-block, channel group) of layer k, then += 1 per
+                                  // workgroup of layer k + 1 that has read it; the last reader resets it
+    unsigned *fail;               // one word, |= 1 when a gate gave up (spin_limit polls): the launch then finishes with garbage instead of hanging
+    unsigned spin_limit;
+    // filled by launch_wino_chain
+    int wgs;                      // workgroups per layer
+    FastDiv div_wgs;
+};
+bool wino_chain_supported(const WinoChainParams &p);
+hipError_t launch_wino_chain(const WinoChainParams &p, hipStream_t s);
 void pack_wino_weights(const float *oihw, int cin, int cout, float *out);   // host: OIHW [cout][cin][3][3] -> [cout/32][4][cin/8][4][64][4]
 
 // Winograd F(4x4, 3x3) form of the same conv (wino4.hip): H % 16 == 0, W % 32 == 0, C % 8 == 0, N % 32 == 0.  A workgroup owns 4 x 8 tiles of

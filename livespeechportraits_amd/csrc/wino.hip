@@ -61,7 +61,7 @@ __host__ __device__ constexpr int wino_stats_base(int nb, int ns, bool ur = fals
 // The copies of one wave: two raw-patch pieces per K-step by LDS-DMA, and its own U fragments -- by LDS-DMA into its slice of the U ring, or (UR form,
 // one channel block per wave) by plain loads into registers.  Built once in the kernel: the first step(s) are requested BEFORE the epilogue operands'
 // address arithmetic, which then runs under their latency instead of ahead of it.
-template <int NB, int NS, bool UR>
+template <int NB, int NS, bool UR, bool SC1 = false>      // SC1: the raw patch is read past the L1 (wino3x3_chain: other workgroups of the launch wrote it)
 struct WinoCopy {
     static constexpr int USTAGE = wino_u_stage(NB);
     static constexpr int RAWB = UR ? 0 : wino_raw_base(NB, NS);
@@ -80,7 +80,8 @@ struct WinoCopy {
     }
     __device__ __forceinline__ void raw(int ks, int slot) const
     {
-        dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
+        if constexpr (SC1) dma16_two_sc1(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
+        else dma16_two(lds_r0 + (unsigned)(slot * kRawStage), wave < 2 ? lds_r1 + (unsigned)(slot * kRawStage) : lds_r1, vraw0, vraw1, srd_src, ks * 32);
     }
     // the wave's four j fragments of one channel block: consecutive 1-KB pieces in memory and in LDS (dma16_group advances M0; the per-piece
     // voffsets are registers rather than instruction offsets, which the LDS-DMA form would also add to the LDS address)
@@ -245,9 +246,16 @@ __device__ __forceinline__ void wino_loop(const WinoCopy<NB, NS, false> &cp, con
 
 // NS = register sets = ring slots of the raw patch = how far ahead a step's operands are requested (NS - 1 steps): 3 is the shipped form, 4 (tune key
 // `wino_ureg=2`, 16 more registers) an A-B arm of round 5 for the waves whose loads take longer than two steps.
-template <int ROW, int EPL, int NS, class EpiLoads>
-__device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][1], const char *smem_c, int lane,
-                                             int ks_begin, int ks_end, unsigned long long *first_landed, int prio_mode)
+// Gate (wino3x3_chain): what stands between a workgroup's weight requests and its first raw-patch request.  NoGate = the plain kernel.
+struct NoGate {
+    static constexpr bool active = false;
+    static constexpr int LPL = 0;
+    __device__ __forceinline__ void wait() const {}
+    __device__ __forceinline__ void late_loads() const {}
+};
+template <int ROW, int EPL, int NS, class EpiLoads, bool SC1 = false, class Gate = NoGate>
+__device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true, SC1> &cp, const EpiLoads &epi_loads, f32x16 (&acc)[4][1], const char *smem_c, int lane,
+                                             int ks_begin, int ks_end, unsigned long long *first_landed, int prio_mode, const Gate &gate = Gate())
 {
     static_assert(NS == 3 || NS == 4, "register sets");
     constexpr int RA = ROW == 0 ? 0 : 1, RB = ROW == 3 ? 3 : 2;
@@ -271,6 +279,20 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, co
         for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(ur[a][j]));      // "defined" without an instruction: no write may trail the first load
     // steps 0 .. NS - 2 requested first; behind them the kernel's EPL epilogue-operand loads (see wino_loop)
     const int nsteps = ks_end - ks_begin;
+    if constexpr (Gate::active) {
+        // chain form: everything that does NOT depend on the previous layer of the launch goes out first (the U fragments of steps 0 and 1, scale / shift), then the
+        // gate (arrival counters of the tile-blocks the raw patch reads; ends on a barrier), then the raw patch and the operands that may be fresh (LPL loads)
+        static_assert(NS == 3, "the chain form has three register sets");
+        cp.template ureg2<0>(ur[0], ks_begin); cp.template ureg2<1>(ur[0], ks_begin);
+        if (nsteps > 1) { cp.template ureg2<0>(ur[1], ks_begin + 1); cp.template ureg2<1>(ur[1], ks_begin + 1); }
+        epi_loads();
+        gate.wait();
+        cp.raw(ks_begin, 0);
+        if (nsteps > 1) cp.raw(ks_begin + 1, 1);
+        gate.late_loads();
+        if (nsteps > 1) dma_wait<2 + Gate::LPL>(); else dma_wait<Gate::LPL>();
+        __syncthreads();
+    } else {
     cp.raw(ks_begin, 0);
     cp.template ureg2<0>(ur[0], ks_begin); cp.template ureg2<1>(ur[0], ks_begin);
     if (nsteps > 1) {
@@ -287,6 +309,7 @@ __device__ __forceinline__ void wino_loop_ur(const WinoCopy<1, NS, true> &cp, co
     // step 0 has landed when only the younger loads can be outstanding: 6 per further requested step + the epilogue operands
     if (NS == 4 && nsteps > 2) dma_wait<12 + EPL>(); else if (nsteps > 1) dma_wait<6 + EPL>(); else dma_wait<EPL>();
     __syncthreads();
+    }
 #ifdef LSPF2F_WINO_STAMPS
     *first_landed = __builtin_amdgcn_s_memtime();
 #endif
@@ -637,6 +660,292 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
     WSTAMP_FLUSH;
 }
 
+
+// ---- Round 6: 2..4 consecutive wino3x3<1> layers of one shape in ONE launch (the convs of one or two ResidualBlocks, models/networks.py:650-675: conv -> BN -> ReLU ->
+// conv -> BN -> += x -> ReLU).  At one frame every such layer is ONE round of 512 workgroups and a dependent kernel boundary: ~10 000 of a launch's ~57 500 cycles pass
+// outside any wave's lifetime, the prologue and the first landing (~4 000) overlap nothing.  Here the grid is nlayers x 512 workgroups; blockIdx / 512 is
+// the layer.  A workgroup of layer k > 0 takes the slot a finished workgroup of layer k - 1 leaves, requests its U fragments and scale / shift (which depend on nothing),
+// then polls the arrival counters of the <= 9 tile-blocks of layer k - 1 its 10 x 18 raw patch reads (one wave, one relaxed sc1 load per lane and counter, s_sleep between
+// polls), then requests the patch with sc1 LDS-DMA loads -- the producers stored write-through (sc1) and drained (vmcnt(0) + barrier) before their one counter increment:
+// the guide's "16-B sc1 stores AND sc1 loads" hand-off, no fence on either side.  Arithmetic and summation order are those of wino3x3<1, 3, .., UR, WT>: bit-identical.
+//
+// Progress (why a gate cannot wait for ever): the dispatcher hands out blocks in blockIdx order per XCD, so when a workgroup of layer k runs, every workgroup of a lower
+// layer on its XCD's queue has been dispatched; the lowest unfinished layer m has nothing to wait for (its producers are finished), so its resident workgroups finish and
+// free the slots its remaining ones need -- by induction every layer finishes, whatever else shares the chip.  HIP does not promise that order, so every gate is also bounded:
+// after spin_limit polls it sets *fail and goes on (garbage out, never a hang); hosts that run the chain check the word in their tests.
+// Counters: arrive[k][tb] += 1 per finished (tile-block tb, channel group) of layer k (split-K: by the last arriver, after its combine), so "ready" is >= nng; every
+// workgroup of layer k + 1 that read it adds 1 on its way out and the last of them (the counter then reads nng + readers(tb)) stores 0: zero between launches, like tile_cnt.
+// A buffer is written at most once per launch (the host keeps the chain's tensors apart), so no L2 can hold an older copy of a line a gate has released.
+struct ChainGate {
+    static constexpr bool active = true;
+    static constexpr int kArriveStride = kWinoArriveStride;     // one counter per 128-byte line: 512 pollers on 8 adjacent words were one memory channel's queue
+    static constexpr int LPL = 4;                               // the residual's four pixels, requested behind the gate
+    const unsigned *cnt;                                        // arrive[layer - 1] + (frame's first tile-block), nullptr for layer 0
+    unsigned *fail;
+    int by, bx, tby, tbx, wave, lane;
+    unsigned target, limit;
+    __amdgpu_buffer_rsrc_t rs_res;
+    unsigned res_off[4];
+    float4 *rpre;
+    __device__ __forceinline__ bool neighbour(int &t) const      // lane l < 9 looks at tile-block (by + l / 3 - 1, bx + l % 3 - 1)
+    {
+        const int dy = lane / 3 - 1, dx = lane - (lane / 3) * 3 - 1;
+        const int ny = by + dy, nx = bx + dx;
+        const bool ok = lane < 9 && (unsigned)ny < (unsigned)tby && (unsigned)nx < (unsigned)tbx;
+        t = ok ? ny * tbx + nx : by * tbx + bx;
+        return ok;
+    }
+    __device__ __forceinline__ void wait() const
+    {
+        if (cnt) {
+            if (wave == 0) {
+                int t;
+                bool pending = neighbour(t);                     // a lane stops polling the moment ITS counter is ready: the last polls touch one line, not nine
+                const unsigned *c = cnt + (size_t)t * kArriveStride;
+                unsigned spins = 0;
+                for (;;) {
+                    if (pending && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) pending = false;
+                    if (!__any(pending)) break;
+                    if (++spins > limit) { if (lane == 0) __hip_atomic_fetch_or(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (spins < 4) __builtin_amdgcn_s_sleep(2); else if (spins < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __device__ __forceinline__ void late_loads() const          // always LPL loads (zero-range descriptor when the layer has no residual): the waits count them
+    {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) rpre[ab] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off[ab], 0, 16));
+    }
+    // on the way out: this workgroup has read its <= 9 counters' tile-blocks; the last reader of a counter resets it
+    __device__ __forceinline__ void release(int nng, int splits) const
+    {
+        if (cnt && wave == 0) {
+            int t;
+            const bool ok = neighbour(t);
+            if (ok) {
+                const int dy = lane / 3 - 1, dx = lane - (lane / 3) * 3 - 1;
+                const int ny = by + dy, nx = bx + dx;
+                const unsigned readers = (unsigned)((1 + (ny > 0) + (ny < tby - 1)) * (1 + (nx > 0) + (nx < tbx - 1)) * nng * splits);
+                unsigned *c = const_cast<unsigned *>(cnt) + (size_t)t * kArriveStride;
+                const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == target + readers - 1u) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
+
+__global__ __launch_bounds__(256, 2) void wino3x3_chain(const WinoChainParams pc)
+{
+    constexpr int NB = 1, NS = 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_float *)smem;
+    const char *smem_c = reinterpret_cast<const char *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WinoParams &p = pc.c;
+    WSTAMP_DECL;
+    WSTAMP(0);
+    // the layer: blockIdx order IS the dispatch order, which the progress argument above leans on -- so the layer comes from blockIdx itself, the XCD-aware
+    // renumbering below only moves a workgroup inside its layer (wgs % 8 == 0: block b of the launch and block b % wgs of its layer sit on the same XCD)
+    const int layer = (int)pc.div_wgs.div(blockIdx.x);
+    const WinoChainLayer &L = pc.L[layer];
+    const float *const l_src = L.src, *const l_u = L.u, *const l_scale = L.scale, *const l_shift = L.shift, *const l_res = L.residual;
+    float *const l_out = L.out;
+    const int l_relu = L.relu;
+    const bool publish = layer + 1 < pc.nlayers;
+
+    unsigned lin = blockIdx.x - (unsigned)layer * (unsigned)pc.wgs;
+    if (p.xcd) {
+        const unsigned total = (unsigned)pc.wgs, qq = total >> 3, rr = total & 7, x = lin & 7;
+        lin = x * qq + (x < rr ? x : rr) + (lin >> 3);
+    }
+    const int z = (int)p.div_plane.div(lin);
+    const unsigned rem = lin - (unsigned)z * (unsigned)(p.ntb * p.nng);
+    int tb, ng;
+    if (p.nmajor) { ng = (int)p.div_fast.div(rem); tb = (int)rem - ng * p.ntb; }
+    else { tb = (int)p.div_fast.div(rem); ng = (int)rem - tb * p.nng; }
+    const int b = (int)p.div_tbf.div((unsigned)tb);
+    const int tbi = tb - b * (p.tby * p.tbx);
+    const int by = (int)p.div_tbx.div((unsigned)tbi), bx = tbi - by * p.tbx;
+    const int Y0 = by * 8, X0 = bx * 16;
+    const int n0 = ng * 32;
+    const int S = p.C >> 3;
+    const int ks_begin = z * p.steps_per_split;
+    int ks_end = ks_begin + p.steps_per_split;
+    if (ks_end > S) ks_end = S;
+
+    unsigned vraw[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int ci = (wave + 4 * k) * 64 + lane;
+        const int par = ci / 90, rem2 = ci - par * 90, qd = rem2 / 45, r2 = rem2 - qd * 45, hy = r2 / 9, hx = r2 - hy * 9;
+        const int y = Y0 - 1 + 2 * hy + (par >> 1), x = X0 - 1 + 2 * hx + (par & 1);
+        const bool ok = ci < 360 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        vraw[k] = ok ? ((unsigned)((b * p.H + y) * p.W + x) * (unsigned)p.C + (unsigned)(qd * 4)) * 4u : kOOBw;
+    }
+    const i32x4 srd_src = make_srd(l_src, (unsigned)(p.B * p.H * p.W) * (unsigned)p.C * 4u);
+    const i32x4 srd_u = make_srd(l_u, 16u * (unsigned)p.C * (unsigned)p.N * 4u);
+    const unsigned soff_nb = 4u * (unsigned)S * 4096u;
+    const unsigned soff_u0 = (unsigned)((n0 >> 5) * 4 + wave) * (unsigned)S * 4096u;
+
+    constexpr int EPL = 2;                                         // scale, shift (ahead of the gate); the residual follows it (ChainGate::LPL)
+    WinoCopy<NB, NS, true, true> cp;
+    cp.init(lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb);
+
+    const int trow = tid >> 3, cq = (tid & 7) * 4;
+    const int oy = Y0 + 2 * (trow >> 3), ox = X0 + 2 * (trow & 7);
+    const bool pre = p.splits == 1;
+    const bool pre_sc = pre && l_scale != nullptr, pre_res = pre && l_res != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_scale = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(l_scale), 0, pre_sc ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_shift = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(l_shift), 0, pre_sc ? p.N * 4 : 0, 0x00020000);
+    const int nres_bytes = (int)((unsigned)(p.B * p.H * p.W) * (unsigned)p.N * 4u);
+    float4 scv, shv, rpre[4];
+    const int n = n0 + cq;
+    auto epi_loads = [&]() {
+        scv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_scale, (unsigned)n * 4u, 0, 0));
+        shv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_shift, (unsigned)n * 4u, 0, 0));
+    };
+    ChainGate gate;
+    gate.cnt = layer > 0 ? pc.arrive + ((size_t)(layer - 1) * (size_t)p.ntb + (size_t)b * (size_t)(p.tby * p.tbx)) * kWinoArriveStride : nullptr;
+    gate.fail = pc.fail; gate.by = by; gate.bx = bx; gate.tby = p.tby; gate.tbx = p.tbx; gate.wave = wave; gate.lane = lane;
+    gate.target = (unsigned)p.nng; gate.limit = pc.spin_limit;
+    gate.rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(l_res), 0, pre_res ? nres_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+        const unsigned pix = (unsigned)((b * p.H + oy + (ab >> 1)) * p.W + ox + (ab & 1));
+        gate.res_off[ab] = (pix * (unsigned)p.N + (unsigned)n) * 4u;
+    }
+    gate.rpre = rpre;
+    WSTAMP(1);
+#ifdef LSPF2F_WINO_STAMPS
+    unsigned long long *fl = &stamp_t[2];
+#else
+    unsigned long long *fl = nullptr;
+#endif
+
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][0][e] = 0.f;
+
+    switch (wave) {
+    case 0: wino_loop_ur<0, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio, gate); break;
+    case 1: wino_loop_ur<1, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio, gate); break;
+    case 2: wino_loop_ur<2, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio, gate); break;
+    default: wino_loop_ur<3, EPL, NS>(cp, epi_loads, acc, smem_c, lane, ks_begin, ks_end, fl, p.prio >= 4 ? p.prio - 3 : p.prio, gate); break;
+    }
+    WSTAMP(3);
+
+    // ---- output transform: as in wino3x3
+    constexpr int EP = 36;
+    {
+        const int ccol = lane & 31, crow = 4 * (lane >> 5);
+        float *pz0 = smem + ((wave * 2 + 0) * NB) * (32 * EP);
+        float *pz1 = smem + ((wave * 2 + 1) * NB) * (32 * EP);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + crow;
+            pz0[row * EP + ccol] = (acc[0][0][e] + acc[1][0][e]) + acc[2][0][e];
+            pz1[row * EP + ccol] = (acc[1][0][e] - acc[2][0][e]) - acc[3][0][e];
+        }
+    }
+    __syncthreads();
+    WSTAMP(4);
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.splits > 1 ? (int)p.slab_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(l_out, 0, nres_bytes, 0x00020000);
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    {
+        float4 zz[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+                zz[i][bb] = *reinterpret_cast<const float4 *>(smem + ((i * 2 + bb) * NB) * (32 * EP) + trow * EP + cq);
+        float4 sc = scv, sh = shv;
+        if (!pre_sc) { sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                float4 v = a == 0 ? f4add(f4add(zz[0][bb], zz[1][bb]), zz[2][bb]) : f4sub(f4sub(zz[1][bb], zz[2][bb]), zz[3][bb]);
+                const size_t pix = ((size_t)b * p.H + (size_t)(oy + a)) * p.W + (size_t)(ox + bb);
+                const size_t e = pix * p.N + n;
+                if (p.splits > 1) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab_rsrc, (unsigned)(((size_t)z * npix * p.N + e) * 4), 0, 16);
+                } else {
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    const float4 rv = rpre[a * 2 + bb];                 // zeros when the layer has no residual
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    if (l_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (unsigned)(e * 4), 0, 16);
+                }
+            }
+    }
+    WSTAMP(5);
+    // every wave's stores have left the chip before the counter says so (write-through + drained: nothing sits dirty in this XCD's L2)
+    auto arrive = [&]() {
+        if (publish) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) (void)__hip_atomic_fetch_add(pc.arrive + ((size_t)layer * (size_t)p.ntb + (size_t)tb) * kWinoArriveStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (p.splits == 1) { arrive(); gate.release(p.nng, p.splits); WSTAMP_FLUSH; return; }
+
+    // ---- split-K combine inside the launch: the protocol of wino3x3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float4 sc2 = make_float4(1.f, 1.f, 1.f, 1.f), sh2 = make_float4(0.f, 0.f, 0.f, 0.f), rv2[4];
+    if (l_scale) {
+        sc2 = *reinterpret_cast<const float4 *>(l_scale + n);
+        sh2 = *reinterpret_cast<const float4 *>(l_shift + n);
+    }
+    const __amdgpu_buffer_rsrc_t rs_res2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(l_res), 0, l_res ? nres_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) rv2[ab] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res2, gate.res_off[ab], 0, 16));
+    unsigned *flag = reinterpret_cast<unsigned *>(smem);
+    const unsigned tile = (unsigned)(tb * p.nng + ng);
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tile_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    WSTAMP(6);
+    if (flag[0] != (unsigned)p.splits - 1u) { gate.release(p.nng, p.splits); WSTAMP_FLUSH; return; }
+    if (tid == 0) __hip_atomic_store(p.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        float4 tsl[4][8];
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const size_t pix = ((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1));
+            const size_t e = pix * p.N + n;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl)
+                if (sl < p.splits)
+                    tsl[ab][sl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, (unsigned)(((size_t)sl * npix * p.N + e) * 4), 0, 16));
+        }
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const size_t pix = ((size_t)b * p.H + (size_t)(oy + (ab >> 1))) * p.W + (size_t)(ox + (ab & 1));
+            const size_t e = pix * p.N + n;
+            float4 v = tsl[ab][0];
+#pragma unroll
+            for (int sl = 1; sl < 8; ++sl)
+                if (sl < p.splits) { v.x += tsl[ab][sl].x; v.y += tsl[ab][sl].y; v.z += tsl[ab][sl].z; v.w += tsl[ab][sl].w; }
+            v.x = v.x * sc2.x + sh2.x; v.y = v.y * sc2.y + sh2.y; v.z = v.z * sc2.z + sh2.z; v.w = v.w * sc2.w + sh2.w;
+            const float4 rv = rv2[ab];
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            if (l_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (unsigned)(e * 4), 0, 16);
+        }
+    }
+    arrive();
+    gate.release(p.nng, p.splits);
+    WSTAMP(7);
+    WSTAMP_FLUSH;
+}
+
 bool wino_supported(const WinoParams &p, int nb)
 {
     if (nb != 1 && nb != 2) return false;
@@ -696,6 +1005,55 @@ hipError_t launch_wino(const WinoParams &p_in, int nb, hipStream_t s)
     if (nb == 1 && p.ureg == 2) return launch_wino_t<1, 4, true, true, true>(p, s);       // four register sets (A-B arm)
     if (nb == 1 && p.ureg) return launch_wino_t<1, 3, true, true, true>(p, s);
     return nb == 2 ? launch_wino_t<2, 2, true, true>(p, s) : launch_wino_t<1, 3, true, true>(p, s);
+}
+
+bool wino_chain_supported(const WinoChainParams &pc)
+{
+    if (pc.nlayers < 1 || pc.nlayers > kWinoChainMax || !pc.arrive || !pc.fail) return false;
+    if (!wino_supported(pc.c, 1)) return false;
+    for (int k = 0; k < pc.nlayers; ++k) {
+        const WinoChainLayer &l = pc.L[k];
+        if (!l.src || !l.u || !l.out || ((l.scale == nullptr) != (l.shift == nullptr))) return false;
+        // a buffer is written once per launch, and nothing a later layer writes may be something an earlier one still reads through a cache
+        for (int j = 0; j < pc.nlayers; ++j) {
+            if (j != k && pc.L[j].out == l.out) return false;
+            if (j <= k && (pc.L[j].src == l.out || pc.L[j].residual == l.out)) return false;
+        }
+    }
+    for (int k = 1; k < pc.nlayers; ++k)
+        if (pc.L[k].src != pc.L[k - 1].out) return false;          // the gate orders exactly this edge (and, through it, every older one)
+    return true;
+}
+
+hipError_t launch_wino_chain(const WinoChainParams &pc_in, hipStream_t s)
+{
+    if (!wino_chain_supported(pc_in)) return hipErrorInvalidValue;
+    WinoChainParams pc = pc_in;
+    WinoParams &p = pc.c;
+    const int S = p.C / 8;
+    p.steps_per_split = (S + p.splits - 1) / p.splits;
+    if ((p.splits - 1) * p.steps_per_split >= S) return hipErrorInvalidValue;
+    p.tby = p.H / 8; p.tbx = p.W / 16;
+    p.ntb = p.B * p.tby * p.tbx;
+    p.nng = p.N / 32;
+    if (p.splits > 1) p.slab_bytes = (size_t)p.splits * p.B * p.H * p.W * p.N * 4;
+    const size_t act = (size_t)p.B * p.H * p.W * p.C * 4, wgt = (size_t)16 * p.C * p.N * 4;
+    p.nmajor = wgt > act ? 1 : 0;
+    p.xcd = 1;
+    if (p.xcd_force == 1) p.xcd = 0;
+    if (p.xcd_force == 2) p.nmajor = 0;
+    if (p.xcd_force == 3) p.nmajor = 1;
+    p.div_plane = FastDiv::make((unsigned)(p.ntb * p.nng));
+    p.div_fast = FastDiv::make((unsigned)(p.nmajor ? p.ntb : p.nng));
+    p.div_tbf = FastDiv::make((unsigned)(p.tby * p.tbx));
+    p.div_tbx = FastDiv::make((unsigned)p.tbx);
+    pc.wgs = p.ntb * p.nng * p.splits;
+    pc.div_wgs = FastDiv::make((unsigned)pc.wgs);
+    if (!pc.spin_limit) pc.spin_limit = 1u << 18;
+    if ((size_t)pc.wgs * (size_t)pc.nlayers > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr int smem = wino_lds_bytes(1, 3, true);
+    hipLaunchKernelGGL(wino3x3_chain, dim3((unsigned)(pc.wgs * pc.nlayers)), dim3(256), smem, s, pc);
+    return hipGetLastError();
 }
 
 // Host: OIHW [N][C][3][3] -> U = G g G^T (double, rounded once) in the MFMA fragment order [n-block N/32][xi-row 4][k-step C/8][j 4][lane 64][4]:

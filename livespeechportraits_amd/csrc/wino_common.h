@@ -14,6 +14,17 @@ __device__ __forceinline__ void dma16_two(unsigned lds_a, unsigned lds_b, unsign
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_a), "s"(lds_b), "v"(va), "v"(vb), "s"(srd), "s"(soff) : "memory");
 }
+// the same with sc1 (past the L1, served by L2): what a workgroup reads of a tensor that OTHER workgroups of the same launch have just written through
+// (wino3x3_chain; the guide's "16-B sc1 stores AND sc1 loads" hand-off form)
+__device__ __forceinline__ void dma16_two_sc1(unsigned lds_a, unsigned lds_b, unsigned va, unsigned vb, i32x4 srd, int soff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %3, %5, %6 offen sc1 lds\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %4, %5, %6 offen sc1 lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_a), "s"(lds_b), "v"(va), "v"(vb), "s"(srd), "s"(soff) : "memory");
+}
 // One U fragment (the B operand of 4 MFMAs: 16 bytes per lane) by a plain load into registers -- the UR form of the K loop (wino.hip).
 // Inline asm like the LDS-DMA copies: the compiler does not see those, so its own vmcnt arithmetic would over-wait; the kernel counts.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
