@@ -339,6 +339,20 @@ def main():
 
     extra = None
     if not a.no_extra and world == 1 and B == 1:
+        extra = {}
+
+        def guard(key, fn, *args):
+            """an informational probe must never cost the headline line that is already measured: its failure is recorded in its own slot"""
+            try:
+                extra[key] = fn(*args)
+            except Exception as ex:                      # noqa: BLE001
+                extra[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:                        # noqa: BLE001
+                    pass
+    if extra is not None:
+      try:
         # throughput configuration (BASELINE.json configs[3] shape: 8 frames per GPU, shared candidates)
         f8 = torch.from_numpy(synth.make_inputs(8, a.size, seed=99, cand_batch=1)[0]).to(dev)
         o8 = torch.empty((8, 3, a.size, a.size), device=dev)
@@ -351,8 +365,8 @@ def main():
             eng.forward(f8, cand, o8)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        extra = {"batch8_frames_per_s": round(8 * n8 / dt, 2),
-                 "batch8_tflops": round(topo.flops_per_frame() * 8 * n8 / dt / 1e12, 2)}
+        extra.update({"batch8_frames_per_s": round(8 * n8 / dt, 2),
+                      "batch8_tflops": round(topo.flops_per_frame() * 8 * n8 / dt / 1e12, 2)})
         # PCIe-inclusive rate of a demo.py-style loop (never `value`): per frame, H2D of a host feature map
         # (1 MiB, pinned), forward with fused tensor2im, D2H of the uint8 frame (0.75 MiB), synchronised
         hfeat = torch.from_numpy(feat_np).pin_memory()
@@ -402,15 +416,31 @@ def main():
         extra["edge_map_rasteriser"] = {"us_per_frame_batch8": round(e0.elapsed_time(e1) * 1e3 / 160, 2),
                                         "hbm_frac_of_8TBs": round(8 * a.size * a.size * 4 / (e0.elapsed_time(e1) * 1e-3 / 20) / 8e12, 4),
                                         "note": "lspraster_edge_maps: 88 thick edges per frame -> fp32 [8,1,512,512]; parity unpinned vs cv2 (bit-exact to oracle/raster_oracle.c)"}
-        extra["torch_rocm_baseline"] = torch_rocm_extra(dev, sd, topo, feat_np, cand_np, a)
-        extra["config2_normal_b8_bf16"] = config2_extra(dev, a)
-        extra["small_unet_native_plan"] = small_unet_extra(dev, a)
-        extra["concurrent_batch1_forwards"] = concurrent_extra(dev, eng, a)
-        extra["render_loop_end_to_end"] = render_loop_extra(dev, sd, a)
-        extra["headpose"] = headpose_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
-        extra["manifold_projection"] = manifold_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
-        extra["audio_recurrent"] = recurrent_extra(dev, None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8))
-        extra["pipeline_gpu_stages_plumbing_only"] = pipeline_extra(dev, eng, cand)
+      except Exception as ex:                            # noqa: BLE001
+        extra["inline_probes_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+      cores = None if a.no_cpu_baseline else (cpu_baseline or {}).get("cores", 8)
+      guard("torch_rocm_baseline", torch_rocm_extra, dev, sd, topo, feat_np, cand_np, a)
+      guard("small_unet_native_plan", small_unet_extra, dev, a)
+      guard("concurrent_batch1_forwards", concurrent_extra, dev, eng, a)
+      guard("render_loop_end_to_end", render_loop_extra, dev, sd, a)
+      guard("headpose", headpose_extra, dev, cores)
+      guard("manifold_projection", manifold_extra, dev, cores)
+      guard("audio_recurrent", recurrent_extra, dev, cores)
+      guard("pipeline_gpu_stages_plumbing_only", pipeline_extra, dev, eng, cand)
+      # BASELINE.json configs[2] LAST and compact: the driver keeps only the tail of this line; the per-frame detail sits in its own key ahead of it
+      guard("config2_detail", config2_extra, dev, a)
+      c2 = extra.get("config2_detail") or {}
+      if "error" in c2:
+          extra["config2_normal_b8_bf16"] = c2
+      else:
+          vo = c2.get("vs_fp32_oracle") or {}
+          extra["config2_normal_b8_bf16"] = {
+              "frames_per_s": c2.get("frames_per_s"), "ms_per_step": c2.get("ms_per_step"), "steps": c2.get("steps"), "dtype": "bf16", "batch": 8,
+              "executed_frac_of_dense_bf16_peak": c2.get("whole_forward_frac_of_dense_bf16_peak"),
+              "algorithmic_frac_of_dense_bf16_peak": c2.get("whole_forward_algorithmic_frac_of_dense_bf16_peak"),
+              "dominant_class": c2.get("dominant_class"),
+              "max_abs_vs_fp32_oracle": max(vo.get("max_abs_per_frame") or [float("nan")]), "mean_abs_vs_fp32_oracle": max(vo.get("mean_abs_per_frame") or [float("nan")]),
+              "declared_tolerance": "1e-2 max / 2.5e-3 mean per frame (parity-unpinned: the reference has no bf16 path)"}
 
     line = {
         "metric": "512x512 frames/sec (Feature2FaceGenerator fwd)", "value": round(fps, 3), "unit": "frames/s",
@@ -620,6 +650,24 @@ def config2_extra(dev, a):
         r["vs_fp32_oracle"] = {"max_abs_per_frame": [round(float(v), 6) for v in d.max(1).values],
                                "mean_abs_per_frame": [round(float(v), 6) for v in d.mean(1)],
                                "note": "parity-unpinned by construction (the reference has only fp16 autocast); tests/test_gpu_plans.py declares 1e-2 max / 2.5e-3 mean per frame for this variant"}
+    # the plan's dominant kernel class, replayed from its own graph like the headline's roofline rows (lspf2f_subset_timed)
+    layers = eng.layers(8)
+    groups = {}
+    for i, l in enumerate(layers):
+        k = l["kernel"]
+        groups.setdefault("igemm3x3<%dx%d>" % (l["tile_m"], l["tile_n"]) if k.startswith("igemm3x3") else k.split(" ")[0], []).append(i)
+    best = None
+    for name, idxs in groups.items():
+        sel = [0] * len(layers)
+        for i in idxs:
+            sel[i] = 1 if name.startswith("igemm3x3") else 3
+        ms = eng.subset_timed(feat, cand, sel, out, reps=10)
+        if best is None or ms > best[1]:
+            best = (name, ms, idxs)
+    name, ms, idxs = best
+    ex = sum(layers[i]["exec_flops_per_frame"] for i in idxs) * 8
+    r["dominant_class"] = {"kernel": name, "launches": len(idxs), "ms": round(ms, 4), "us_per_launch": round(1e3 * ms / len(idxs), 2),
+                           "executed_frac_of_dense_bf16_peak": round(ex / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
     eng.close()
     return r
 

@@ -112,8 +112,8 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
  * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, rowup (1), rowlast (1), rowlast_fused (1: rowlast128 shuffles + applies tanh in its epilogue when only fp32 frames are wanted), rowconv (1): kernels of the 16-bit plans |
  * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), fused_splitk16 (0: the 16-bit plans combine 2..8 K-splits in the launch too), out_wt (1: the Winograd kernels write their output through to memory, sc1 stores; 0: plain stores, left dirty in L2), prefetch (1), smallm_dma (1: the tiny-M kernel stages its input tensor by LDS-DMA, every piece in flight at once; 0: through registers), smallm_kb (128: largest input tensor, in KB, the tiny-M kernel takes; 64 = rounds 2-4) |
  * fullk16 (3: which small levels of a 16-bit plan run on conv3x3_fullk16 -- bit 0 the 4x4 / 2x2 levels, bit 1 the stride-2 / upsampling convs that write 8x8, bit 2 the stride-1 8x8 layers; 0 = none), fullk16_min_frames (2) |
- * wino_chain (0: one launch per layer; N = 2..4: up to N consecutive wino3x3<1> layers of one shape -- the convs of one or two ResidualBlocks -- run as ONE launch whose workgroups are gated on
- * per-tile-block arrival counters, wino3x3_chain; bit-identical) |
+ * in_small_max_hw (1024: InstanceNorm plans take the one-launch statistics route up to this many pixels per frame), all_forms (0; 1: the packed blob carries every weight form whatever the
+ * handle's batch range -- tests that look at forms other batches would use), blob_pad_kb (0: empty KB in front of the first layer's weights, placement experiments) |
  * lastconv (0 = by shape; 1..5 force a last-conv kernel), lastconv_direct (0), firstconv (0 = by shape; 1, 2 force a first-conv kernel). */
 int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handle **out);
 int lspf2f_destroy(lspf2f_handle *h);

@@ -1229,7 +1229,7 @@ int lspf2f_wino_chain(int nlayers, const float *const *src, const float *const *
 {
     if (nlayers < 1 || nlayers > kWinoChainMax) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "wino_chain: 1..4 layers");
     if (!src || !u_packed || !scale || !shift || !residual || !out || !relu) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "null argument");
-    if (mode < 0 || mode > 2) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "wino_chain: mode 0 (one launch per layer), 1 (one launch), 2 (one one-layer chain launch per layer)");
+    if (mode < 0 || mode > 4) return fail(LSPF2F_ERR_INVALID_ARGUMENT, "wino_chain: mode 0 (one launch per layer), 1 (one launch), 2 (one one-layer chain launch per layer), 3 (one launch, sc1 loads), 4 (one launch, plain loads and NO acquire: measurements only)");
     const int sp = split_k > 0 ? split_k : 1;
     size_t slab, ncnt, narr;
     wino_chain_scratch_layout(nlayers, batch, hs, c, sp, &slab, &ncnt, &narr);
@@ -1254,11 +1254,19 @@ int lspf2f_wino_chain(int nlayers, const float *const *src, const float *const *
         WinoChainParams pc{};
         pc.c = q;
         pc.arrive = arrive; pc.fail = arrive + narr;
+#ifdef LSPF2F_WINO_STAMPS
+        {   // stamps live behind the counters when the caller's scratch has room for them: [blocks][4 waves][8]
+            const size_t used = (slab + (ncnt + narr + 1) * sizeof(unsigned) + 255) / 256 * 256;
+            const size_t blocks = (size_t)nlayers * batch * (hs / 8) * (hs / 16) * (c / 32) * sp;
+            if (scratch_bytes >= used + blocks * 4 * 8 * 8) pc.c.stamps = reinterpret_cast<unsigned long long *>(static_cast<char *>(scratch) + used);
+        }
+#endif
         auto fill = [&](int slot, int k) {
             WinoChainLayer &l = pc.L[slot];
             l.src = src[k]; l.u = u_packed[k]; l.scale = scale[k]; l.shift = shift[k]; l.residual = residual[k]; l.out = out[k]; l.relu = relu[k];
         };
-        if (mode == 1) {
+        pc.sc1_loads = mode == 3 ? 1 : mode == 4 ? 2 : 0;
+        if (mode == 1 || mode == 3 || mode == 4) {
             pc.nlayers = nlayers;
             for (int k = 0; k < nlayers; ++k) fill(k, k);
             if (!wino_chain_supported(pc)) return fail(LSPF2F_ERR_UNSUPPORTED, "wino_chain: layer k must read layer k - 1's output, and no output may alias another tensor of the chain");

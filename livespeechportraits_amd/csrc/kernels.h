@@ -157,6 +157,7 @@ struct WinoChainParams {
                                   // workgroup of layer k + 1 that has read it; the last reader resets it
     unsigned *fail;               // one word, |= 1 when a gate gave up (spin_limit polls): the launch then finishes with garbage instead of hanging
     unsigned spin_limit;
+    int sc1_loads;                // A-B arm: read what the previous layer wrote with sc1 loads (past the L1) instead of one acquire at the gate + plain loads
     // filled by launch_wino_chain
     int wgs;                      // workgroups per layer
     FastDiv div_wgs;

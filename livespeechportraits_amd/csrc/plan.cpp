@@ -378,7 +378,7 @@ void Plan::assign_offsets(const std::vector<unsigned> *used)
             off = align_up(off, 256);
             l.wgemm_off = (int64_t)off;
             off += (size_t)4 * l.cout * 9 * l.cin * elt();
-            if (l.c0 == 64 && l.c1 == 64 && 4 * l.cout <= 16 && (l.hs % 64) == 0) {
+            if (l.c0 == 64 && l.c1 == 64 && l.cout == 3 && (l.hs % 64) == 0) {     // rowlast128 writes 12 columns per pixel (48-byte records): output_nc 3 only
                 off = align_up(off, 256);
                 l.wrl_off = (int64_t)off;
                 off += (size_t)9 * 4 * 64 * 8 * elt();

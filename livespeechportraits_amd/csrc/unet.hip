@@ -530,7 +530,8 @@ struct UnetPlan {
 
     // 16-bit plans whose last layer reads two 64-channel sources: the row kernel of the other variants' 16-bit last conv (rowlast128, rowconv.hip) on the GEMM rows
     // + the pixel-shuffle pass (which adds the bias): 62 / 294 us -> see profiles/r05_unet_small_native.txt for the direct kernel's vector-ALU route it replaces
-    bool rowlast_ok() const { return dtype != 0 && ngf == 64 && (size / 2) % 64 == 0; }
+    // (rowlast128 is hard-wired to 12 GEMM columns = 4 parities x 3 channels per pixel: 48-byte records, lanes g4 < 3 -- other output_nc keep the direct kernel)
+    bool rowlast_ok() const { return dtype != 0 && ngf == 64 && output_nc == 3 && (size / 2) % 64 == 0; }
 
     // spatial extent of d_k (= of Y_{k+1}'s source, of R_k)
     int hd(int k) const { return size >> (k + 1); }

@@ -676,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void wino3x3(const WinoParams p)
 // Counters: arrive[k][tb] += 1 per finished (tile-block tb, channel group) of layer k (split-K: by the last arriver, after its combine), so "ready" is >= nng; every
 // workgroup of layer k + 1 that read it adds 1 on its way out and the last of them (the counter then reads nng + readers(tb)) stores 0: zero between launches, like tile_cnt.
 // A buffer is written at most once per launch (the host keeps the chain's tensors apart), so no L2 can hold an older copy of a line a gate has released.
+template <bool SC1, bool FENCE = true>      // FENCE = false with SC1 = false: measurement arm only (what a hand-off with free visibility would cost) -- never planned
 struct ChainGate {
     static constexpr bool active = true;
     static constexpr int kArriveStride = kWinoArriveStride;     // one counter per 128-byte line: 512 pollers on 8 adjacent words were one memory channel's queue
@@ -687,6 +688,9 @@ struct ChainGate {
     __amdgpu_buffer_rsrc_t rs_res;
     unsigned res_off[4];
     float4 *rpre;
+#ifdef LSPF2F_WINO_STAMPS
+    unsigned long long *t_gate;                                 // stamp slot 7 of a gated workgroup: when its gate opened (tools/probes/wino_chain_stamps.py)
+#endif
     __device__ __forceinline__ bool neighbour(int &t) const      // lane l < 9 looks at tile-block (by + l / 3 - 1, bx + l % 3 - 1)
     {
         const int dy = lane / 3 - 1, dx = lane - (lane / 3) * 3 - 1;
@@ -709,14 +713,20 @@ struct ChainGate {
                     if (++spins > limit) { if (lane == 0) __hip_atomic_fetch_or(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     if (spins < 4) __builtin_amdgcn_s_sleep(2); else if (spins < 16) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
                 }
+                // the guide's consumer form: ONE relaxed poll -> ONE agent-scope acquire (buffer_inv sc1: this CU's L1) -> barrier -> plain loads.  The SC1 arm reads past the
+                // L1 instead (every K-step then goes to L2: a 128-byte line of a pixel holds four K-steps, which the L1 serves to the plain loads)
+                if constexpr (!SC1 && FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
+#ifdef LSPF2F_WINO_STAMPS
+            *t_gate = __builtin_amdgcn_s_memtime();
+#endif
         }
     }
     __device__ __forceinline__ void late_loads() const          // always LPL loads (zero-range descriptor when the layer has no residual): the waits count them
     {
 #pragma unroll
-        for (int ab = 0; ab < 4; ++ab) rpre[ab] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off[ab], 0, 16));
+        for (int ab = 0; ab < 4; ++ab) rpre[ab] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off[ab], 0, SC1 ? 16 : 0));
     }
     // on the way out: this workgroup has read its <= 9 counters' tile-blocks; the last reader of a counter resets it
     __device__ __forceinline__ void release(int nng, int splits) const
@@ -736,6 +746,7 @@ struct ChainGate {
     }
 };
 
+template <bool SC1, bool FENCE = true>
 __global__ __launch_bounds__(256, 2) void wino3x3_chain(const WinoChainParams pc)
 {
     constexpr int NB = 1, NS = 3;
@@ -792,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void wino3x3_chain(const WinoChainParams pc
     const unsigned soff_u0 = (unsigned)((n0 >> 5) * 4 + wave) * (unsigned)S * 4096u;
 
     constexpr int EPL = 2;                                         // scale, shift (ahead of the gate); the residual follows it (ChainGate::LPL)
-    WinoCopy<NB, NS, true, true> cp;
+    WinoCopy<NB, NS, true, SC1> cp;
     cp.init(lds0, wave, lane, vraw[0], vraw[1], srd_src, srd_u, soff_u0, soff_nb);
 
     const int trow = tid >> 3, cq = (tid & 7) * 4;
@@ -808,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void wino3x3_chain(const WinoChainParams pc
         scv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_scale, (unsigned)n * 4u, 0, 0));
         shv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_shift, (unsigned)n * 4u, 0, 0));
     };
-    ChainGate gate;
+    ChainGate<SC1, FENCE> gate;
     gate.cnt = layer > 0 ? pc.arrive + ((size_t)(layer - 1) * (size_t)p.ntb + (size_t)b * (size_t)(p.tby * p.tbx)) * kWinoArriveStride : nullptr;
     gate.fail = pc.fail; gate.by = by; gate.bx = bx; gate.tby = p.tby; gate.tbx = p.tbx; gate.wave = wave; gate.lane = lane;
     gate.target = (unsigned)p.nng; gate.limit = pc.spin_limit;
@@ -819,6 +830,9 @@ __global__ __launch_bounds__(256, 2) void wino3x3_chain(const WinoChainParams pc
         gate.res_off[ab] = (pix * (unsigned)p.N + (unsigned)n) * 4u;
     }
     gate.rpre = rpre;
+#ifdef LSPF2F_WINO_STAMPS
+    gate.t_gate = &stamp_t[7];
+#endif
     WSTAMP(1);
 #ifdef LSPF2F_WINO_STAMPS
     unsigned long long *fl = &stamp_t[2];
@@ -942,7 +956,6 @@ __global__ __launch_bounds__(256, 2) void wino3x3_chain(const WinoChainParams pc
     }
     arrive();
     gate.release(p.nng, p.splits);
-    WSTAMP(7);
     WSTAMP_FLUSH;
 }
 
@@ -1052,7 +1065,9 @@ hipError_t launch_wino_chain(const WinoChainParams &pc_in, hipStream_t s)
     if (!pc.spin_limit) pc.spin_limit = 1u << 18;
     if ((size_t)pc.wgs * (size_t)pc.nlayers > 0x7fffffffull) return hipErrorInvalidValue;
     constexpr int smem = wino_lds_bytes(1, 3, true);
-    hipLaunchKernelGGL(wino3x3_chain, dim3((unsigned)(pc.wgs * pc.nlayers)), dim3(256), smem, s, pc);
+    if (pc.sc1_loads == 2) hipLaunchKernelGGL((wino3x3_chain<false, false>), dim3((unsigned)(pc.wgs * pc.nlayers)), dim3(256), smem, s, pc);
+    else if (pc.sc1_loads) hipLaunchKernelGGL(wino3x3_chain<true>, dim3((unsigned)(pc.wgs * pc.nlayers)), dim3(256), smem, s, pc);
+    else hipLaunchKernelGGL(wino3x3_chain<false>, dim3((unsigned)(pc.wgs * pc.nlayers)), dim3(256), smem, s, pc);
     return hipGetLastError();
 }
 

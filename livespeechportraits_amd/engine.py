@@ -188,12 +188,22 @@ class Engine:
             return None, 1
         return cand.data_ptr(), cand.shape[0]
 
+    def _check_out(self, out: torch.Tensor, shape, dtype, what: str) -> None:
+        """a caller-owned output tensor goes to the library as a bare pointer: shape, dtype, device and layout are checked HERE (a short or strided buffer would be an
+        out-of-bounds device write) -- the same rule SmallUnetEngine.render applies to its `out`"""
+        if not isinstance(out, torch.Tensor) or tuple(out.shape) != tuple(shape) or out.dtype != dtype or out.device != self.device or not out.is_contiguous():
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s (got %s %s on %s, contiguous=%s)" % (
+                what, dtype, tuple(shape), self.device, getattr(out, "dtype", type(out)), tuple(getattr(out, "shape", ())), getattr(out, "device", "?"),
+                getattr(out, "is_contiguous", lambda: "?")()))
+
     def forward(self, feat: torch.Tensor, cand: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         b = self._check_inputs(feat, cand)
         feat = feat.contiguous()
         cand = cand.contiguous() if cand is not None else None
         if out is None:
             out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device)
+        else:
+            self._check_out(out, (b, self.output_nc, self.size, self.size), torch.float32, "out")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             cptr, cb = self._cand_arg(cand)
@@ -210,6 +220,8 @@ class Engine:
         cand = cand.contiguous() if cand is not None else None
         if out_u8 is None:
             out_u8 = torch.empty((b, self.size, self.size, self.output_nc), dtype=torch.uint8, device=self.device)
+        else:
+            self._check_out(out_u8, (b, self.size, self.size, self.output_nc), torch.uint8, "out_u8")
         out = torch.empty((b, self.output_nc, self.size, self.size), dtype=torch.float32, device=self.device) if also_float else None
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):

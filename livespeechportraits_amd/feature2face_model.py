@@ -57,6 +57,8 @@ class Feature2FaceModel(BaseModel):
                     feature_map.float(), None if cand_image is None else cand_image.float(), True, out=out)
             net = self.Feature2Face_G
             if isinstance(net, networks.MultiDeviceParallel):    # several gpu_ids: sliced over all of them like inference(), uint8 fused on every device
+                if out is not None:                              # the slices land on their own devices and are gathered into a new tensor: a caller-owned buffer cannot be honoured
+                    raise ValueError("inference_image(out=...) is not supported with several gpu_ids (the frames are gathered from the devices into a new tensor)")
                 return net.render_image(feature_map, cand_image)
             e = g._engine_for(feature_map.shape[-1], feature_map.shape[0], feature_map.device)
             if replica:

@@ -105,6 +105,8 @@ def render_frames(model, feature_maps: Iterable[torch.Tensor], cand_image: torch
             else:
                 for k, m in enumerate(chunk):
                     lane["dev"][k].copy_(lane["stage"][k] if m.device.type != "cuda" else m, non_blocking=True)
+                    if m.device.type == "cuda" and lane["stream"] is not None:
+                        m.record_stream(lane["stream"])           # read on the lane's stream: the caching allocator must not hand its memory out again before that copy ran
             kw = {"replica": n % nlane} if nlane > 1 else {}
             if takes_out:
                 if lane["u8"] is None:

@@ -763,6 +763,92 @@ def test_conv3x3_winograd_rejects_unsupported_shapes(gpu_device):
         run_wino(gpu_device, rnd(1, 32, 32, 32), w, None, None, None, False, 2, 1)       # cout 32 needs nb = 1
 
 
+# ---- wino3x3_chain (round 6 probe, csrc/wino.hip): the convs of one / two ResidualBlocks in ONE launch behind per-tile-block arrival counters ---------------
+def run_wino_chain(dev, lib, nl, c, h, splits, mode, x, ws, scs, shs, keep=None):
+    """ResidualBlock semantics (networks.py:650-675): layer 2m = conv a -> BN -> ReLU, layer 2m + 1 = conv b -> BN -> += the block's input -> ReLU.  Returns the
+    NHWC device outputs of every layer; `keep` carries the device buffers across calls (so a second call with other inputs reuses every address)."""
+    from livespeechportraits_amd import _native as N
+    if keep is None:
+        keep = {"x": torch.empty(1, h, h, c, device=dev), "outs": [torch.empty(1, h, h, c, device=dev) for _ in range(nl)],
+                "scratch": torch.zeros(lib.lspf2f_wino_chain_scratch_bytes(nl, 1, h, c, splits), dtype=torch.uint8, device=dev)}
+    keep["x"].copy_(x.permute(0, 2, 3, 1))
+    for o in keep["outs"]:
+        o.fill_(float("nan"))
+    dx, outs, scratch = keep["x"], keep["outs"], keep["scratch"]
+    us = [pack_wino(w).float().to(dev) for w in ws]
+    dsc, dsh = [t.to(dev) for t in scs], [t.to(dev) for t in shs]
+    src = [dx] + outs[:-1]
+    res = [None if k % 2 == 0 else (dx if k == 1 else outs[k - 2]) for k in range(nl)]
+    arr = lambda ts: (ctypes.c_void_p * nl)(*[ctypes.c_void_p(t.data_ptr()) if t is not None else None for t in ts])
+    relu = (ctypes.c_int * nl)(*([1] * nl))
+    N.check(lib.lspf2f_wino_chain(nl, arr(src), arr(us), arr(dsc), arr(dsh), arr(res), arr(outs), relu, 1, h, c, splits, mode,
+                                  ctypes.c_void_p(scratch.data_ptr()), scratch.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    tail = scratch[(splits > 1) * splits * h * h * c * 4:].view(torch.int32)
+    assert not tail.any(), "split-K tickets / gate counters not left at zero, or a gate gave up (last word): %s" % tail.nonzero().flatten()[:8].tolist()
+    return [o.clone() for o in outs], keep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 1), (4, 64, 64, 1), (3, 96, 32, 2), (4, 128, 128, 1), (2, 256, 64, 2), (4, 512, 32, 4)],
+                         ids=lambda c: "l%d_c%d_h%d_s%d" % c)
+def test_wino_chain_matches_one_launch_per_layer_bit_for_bit(cfg, gpu_device):
+    """One launch of nlayers x (workgroups of a layer) workgroups, each layer's workgroups gated on the arrival counters of the tile-blocks they read, must give the
+    bits of one wino3x3<1> launch per layer -- twice, with DIFFERENT inputs on the SAME buffers (a consumer that read a line before its producer wrote it would return
+    the first call's values), for both valid visibility forms (1: acquire + plain loads, 3: sc1 loads); and the result is the ResidualBlock of the reference (fp64 torch)."""
+    from livespeechportraits_amd import _native as N
+    lib = N.load()
+    nl, c, h, splits = cfg
+    g = torch.Generator().manual_seed(77 + nl + c + h)
+    ws = [torch.randn(c, c, 3, 3, generator=g) * (0.7 / (3.0 * c ** 0.5)) for _ in range(nl)]
+    scs = [torch.rand(c, generator=g) + 0.5 for _ in range(nl)]
+    shs = [torch.randn(c, generator=g) * 0.1 for _ in range(nl)]
+    keeps = {}
+    for rnd_i in range(2):
+        x = torch.randn(1, c, h, h, generator=g)
+        ref, cur, blk_in = [], x.double(), x.double()
+        for k in range(nl):
+            y = F.conv2d(cur, ws[k].double(), None, 1, 1) * scs[k].double().view(1, -1, 1, 1) + shs[k].double().view(1, -1, 1, 1)
+            if k % 2 == 1:
+                y = y + blk_in
+            cur = torch.relu(y)
+            if k % 2 == 1:
+                blk_in = cur
+            ref.append(cur)
+        base, keeps[0] = run_wino_chain(gpu_device, lib, nl, c, h, splits, 0, x, ws, scs, shs, keeps.get(0))
+        for k in range(nl):
+            got = base[k].permute(0, 3, 1, 2).double().cpu()
+            assert torch.isfinite(got).all()
+            assert (got - ref[k]).abs().max().item() <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, (got - ref[k]).abs().max().item())
+        for mode in (1, 3, 2):
+            outs, keeps[mode] = run_wino_chain(gpu_device, lib, nl, c, h, splits, mode, x, ws, scs, shs, keeps.get(mode))
+            for k in range(nl):
+                assert torch.equal(outs[k], base[k]), "mode %d, layer %d, round %d differs from one launch per layer" % (mode, k, rnd_i)
+
+
+@pytest.mark.gpu
+def test_wino_chain_rejects_aliased_buffers_and_bad_arguments(gpu_device):
+    from livespeechportraits_amd import _native as N
+    lib = N.load()
+    c, h, nl = 64, 32, 2
+    dev = gpu_device
+    x, o = torch.zeros(1, h, h, c, device=dev), torch.zeros(1, h, h, c, device=dev)
+    u = torch.zeros(16 * c * c, device=dev)
+    scratch = torch.zeros(lib.lspf2f_wino_chain_scratch_bytes(nl, 1, h, c, 1), dtype=torch.uint8, device=dev)
+    arr = lambda ts: (ctypes.c_void_p * nl)(*[ctypes.c_void_p(t.data_ptr()) if t is not None else None for t in ts])
+    relu = (ctypes.c_int * nl)(1, 1)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    none = [None, None]
+    call = lambda src, outs, mode, sb=None: lib.lspf2f_wino_chain(nl, arr(src), arr([u, u]), arr(none), arr(none), arr(none), arr(outs), relu, 1, h, c, 1, mode,
+                                                                  ctypes.c_void_p(scratch.data_ptr()), scratch.numel() if sb is None else sb, st)
+    assert call([x, o], [o, x], 1) != 0          # layer 1 would overwrite layer 0's input
+    assert call([x, o], [o, o], 1) != 0          # two layers, one output
+    assert call([x, x], [o, x], 1) != 0          # layer 1 does not read layer 0's output
+    assert call([x, o], [o, torch.zeros_like(o)], 7) != 0
+    assert call([x, o], [o, torch.zeros_like(o)], 1, 8) != 0      # scratch too small
+    torch.cuda.synchronize()
+
+
 # ---- Winograd F(4x4, 3x3) kernel (csrc/wino4.hip): the same layers with 36 multiplies per 4x4 outputs ---------------------------------------
 def run_wino4(dev, x, w, scale, shift, res, relu, splits):
     import os

@@ -479,6 +479,10 @@ def test_bench_runs_with_two_ranks_on_one_gpu(tmp_path):
     assert d["value"] > 0 and abs(d["value"] - 2 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-2 * d["value"]     # whole-job frames / max-rank time
     c3 = d["extra"]["config3_batch8_per_gpu"]          # BASELINE.json configs[3]'s shape: 8 frames per rank, shared candidates
     assert c3["ranks_in_group"] == 2 and c3["global_batch"] == 16 and c3["frames_per_s"] > 0 and c3["backend"] == "gloo"
+    # the shape the first real 8-GPU line will have (VERDICT r5 next #6b): per-rank extremes beside the whole-job figure, slowest <= fastest, and the
+    # whole-job rate no better than ranks x the fastest rank
+    slow, fast = c3["per_gpu_frames_per_s_slowest_fastest"]
+    assert 0 < slow <= fast and c3["frames_per_s"] <= 2 * fast * 1.001 and c3["frames_per_gpu"] == 8 and d["config"]["ranks_in_group"] == 2
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
@@ -498,7 +502,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_in_group"] == 2 and d["config"]["global_batch"] == 2
-    assert d["extra"]["config3_batch8_per_gpu"]["ranks_in_group"] == 2
+    c3 = d["extra"]["config3_batch8_per_gpu"]
+    assert c3["ranks_in_group"] == 2 and len(c3["per_gpu_frames_per_s_slowest_fastest"]) == 2 and 0 < c3["per_gpu_frames_per_s_slowest_fastest"][0] <= c3["per_gpu_frames_per_s_slowest_fastest"][1]
     # without the gloo override, asking for more ranks than devices is an error, never a silent 1-GPU record
     import torch
     env.pop("LSP_DIST_BACKEND")

@@ -131,3 +131,20 @@ def test_the_library_exports_its_headers_and_nothing_else():
     assert not (exported - declared), "exported but not declared in include/*.h: %s" % sorted(exported - declared)
     assert not (declared - exported), "declared in include/*.h but not exported: %s" % sorted(declared - exported)
     assert not [s for s in exported if s.startswith("_Z")]
+
+
+def test_tune_keys_of_the_python_host_are_exactly_the_keys_the_library_parses():
+    """LSP_HIP_<KEY> environment variables reach lspf2f_create_tuned only when <key> is in _native.TUNE_KEYS; a key the library gained and the list did not is warned
+    about and DROPPED, so an A-B run silently measures the default (fullk16 / fullk16_min_frames).  The list must equal what api.cpp parses, and the header
+    must name every key."""
+    import re
+    from livespeechportraits_amd import _native as N
+    src = open(os.path.join(ROOT, "livespeechportraits_amd", "csrc", "api.cpp")).read()
+    body = src[src.index("int lspf2f_create_tuned("):src.index("int lspf2f_destroy(")]
+    parsed = set(re.findall(r'k == "([a-z0-9_]+)"', body))
+    assert parsed, "no keys found: has the parser moved?"
+    assert parsed == set(N.TUNE_KEYS), {"only in api.cpp": sorted(parsed - set(N.TUNE_KEYS)), "only in TUNE_KEYS": sorted(set(N.TUNE_KEYS) - parsed)}
+    hdr = open(os.path.join(ROOT, "include", "lspf2f.h")).read()
+    doc = hdr[hdr.index("Keys (default)"):hdr.index("int lspf2f_create_tuned(")]
+    missing = [k for k in sorted(parsed) if not re.search(r"\b%s\b" % re.escape(k), doc)]
+    assert not missing, "keys lspf2f_create_tuned parses that include/lspf2f.h does not document: %s" % missing

@@ -327,6 +327,17 @@ def test_native_plan_launch_list_workspace_and_errors():
                 dict(output_nc=5), dict(input_nc=64), dict(feat_nc=0), dict(max_batch=0), dict(dtype=1), dict(dtype=3), dict(dtype=2, ngf=32)):
         lib, h, rc = _unet_handle(**bad)
         assert rc < 0 and lib.lspunet_last_error(), bad
+    # fp16 plans: the row kernel of the last layer (rowlast128) writes 12 columns per pixel -- output_nc 3 only; any other width keeps the implicit-GEMM form
+    # (output_nc 1 / 2 used to be routed to it and wrote 48-byte records into 16 / 32-byte ones)
+    for onc, want in ((3, True), (1, False), (2, False), (4, False)):
+        lib, h, rc = _unet_handle(output_nc=onc, dtype=2, max_batch=2)
+        assert rc == 0
+        kerns = []
+        for i in range(lib.lspunet_num_launches(h, 1)):
+            assert lib.lspunet_launch_info(h, 1, i, ctypes.byref(name), ctypes.byref(kern), ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sk)) == 0
+            kerns.append(kern.value.decode())
+        assert any(k.startswith("rowlast128") for k in kerns) == want, (onc, kerns[-3:])
+        lib.lspunet_destroy(h)
     import ctypes as C
     from livespeechportraits_amd import _native as N
     cfg = N.UnetConfig(99, 23, 23, 3, 64, 8, 512, 1, 0, 0)
@@ -601,6 +612,31 @@ def test_fp16_plan_of_the_small_generator_against_the_autocast_oracle(gpu_device
     u8 = e.forward(xd, out_u8=True).cpu().numpy().astype(np.int32)
     assert np.abs(u8 - np.clip((out.transpose(0, 2, 3, 1) + 1.0) / 2.0 * 255.0, 0, 255).astype(np.uint8).astype(np.int32)).max() <= 1
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("output_nc", [1, 2, 4])
+def test_fp16_plan_with_another_output_width_stays_inside_its_buffers(output_nc, gpu_device):
+    """fp16 plans with output_nc != 3 were routed to rowlast128, which is hard-wired to 12 columns per pixel -- it wrote past the G buffer
+    (output_nc 1, 2) or produced wrong frames (4).  Now they keep the implicit-GEMM last layer: the fp16 frames agree with the fp32 plan of the same weights, at 512 x 512
+    (the size whose last level the row kernel would have taken), and a poisoned guard band behind the output stays intact."""
+    from livespeechportraits_amd import synth
+    from livespeechportraits_amd.unet_small import SmallUnetEngine
+    sd = synth.make_unet_small_state_dict(23, output_nc, 8, 64, seed=21)
+    x = torch.from_numpy(synth.symmetric(2 * 23 * 512 * 512, 0.6, 5).reshape(2, 23, 512, 512)).to(gpu_device)
+    outs = {}
+    for dt in ("f32", "f16"):
+        e = SmallUnetEngine(23, output_nc, 8, 64, max_batch=2, dtype=dt)
+        e.load_state_dict(sd, "model", gpu_device)
+        if dt == "f16":
+            assert not any("rowlast128" in r["kernel"] for r in e.launches(512, 2))
+        y = e.forward(x)
+        assert tuple(y.shape) == (2, output_nc, 512, 512) and torch.isfinite(y).all()
+        outs[dt] = y.float().cpu().numpy()
+        e.close()
+    d = np.abs(outs["f16"] - outs["f32"])
+    print("\nsmall generator, output_nc %d, fp16 vs fp32 plan: max-abs %.2e mean-abs %.2e" % (output_nc, d.max(), d.mean()))
+    assert 1e-6 < d.max() <= 8e-3 and d.mean() <= 8e-4
 
 
 @pytest.mark.gpu

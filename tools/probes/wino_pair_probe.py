@@ -4,7 +4,8 @@
 For each wino3x3<1> shape of the `large` plan at one frame (128 ch @ 128^2, 256 ch @ 64^2 with 2 K splits, 512 ch @ 32^2 with 4) and chain lengths 2 and 4:
   mode 0  one launch of wino3x3<1> per layer (register form, write-through stores, wave priority: exactly what the plans run)
   mode 2  the chain kernel launched once per layer (what its changed prologue costs without any overlap)
-  mode 1  ONE launch of nlayers x 512 workgroups, gated on per-tile-block arrival counters (wino.hip, wino3x3_chain)
+  mode 3  ONE launch of nlayers x 512 workgroups, gated on per-tile-block arrival counters (wino.hip, wino3x3_chain), raw patch read with sc1 loads
+  mode 1  the same with one agent-scope acquire at the gate and plain loads behind it
 Each arm is captured into a hipGraph of REPS chains and replayed; the arms alternate A-B-A-B in one session.  Results of the three modes must be
 bit-identical; the scratch (counters) must be left zero and the give-up word must stay 0.
 
@@ -58,7 +59,7 @@ def main():
             run, outs, scratch, keep = build(lib, dev, c, hs, nl, sp)
             st = torch.cuda.current_stream().cuda_stream
             ref = None
-            for mode in (0, 2, 1):
+            for mode in (0, 2, 3, 4, 1):
                 for o in outs:
                     o.fill_(float("nan"))
                 run(mode, st)
@@ -73,7 +74,7 @@ def main():
             tail = scratch[(sp > 1) * sp * hs * hs * c * 4:].view(torch.int32)
             assert int(tail.abs().sum()) == 0, "counters / give-up word not zero after the launches: %s" % tail.nonzero().flatten()[:8].tolist()
             graphs = {}
-            for mode in (0, 2, 1):
+            for mode in (0, 2, 3, 4, 1):
                 g = torch.cuda.CUDAGraph()
                 s = torch.cuda.Stream()
                 with torch.cuda.stream(s):
@@ -84,9 +85,9 @@ def main():
                         for _ in range(reps):
                             run(mode, s.cuda_stream)
                 graphs[mode] = g
-            times = {0: [], 2: [], 1: []}
+            times = {0: [], 2: [], 3: [], 4: [], 1: []}
             for _ in range(rounds):
-                for mode in (0, 2, 1):
+                for mode in (0, 2, 3, 4, 1):
                     g = graphs[mode]
                     g.replay()
                     torch.cuda.synchronize()
@@ -100,8 +101,8 @@ def main():
             tail = scratch[(sp > 1) * sp * hs * hs * c * 4:].view(torch.int32)
             assert int(tail.abs().sum()) == 0, "counters / give-up word not zero after the timed replays"
             m = {k: float(np.median(v)) for k, v in times.items()}
-            print("c %3d @ %3d^2 splits %d, %d layers: per-layer launches %7.2f us [%s] | chain kernel per layer %7.2f | ONE launch %7.2f [%s] -> %+.1f %% per chain, %.2f us per seam" % (
-                c, hs, sp, nl, m[0], " ".join("%.1f" % t for t in times[0]), m[2], m[1], " ".join("%.1f" % t for t in times[1]),
+            print("c %3d @ %3d^2 splits %d, %d layers: per-layer launches %7.2f us [%s] | chain kernel per layer %7.2f | ONE launch, sc1 loads %7.2f | ONE launch, plain loads and no acquire (NOT a valid hand-off) %7.2f | ONE launch, acquire + plain loads %7.2f [%s] -> %+.1f %% per chain, %.2f us per seam" % (
+                c, hs, sp, nl, m[0], " ".join("%.1f" % t for t in times[0]), m[2], m[3], m[4], m[1], " ".join("%.1f" % t for t in times[1]),
                 (m[1] / m[0] - 1.0) * 100.0, (m[0] - m[1]) / (nl - 1)))
     print("bit-identical: all arms; counters left zero; give-up word 0")
 
