@@ -938,6 +938,7 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
         if (sp == 1) return 0;
         return (size_t)sp * batch * hs * ws * cout * sizeof(float) + (size_t)batch * (hs / 8) * (ws / 16) * (cout / (32 * (tile_m - 4000))) * sizeof(unsigned);
     }
+    if (tile_m == 7064 || tile_m == 7032) return 0;                    // patch-staged 16-bit kernel: no scratch
     (void)ws;
     const int ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
     if ((tile_m == 16 || tile_m == 32) && tile_n == 16 && split_k == 2) {      // K-split full-K kernel: two partial tiles per tile + arrival counters
@@ -1083,6 +1084,19 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the Winograd kernel does not support this shape");
             e = launch_wino(q, tile_m - 4000, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (wino) launch");
+            return LSPF2F_OK;
+        }
+        if ((tile_m == 7064 || tile_m == 7032) && k_group != -4) {   // 7000 + tile width: the patch-staged 16-bit kernel (patch16.hip), tile_n = 128 | 64 channels per workgroup; igemm weight rows
+            PatchConvParams q{};
+            q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
+            q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.Cout = cout; q.relu = relu; q.dtype = dtype;
+#ifdef LSPF2F_ABLATE
+            if (const char *env = std::getenv("LSP_HIP_DBG")) q.dbg = std::atoi(env);
+#endif
+            if (c1 != 0 || stride != 1 || upsample != 0 || !patch16_supported(q, tile_m - 7000, tile_n))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "the patch-staged 16-bit kernel does not support this shape");
+            e = launch_patch16(q, tile_m - 7000, tile_n, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (patch16) launch");
             return LSPF2F_OK;
         }
         if (tile_m == 2000 && k_group == -1) {     // the activation-stationary bf16 kernel of the 16x16 / 8x8 levels; weights in its fragment order

@@ -261,6 +261,23 @@ bool fullk16_supported(const FullK16Params &p, int pb);
 hipError_t launch_fullk16(const FullK16Params &p, int pb, hipStream_t s);
 void pack_fullk16_weights(const uint16_t *rows, int c0, int nch, int cout, uint16_t *out);   // host: 16-bit [Cout][9][nch * c0] -> tile-blocked
 
+// Patch-staged implicit GEMM for the stride-1 single-source convs of the 64x64 / 32x32 levels in 16-bit storage (patch16.hip): a workgroup owns
+// 256 output pixels (4 rows x 64 or 8 rows x 32) x bn channels; the halo patch of each 64-channel block is staged once and read for all nine taps.
+// H % (256 / tw) == 0, W % tw == 0, C % 64 == 0, Cout % bn == 0; weights = the implicit GEMM's rows [Cout][9][C].
+struct PatchConvParams {
+    const void *src, *w;          // NHWC 16-bit [B][H][W][C]; weights 16-bit [Cout][9][C]
+    const float *scale, *shift;   // [Cout] or nullptr
+    const void *residual;         // NHWC 16-bit [B][H][W][Cout] or nullptr
+    void *out;                    // NHWC 16-bit [B][H][W][Cout]
+    int B, H, W, C, Cout, relu;
+    int dtype;                    // 1 = bf16, 2 = fp16
+    int dbg;                      // -DLSPF2F_ABLATE builds: 1 no copies in the K loop, 2 no fragment reads, 4 no MFMAs, 16 no epilogue
+    int tiles_x, tiles_per_img, ntm, ntn;   // filled by launch_patch16
+    FastDiv div_tpi, div_tx, div_ntn;
+};
+bool patch16_supported(const PatchConvParams &p, int tw, int bn);
+hipError_t launch_patch16(const PatchConvParams &p, int tw, int bn, hipStream_t s);
+
 // Weights-stationary conv for the 64 -> 64 and 128 -> 128 channel layers in bf16 storage (rowconv.hip): stride 1, one source,
 // W % 64 == 0 (64 channels) / W % 32 == 0 (128 channels).
 struct RowConvParams {

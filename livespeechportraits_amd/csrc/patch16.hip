@@ -1,0 +1,293 @@
+// gfx950: the stride-1 3x3 convolutions of the 64x64 / 32x32 levels of the 16-bit plans (bf16 | fp16 storage, fp32 accumulate) from 8 frames up -- the ResidualBlock
+// convs 256 -> 256 @ 64x64 and 512 -> 512 @ 32x32 of BASELINE.json configs[2], which ran on igemm3x3<128x128> at 0.33 of the dense 16-bit MFMA peak.  DESIGN.md 4.12.
+//
+// What bound the implicit GEMM there (round 6 ablation, profiles/r06_igemm16_ablate.txt): a 128 x 128 tile pulls 8 LDS-DMA pieces per wave and K-tile through the
+// CU's vector-memory path for 16 MFMAs (512 cycles) -- 64 KB per 1024 MFMA cycles of a SIMD, the path's own rate -- because im2col re-stages every input pixel
+// once per tap.  This kernel stages each pixel ONCE per 64-channel block and reads it for all nine taps:
+//   * a workgroup (8 waves) owns TR x TW = 256 output pixels of one frame x BN output channels; per 64-channel block `cb` the (TR + 2) x (TW + 2) halo patch of the
+//     source arrives by LDS-DMA (128-byte pixel records, zero padding by out-of-range pieces), double-buffered: the pieces of block cb + 1 ride one per tap step
+//     under the nine K-tiles of block cb.  Vector-memory traffic per K-tile: 16 KB of weights + 1/9 of a 50-KB patch = 21.6 KB instead of 64 KB;
+//   * tap (ky, kx) of a K-tile is an address offset into the patch: the A fragment of output pixels (r, c .. c + 31) is patch pixels (r + ky, c + kx ..) -- 32
+//     consecutive records, whose 16-byte k-slots are XOR-swizzled on the record index so every ds_read_b128 lane group covers the 64 banks once;
+//   * weights: the implicit GEMM's own rows [Cout][9][Cin] (no second packed copy), BN x 128 B per K-tile through a 3-slot LDS ring, two K-tiles ahead;
+//   * the eight waves form two groups of four (one wave of each per SIMD) that run half a K-tile step apart: while one group issues its 16 MFMAs (s_setprio 1)
+//     the other reads the next K-tile's fragments and issues its copies; two s_barrier per K-tile keep the groups in that alternation, every vmcnt wait is
+//     counted (never 0 inside the loop) -- the schedule of the guide's 8-phase GEMM template carried over to an implicit GEMM;
+//   * K order: channel block outer, tap inner (the implicit GEMM: tap outer) -> same products, different fp32 summation order: the two kernels agree to one
+//     16-bit ulp of the result, not bit for bit.
+// Fused epilogue (folded BatchNorm scale / shift, residual, ReLU, RNE store) as in the implicit-GEMM kernel.
+// Reference semantics: ResidualBlock's Conv2d 3x3 p1 s1 (models/networks.py:650-675) under torch.cuda.amp.autocast (models/feature2face_G.py:28-30) for fp16 storage;
+// bf16 storage is this repo's configs[2] (parity-unpinned, declared tolerance).
+#include "device_common.h"
+#include "kernels.h"
+
+namespace lspf2f {
+
+static constexpr unsigned kOOBp = 0x80000000u;   // voffset beyond any num_records: the piece lands as zeros
+
+#ifdef LSPF2F_ABLATE
+#define PABL(p, bit) ((p).dbg & (bit))
+#else
+#define PABL(p, bit) 0
+#endif
+
+// both barriers of a K-tile step: nothing moves across (the compiler sees a memory clobber, the scheduler a fence)
+#define PATCH_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <bool F16, int TW, int TR, int BN>
+__global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
+{
+    typedef typename St16<F16>::type T;
+    constexpr int PW = TW + 2, PPX = PW * (TR + 2);          // patch width / pixels
+    constexpr int NPIECE = (PPX + 7) / 8;                    // 1-KB pieces (8 pixel records) per patch
+    constexpr int NPA = (NPIECE + 7) / 8;                    // ... per wave
+    constexpr int NPB = BN / 64;                             // weight pieces per wave and K-tile (BN rows x 128 B over 8 waves)
+    constexpr int TN = BN / 64;                              // 32-channel MFMA blocks per wave (waves: 4 along pixels x 2 along channels)
+    constexpr int PATCH_BYTES = (NPIECE + 1) * 1024;         // + one KB behind each buffer where the pieces past the patch's end land (zeros; piece slot NPIECE)
+    constexpr int BRING = 2 * PATCH_BYTES;                   // 3 slots of BN x 128 B
+    constexpr int BTILE = BN * 128;
+    static_assert(TW * TR == 256 && TW % 32 == 0, "a wave's 32-pixel MFMA block is 32 consecutive pixels of one row");
+    static_assert(NPA <= 8, "one patch piece per tap step, landed a step before the block is read");
+    static_assert(8 * 32 * 36 * 4 <= PATCH_BYTES, "the epilogue's transpose patches live in the patch buffer of the last channel block");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_p16[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_char *)smem_p16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    // one scalar-load round trip for the whole argument block (see igemm.hip)
+    asm volatile("" :: "s"(p.src), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C), "s"(p.Cout),
+                       "s"(p.relu), "s"(p.ntm), "s"(p.ntn), "s"(p.div_tpi.m), "s"(p.div_tpi.s1), "s"(p.div_tpi.s2), "s"(p.div_tx.m), "s"(p.div_tx.s1), "s"(p.div_tx.s2),
+                       "s"(p.div_ntn.m), "s"(p.div_ntn.s1), "s"(p.div_ntn.s2));
+
+    // ---- tile.  XCD-aware order: the dispatcher deals workgroups round-robin over the 8 XCDs; logical ids are handed out in 8 contiguous chunks, n fastest, so one
+    // XCD's L2 sees a band of pixel tiles once (every channel tile of it) and each XCD streams the weights
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned total = gridDim.x, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const int mt = (int)p.div_ntn.div(lin), nt = (int)lin - mt * p.ntn;
+    const int fb = (int)p.div_tpi.div((unsigned)mt);                       // frame
+    const int rem = mt - fb * p.tiles_per_img;
+    const int ty = (int)p.div_tx.div((unsigned)rem), tx = rem - ty * p.tiles_x;
+    const int y0 = ty * TR, x0 = tx * TW, n0 = nt * BN;
+    const int NCB = p.C >> 6;                                              // 64-channel blocks
+    const int Krow = 9 * p.C;                                              // elements per weight row
+
+    // ---- copy descriptors (fixed for the whole K loop).  Patch piece q = j * 8 + wave: records q * 8 .. + 7, lane -> (record lane >> 3, 16-byte slot lane & 7);
+    // slot s of record pp holds k-quad s ^ ((pp >> 1) & 7)
+    unsigned voffA[NPA], voffB[NPB];
+    unsigned dstA[NPA];                                                    // (wave-uniform) byte offset of piece j inside a patch buffer (the dump slot behind it for q >= NPIECE)
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int q = j * 8 + wave;
+        const int pp = q * 8 + (lane >> 3), s = lane & 7;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+        const bool ok = pp < PPX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        voffA[j] = ok ? (unsigned)((fb * p.H + y) * p.W + x) * (unsigned)(p.C * 2) + (unsigned)((s ^ ((pp >> 1) & 7)) << 4) : kOOBp;
+        dstA[j] = (unsigned)((q < NPIECE ? q : NPIECE) * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+        const int row = wave * 8 + k * 64 + (lane >> 3), s = lane & 7;
+        voffB[k] = (unsigned)((n0 + row) * Krow * 2) + (unsigned)((s ^ ((row >> 1) & 7)) << 4);
+    }
+    const i32x4 rsa = make_srd(p.src, (unsigned)(p.B * p.H * p.W) * (unsigned)(p.C * 2));
+    const i32x4 rsw = make_srd(p.w, (unsigned)(p.Cout * Krow * 2));
+    const unsigned ldsB = lds0 + BRING + (unsigned)(wave * 8 * 128);        // this wave's first weight piece in ring slot 0
+
+    // ---- fragment addresses.  Lane l supplies row (l & 31), k-quad (l >> 5) of each 8-wide k group (the implicit GEMM's operand order).
+    const int l31 = lane & 31, hh = lane >> 5;
+    int p0[2];                                                             // patch record of tap (0, 0) for this lane's pixel of MFMA block i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + l31;
+        p0[i] = (m / TW) * PW + (m % TW);
+    }
+    unsigned boff[TN][4];                                                  // B fragment byte addresses in ring slot 0, per k-step (the slot is an immediate offset)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * (BN / 2) + j * 32 + l31;
+        const unsigned base = (unsigned)BRING + (unsigned)(nl * 128) + (unsigned)(((hh ^ (nl >> 1)) & 7) << 4);      // (BRING is a multiple of 1 KB: the k-step XOR below stays inside the record)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) boff[j][ks] = base ^ (unsigned)(ks << 5);
+    }
+
+    // ---- epilogue operands first in the queue (older than every copy: the counted waits below are unaffected)
+    const int erow = lane >> 3, ecol = (lane & 7) * 4;
+    float4 scv[TN], shv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + ecol;
+        scv[j] = make_float4(1.f, 1.f, 1.f, 1.f); shv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) {
+            scv[j] = *reinterpret_cast<const float4 *>(p.scale + n);
+            shv[j] = *reinterpret_cast<const float4 *>(p.shift + n);
+        }
+    }
+
+    // ---- prologue: patch of block 0, weights of K-tiles 0 and 1
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) dma16(lds0 + dstA[j], voffA[j], rsa, 0);
+    dma16_group<NPB, 64 * 128>(ldsB, voffB, rsw, 0);
+    dma16_group<NPB, 64 * 128>(ldsB + BTILE, voffB, rsw, p.C * 2);                                // K-tile 1 = (block 0, tap 1)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB) : "memory");            // patch 0 and K-tile 0 have landed (this wave's share)
+    PATCH_BAR();
+    if (grp == 1 && !PABL(p, 32)) PATCH_BAR();                             // the second group runs half a step behind
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8 fa[2][4], fb_[TN][4];
+    for (int cb = 0; cb < NCB; ++cb) {
+        const unsigned abuf = (cb & 1) ? (unsigned)PATCH_BYTES : 0u, anext = (cb & 1) ? 0u : (unsigned)PATCH_BYTES;
+        const bool more = cb + 1 < NCB;
+        const bool last = !more;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int slot = tap % 3;
+            // ---- load segment: fragments of this K-tile ...
+            if (!PABL(p, 2)) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        fb_[j][ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + slot * BTILE + boff[j][ks]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int P = p0[i] + ky * PW + kx;
+                    const unsigned base = abuf + (unsigned)(P << 7) + (unsigned)(((hh ^ (P >> 1)) & 7) << 4);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        fa[i][ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + (base ^ (unsigned)(ks << 5)));
+                }
+            }
+            // ... and the copies: one piece of the next block's patch, the weights two K-tiles ahead (into the slot K-tile t - 1 has left)
+            if (!PABL(p, 1)) {
+                if (tap < NPA) dma16(lds0 + anext + dstA[tap < NPA ? tap : 0], more ? voffA[tap < NPA ? tap : 0] : kOOBp, rsa, (cb + 1) * 128);
+                {
+                    const int tap2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
+                    const int cb2 = tap + 2 < 9 ? cb : cb + 1;
+                    const bool live = tap + 2 < 9 || more;
+                    unsigned vb[NPB];
+#pragma unroll
+                    for (int k = 0; k < NPB; ++k) vb[k] = live ? voffB[k] : kOOBp;
+                    dma16_group<NPB, 64 * 128>(ldsB + (unsigned)(((tap + 2) % 3) * BTILE), vb, rsw, (tap2 * p.C + cb2 * 64) * 2);
+                }
+                // K-tile t + 1 (and everything older: the patch pieces too) has landed; this step's own pieces may still fly
+                if (PABL(p, 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (tap < NPA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PATCH_BAR();
+            if (PABL(p, 256)) { PATCH_BAR(); PATCH_BAR(); }
+            // ---- MFMA segment (the other group is in its load segment)
+            __builtin_amdgcn_s_setprio(1);
+            if (!PABL(p, 4)) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = mfma32_16b<F16>(fa[i][ks], fb_[j][ks], acc[i][j]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            // the second group skips the very last barrier: both groups then pass the same number, and the first one starts its epilogue under the second one's last MFMAs
+            if (!(tap == 8 && last && grp == 1 && !PABL(p, 32))) PATCH_BAR();
+        }
+    }
+
+    // ---- epilogue (the implicit GEMM's: each wave transposes its 32 x 32 tiles through a private LDS patch so a lane ends up with 4 consecutive channels of a pixel).
+    // Every K-loop read of LDS is complete (the last barrier above); the patches live in the patch buffer of the LAST channel block, which no copy in flight targets.
+    if (PABL(p, 16)) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int EP = 36;
+    float *patch = reinterpret_cast<float *>(smem_p16 + (((NCB - 1) & 1) ? PATCH_BYTES : 0)) + wave * (32 * EP);
+    const int ccol = lane & 31, crow = 4 * (lane >> 5);
+    T *outp = static_cast<T *>(p.out);
+    const T *resp = static_cast<const T *>(p.residual);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + ecol;
+        const float4 sc = scv[j], sh = shv[j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + crow) * EP + ccol] = acc[i][j][r];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + erow;
+                float4 v = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
+                const int m = wm * 64 + i * 32 + row;
+                const size_t opix = (size_t)(fb * p.H + y0 + m / TW) * p.W + x0 + (m % TW);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (resp) {
+                    const float4 rv = load4(resp + opix * p.Cout + n);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                store4(outp + opix * p.Cout + n, v);
+            }
+        }
+    }
+}
+
+template <bool F16, int TW, int TR, int BN>
+static hipError_t launch_patch16_t(const PatchConvParams &p_in, hipStream_t s)
+{
+    constexpr int PPX = (TW + 2) * (TR + 2), NPIECE = (PPX + 7) / 8;
+    constexpr size_t smem = (size_t)2 * (NPIECE + 1) * 1024 + (size_t)3 * BN * 128;
+    static_assert(smem <= 160 * 1024, "LDS");
+    PatchConvParams p = p_in;
+    p.tiles_x = p.W / TW;
+    p.tiles_per_img = (p.H / TR) * p.tiles_x;
+    p.ntm = p.B * p.tiles_per_img; p.ntn = p.Cout / BN;
+    p.div_tpi = FastDiv::make((unsigned)p.tiles_per_img);
+    p.div_tx = FastDiv::make((unsigned)p.tiles_x);
+    p.div_ntn = FastDiv::make((unsigned)p.ntn);
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_patch16<F16, TW, TR, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    hipLaunchKernelGGL((conv3x3_patch16<F16, TW, TR, BN>), dim3((unsigned)(p.ntm * p.ntn)), dim3(512), smem, s, p);
+    return hipGetLastError();
+}
+
+bool patch16_supported(const PatchConvParams &p, int tw, int bn)
+{
+    if (p.dtype != 1 && p.dtype != 2) return false;
+    if (!((tw == 64 && (bn == 128 || bn == 64)) || (tw == 32 && (bn == 128 || bn == 64)))) return false;
+    const int tr = 256 / tw;
+    if (p.B < 1 || p.W % tw || p.H % tr || p.C % 64 || p.C < 128 || p.Cout % bn) return false;
+    // 32-bit buffer offsets with the top bit reserved as the out-of-range marker
+    if ((size_t)p.B * p.H * p.W * p.C * 2 > 0x7fffffffull || (size_t)p.Cout * 9 * p.C * 2 > 0x7fffffffull) return false;
+    return true;
+}
+
+hipError_t launch_patch16(const PatchConvParams &p, int tw, int bn, hipStream_t s)
+{
+    if (!patch16_supported(p, tw, bn)) return hipErrorInvalidValue;
+    if (p.dtype == 2) {
+        if (tw == 64) return bn == 128 ? launch_patch16_t<true, 64, 4, 128>(p, s) : launch_patch16_t<true, 64, 4, 64>(p, s);
+        return bn == 128 ? launch_patch16_t<true, 32, 8, 128>(p, s) : launch_patch16_t<true, 32, 8, 64>(p, s);
+    }
+    if (tw == 64) return bn == 128 ? launch_patch16_t<false, 64, 4, 128>(p, s) : launch_patch16_t<false, 64, 4, 64>(p, s);
+    return bn == 128 ? launch_patch16_t<false, 32, 8, 128>(p, s) : launch_patch16_t<false, 32, 8, 64>(p, s);
+}
+
+}  // namespace lspf2f

@@ -570,6 +570,56 @@ def test_conv3x3_rows_kernel_rejects_other_shapes(gpu_device):
         run_conv(gpu_device, rnd(1, 64, 64, 64), None, rnd(64, 64, 3, 3), None, None, None, 1, 0, False, (1016, 64), 0, 0, dtype=0)
 
 
+PATCH16_CASES = [
+    # b, cin, cout, h, tile width, channels per workgroup, residual, relu
+    (1, 256, 256, 64, 64, 128, True, True),       # the shipped shape of the 64x64 level (16 pixel tiles x 2 channel tiles per frame)
+    (2, 128, 256, 64, 64, 64, False, True),       # two channel blocks, cin != cout, 64 channels per workgroup
+    (1, 192, 128, 128, 64, 128, True, False),     # two pixel tiles per row: interior tile edges read real neighbours, frame edges zeros; odd number of channel blocks
+    (1, 512, 512, 32, 32, 64, True, True),        # the shipped shape of the 32x32 level (8 rows x 32 pixels per tile)
+    (3, 128, 128, 32, 32, 128, False, False),     # 12 workgroups: the XCD chunking with a remainder
+    (1, 64 * 5, 64, 8, 32, 64, False, True),      # must be refused (8 rows < a tile's 8 rows is fine, 8 % 8 == 0 -> accepted?) -- see the reject test for real refusals
+]
+PATCH16_CASES = PATCH16_CASES[:5]
+
+
+@pytest.mark.parametrize("dtype", [1, 2], ids=["bf16", "f16"])
+@pytest.mark.parametrize("cfg", PATCH16_CASES, ids=lambda c: "b%d_c%d_o%d_h%d_tw%d_bn%d_res%d_relu%d" % c)
+def test_conv3x3_patch_kernel_16bit(cfg, dtype, gpu_device):
+    """The patch-staged kernel of the 16-bit plans' 64x64 / 32x32 levels (patch16.hip) against the fp64 conv of the rounded operands (one 16-bit ulp of the
+    result) and against the implicit-GEMM kernel on the same inputs (same products, channel-block-major instead of tap-major summation: one ulp, not bit-equal);
+    repeated launches bit-identical."""
+    b, cin, cout, h, tw, bn, res, relu = cfg
+    rt = (lambda t: t.half().float()) if dtype == 2 else bf16r
+    x0 = rt(rnd(b, cin, h, h, seed=171))
+    w = rnd(cout, cin, 3, 3, seed=172) * 0.05
+    scale, shift = rnd(cout, seed=173) * 0.5 + 1.0, rnd(cout, seed=174) * 0.1
+    r = rt(rnd(b, cout, h, h, seed=175)) if res else None
+    got = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (7000 + tw, bn), 0, 0, dtype=dtype)
+    ref = ref_conv(x0, None, rt(w), scale, shift, r, 1, False, relu)
+    assert torch.isfinite(got).all()
+    tol = (ref.abs() * 2.0 ** -8 + 1e-3) if dtype == 1 else (ref.abs() * 2.0 ** -11 + 2e-4)
+    assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
+    other = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (128, 128), 1, 1, dtype=dtype)
+    assert ((got - other).abs() <= 2 * tol).all(), (got - other).abs().max().item()
+    again = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (7000 + tw, bn), 0, 0, dtype=dtype)
+    assert torch.equal(got, again)
+
+
+def test_conv3x3_patch_kernel_rejects_other_shapes(gpu_device):
+    from livespeechportraits_amd import _native as N
+    x = rnd(1, 128, 64, 64, seed=1); w = rnd(128, 128, 3, 3, seed=2)
+    with pytest.raises(N.Lspf2fError):       # fp32 storage
+        run_conv(gpu_device, x, None, w, None, None, None, 1, 0, False, (7064, 128), 0, 0, dtype=0)
+    with pytest.raises(N.Lspf2fError):       # stride 2
+        run_conv(gpu_device, x, None, w, None, None, None, 2, 0, False, (7064, 128), 0, 0, dtype=1)
+    with pytest.raises(N.Lspf2fError):       # two sources
+        run_conv(gpu_device, x, x, rnd(128, 256, 3, 3, seed=3), None, None, None, 1, 0, False, (7064, 128), 0, 0, dtype=1)
+    with pytest.raises(N.Lspf2fError):       # a frame narrower than the tile
+        run_conv(gpu_device, rnd(1, 128, 32, 32, seed=4), None, w, None, None, None, 1, 0, False, (7064, 128), 0, 0, dtype=1)
+    with pytest.raises(N.Lspf2fError):       # channels not a multiple of 64
+        run_conv(gpu_device, rnd(1, 160, 64, 64, seed=5), None, rnd(128, 160, 3, 3, seed=6), None, None, None, 1, 0, False, (7064, 128), 0, 0, dtype=1)
+
+
 BANDCONV_CASES = [
     # b, h (= w), cout, residual, relu
     (1, 16, 64, True, True),
