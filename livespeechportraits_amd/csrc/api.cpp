@@ -148,6 +148,8 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "bandconv") P.use_bandconv = v != 0;
         else if (k == "bandconv_min_blocks") P.bandconv_min_blocks = v;
         else if (k == "bandconv_min_frames") P.bandconv_min_frames_small = v;
+        else if (k == "patch16") P.use_patch16 = v != 0;
+        else if (k == "patch16_min_blocks") P.patch16_min_blocks = v;
         else if (k == "rowup") P.use_rowup = v != 0;
         else if (k == "rowlast") P.use_rowlast = v != 0;
         else if (k == "rowlast_fused") P.rowlast_fused = v != 0;
@@ -299,6 +301,7 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
         if (l.fullk) return P.dtype ? "conv3x3_fullk16" : "conv3x3_fullk";
         if (l.rowup) return "rowup256";
+        if (l.patch16) return "conv3x3_patch16";
         if (l.bandconv) return "bandconv512";
         if (l.rowconv) return l.c0 == 64 ? "rowconv64" : "rowconv128";
         if (l.inorm) return l.smallm ? (P.in_smallm_fused ? "conv3x3_smallm(in)" : "conv3x3_smallm+in_small") : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
@@ -588,6 +591,12 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.out = tptr(l.out);
         p.B = batch; p.H = l.hs; p.W = l.hs; p.R = l.rowup; p.relu = l.relu; p.dtype = P.dtype;
         e = launch_rowup(p, s);
+    } else if (l.patch16) {
+        PatchConvParams p{};
+        p.src = tptr(l.src0); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.c0; p.Cout = l.cout; p.relu = l.relu; p.dtype = P.dtype;
+        e = launch_patch16(p, l.patch16, l.bn, s);
     } else if (l.bandconv) {
         BandConvParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.wbc_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
@@ -918,6 +927,11 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
     return rc;
 }
 
+#ifdef LSPF2F_ABLATE
+// tools/ablate.sh builds only: the ablation bits of the kernels behind lspf2f_conv3x3 (the shipped library never reads the process environment)
+static int ablate_dbg() { const char *env = std::getenv("LSP_HIP_DBG"); return env ? std::atoi(env) : 0; }
+#endif
+
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride, int upsample,
                                     int tile_m, int tile_n, int split_k, int k_group, int dtype)
 {
@@ -1091,7 +1105,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
             q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.Cout = cout; q.relu = relu; q.dtype = dtype;
 #ifdef LSPF2F_ABLATE
-            if (const char *env = std::getenv("LSP_HIP_DBG")) q.dbg = std::atoi(env);
+            q.dbg = ablate_dbg();
 #endif
             if (c1 != 0 || stride != 1 || upsample != 0 || !patch16_supported(q, tile_m - 7000, tile_n))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the patch-staged 16-bit kernel does not support this shape");
@@ -1208,7 +1222,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
         p.partial = static_cast<float *>(scratch);
     }
 #ifdef LSPF2F_ABLATE
-    if (const char *env = std::getenv("LSP_HIP_DBG")) p.dbg = std::atoi(env);   // tools/ablate.sh builds only
+    p.dbg = ablate_dbg();   // tools/ablate.sh builds only
 #endif
 #ifdef LSPF2F_IGEMM_STAMPS
     if (sp == 1 && scratch && scratch_bytes >= (size_t)2048 * 4 * 16 * 8) p.stamps = static_cast<unsigned long long *>(scratch);

@@ -65,6 +65,7 @@ struct LayerDesc {
     int wino = 0;          // > 0: executed by the Winograd F(2x2,3x3) kernel (wino.hip) with this many 32-channel blocks per wave (1 | 2); `splits` = its K splits
     int wino4 = 0;         // 1: executed by the Winograd F(4x4,3x3) kernel (wino4.hip); `splits` = its K splits
     int winoup = 0;        // > 0: executed by the up-conv Winograd kernel (winoup.hip) with this many 32-channel blocks per wave; `splits` = its K splits
+    int patch16 = 0;       // > 0: executed by the patch-staged 16-bit kernel (patch16.hip) with this tile width (64 | 32 pixels; 4 | 8 rows); bn = channels per workgroup
     int fullk = 0;         // > 0: executed by the full-K single-launch kernel (fullk.hip) with this many 16-pixel blocks per tile
                            // (splits == 2 with it: K in two halves over twice the workgroups, combined in the launch)
 };
@@ -92,6 +93,8 @@ struct Plan {
     int bandconv_min_frames_small = 1 << 30;   // 4x4 / 2x2 levels (a tile = 2 / 8 whole frames): never by default -- at 8 frames the 64 / 16
                                                // workgroups of such a launch lose to the igemm (normal 4460 -> 4388, large 2881 -> 2840 frames/s,
                                                // A-B-A-B); tune key `bandconv_min_frames` lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
+    bool use_patch16 = true;   // 16-bit plans: tune key `patch16=0` keeps the stride-1 convs of the 64x64 / 32x32 levels on the implicit GEMM (A-B runs)
+    int patch16_min_blocks = 192;   // ... which they only leave when the launch has at least this many workgroups (tune key `patch16_min_blocks`)
     bool use_rowup = true;     // bf16 plans: tune key `rowup=0` keeps L1.up on the implicit GEMM (A-B runs)
     bool rowlast_fused = true; // bf16 plans: rowlast128 applies pixel shuffle + tanh in its epilogue when only fp32 frames are wanted (tune key `rowlast_fused=0`: the two-launch form, A-B runs)
     bool use_rowlast = true;   // bf16 plans: tune key `rowlast=0` keeps the GEMM-form last conv on the implicit-GEMM kernel (A-B runs)
@@ -190,6 +193,17 @@ inline bool rowup_layer(int hs, int c0, int c1, int cout, bool up4, int dtype, b
 inline bool bandconv_layer(int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm)
 {
     return dtype != 0 && c0 == 512 && c1 == 0 && cout % 32 == 0 && stride == 1 && !up && !up4 && !inorm && (ho == 16 || ho == 8 || ho == 4 || ho == 2);
+}
+// patch-staged 16-bit kernel (mirrors patch16_supported() in patch16.hip): stride-1 single-source convs of >= 128 channels at 64x64 (tiles of 4 rows x 64 pixels) and
+// 32x32 (8 rows x 32); returns the tile width (0 = keep the implicit GEMM) and the channels per workgroup: 128 when that still fills the chip, else 64
+inline int patch16_choice(int batch, int ho, int c0, int c1, int cout, int stride, bool up, bool up4, int dtype, bool inorm, int min_blocks, int *bn)
+{
+    if (dtype == 0 || c1 != 0 || stride != 1 || up || up4 || inorm) return 0;
+    if ((ho != 64 && ho != 32) || c0 % 64 || c0 < 128 || cout % 64) return 0;
+    const long mtiles = (long)batch * ho * ho / 256;
+    if (cout % 128 == 0 && mtiles * (cout / 128) >= min_blocks) { *bn = 128; return ho == 64 ? 64 : 32; }
+    if (mtiles * (cout / 64) >= min_blocks) { *bn = 64; return ho == 64 ? 64 : 32; }
+    return 0;
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0
 // which layers get the tile-blocked weight copy at pack time (independent of the batch: the blob layout must not depend on it)

@@ -346,6 +346,24 @@ def test_bf16_plans_route_small_512_channel_layers_to_the_band_kernel(monkeypatc
     assert checked >= 2
 
 
+def test_16bit_plans_route_the_64_and_32_levels_to_the_patch_staged_kernel():
+    """DESIGN.md 4.12 (round 6): from the batch that fills the chip with 256-pixel tiles the stride-1 single-source convs of the 64x64 / 32x32 levels of a 16-bit plan run on
+    conv3x3_patch16 (the ResidualBlock convs, models/networks.py:650-675) -- 128 channels per workgroup when that gives >= patch16_min_blocks workgroups, else 64; it reads the
+    implicit GEMM's own weight rows, so the blob carries no extra form for it; `patch16=0` puts them back."""
+    from livespeechportraits_amd.engine import Engine
+    e = Engine("normal", dtype="bf16", max_batch=8)
+    at8 = {l["name"]: l for l in e.layers(8)}
+    names = [n for n, l in at8.items() if l["kernel"] == "conv3x3_patch16"]
+    assert names == ["L2.d.res0.a", "L2.d.res0.b", "L3.d.res0.a", "L3.d.res0.b", "L4.u.res0.a", "L4.u.res0.b", "L3.u.res0.a", "L3.u.res0.b"]
+    assert (at8["L2.d.res0.a"]["tile_m"], at8["L2.d.res0.a"]["tile_n"]) == (256, 128)      # 8 x 16 pixel tiles x 2 channel tiles = 256 workgroups
+    assert (at8["L3.d.res0.a"]["tile_m"], at8["L3.d.res0.a"]["tile_n"]) == (256, 64)       # 8 x 4 x 8 = 256
+    assert all(at8[n]["split_k"] == 1 for n in names)
+    assert not any(l["kernel"] == "conv3x3_patch16" for l in e.layers(1))                  # one frame: 16 / 4 pixel tiles, the implicit GEMM keeps them
+    assert not any(l["kernel"] == "conv3x3_patch16" for l in Engine("normal", max_batch=8).layers(8))      # fp32 plans: Winograd
+    assert not any(l["kernel"] == "conv3x3_patch16" for l in Engine("normal", dtype="bf16", max_batch=8, tune={"patch16": 0}).layers(8))
+    assert len([l for l in Engine("large", dtype="f16", max_batch=8).layers(8) if l["kernel"] == "conv3x3_patch16"]) == 16
+
+
 def test_16bit_plans_route_the_smallest_levels_to_the_full_k_kernel():
     """DESIGN.md 4.5 (round 5): from 2 frames up the 16-bit plans run the 4x4 / 2x2 levels and the convs that write 8x8 through a stride or an upsample on
     conv3x3_fullk16 -- whole K per workgroup, no split-K, no splitk_reduce launch (19 -> 8 of them in configs[2]); the packer's tile-blocked copy equals the
@@ -356,7 +374,7 @@ def test_16bit_plans_route_the_smallest_levels_to_the_full_k_kernel():
     at8 = e.layers(8)
     fk = [l["name"] for l in at8 if l["kernel"] == "conv3x3_fullk16"]
     assert fk == ["L5.down", "L6.down", "L6.d.res0.a", "L6.d.res0.b", "L7.down", "L7.d.res0.a", "L7.d.res0.b", "L7.up", "L7.u.res0.a", "L7.u.res0.b", "L6.up"]
-    assert sum("splitk_reduce" in l["kernel"] for l in at8) == 7                      # <= 8 (19 in round 4; L3.down runs 64x128 tiles unsplit since the tile sweep of round 5)
+    assert sum("splitk_reduce" in l["kernel"] for l in at8) == 3                      # <= 8 (19 in round 4; 7 in round 5; the four 32x32 ResidualBlock convs left their 2 K-splits for conv3x3_patch16 in round 6)
     for l in at8:
         if l["kernel"] == "conv3x3_fullk16":
             assert l["split_k"] == 1 and l["h_out"] in (2, 4, 8) and l["cout"] == 512

@@ -139,6 +139,9 @@ def test_winograd_kernel_instances_do_not_spill(tmp_path):
         if "wino4_3x3" in name:            # one workgroup per CU by design (two ring slots of 56 KB): 400 registers, no scratch
             assert scratch == 0 and occ == 1, (name, scratch, occ)
             continue
+        if "wino3x3_chain" in name:        # the probe instance of round 6 (2..4 layers in one launch, nb = 1): same budget as wino3x3<1>
+            assert scratch == 0 and occ >= 2, (name, scratch, occ)
+            continue
         nb = int(re.search(r"wino(?:up)?3x3ILi(\d)E", name).group(1))
         assert scratch == 0, (name, scratch)
         assert occ >= 2, (name, occ)          # two workgroups per CU share every SIMD (nb = 2: 79 KB of LDS each; nb = 1: up to three)
