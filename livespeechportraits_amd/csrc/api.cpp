@@ -1107,6 +1107,9 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
 #ifdef LSPF2F_ABLATE
             q.dbg = ablate_dbg();
 #endif
+#ifdef LSPF2F_PATCH_STAMPS
+            if (scratch && scratch_bytes >= (size_t)4096 * 8 * 8 * 8) q.stamps = static_cast<unsigned long long *>(scratch);
+#endif
             if (c1 != 0 || stride != 1 || upsample != 0 || !patch16_supported(q, tile_m - 7000, tile_n))
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the patch-staged 16-bit kernel does not support this shape");
             e = launch_patch16(q, tile_m - 7000, tile_n, static_cast<hipStream_t>(hip_stream));

@@ -272,6 +272,7 @@ struct PatchConvParams {
     int B, H, W, C, Cout, relu;
     int dtype;                    // 1 = bf16, 2 = fp16
     int dbg;                      // -DLSPF2F_ABLATE builds: 1 no copies in the K loop, 2 no fragment reads, 4 no MFMAs, 16 no epilogue
+    unsigned long long *stamps;   // -DLSPF2F_PATCH_STAMPS builds: [blocks][8 waves][8] cycle sums (tools/probes/patch16_stamps.py)
     int tiles_x, tiles_per_img, ntm, ntn;   // filled by launch_patch16
     FastDiv div_tpi, div_tx, div_ntn;
 };

@@ -10,7 +10,7 @@
 //   * tap (ky, kx) of a K-tile is an address offset into the patch: the A fragment of output pixels (r, c .. c + 31) is patch pixels (r + ky, c + kx ..) -- 32
 //     consecutive records, whose 16-byte k-slots are XOR-swizzled on the record index so every ds_read_b128 lane group covers the 64 banks once;
 //   * weights: the implicit GEMM's own rows [Cout][9][Cin] (no second packed copy), BN x 128 B per K-tile through a 3-slot LDS ring, two K-tiles ahead;
-//   * the eight waves form two groups of four (one wave of each per SIMD) that run half a K-tile step apart: while one group issues its 16 MFMAs (s_setprio 1)
+//   * the eight waves form two groups of four (one wave of each per SIMD) that run half a K-tile step apart: while one group issues its 16 MFMAs
 //     the other reads the next K-tile's fragments and issues its copies; two s_barrier per K-tile keep the groups in that alternation, every vmcnt wait is
 //     counted (never 0 inside the loop) -- the schedule of the guide's 8-phase GEMM template carried over to an implicit GEMM;
 //   * K order: channel block outer, tap inner (the implicit GEMM: tap outer) -> same products, different fp32 summation order: the two kernels agree to one
@@ -29,6 +29,14 @@ static constexpr unsigned kOOBp = 0x80000000u;   // voffset beyond any num_recor
 #define PABL(p, bit) ((p).dbg & (bit))
 #else
 #define PABL(p, bit) 0
+#endif
+
+// segment timers (tools/probes/patch16_stamps.py; builds with -DLSPF2F_PATCH_STAMPS only): s_memtime values are wave-uniform scalars; a sample is only USED behind a wait
+// the schedule has anyway, so the instrumented loop keeps its waits
+#ifdef LSPF2F_PATCH_STAMPS
+#define PSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(v) do {} while (0)
 #endif
 
 // both barriers of a K-tile step: nothing moves across (the compiler sees a memory clobber, the scheduler a fence)
@@ -117,16 +125,21 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
         for (int ks = 0; ks < 4; ++ks) boff[j][ks] = base ^ (unsigned)(ks << 5);
     }
 
-    // ---- epilogue operands first in the queue (older than every copy: the counted waits below are unaffected)
-    const int erow = lane >> 3, ecol = (lane & 7) * 4;
-    float4 scv[TN], shv[TN];
+    // ---- epilogue operands first in the queue (older than every copy: the counted waits below are unaffected).  Epilogue role of a lane: 8 consecutive channels
+    // (16 bytes of output) of one pixel -- 4 lanes per 32-channel row segment, 16 rows per pass: half the store / residual-load instructions of the 4-channel form
+    // (the store tail of such an epilogue is issue-bound, guide T21)
+    const int erow = lane >> 2, ecol = (lane & 3) * 8;
+    float4 scv[TN][2], shv[TN][2];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + ecol;
-        scv[j] = make_float4(1.f, 1.f, 1.f, 1.f); shv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) {
-            scv[j] = *reinterpret_cast<const float4 *>(p.scale + n);
-            shv[j] = *reinterpret_cast<const float4 *>(p.shift + n);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            scv[j][q] = make_float4(1.f, 1.f, 1.f, 1.f); shv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) {
+                scv[j][q] = *reinterpret_cast<const float4 *>(p.scale + n + 4 * q);
+                shv[j][q] = *reinterpret_cast<const float4 *>(p.shift + n + 4 * q);
+            }
         }
     }
 
@@ -148,6 +161,10 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     bf16x8 fa[2][4], fb_[TN][4];
+#ifdef LSPF2F_PATCH_STAMPS
+    unsigned long long t_l0 = 0, t_l1 = 0, t_m0 = 0, t_m1 = 0, t_prev = 0, acc_l = 0, acc_b1 = 0, acc_m = 0, acc_b2 = 0, t_start = 0, t_rd = 0, acc_rd = 0;
+    PSTAMP(t_start);
+#endif
     for (int cb = 0; cb < NCB; ++cb) {
         const unsigned abuf = (cb & 1) ? (unsigned)PATCH_BYTES : 0u, anext = (cb & 1) ? 0u : (unsigned)PATCH_BYTES;
         const bool more = cb + 1 < NCB;
@@ -157,6 +174,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
             const int ky = tap / 3, kx = tap - ky * 3;
             const int slot = tap % 3;
             // ---- load segment: fragments of this K-tile ...
+            PSTAMP(t_l0);
             if (!PABL(p, 2)) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
                         fb_[j][ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + slot * BTILE + boff[j][ks]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int P = p0[i] + ky * PW + kx;
+                    const int P = PABL(p, 1024) ? p0[i] : p0[i] + ky * PW + kx;
                     const unsigned base = abuf + (unsigned)(P << 7) + (unsigned)(((hh ^ (P >> 1)) & 7) << 4);
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
@@ -189,11 +207,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
                 else if (tap < NPA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB + 1) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB) : "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!PABL(p, 2048)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PSTAMP(t_l1);
             PATCH_BAR();
+            PSTAMP(t_m0);
             if (PABL(p, 256)) { PATCH_BAR(); PATCH_BAR(); }
             // ---- MFMA segment (the other group is in its load segment)
-            __builtin_amdgcn_s_setprio(1);
+            if (PABL(p, 512)) __builtin_amdgcn_s_setprio(1);      // (measured: the MFMA group at raised priority is 0.8 us per layer SLOWER, profiles/r06_patch16_ab.txt)
             if (!PABL(p, 4)) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
@@ -203,7 +223,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = mfma32_16b<F16>(fa[i][ks], fb_[j][ks], acc[i][j]);
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (PABL(p, 512)) __builtin_amdgcn_s_setprio(0);
+#ifdef LSPF2F_PATCH_STAMPS
+            PSTAMP(t_m1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t_prev) acc_b2 += t_l0 - t_prev;
+            acc_l += t_l1 - t_l0; acc_b1 += t_m0 - t_l1; acc_m += t_m1 - t_m0; t_prev = t_m1;
+#endif
             // the second group skips the very last barrier: both groups then pass the same number, and the first one starts its epilogue under the second one's last MFMAs
             if (!(tap == 8 && last && grp == 1 && !PABL(p, 32))) PATCH_BAR();
         }
@@ -211,6 +237,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
 
     // ---- epilogue (the implicit GEMM's: each wave transposes its 32 x 32 tiles through a private LDS patch so a lane ends up with 4 consecutive channels of a pixel).
     // Every K-loop read of LDS is complete (the last barrier above); the patches live in the patch buffer of the LAST channel block, which no copy in flight targets.
+#ifdef LSPF2F_PATCH_STAMPS
+    unsigned long long t_end; PSTAMP(t_end);
+    if (p.stamps && lane == 0) {
+        unsigned long long *q = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        q[0] = acc_l; q[1] = acc_b1; q[2] = acc_m; q[3] = acc_b2; q[4] = t_end - t_start; q[5] = t_start;
+    }
+#endif
     if (PABL(p, 16)) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     constexpr int EP = 36;
@@ -218,28 +251,50 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
     const int ccol = lane & 31, crow = 4 * (lane >> 5);
     T *outp = static_cast<T *>(p.out);
     const T *resp = static_cast<const T *>(p.residual);
+    // output pixel of this lane in each (pixel block i, pass): fixed per lane; the residual rows are all requested before the first transpose
+    size_t opix[2][2];
+    u32x4 rres[TN][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int m = wm * 64 + i * 32 + pass * 16 + erow;
+            opix[i][pass] = (size_t)(fb * p.H + y0 + m / TW) * p.W + x0 + (m % TW);
+        }
+    if (resp) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass)
+                    rres[j][i][pass] = *reinterpret_cast<const u32x4 *>(resp + opix[i][pass] * p.Cout + n0 + wn * (BN / 2) + j * 32 + ecol);
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + ecol;
-        const float4 sc = scv[j], sh = shv[j];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + crow) * EP + ccol] = acc[i][j][r];
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int row = pass * 8 + erow;
-                float4 v = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
-                const int m = wm * 64 + i * 32 + row;
-                const size_t opix = (size_t)(fb * p.H + y0 + m / TW) * p.W + x0 + (m % TW);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (resp) {
-                    const float4 rv = load4(resp + opix * p.Cout + n);
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = pass * 16 + erow;
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(patch + row * EP + ecol + 4);
+                const float sc[8] = {scv[j][0].x, scv[j][0].y, scv[j][0].z, scv[j][0].w, scv[j][1].x, scv[j][1].y, scv[j][1].z, scv[j][1].w};
+                const float sh[8] = {shv[j][0].x, shv[j][0].y, shv[j][0].z, shv[j][0].w, shv[j][1].x, shv[j][1].y, shv[j][1].z, shv[j][1].w};
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = v[2 * q] * sc[2 * q] + sh[2 * q], b = v[2 * q + 1] * sc[2 * q + 1] + sh[2 * q + 1];
+                    if (resp) { a += lo16<F16>(rres[j][i][pass][q]); b += hi16<F16>(rres[j][i][pass][q]); }
+                    if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                    o[q] = pack16x2<F16>(a, b);
                 }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                store4(outp + opix * p.Cout + n, v);
+                *reinterpret_cast<u32x4 *>(outp + opix[i][pass] * p.Cout + n) = o;
             }
         }
     }
