@@ -169,6 +169,20 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
         const unsigned abuf = (cb & 1) ? (unsigned)PATCH_BYTES : 0u, anext = (cb & 1) ? 0u : (unsigned)PATCH_BYTES;
         const bool more = cb + 1 < NCB;
         const bool last = !more;
+        // the copies of tap step `tap` of this block: piece `tap` of the next block's patch (zeros past the last block) ...
+        auto issue_a = [&](int tap) {
+            if (tap < NPA) dma16(lds0 + anext + dstA[tap < NPA ? tap : 0], more ? voffA[tap < NPA ? tap : 0] : kOOBp, rsa, (cb + 1) * 128);
+        };
+        // ... and the weights of K-tile t + 2
+        auto issue_b = [&](int tap) {
+            const int tap2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
+            const int cb2 = tap + 2 < 9 ? cb : cb + 1;
+            const bool live = tap + 2 < 9 || more;
+            unsigned vb[NPB];
+#pragma unroll
+            for (int k = 0; k < NPB; ++k) vb[k] = live ? voffB[k] : kOOBp;
+            dma16_group<NPB, 64 * 128>(ldsB + (unsigned)(((tap + 2) % 3) * BTILE), vb, rsw, (tap2 * p.C + cb2 * 64) * 2);
+        };
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -190,23 +204,20 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
                         fa[i][ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + (base ^ (unsigned)(ks << 5)));
                 }
             }
-            // ... and the copies: one piece of the next block's patch, the weights two K-tiles ahead (into the slot K-tile t - 1 has left)
+#ifndef LSPF2F_PATCH_COPIES_IN_M
+            // ... and the copies: one piece of the next block's patch, the weights two K-tiles ahead (into the slot K-tile t - 1 has left); counted wait: K-tile t + 1
+            // (and everything older: the patch pieces too) has landed, this step's own pieces may still fly
             if (!PABL(p, 1)) {
-                if (tap < NPA) dma16(lds0 + anext + dstA[tap < NPA ? tap : 0], more ? voffA[tap < NPA ? tap : 0] : kOOBp, rsa, (cb + 1) * 128);
-                {
-                    const int tap2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
-                    const int cb2 = tap + 2 < 9 ? cb : cb + 1;
-                    const bool live = tap + 2 < 9 || more;
-                    unsigned vb[NPB];
-#pragma unroll
-                    for (int k = 0; k < NPB; ++k) vb[k] = live ? voffB[k] : kOOBp;
-                    dma16_group<NPB, 64 * 128>(ldsB + (unsigned)(((tap + 2) % 3) * BTILE), vb, rsw, (tap2 * p.C + cb2 * 64) * 2);
-                }
-                // K-tile t + 1 (and everything older: the patch pieces too) has landed; this step's own pieces may still fly
+                issue_a(tap); issue_b(tap);
                 if (PABL(p, 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (tap < NPA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB + 1) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB) : "memory");
             }
+#else
+            // (A-B build -DLSPF2F_PATCH_COPIES_IN_M: the copies ride between the MFMAs instead.  Measured SLOWER: a 256 -> 256 @64x64 layer takes 0.79 instead of 0.74 of
+            // the same box's implicit-GEMM time, the forward gains 4 % instead of 8 % (profiles/r06_patch16_ab.txt): a copy then has one and a half segments to land instead of two and the vmcnt(0) here waits for it.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             if (!PABL(p, 2048)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PSTAMP(t_l1);
             PATCH_BAR();
@@ -216,13 +227,25 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
             if (PABL(p, 512)) __builtin_amdgcn_s_setprio(1);      // (measured: the MFMA group at raised priority is 0.8 us per layer SLOWER, profiles/r06_patch16_ab.txt)
             if (!PABL(p, 4)) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = mfma32_16b<F16>(fa[i][ks], fb_[j][ks], acc[i][j]);
+#ifdef LSPF2F_PATCH_COPIES_IN_M
+                    if (!PABL(p, 1)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ks == 0) issue_a(tap);
+                        if (ks == 1) issue_b(tap);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+                }
             }
+#ifdef LSPF2F_PATCH_COPIES_IN_M
+            else if (!PABL(p, 1)) { issue_a(tap); issue_b(tap); }
+#endif
             if (PABL(p, 512)) __builtin_amdgcn_s_setprio(0);
 #ifdef LSPF2F_PATCH_STAMPS
             PSTAMP(t_m1);
