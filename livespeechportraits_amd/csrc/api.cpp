@@ -59,6 +59,13 @@ struct lspf2f_handle {
     int last_route = 0;           // lastconv=<route>: forced direct last-conv kernel (LastConvParams::route; tests only)
     const void *cand_cached = nullptr;   // candidate stack whose first-conv contribution sits in the workspace cache
     hipStream_t cap_stream = nullptr;
+    // tail_prefetch (round 6, off by default): a side branch of the captured forward reads the weights of the <= 16x16 levels while the levels above compute
+    int tail_prefetch = 0;        // 0 off | 1 plain loads | 2 non-temporal loads
+    int tail_prefetch_at = -1;    // layer index the branch forks in front of (-1: the first layer)
+    int tail_prefetch_wgs = 32;   // workgroups of the touching kernel
+    int tail_prefetch_mb = 0;     // 0 = the whole range, else only its first MB
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<CachedGraph> graphs;
     size_t next_victim = 0;
     void drop_graphs()
@@ -70,6 +77,9 @@ struct lspf2f_handle {
     {
         drop_graphs();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 
@@ -166,6 +176,10 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "fullk16_min_frames") P.fullk16_min_frames = v;
         else if (k == "wino_prio") P.wino_prio = v;
         else if (k == "prefetch") h->prefetch = v != 0;
+        else if (k == "tail_prefetch") h->tail_prefetch = v;
+        else if (k == "tail_prefetch_at") h->tail_prefetch_at = v;
+        else if (k == "tail_prefetch_wgs") h->tail_prefetch_wgs = v;
+        else if (k == "tail_prefetch_mb") h->tail_prefetch_mb = v;
         else if (k == "smallm_dma") h->smallm_dma = v != 0;
         else if (k == "smallm_kb") P.smallm_kb = v;
         else if (k == "in_small_regs") h->in_small_regs = v != 0;
@@ -776,12 +790,42 @@ int lspf2f_forward_ex(lspf2f_handle *h, const float *feat_dev, const float *cand
         if (h->graphs.size() < kMaxCachedGraphs) h->graphs.emplace_back();
         g = &h->graphs[h->next_victim++ % h->graphs.size()];
         g->reset();
+        // tail_prefetch: the byte range of the blob the <= 16x16 levels read (the forms this batch's plan takes), walked by a side branch of the graph
+        const char *tp_lo = nullptr, *tp_hi = nullptr;
+        if (h->tail_prefetch) {
+            if (!h->side_stream && hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) return fail(LSPF2F_ERR_HIP, "tail_prefetch: side stream");
+            if (!h->ev_fork && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(LSPF2F_ERR_HIP, "tail_prefetch: event");
+            if (!h->ev_join && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return fail(LSPF2F_ERR_HIP, "tail_prefetch: event");
+            for (const auto &l : h->plan.layers) {
+                if (l.kind != kIgemm || l.ho > 16) continue;
+                const size_t wb = (size_t)(l.up4 ? 16 : 9) * l.cin * l.cout * h->plan.elt();
+                const int64_t off = l.fullk ? ((h->plan.dtype == 0 && (l.stride == 2 || (l.splits == 2 && !l.c1))) ? l.wfk2_off : l.wfk_off) : l.bandconv ? l.wbc_off : l.w_off;
+                if (off < 0) continue;
+                const char *lo = h->blob + off, *hi = lo + wb;
+                if (!tp_lo || lo < tp_lo) tp_lo = lo;
+                if (!tp_hi || hi > tp_hi) tp_hi = hi;
+            }
+            if (tp_lo && h->tail_prefetch_mb > 0 && (size_t)(tp_hi - tp_lo) > ((size_t)h->tail_prefetch_mb << 20)) tp_hi = tp_lo + ((size_t)h->tail_prefetch_mb << 20);
+        }
         hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) return hipfail(e, "hipStreamBeginCapture");
+        bool forked = false;
+        int li = 0;
         for (const auto &l : h->plan.layers) {
+            if (tp_lo && !forked && li >= h->tail_prefetch_at) {
+                e = hipEventRecord(h->ev_fork, h->cap_stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(h->side_stream, h->ev_fork, 0);
+                if (e == hipSuccess) e = launch_touch_range(tp_lo, (size_t)(tp_hi - tp_lo) & ~(size_t)15, h->tail_prefetch, h->tail_prefetch_wgs,
+                                                            reinterpret_cast<unsigned *>(h->ws + h->plan.counters_offset()), h->side_stream);
+                if (e == hipSuccess) e = hipEventRecord(h->ev_join, h->side_stream);
+                if (e != hipSuccess) { rc = hipfail(e, "tail_prefetch fork"); break; }
+                forked = true;
+            }
             rc = run_layer(h, l, feat_dev, cand_dev, cand_batch, out_dev, out_u8_dev, batch, h->cap_stream);
             if (rc) break;
+            ++li;
         }
+        if (forked) (void)hipStreamWaitEvent(h->cap_stream, h->ev_join, 0);      // the branch joins at the end: it never holds a layer up
         e = hipStreamEndCapture(h->cap_stream, &g->graph);
         if (rc) { g->reset(); return rc; }
         if (e != hipSuccess) { g->reset(); return hipfail(e, "hipStreamEndCapture"); }

@@ -396,6 +396,8 @@ hipError_t launch_pixel_shuffle(const ShuffleParams &p, hipStream_t s);
 hipError_t launch_clock_probe(unsigned long long *out, unsigned duration_us, hipStream_t s);
 // dst[0 .. bytes) = src[0 .. bytes) by a kernel (16-byte aligned pointers and size); either side may be pinned host memory
 hipError_t launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t s);
+// read [src, src + bytes) with `blocks` workgroups and drop it (policy 1 plain loads, 2 non-temporal): the graph side branch of tune key `tail_prefetch`
+hipError_t launch_touch_range(const void *src, size_t bytes, int policy, int blocks, unsigned *sink, hipStream_t s);
 
 // InstanceNorm2d(affine=False, eps=1e-5) after a conv, fp32 NHWC (instnorm.hip).  `x` holds the raw conv output (bias included)
 // and is normalised in place: x = relu?((x - mean[b][c]) * rstd[b][c] + residual?).

@@ -259,6 +259,34 @@ hipError_t launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t s
     return hipGetLastError();
 }
 
+// Side branch of the forward's graph (tune key `tail_prefetch`, round 6): a few workgroups walk the byte range the <= 16x16 levels will stream (their weights do not depend on
+// activations) towards the chip while the >= 32x32 levels compute, so the tail's first-byte latency is a memory-side cache hit instead of an HBM access.  Plain loads (policy 1) or
+// non-temporal ones (policy 2: past the L2s of the XCDs the touching workgroups happen to sit on).  The XOR of everything read is stored only if it equals a value it cannot take.
+__global__ __launch_bounds__(256) void touch_range(const uint4 *__restrict__ src, size_t n16, int nt, unsigned *sink)
+{
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {          // four 16-byte loads per lane in flight
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        const v4u *q = reinterpret_cast<const v4u *>(src);
+        v4u a, b, c, d;
+        if (nt) { a = __builtin_nontemporal_load(q + i); b = __builtin_nontemporal_load(q + i + stride); c = __builtin_nontemporal_load(q + i + 2 * stride); d = __builtin_nontemporal_load(q + i + 3 * stride); }
+        else { a = q[i]; b = q[i + stride]; c = q[i + 2 * stride]; d = q[i + 3 * stride]; }
+        acc.x ^= a.x ^ b.x ^ c.x ^ d.x; acc.y ^= a.y ^ b.y ^ c.y ^ d.y; acc.z ^= a.z ^ b.z ^ c.z ^ d.z; acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = src[i]; acc.x ^= a.x; acc.y ^= a.y; acc.z ^= a.z; acc.w ^= a.w; }
+    if (sink && (acc.x & acc.y & acc.z & acc.w) == 0xffffffffu && (acc.x | acc.y) == 0u) *sink = acc.x;      // never true: keeps the loads
+}
+
+hipError_t launch_touch_range(const void *src, size_t bytes, int policy, int blocks, unsigned *sink, hipStream_t s)
+{
+    if (bytes < 16 || blocks < 1) return hipSuccess;
+    if ((uintptr_t)src & 15) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(touch_range, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint4 *>(src), bytes >> 4, policy == 2 ? 1 : 0, sink);
+    return hipGetLastError();
+}
+
 // bench.py's clock probe: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz reference
 __global__ __launch_bounds__(64) void clock_probe(unsigned long long *out, unsigned long long ticks)
 {

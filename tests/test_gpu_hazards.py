@@ -64,7 +64,7 @@ def _inputs(batch, size, seed, dev, cand_batch=1):
 
 # (variant, frame size, frames, storage, norm, tune): every kernel family of the shipped plans -- Winograd register form and its split-K tickets,
 # up-conv Winograd, full-K (split and unsplit), tiny-M, igemm + reduce, the 16-bit row / band / up kernels, the InstanceNorm statistics routes --
-# plus the two A-B arms of round 5 that change how wino3x3 stores (out_wt) and how far ahead it loads (wino_ureg=2)
+# plus the two A-B arms of round 5 that change how wino3x3 stores (out_wt) and how far ahead it loads (wino_ureg=2), and round 6's patch-staged kernel / side branch
 CASES = [
     ("large", 512, 1, "f32", "batch", None),
     ("large", 512, 1, "f32", "batch", {"out_wt": 0}),
@@ -75,6 +75,8 @@ CASES = [
     ("large", 512, 2, "f16", "batch", None),
     ("normal", 256, 2, "f32", "instance", None),
     ("large", 512, 1, "f32", "instance", None),
+    ("large", 512, 8, "f16", "batch", None),                                            # round 6: conv3x3_patch16 on 16 layers (two wave groups half a K-tile step apart, counted waits)
+    ("large", 512, 1, "f32", "batch", {"tail_prefetch": 1, "tail_prefetch_at": 10}),    # round 6: the graph's side branch (measured null, kept as a tune key) only ever READS the blob
 ]
 
 
