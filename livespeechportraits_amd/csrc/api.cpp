@@ -83,6 +83,11 @@ struct lspf2f_handle {
     }
 };
 
+#ifdef LSPF2F_ABLATE
+// tools/ablate.sh builds only: the ablation bits of the kernels (the shipped library never reads the process environment)
+static int ablate_dbg() { const char *env = std::getenv("LSP_HIP_DBG"); return env ? std::atoi(env) : 0; }
+#endif
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 static int hipfail(hipError_t e, const char *what)
@@ -449,6 +454,9 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         // broadcast stack -- separate, so a broadcast forward never overwrites what the cache holds
         float *cache = reinterpret_cast<float *>(cand != nullptr ? h->ws + P.cand_cache_bytes() : h->ws);
         p.force_direct = h->first_direct;
+#ifdef LSPF2F_ABLATE
+        p.dbg = ablate_dbg();
+#endif
         // a candidate stack shared by a batch (cand_batch == 1, batch > 1): its 12-channel share is computed once (matrix-core kernel,
         // channel range) and every frame adds its feature-map channel in a streaming pass -- measured 77 us vs 150 us at batch 8 for
         // running the full 13-channel layer per frame
@@ -970,11 +978,6 @@ int lspf2f_forward_timed(lspf2f_handle *h, const float *feat_dev, const float *c
     for (auto &x : ev) (void)hipEventDestroy(x);
     return rc;
 }
-
-#ifdef LSPF2F_ABLATE
-// tools/ablate.sh builds only: the ablation bits of the kernels behind lspf2f_conv3x3 (the shipped library never reads the process environment)
-static int ablate_dbg() { const char *env = std::getenv("LSP_HIP_DBG"); return env ? std::atoi(env) : 0; }
-#endif
 
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride, int upsample,
                                     int tile_m, int tile_n, int split_k, int k_group, int dtype)

@@ -316,6 +316,11 @@ __global__ __launch_bounds__(256) void first_conv_mfma(const FirstConvParams p)
 //   * piece P = 4 j + wave, so the window lands in channel order and the K loop starts on channels 0..3 while 4..8 and 9..12 are still in
 //     flight (three counted waits + barriers instead of one);
 //   * epilogue addresses are one base pointer + compile-time offsets.
+#ifdef LSPF2F_ABLATE
+#define FABL(p, bit) ((p).dbg & (bit))
+#else
+#define FABL(p, bit) 0
+#endif
 template <typename T, int NH>
 __global__ __launch_bounds__(256) void first_conv_dma(const FirstConvParams p)
 {
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(256) void first_conv_dma(const FirstConvParams p)
         for (int j = 0; j < WJ; ++j) {
             const int P = 4 * j + wave;
             const int slot = 64 * P + lane, k = (slot * 4) / N, ci = k / 9;
-            const bool ok = P < WPIECES && k < CIN * 9 && ci >= p.ci_begin && ci < p.ci_end;
+            const bool ok = P < WPIECES && k < CIN * 9 && ci >= p.ci_begin && ci < p.ci_end && !FABL(p, 8);
             const unsigned voff[1] = {ok ? (unsigned)slot * 16u : OOB};
             dma16_group<1, 0>(lds0 + (unsigned)(P < WPIECES ? P * 1024 : DUMP), voff, srd, 0);
         }
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void first_conv_dma(const FirstConvParams p)
             const int ci = isf ? 0 : 1 + cl;
             const int iy = 2 * oy0 - 1 + r, x0 = 2 * ox0 - 4 + 4 * c4;
             const bool ok = P < FPIECES + CPIECES && s < (isf ? 5 * 33 : 60 * 33) && ci >= p.ci_begin && ci < p.ci_end &&
-                            (unsigned)iy < (unsigned)p.H && x0 >= 0;
+                            (unsigned)iy < (unsigned)p.H && x0 >= 0 && !FABL(p, 4);
             const unsigned voff[1] = {ok ? (unsigned)(((cl * p.H + iy) * p.W + x0) * 4) : OOB};
             const unsigned dst = lds0 + (unsigned)(P < FPIECES + CPIECES ? WIN0 + P * 1024 : DUMP);
             if (isf) dma16_group<1, 0>(dst, voff, srd_f, 0);
@@ -409,8 +414,11 @@ __global__ __launch_bounds__(256) void first_conv_dma(const FirstConvParams p)
                 for (int h = 0; h < NH; ++h) b_nxt[h] = wl[(2 * (s2 + 1) + kp) * N + h * 32 + m];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (FABL(p, 1)) { acc[0][s2 & 15] += a_cur * b_cur[0]; if (NH > 1) acc[NH - 1][s2 & 15] += a_cur * b_cur[NH - 1]; }      // (keeps the operand reads alive)
+            else {
 #pragma unroll
-            for (int h = 0; h < NH; ++h) acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[h], acc[h], 0, 0, 0);
+                for (int h = 0; h < NH; ++h) acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[h], acc[h], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             a_cur = a_nxt;
 #pragma unroll
@@ -438,6 +446,7 @@ __global__ __launch_bounds__(256) void first_conv_dma(const FirstConvParams p)
         for (int r = 0; r < 16; ++r) {
             float v = acc[h][r] + bias;
             if (p.relu) v = fmaxf(v, 0.f);
+            if (FABL(p, 2) && v != 12345.678f) continue;      // (ablation: no stores, the value stays live)
             st1(ob + ((r & 3) + 8 * (r >> 2)) * N + h * 32, v);
         }
     }

@@ -363,6 +363,7 @@ struct FirstConvParams {
     int relu;
     const float *bias;      // [Cout] conv bias (InstanceNorm plans: use_bias, networks.py:590) or nullptr; final pass only
     int force_direct;       // tests / A-B runs: 1 = the vector-ALU kernel, 2 = the register-staged matrix-core kernel (0 = by shape)
+    int dbg;                // -DLSPF2F_ABLATE builds (first_conv_dma): 1 no MFMAs, 2 no stores, 4 no window copies, 8 no weight copies
 };
 hipError_t launch_first_conv(const FirstConvParams &p, hipStream_t s);
 
