@@ -13,6 +13,14 @@
 //   * the eight waves form two groups of four (one wave of each per SIMD) that run half a K-tile step apart: while one group issues its 16 MFMAs
 //     the other reads the next K-tile's fragments and issues its copies; two s_barrier per K-tile keep the groups in that alternation, every vmcnt wait is
 //     counted (never 0 inside the loop) -- the schedule of the guide's 8-phase GEMM template carried over to an implicit GEMM;
+//     Hazards by barrier interval (interval k lies between the k-th and (k+1)-th barrier a wave passes inside the loop; group 0 = waves 0-3, group 1 = waves 4-7):
+//         group 0: load segment of K-tile t in interval 2t,     MFMA segment in 2t + 1        group 1: load segment in 2t + 1, MFMA segment in 2t + 2
+//       WAR  the copies of K-tile t + 2 go into the ring slot of K-tile t - 1, issued in load segment t = interval >= 2t; the last read of t - 1 (group 1, interval 2t - 1)
+//            completed (lgkmcnt(0)) in front of barrier 2t - 1.  The patch pieces of block cb + 1 go into the buffer block cb - 1 was read from: same argument.
+//       RAW  K-tile t + 1 is read in interval >= 2t + 2; every wave waited (counted vmcnt: everything but this step's own pieces) for its share of it at the end of its load
+//            segment t, in front of barrier <= 2t + 1.  The last patch piece (tap NPA - 1 <= 7) is older than the weights waited for at tap 8.
+//       The epilogue's transpose patches live in the patch buffer of the LAST block: every read of it completed in front of the loop's last barrier, and the copies still in flight
+//       then (zeros: out-of-range pieces of a block and K-tiles that do not exist) target the other buffer, its dump KB and the ring.
 //   * K order: channel block outer, tap inner (the implicit GEMM: tap outer) -> same products, different fp32 summation order: the two kernels agree to one
 //     16-bit ulp of the result, not bit for bit.
 // Fused epilogue (folded BatchNorm scale / shift, residual, ReLU, RNE store) as in the implicit-GEMM kernel.
