@@ -275,7 +275,7 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC passes (offline: rocprofv3 --pmc cannot run inside this process);
     # only quoted for the workload it was measured on
     traffic, traffic_src = None, None
-    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_%s_b%d_%s.json" % (r, a.variant, B, a.dtype)) for r in ("r05", "r04", "r03")) if os.path.exists(q)),
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", "%s_pmc_%s_b%d_%s.json" % (r, a.variant, B, a.dtype)) for r in ("r06", "r05", "r04", "r03")) if os.path.exists(q)),
                     os.path.join(ROOT, "profiles", "r04_pmc_%s_b%d_%s.json" % (a.variant, B, a.dtype)))
     family = "wino3x3" if dom["kernel"].startswith("wino3x3") else dom["kernel"].split("<")[0]
     if a.size == 512 and os.path.exists(pmc_path):
