@@ -1,7 +1,7 @@
 // gfx950: the stride-1 3x3 convolutions of the 64x64 / 32x32 levels of the 16-bit plans (bf16 | fp16 storage, fp32 accumulate) from 8 frames up -- the ResidualBlock
 // convs 256 -> 256 @ 64x64 and 512 -> 512 @ 32x32 of BASELINE.json configs[2], which ran on igemm3x3<128x128> at 0.33 of the dense 16-bit MFMA peak.  DESIGN.md 4.12.
 //
-// What bound the implicit GEMM there (round 6 ablation, profiles/r06_igemm16_ablate.txt): a 128 x 128 tile pulls 8 LDS-DMA pieces per wave and K-tile through the
+// What bound the implicit GEMM there (round 6 ablation, profiles/r06_patch16_ab.txt (1)): a 128 x 128 tile pulls 8 LDS-DMA pieces per wave and K-tile through the
 // CU's vector-memory path for 16 MFMAs (512 cycles) -- 64 KB per 1024 MFMA cycles of a SIMD, the path's own rate -- because im2col re-stages every input pixel
 // once per tap.  This kernel stages each pixel ONCE per 64-channel block and reads it for all nine taps:
 //   * a workgroup (8 waves) owns TR x TW = 256 output pixels of one frame x BN output channels; per 64-channel block `cb` the (TR + 2) x (TW + 2) halo patch of the
@@ -33,6 +33,9 @@ namespace lspf2f {
 
 static constexpr unsigned kOOBp = 0x80000000u;   // voffset beyond any num_records: the piece lands as zeros
 
+// Ablation switches (-DLSPF2F_ABLATE builds, LSP_HIP_DBG of tools/time_conv.py; the shipped kernel has none of them): 1 no copies in the K loop, 2 no fragment reads, 4 no MFMAs,
+// 16 no epilogue, 32 both wave groups in lockstep, 64 vmcnt(0) instead of the counted waits, 256 two extra barriers per step, 512 s_setprio 1 around the MFMAs,
+// 1024 tap-invariant fragment addresses, 2048 no lgkmcnt(0) in front of the barrier
 #ifdef LSPF2F_ABLATE
 #define PABL(p, bit) ((p).dbg & (bit))
 #else
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
 
     bf16x8 fa[2][4], fb_[TN][4];
 #ifdef LSPF2F_PATCH_STAMPS
-    unsigned long long t_l0 = 0, t_l1 = 0, t_m0 = 0, t_m1 = 0, t_prev = 0, acc_l = 0, acc_b1 = 0, acc_m = 0, acc_b2 = 0, t_start = 0, t_rd = 0, acc_rd = 0;
+    unsigned long long t_l0 = 0, t_l1 = 0, t_m0 = 0, t_m1 = 0, t_prev = 0, acc_l = 0, acc_b1 = 0, acc_m = 0, acc_b2 = 0, t_start = 0;
     PSTAMP(t_start);
 #endif
     for (int cb = 0; cb < NCB; ++cb) {
