@@ -62,6 +62,8 @@ void choose_tiling(int M, int N, int ktiles, int par, bool up9, int dtype, int *
             // 8-frame plan, 256 -> 512 at stride 2): 36.6 us with 128x128 x 2 splits + splitk_reduce, 32.8 us with 64x128 unsplit (profiles/r05_bf16_tilings.txt); at K = 4608
             // the 128-row tile keeps its lead (53.4 vs 59.2 us)
             if (tbig >= 256 && tbig < 512 && ktiles <= 36 && N >= 128 && t128 >= 512) { bm = 64; bn = 128; tiles = t128; }
+            // (the sub-pixel up-conv in the same position -- L4.up of an 8-frame plan, 256 tiles of 128x128 x 2 K-splits + reduce -- measures 49.0 us on unsplit 64x128 tiles against 49.5 + 6.8 us
+            // back to back, but the FORWARD is 0.8-1 % slower with it, A-B-A-B: profiles/r06_patch16_ab.txt (9); not taken)
         }
         if (tiles < (bm == 128 ? 512 : want)) {
             // workgroups to aim for when splitting K.  fp32: 768 beats 512 (batch 1 `large` 388.8-389.5 -> 392.3-393.2 frames/s,
