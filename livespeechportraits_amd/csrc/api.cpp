@@ -164,6 +164,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "bandconv_min_blocks") P.bandconv_min_blocks = v;
         else if (k == "bandconv_min_frames") P.bandconv_min_frames_small = v;
         else if (k == "patch16") P.use_patch16 = v != 0;
+        else if (k == "patchup16") P.use_patchup16 = v != 0;
         else if (k == "patch16_min_blocks") P.patch16_min_blocks = v;
         else if (k == "rowup") P.use_rowup = v != 0;
         else if (k == "rowlast") P.use_rowlast = v != 0;
@@ -320,7 +321,7 @@ static const char *kernel_name(const LayerDesc &l, const Plan &P)
         if (l.inorm && l.fullk) return "conv3x3_fullk+in_small";
         if (l.fullk) return P.dtype ? "conv3x3_fullk16" : "conv3x3_fullk";
         if (l.rowup) return "rowup256";
-        if (l.patch16) return "conv3x3_patch16";
+        if (l.patch16) return l.up4 ? "conv3x3_patchup16" : "conv3x3_patch16";
         if (l.bandconv) return "bandconv512";
         if (l.rowconv) return l.c0 == 64 ? "rowconv64" : "rowconv128";
         if (l.inorm) return l.smallm ? (P.in_smallm_fused ? "conv3x3_smallm(in)" : "conv3x3_smallm+in_small") : l.in_route == kInFused ? "igemm3x3(stats)+in_finalize+in_apply"
@@ -613,6 +614,12 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.out = tptr(l.out);
         p.B = batch; p.H = l.hs; p.W = l.hs; p.R = l.rowup; p.relu = l.relu; p.dtype = P.dtype;
         e = launch_rowup(p, s);
+    } else if (l.patch16 && l.up4) {
+        PatchConvParams p{};
+        p.src = tptr(l.src0); p.src1 = tptr(l.src1); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
+        p.residual = tptr(l.res); p.out = tptr(l.out);
+        p.B = batch; p.H = l.hs; p.W = l.hs; p.C = l.c0; p.C1 = l.c1; p.Cout = l.cout; p.relu = l.relu; p.dtype = P.dtype;
+        e = launch_patchup16(p, l.patch16, l.bn, s);
     } else if (l.patch16) {
         PatchConvParams p{};
         p.src = tptr(l.src0); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
@@ -999,7 +1006,7 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
         if (sp == 1) return 0;
         return (size_t)sp * batch * hs * ws * cout * sizeof(float) + (size_t)batch * (hs / 8) * (ws / 16) * (cout / (32 * (tile_m - 4000))) * sizeof(unsigned);
     }
-    if (tile_m == 7064 || tile_m == 7032) return 0;                    // patch-staged 16-bit kernel: no scratch
+    if (tile_m == 7064 || tile_m == 7032 || tile_m == 7164 || tile_m == 7132) return 0;      // patch-staged 16-bit kernels: no scratch
     (void)ws;
     const int ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
     if ((tile_m == 16 || tile_m == 32) && tile_n == 16 && split_k == 2) {      // K-split full-K kernel: two partial tiles per tile + arrival counters
@@ -1145,6 +1152,16 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
                 return fail(LSPF2F_ERR_UNSUPPORTED, "the Winograd kernel does not support this shape");
             e = launch_wino(q, tile_m - 4000, static_cast<hipStream_t>(hip_stream));
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (wino) launch");
+            return LSPF2F_OK;
+        }
+        if ((tile_m == 7164 || tile_m == 7132) && k_group != -4) {   // 7100 + tile width: the patch-staged kernel's sub-pixel up-conv form (conv3x3_patchup16); upsample == 2, w_packed = [4][cout][2][2][c0 + c1]
+            PatchConvParams q{};
+            q.src = src0; q.src1 = c1 ? src1 : nullptr; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
+            q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.C1 = c1; q.Cout = cout; q.relu = relu; q.dtype = dtype;
+            if (stride != 1 || upsample != 2 || !patchup16_supported(q, tile_m - 7100, tile_n))
+                return fail(LSPF2F_ERR_UNSUPPORTED, "the patch-staged 16-bit up-conv kernel does not support this shape");
+            e = launch_patchup16(q, tile_m - 7100, tile_n, static_cast<hipStream_t>(hip_stream));
+            if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (patchup16) launch");
             return LSPF2F_OK;
         }
         if ((tile_m == 7064 || tile_m == 7032) && k_group != -4) {   // 7000 + tile width: the patch-staged 16-bit kernel (patch16.hip), tile_n = 128 | 64 channels per workgroup; igemm weight rows

@@ -270,6 +270,10 @@ struct PatchConvParams {
     const void *residual;         // NHWC 16-bit [B][H][W][Cout] or nullptr
     void *out;                    // NHWC 16-bit [B][H][W][Cout]
     int B, H, W, C, Cout, relu;
+    // sub-pixel up-conv form only (conv3x3_patchup16): second source of the concat (C1 = 0 | C channels), H x W = the LOW-res extent, out = [B][2H][2W][Cout], residual likewise,
+    // weights = the implicit GEMM's up4 operand [4 parities][Cout][2][2][C + C1]
+    const void *src1;
+    int C1;
     int dtype;                    // 1 = bf16, 2 = fp16
     int dbg;                      // -DLSPF2F_ABLATE builds: 1 no copies in the K loop, 2 no fragment reads, 4 no MFMAs, 16 no epilogue
     unsigned long long *stamps;   // -DLSPF2F_PATCH_STAMPS builds: [blocks][8 waves][8] cycle sums (tools/probes/patch16_stamps.py)
@@ -278,6 +282,8 @@ struct PatchConvParams {
 };
 bool patch16_supported(const PatchConvParams &p, int tw, int bn);
 hipError_t launch_patch16(const PatchConvParams &p, int tw, int bn, hipStream_t s);
+bool patchup16_supported(const PatchConvParams &p, int tw, int bn);
+hipError_t launch_patchup16(const PatchConvParams &p, int tw, int bn, hipStream_t s);
 
 // Weights-stationary conv for the 64 -> 64 and 128 -> 128 channel layers in bf16 storage (rowconv.hip): stride 1, one source,
 // W % 64 == 0 (64 channels) / W % 32 == 0 (128 channels).

@@ -334,6 +334,269 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// The same structure for the sub-pixel up-convs (Upsample x2 + Conv3x3 over the concat of two equally wide sources, models/networks.py:610-611, in the implicit GEMM's
+// up4 form: 4 output parities x 2x2 taps on the LOW-res source with pre-summed weights [4][Cout][2][2][Cin]).  A workgroup = (parity, 256 low-res pixels, BN channels):
+// tap (a, b) of parity (py, px) reads patch records (r + py + a, c + px + b), so the same (TR + 2) x (TW + 2) patch serves every parity; the four workgroups of a
+// tile sit next to each other in an XCD's chunk and share it in L2.  Per 64-channel block there are 4 K-tiles instead of 9: the ring slot of a K-tile is no longer a
+// constant of the unrolled tap ((4 cb + tap) mod 3 = (cb + tap) mod 3: a scalar per block), and the next block's patch rides in ceil(NPA / 3) pieces per tap over
+// taps 0..2.  Everything else -- two wave groups half a step apart, counted waits, hazards by barrier interval, epilogue -- as in conv3x3_patch16 above.
+template <bool F16, int TW, int TR, int BN>
+__global__ __launch_bounds__(512) void conv3x3_patchup16(const PatchConvParams p)
+{
+    typedef typename St16<F16>::type T;
+    constexpr int PW = TW + 2, PPX = PW * (TR + 2);
+    constexpr int NPIECE = (PPX + 7) / 8;
+    constexpr int NPA = (NPIECE + 7) / 8;
+    constexpr int PPS = (NPA + 2) / 3;                       // patch pieces per tap step (taps 0..2)
+    constexpr int NPB = BN / 64;
+    constexpr int TN = BN / 64;
+    constexpr int PATCH_BYTES = (NPIECE + 1) * 1024;
+    constexpr int BRING = 2 * PATCH_BYTES;
+    constexpr int BTILE = BN * 128;
+    static_assert(TW * TR == 256 && TW % 32 == 0, "a wave's 32-pixel MFMA block is 32 consecutive pixels of one row");
+    static_assert(8 * 32 * 36 * 4 <= PATCH_BYTES, "the epilogue's transpose patches live in the patch buffer of the last channel block");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_p16[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_char *)smem_p16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    asm volatile("" :: "s"(p.src), "s"(p.src1), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C), "s"(p.C1), "s"(p.Cout),
+                       "s"(p.relu), "s"(p.ntm), "s"(p.ntn), "s"(p.div_tpi.m), "s"(p.div_tpi.s1), "s"(p.div_tpi.s2), "s"(p.div_tx.m), "s"(p.div_tx.s1), "s"(p.div_tx.s2),
+                       "s"(p.div_ntn.m), "s"(p.div_ntn.s1), "s"(p.div_ntn.s2));
+
+    // ---- tile: channel tile fastest, then the 4 parities of a pixel tile (they share its patch), then pixel tiles; 8 contiguous chunks, one per XCD
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned total = gridDim.x, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const int t2 = (int)p.div_ntn.div(lin), nt = (int)lin - t2 * p.ntn;
+    const int par = t2 & 3, mt = t2 >> 2;
+    const int py = par >> 1, px = par & 1;
+    const int fb = (int)p.div_tpi.div((unsigned)mt);
+    const int rem = mt - fb * p.tiles_per_img;
+    const int ty = (int)p.div_tx.div((unsigned)rem), tx = rem - ty * p.tiles_x;
+    const int y0 = ty * TR, x0 = tx * TW, n0 = nt * BN;
+    const int Cin = p.C + p.C1;
+    const int NCB = Cin >> 6, NCB0 = p.C >> 6;
+    const int Krow = 4 * Cin;
+
+    unsigned voffA[NPA], voffB[NPB];
+    unsigned dstA[NPA];
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int q = j * 8 + wave;
+        const int pp = q * 8 + (lane >> 3), s = lane & 7;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+        const bool ok = pp < PPX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        voffA[j] = ok ? (unsigned)((fb * p.H + y) * p.W + x) * (unsigned)(p.C * 2) + (unsigned)((s ^ ((pp >> 1) & 7)) << 4) : kOOBp;      // (both sources have p.C channels)
+        dstA[j] = (unsigned)((q < NPIECE ? q : NPIECE) * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+        const int row = wave * 8 + k * 64 + (lane >> 3), s = lane & 7;
+        voffB[k] = (unsigned)((n0 + row) * Krow * 2) + (unsigned)((s ^ ((row >> 1) & 7)) << 4);
+    }
+    const unsigned src_bytes = (unsigned)(p.B * p.H * p.W) * (unsigned)(p.C * 2);
+    const i32x4 rsa0 = make_srd(p.src, src_bytes);
+    const i32x4 rsa1 = make_srd(p.C1 ? p.src1 : p.src, src_bytes);
+    const i32x4 rsw = make_srd(static_cast<const char *>(p.w) + (size_t)par * p.Cout * Krow * 2, (unsigned)(p.Cout * Krow * 2));
+    const unsigned ldsB = lds0 + BRING + (unsigned)(wave * 8 * 128);
+
+    const int l31 = lane & 31, hh = lane >> 5;
+    int p0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + l31;
+        p0[i] = (m / TW + py) * PW + (m % TW) + px;                        // patch record of tap (0, 0) of THIS parity
+    }
+    unsigned boff[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * (BN / 2) + j * 32 + l31;
+        const unsigned base = (unsigned)BRING + (unsigned)(nl * 128) + (unsigned)(((hh ^ (nl >> 1)) & 7) << 4);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) boff[j][ks] = base ^ (unsigned)(ks << 5);
+    }
+
+    const int erow = lane >> 2, ecol = (lane & 3) * 8;
+    float4 scv[TN][2], shv[TN][2];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + ecol;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            scv[j][q] = make_float4(1.f, 1.f, 1.f, 1.f); shv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) {
+                scv[j][q] = *reinterpret_cast<const float4 *>(p.scale + n + 4 * q);
+                shv[j][q] = *reinterpret_cast<const float4 *>(p.shift + n + 4 * q);
+            }
+        }
+    }
+
+    // ---- prologue: patch of block 0, weights of K-tiles 0 and 1 (ring slots 0 and 1)
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) dma16(lds0 + dstA[j], voffA[j], rsa0, 0);
+    dma16_group<NPB, 64 * 128>(ldsB, voffB, rsw, 0);
+    dma16_group<NPB, 64 * 128>(ldsB + BTILE, voffB, rsw, Cin * 2);                                // K-tile 1 = (block 0, tap 1)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB) : "memory");
+    PATCH_BAR();
+    if (grp == 1) PATCH_BAR();
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8 fa[2][4], fb_[TN][4];
+    int s0 = 0;                                                            // ring slot of this block's tap 0 = (4 cb) mod 3 = cb mod 3
+    for (int cb = 0; cb < NCB; ++cb) {
+        const unsigned abuf = (cb & 1) ? (unsigned)PATCH_BYTES : 0u, anext = (cb & 1) ? 0u : (unsigned)PATCH_BYTES;
+        const bool more = cb + 1 < NCB;
+        const bool last = !more;
+        const bool nsrc1 = cb + 1 >= NCB0;                                 // the NEXT block's source
+        const i32x4 rsn = nsrc1 ? rsa1 : rsa0;
+        const int nsoff = (nsrc1 ? cb + 1 - NCB0 : cb + 1) * 128;
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            int sl = s0 + tap; if (sl >= 3) sl -= 3; if (sl >= 3) sl -= 3;
+            const unsigned slb = (unsigned)(sl * BTILE);
+            // ---- load segment
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    fb_[j][ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + (boff[j][ks] + slb));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int P = p0[i] + (tap >> 1) * PW + (tap & 1);
+                const unsigned base = abuf + (unsigned)(P << 7) + (unsigned)(((hh ^ (P >> 1)) & 7) << 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    fa[i][ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + (base ^ (unsigned)(ks << 5)));
+            }
+            if (tap < 3) {                                                 // PPS pieces of the next block's patch (zeros into the dump slot where a wave has no piece left)
+#pragma unroll
+                for (int k = 0; k < PPS; ++k) {
+                    const int j = tap * PPS + k;
+                    const unsigned va = (j < NPA && more) ? voffA[j < NPA ? j : 0] : kOOBp;
+                    const unsigned dk = j < NPA ? dstA[j < NPA ? j : 0] : (unsigned)(NPIECE * 1024);
+                    dma16(lds0 + anext + dk, va, rsn, nsoff);
+                }
+            }
+            {
+                const int tap2 = tap + 2 < 4 ? tap + 2 : tap + 2 - 4;
+                const int cb2 = tap + 2 < 4 ? cb : cb + 1;
+                const bool live = tap + 2 < 4 || more;
+                int sl2 = sl + 2; if (sl2 >= 3) sl2 -= 3;
+                unsigned vb[NPB];
+#pragma unroll
+                for (int k = 0; k < NPB; ++k) vb[k] = live ? voffB[k] : kOOBp;
+                dma16_group<NPB, 64 * 128>(ldsB + (unsigned)(sl2 * BTILE), vb, rsw, (tap2 * Cin + cb2 * 64) * 2);
+            }
+            if (tap < 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB + PPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPB) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PATCH_BAR();
+            // ---- MFMA segment
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = mfma32_16b<F16>(fa[i][ks], fb_[j][ks], acc[i][j]);
+            if (!(tap == 3 && last && grp == 1)) PATCH_BAR();
+        }
+        s0 = s0 + 1 == 3 ? 0 : s0 + 1;
+    }
+
+    // ---- epilogue: output pixel (2 y + py, 2 x + px) of the [2H][2W] frame
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int EP = 36;
+    float *patch = reinterpret_cast<float *>(smem_p16 + (((NCB - 1) & 1) ? PATCH_BYTES : 0)) + wave * (32 * EP);
+    const int ccol = lane & 31, crow = 4 * (lane >> 5);
+    T *outp = static_cast<T *>(p.out);
+    const T *resp = static_cast<const T *>(p.residual);
+    size_t opix[2][2];
+    u32x4 rres[TN][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int m = wm * 64 + i * 32 + pass * 16 + erow;
+            opix[i][pass] = ((size_t)(fb * 2 * p.H + 2 * (y0 + m / TW) + py) * (2 * p.W)) + 2 * (x0 + (m % TW)) + px;
+        }
+    if (resp) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass)
+                    rres[j][i][pass] = *reinterpret_cast<const u32x4 *>(resp + opix[i][pass] * p.Cout + n0 + wn * (BN / 2) + j * 32 + ecol);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + ecol;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + crow) * EP + ccol] = acc[i][j][r];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = pass * 16 + erow;
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(patch + row * EP + ecol + 4);
+                const float sc[8] = {scv[j][0].x, scv[j][0].y, scv[j][0].z, scv[j][0].w, scv[j][1].x, scv[j][1].y, scv[j][1].z, scv[j][1].w};
+                const float sh[8] = {shv[j][0].x, shv[j][0].y, shv[j][0].z, shv[j][0].w, shv[j][1].x, shv[j][1].y, shv[j][1].z, shv[j][1].w};
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = v[2 * q] * sc[2 * q] + sh[2 * q], b = v[2 * q + 1] * sc[2 * q + 1] + sh[2 * q + 1];
+                    if (resp) { a += lo16<F16>(rres[j][i][pass][q]); b += hi16<F16>(rres[j][i][pass][q]); }
+                    if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                    o[q] = pack16x2<F16>(a, b);
+                }
+                *reinterpret_cast<u32x4 *>(outp + opix[i][pass] * p.Cout + n) = o;
+            }
+        }
+    }
+}
+
+template <bool F16, int TW, int TR, int BN>
+static hipError_t launch_patchup16_t(const PatchConvParams &p_in, hipStream_t s)
+{
+    constexpr int PPX = (TW + 2) * (TR + 2), NPIECE = (PPX + 7) / 8;
+    constexpr size_t smem = (size_t)2 * (NPIECE + 1) * 1024 + (size_t)3 * BN * 128;
+    static_assert(smem <= 160 * 1024, "LDS");
+    PatchConvParams p = p_in;
+    p.tiles_x = p.W / TW;
+    p.tiles_per_img = (p.H / TR) * p.tiles_x;
+    p.ntm = p.B * p.tiles_per_img; p.ntn = p.Cout / BN;
+    p.div_tpi = FastDiv::make((unsigned)p.tiles_per_img);
+    p.div_tx = FastDiv::make((unsigned)p.tiles_x);
+    p.div_ntn = FastDiv::make((unsigned)p.ntn);
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_patchup16<F16, TW, TR, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    hipLaunchKernelGGL((conv3x3_patchup16<F16, TW, TR, BN>), dim3((unsigned)(p.ntm * p.ntn * 4)), dim3(512), smem, s, p);
+    return hipGetLastError();
+}
+
 template <bool F16, int TW, int TR, int BN>
 static hipError_t launch_patch16_t(const PatchConvParams &p_in, hipStream_t s)
 {
@@ -366,6 +629,28 @@ bool patch16_supported(const PatchConvParams &p, int tw, int bn)
     // 32-bit buffer offsets with the top bit reserved as the out-of-range marker
     if ((size_t)p.B * p.H * p.W * p.C * 2 > 0x7fffffffull || (size_t)p.Cout * 9 * p.C * 2 > 0x7fffffffull) return false;
     return true;
+}
+
+bool patchup16_supported(const PatchConvParams &p, int tw, int bn)
+{
+    if (p.dtype != 1 && p.dtype != 2) return false;
+    if ((tw != 64 && tw != 32) || (bn != 128 && bn != 64)) return false;
+    const int tr = 256 / tw;
+    if (p.B < 1 || p.W % tw || p.H % tr || p.C % 64 || (p.C1 != 0 && p.C1 != p.C) || p.C + p.C1 < 128 || p.Cout % bn) return false;
+    if (p.C1 && !p.src1) return false;
+    if ((size_t)p.B * p.H * p.W * p.C * 2 > 0x7fffffffull || (size_t)p.Cout * 4 * (p.C + p.C1) * 2 > 0x7fffffffull) return false;
+    return true;
+}
+
+hipError_t launch_patchup16(const PatchConvParams &p, int tw, int bn, hipStream_t s)
+{
+    if (!patchup16_supported(p, tw, bn)) return hipErrorInvalidValue;
+    if (p.dtype == 2) {
+        if (tw == 64) return bn == 128 ? launch_patchup16_t<true, 64, 4, 128>(p, s) : launch_patchup16_t<true, 64, 4, 64>(p, s);
+        return bn == 128 ? launch_patchup16_t<true, 32, 8, 128>(p, s) : launch_patchup16_t<true, 32, 8, 64>(p, s);
+    }
+    if (tw == 64) return bn == 128 ? launch_patchup16_t<false, 64, 4, 128>(p, s) : launch_patchup16_t<false, 64, 4, 64>(p, s);
+    return bn == 128 ? launch_patchup16_t<false, 32, 8, 128>(p, s) : launch_patchup16_t<false, 32, 8, 64>(p, s);
 }
 
 hipError_t launch_patch16(const PatchConvParams &p, int tw, int bn, hipStream_t s)

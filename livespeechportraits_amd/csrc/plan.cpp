@@ -570,7 +570,10 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
             int pbn = 0;
             const int patch16 = (p.use_patch16 && !smallm && !fullk && !rowconv && !bandconv)
                                     ? patch16_choice(batch, l.ho, l.c0, l.c1, l.cout, l.stride, l.up, l.up4, p.dtype, l.inorm, p.patch16_min_blocks, &pbn) : 0;
-            if (patch16) { bm = 256; bn = pbn; splits = 1; group = 1; }
+            int patchup16 = 0;
+            if (!patch16 && p.use_patch16 && p.use_patchup16 && !smallm && !fullk && !rowup && !winoup)
+                patchup16 = patchup16_choice(batch, l.hs, l.c0, l.c1, l.cout, l.up4, p.dtype, l.inorm, p.patch16_min_blocks, &pbn);
+            if (patch16 || patchup16) { bm = 256; bn = pbn; splits = 1; group = 1; }
             int route = kInNone;
             if (l.inorm) {
                 // rows of one wave (32 per 32x32 tile row, bm / 2 waves... = bm / 2 for the 2x2-wave tiles) must stay inside one
@@ -601,7 +604,7 @@ BatchLayout layout_for(const Plan &p, int batch, std::vector<size_t> *offsets, s
                 (*tiled)[li].fused_splitk = (wino || wino4 || winoup) ? splits > 1 : (p.dtype == 0 || p.fused_splitk16) && !rowconv && !bandconv && !rowup && !smallm && !fullk && !l.inorm && splits >= 2 && splits <= 8 && tiles <= (long)Plan::kTileCounters &&
                                             (size_t)splits * Mout * l.cout * sizeof(float) < (size_t)0x7fffffff;
                 (*tiled)[li].bm = bm; (*tiled)[li].bn = bn; (*tiled)[li].splits = splits; (*tiled)[li].group = group;
-                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv; (*tiled)[li].rowup = rowup; (*tiled)[li].patch16 = patch16;
+                (*tiled)[li].smallm = smallm; (*tiled)[li].in_route = route; (*tiled)[li].fullk = fullk; (*tiled)[li].rowconv = rowconv; (*tiled)[li].bandconv = bandconv; (*tiled)[li].rowup = rowup; (*tiled)[li].patch16 = patch16 ? patch16 : patchup16;
             }
             if (splits > 1) partial = std::max(partial, (size_t)splits * Mout * l.cout * sizeof(float));
         }

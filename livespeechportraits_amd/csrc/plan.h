@@ -94,6 +94,7 @@ struct Plan {
                                                // workgroups of such a launch lose to the igemm (normal 4460 -> 4388, large 2881 -> 2840 frames/s,
                                                // A-B-A-B); tune key `bandconv_min_frames` lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_patch16 = true;   // 16-bit plans: tune key `patch16=0` keeps the stride-1 convs of the 64x64 / 32x32 levels on the implicit GEMM (A-B runs)
+    bool use_patchup16 = true; // ... and `patchup16=0` the sub-pixel up-convs over 32x32 / 64x64 sources (conv3x3_patchup16)
     int patch16_min_blocks = 192;   // ... which they only leave when the launch has at least this many workgroups (tune key `patch16_min_blocks`)
     bool use_rowup = true;     // bf16 plans: tune key `rowup=0` keeps L1.up on the implicit GEMM (A-B runs)
     bool rowlast_fused = true; // bf16 plans: rowlast128 applies pixel shuffle + tanh in its epilogue when only fp32 frames are wanted (tune key `rowlast_fused=0`: the two-launch form, A-B runs)
@@ -203,6 +204,16 @@ inline int patch16_choice(int batch, int ho, int c0, int c1, int cout, int strid
     const long mtiles = (long)batch * ho * ho / 256;
     if (cout % 128 == 0 && mtiles * (cout / 128) >= min_blocks) { *bn = 128; return ho == 64 ? 64 : 32; }
     if (mtiles * (cout / 64) >= min_blocks) { *bn = 64; return ho == 64 ? 64 : 32; }
+    return 0;
+}
+// its sub-pixel up-conv form (mirrors patchup16_supported()): up4 layers over one source or two equally wide ones at a 64x64 / 32x32 LOW-res extent
+inline int patchup16_choice(int batch, int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm, int min_blocks, int *bn)
+{
+    if (dtype == 0 || !up4 || inorm || (c1 != 0 && c1 != c0)) return 0;
+    if ((hs != 64 && hs != 32) || c0 % 64 || c0 + c1 < 128 || cout % 64) return 0;
+    const long mtiles = (long)batch * hs * hs / 256 * 4;
+    if (cout % 128 == 0 && mtiles * (cout / 128) >= min_blocks) { *bn = 128; return hs == 64 ? 64 : 32; }
+    if (mtiles * (cout / 64) >= min_blocks) { *bn = 64; return hs == 64 ? 64 : 32; }
     return 0;
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0

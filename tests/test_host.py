@@ -362,6 +362,12 @@ def test_16bit_plans_route_the_64_and_32_levels_to_the_patch_staged_kernel():
     assert not any(l["kernel"] == "conv3x3_patch16" for l in Engine("normal", max_batch=8).layers(8))      # fp32 plans: Winograd
     assert not any(l["kernel"] == "conv3x3_patch16" for l in Engine("normal", dtype="bf16", max_batch=8, tune={"patch16": 0}).layers(8))
     assert len([l for l in Engine("large", dtype="f16", max_batch=8).layers(8) if l["kernel"] == "conv3x3_patch16"]) == 16
+    # its sub-pixel up-conv form takes the up-convs over 32x32 / 64x64 sources (L3.up, L2.up); L4.up (16x16 source) and L1.up (rowup256) keep their kernels
+    ups = [n for n, l in at8.items() if l["kernel"] == "conv3x3_patchup16"]
+    assert ups == ["L3.up", "L2.up"] and (at8["L3.up"]["tile_m"], at8["L3.up"]["tile_n"]) == (256, 128)
+    assert at8["L4.up"]["kernel"].startswith("igemm3x3") and at8["L1.up"]["kernel"] == "rowup256"
+    off = {l["name"]: l["kernel"] for l in Engine("normal", dtype="bf16", max_batch=8, tune={"patchup16": 0}).layers(8)}
+    assert off["L3.up"].startswith("igemm3x3") and off["L2.d.res0.a"] == "conv3x3_patch16"
 
 
 def test_16bit_plans_route_the_smallest_levels_to_the_full_k_kernel():
