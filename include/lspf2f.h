@@ -253,7 +253,7 @@ int lspf2f_subset_timed(lspf2f_handle *h, const float *feat_dev, const float *ca
  *   (3a + f / 3, 3b + f % 3), lane as above; split_k and scratch as for 4001 with tile-blocks of 16 x 32 pixels x 32 channels.
  *   7064 / 7032 with tile_n = 128 | 64 = the patch-staged kernel of the 16-bit plans (bf16 | fp16, one source of c0 % 64 == 0 >= 128 channels, stride 1, no upsample):
  *   a workgroup owns 4 rows x 64 / 8 rows x 32 pixels x tile_n channels (hs % 4 == 0, ws % 64 == 0 / hs % 8 == 0, ws % 32 == 0, cout % tile_n == 0); w_packed in the
- *   default layout [cout][3][3][c0]; no scratch.  7164 / 7132 = its sub-pixel up-conv form (upsample == 2; hs, ws the LOW-res extent; c1 in {0, c0}; w_packed = [4][cout][2][2][c0 + c1]). */
+ *   default layout [cout][3][3][c0]; no scratch.  7164 / 7132 / 7116 (tile_n 64 only) = its sub-pixel up-conv form (upsample == 2; hs, ws the LOW-res extent, multiples of the tile's 4 x 64 / 8 x 32 / 16 x 16 pixels; c1 in {0, c0}; w_packed = [4][cout][2][2][c0 + c1]). */
 size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, int cout, int stride,
                                     int upsample, int tile_m, int tile_n, int split_k, int k_group, int dtype);
 int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, const float *scale,

@@ -1006,7 +1006,7 @@ size_t lspf2f_conv3x3_scratch_bytes(int batch, int hs, int ws, int c0, int c1, i
         if (sp == 1) return 0;
         return (size_t)sp * batch * hs * ws * cout * sizeof(float) + (size_t)batch * (hs / 8) * (ws / 16) * (cout / (32 * (tile_m - 4000))) * sizeof(unsigned);
     }
-    if (tile_m == 7064 || tile_m == 7032 || tile_m == 7164 || tile_m == 7132) return 0;      // patch-staged 16-bit kernels: no scratch
+    if (tile_m == 7064 || tile_m == 7032 || tile_m == 7164 || tile_m == 7132 || tile_m == 7116) return 0;      // patch-staged 16-bit kernels: no scratch
     (void)ws;
     const int ho = upsample ? 2 * hs : (stride == 2 ? (hs + 1) / 2 : hs);
     if ((tile_m == 16 || tile_m == 32) && tile_n == 16 && split_k == 2) {      // K-split full-K kernel: two partial tiles per tile + arrival counters
@@ -1154,7 +1154,7 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             if (e != hipSuccess) return hipfail(e, "lspf2f_conv3x3 (wino) launch");
             return LSPF2F_OK;
         }
-        if ((tile_m == 7164 || tile_m == 7132) && k_group != -4) {   // 7100 + tile width: the patch-staged kernel's sub-pixel up-conv form (conv3x3_patchup16); upsample == 2, w_packed = [4][cout][2][2][c0 + c1]
+        if ((tile_m == 7164 || tile_m == 7132 || tile_m == 7116) && k_group != -4) {   // 7100 + tile width: the patch-staged kernel's sub-pixel up-conv form (conv3x3_patchup16); upsample == 2, w_packed = [4][cout][2][2][c0 + c1]
             PatchConvParams q{};
             q.src = src0; q.src1 = c1 ? src1 : nullptr; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
             q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.C1 = c1; q.Cout = cout; q.relu = relu; q.dtype = dtype;

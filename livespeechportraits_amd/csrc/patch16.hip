@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void conv3x3_patchup16(const PatchConvParams p
     constexpr int PATCH_BYTES = (NPIECE + 1) * 1024;
     constexpr int BRING = 2 * PATCH_BYTES;
     constexpr int BTILE = BN * 128;
-    static_assert(TW * TR == 256 && TW % 32 == 0, "a wave's 32-pixel MFMA block is 32 consecutive pixels of one row");
+    static_assert(TW * TR == 256 && TW % 16 == 0, "a wave's 32-pixel MFMA block is 32 consecutive pixels of one row, or (16-pixel tiles) two half-rows: 2 of a ds_read_b128 group's 16 lanes then share a bank slot");
     static_assert(8 * 32 * 36 * 4 <= PATCH_BYTES, "the epilogue's transpose patches live in the patch buffer of the last channel block");
 
     extern __shared__ __attribute__((aligned(16))) char smem_p16[];
@@ -634,7 +634,7 @@ bool patch16_supported(const PatchConvParams &p, int tw, int bn)
 bool patchup16_supported(const PatchConvParams &p, int tw, int bn)
 {
     if (p.dtype != 1 && p.dtype != 2) return false;
-    if ((tw != 64 && tw != 32) || (bn != 128 && bn != 64)) return false;
+    if ((tw != 64 && tw != 32 && tw != 16) || (bn != 128 && bn != 64) || (tw == 16 && bn != 64)) return false;
     const int tr = 256 / tw;
     if (p.B < 1 || p.W % tw || p.H % tr || p.C % 64 || (p.C1 != 0 && p.C1 != p.C) || p.C + p.C1 < 128 || p.Cout % bn) return false;
     if (p.C1 && !p.src1) return false;
@@ -646,9 +646,11 @@ hipError_t launch_patchup16(const PatchConvParams &p, int tw, int bn, hipStream_
 {
     if (!patchup16_supported(p, tw, bn)) return hipErrorInvalidValue;
     if (p.dtype == 2) {
+        if (tw == 16) return launch_patchup16_t<true, 16, 16, 64>(p, s);
         if (tw == 64) return bn == 128 ? launch_patchup16_t<true, 64, 4, 128>(p, s) : launch_patchup16_t<true, 64, 4, 64>(p, s);
         return bn == 128 ? launch_patchup16_t<true, 32, 8, 128>(p, s) : launch_patchup16_t<true, 32, 8, 64>(p, s);
     }
+    if (tw == 16) return launch_patchup16_t<false, 16, 16, 64>(p, s);
     if (tw == 64) return bn == 128 ? launch_patchup16_t<false, 64, 4, 128>(p, s) : launch_patchup16_t<false, 64, 4, 64>(p, s);
     return bn == 128 ? launch_patchup16_t<false, 32, 8, 128>(p, s) : launch_patchup16_t<false, 32, 8, 64>(p, s);
 }

@@ -210,10 +210,10 @@ inline int patch16_choice(int batch, int ho, int c0, int c1, int cout, int strid
 inline int patchup16_choice(int batch, int hs, int c0, int c1, int cout, bool up4, int dtype, bool inorm, int min_blocks, int *bn)
 {
     if (dtype == 0 || !up4 || inorm || (c1 != 0 && c1 != c0)) return 0;
-    if ((hs != 64 && hs != 32) || c0 % 64 || c0 + c1 < 128 || cout % 64) return 0;
+    if ((hs != 64 && hs != 32 && hs != 16) || c0 % 64 || c0 + c1 < 128 || cout % 64) return 0;
     const long mtiles = (long)batch * hs * hs / 256 * 4;
-    if (cout % 128 == 0 && mtiles * (cout / 128) >= min_blocks) { *bn = 128; return hs == 64 ? 64 : 32; }
-    if (mtiles * (cout / 64) >= min_blocks) { *bn = 64; return hs == 64 ? 64 : 32; }
+    if (hs >= 32 && cout % 128 == 0 && mtiles * (cout / 128) >= min_blocks) { *bn = 128; return hs == 64 ? 64 : 32; }
+    if (mtiles * (cout / 64) >= min_blocks) { *bn = 64; return hs == 64 ? 64 : hs; }      // (16x16 sources: a tile = one whole low-res frame, 64 channels per workgroup only)
     return 0;
 }
 // full-K kernel eligibility (mirrors fullk_supported() in fullk.hip); returns the pixel blocks per tile (1 | 2) or 0

@@ -612,6 +612,8 @@ PATCHUP16_CASES = [
     (1, 64, 64, 64, 64, 64, 64, True),           # 4 x 64-pixel tiles, two channel blocks (one per source)
     (1, 192, 192, 256, 64, 64, 128, True),       # six channel blocks: the ring slot of tap 0 walks 0, 1, 2, 0, 1, 2
     (3, 128, 128, 128, 32, 32, 128, True),       # 48 workgroups: XCD chunks with a remainder
+    (2, 128, 128, 128, 16, 16, 64, True),        # 16 x 16-pixel tiles (a whole low-res frame): a wave's 32-pixel block is two half-rows
+    (1, 256, 256, 64, 16, 16, 64, False),
 ]
 
 

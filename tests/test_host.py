@@ -362,10 +362,11 @@ def test_16bit_plans_route_the_64_and_32_levels_to_the_patch_staged_kernel():
     assert not any(l["kernel"] == "conv3x3_patch16" for l in Engine("normal", max_batch=8).layers(8))      # fp32 plans: Winograd
     assert not any(l["kernel"] == "conv3x3_patch16" for l in Engine("normal", dtype="bf16", max_batch=8, tune={"patch16": 0}).layers(8))
     assert len([l for l in Engine("large", dtype="f16", max_batch=8).layers(8) if l["kernel"] == "conv3x3_patch16"]) == 16
-    # its sub-pixel up-conv form takes the up-convs over 32x32 / 64x64 sources (L3.up, L2.up); L4.up (16x16 source) and L1.up (rowup256) keep their kernels
+    # its sub-pixel up-conv form takes the up-convs over 16x16 / 32x32 / 64x64 sources (L4.up: one whole low-res frame per tile, 64 channels per workgroup; L3.up, L2.up); L5.up
+    # (8x8 source) and L1.up (rowup256) keep their kernels
     ups = [n for n, l in at8.items() if l["kernel"] == "conv3x3_patchup16"]
-    assert ups == ["L3.up", "L2.up"] and (at8["L3.up"]["tile_m"], at8["L3.up"]["tile_n"]) == (256, 128)
-    assert at8["L4.up"]["kernel"].startswith("igemm3x3") and at8["L1.up"]["kernel"] == "rowup256"
+    assert ups == ["L4.up", "L3.up", "L2.up"] and (at8["L3.up"]["tile_m"], at8["L3.up"]["tile_n"]) == (256, 128) and at8["L4.up"]["tile_n"] == 64
+    assert at8["L5.up"]["kernel"].startswith("igemm3x3") and at8["L1.up"]["kernel"] == "rowup256"
     off = {l["name"]: l["kernel"] for l in Engine("normal", dtype="bf16", max_batch=8, tune={"patchup16": 0}).layers(8)}
     assert off["L3.up"].startswith("igemm3x3") and off["L2.d.res0.a"] == "conv3x3_patch16"
 
@@ -380,7 +381,7 @@ def test_16bit_plans_route_the_smallest_levels_to_the_full_k_kernel():
     at8 = e.layers(8)
     fk = [l["name"] for l in at8 if l["kernel"] == "conv3x3_fullk16"]
     assert fk == ["L5.down", "L6.down", "L6.d.res0.a", "L6.d.res0.b", "L7.down", "L7.d.res0.a", "L7.d.res0.b", "L7.up", "L7.u.res0.a", "L7.u.res0.b", "L6.up"]
-    assert sum("splitk_reduce" in l["kernel"] for l in at8) == 3                      # <= 8 (19 in round 4; 7 in round 5; the four 32x32 ResidualBlock convs left their 2 K-splits for conv3x3_patch16 in round 6)
+    assert sum("splitk_reduce" in l["kernel"] for l in at8) == 2                      # <= 8 (19 in round 4; 7 in round 5; the four 32x32 ResidualBlock convs left their 2 K-splits for conv3x3_patch16 in round 6, L4.up for conv3x3_patchup16)
     for l in at8:
         if l["kernel"] == "conv3x3_fullk16":
             assert l["split_k"] == 1 and l["h_out"] in (2, 4, 8) and l["cout"] == 512
