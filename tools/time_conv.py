@@ -18,7 +18,7 @@ def main():
     lib = N.load(); dev = torch.device("cuda:0")
     ho = 2 * hs if up else hs // stride
     d0 = torch.randn(b, hs, hs, c0, device=dev).to(tdt); d1 = torch.randn(b, hs, hs, c1, device=dev).to(tdt) if c1 else None
-    w = (torch.randn(cout, 3, 3, c0 + c1, device=dev) * 0.02).to(tdt)     # timing only: any k_group == -1 layout has the same bytes
+    w = (torch.randn(cout, 4 if up == 2 else 3, 4 if up == 2 else 3, c0 + c1, device=dev) * 0.02).to(tdt)     # timing only: any k_group == -1 layout has the same bytes; up == 2: the sub-pixel operand [4][cout][2][2][cin]
     sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     out = torch.empty(b, ho, ho, cout, device=dev, dtype=tdt)
     res = torch.randn(b, ho, ho, cout, device=dev).to(tdt) if with_res else None
