@@ -109,7 +109,7 @@ int lspf2f_create(const lspf2f_config *cfg, lspf2f_handle **out);
  * key is LSPF2F_ERR_INVALID_ARGUMENT).  The library never reads the process environment -- every switch arrives here, once per handle,
  * before the plan is built.  Keys (default): graph (1) | wino (1), wino4 (flag), winoup (1): the Winograd kernels | wino_ureg (1:
  * U fragments of wino3x3<1> in registers; 2: four register sets), in_wino_stats (1: InstanceNorm statistics from the wino3x3 epilogue), in_small_regs (1: the one-launch InstanceNorm pass keeps its rows in registers -- one read of the slab instead of three), in_smallm_fused (1: the tiny-M kernel normalises in its own epilogue under InstanceNorm plans), wino_prio (wave priority by K-loop progress: 1 = the workgroup that is behind leads, 2 = the one ahead, 3 = 1 with the older half of the grid kept at level 1 through its last quarter -- on wino3x3<1>'s register form; 4..6 = the same three schemes on every Winograd loop; 0 = off; default 1), wino_pre (1), wino_il (1), wino_rot (1), wino_xcd (-1), igemm_xcd (-1), winoup_nb (0), winoup_target (1024): their tiling / issue-order variants |
- * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, patch16 (1: the stride-1 convs of the 64x64 / 32x32 levels on the patch-staged kernel), patchup16 (1: and the sub-pixel up-convs over 32x32 / 64x64 sources on its up-conv form), patch16_min_blocks (192), rowup (1), rowlast (1), rowlast_fused (1: rowlast128 shuffles + applies tanh in its epilogue when only fp32 frames are wanted), rowconv (1): kernels of the 16-bit plans |
+ * bandconv (1), bandconv_min_blocks (128), bandconv_min_frames, patch16 (1: the stride-1 convs of the 64x64 / 32x32 levels on the patch-staged kernel), patch16_deep (1: its 64-channel tiles run the deep-ring form conv3x3_patch16d), patchup16 (1: and the sub-pixel up-convs over 32x32 / 64x64 sources on its up-conv form), patch16_min_blocks (192), rowup (1), rowlast (1), rowlast_fused (1: rowlast128 shuffles + applies tanh in its epilogue when only fp32 frames are wanted), rowconv (1): kernels of the 16-bit plans |
  * fullk_split (1), fullk_split_tiles (128), fullk_s2 (0): the full-K kernel's K split | fused_splitk (1), fused_splitk16 (0: the 16-bit plans combine 2..8 K-splits in the launch too), out_wt (1: the Winograd kernels write their output through to memory, sc1 stores; 0: plain stores, left dirty in L2), prefetch (1), smallm_dma (1: the tiny-M kernel stages its input tensor by LDS-DMA, every piece in flight at once; 0: through registers), smallm_kb (128: largest input tensor, in KB, the tiny-M kernel takes; 64 = rounds 2-4) |
  * tail_prefetch (0; 1 | 2: a side branch of the forward's graph reads the weights of the <= 16x16 levels with plain | non-temporal loads while the levels above compute), tail_prefetch_at (-1: layer index the branch forks in front of), tail_prefetch_wgs (32), tail_prefetch_mb (0 = the whole range): measured, off (profiles/r06_tail_prefetch_ab.txt) |
  * fullk16 (3: which small levels of a 16-bit plan run on conv3x3_fullk16 -- bit 0 the 4x4 / 2x2 levels, bit 1 the stride-2 / upsampling convs that write 8x8, bit 2 the stride-1 8x8 layers; 0 = none), fullk16_min_frames (2) |

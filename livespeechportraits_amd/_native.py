@@ -47,7 +47,7 @@ _RENAMED_ENV = {"LSP_HIP_XCD": "igemm_xcd", "LSP_HIP_FULLK_SPLIT_TILES": "fullk_
 # (LSP_HIP_CAND_CACHE, networks.py) or a typo: it is not handed to the library (a typo gets a warning)
 TUNE_KEYS = frozenset((
     "graph", "wino", "wino4", "wino_pre", "wino_ureg", "wino_prio", "in_wino_stats", "wino_xcd", "wino_il", "wino_rot", "winoup", "winoup_nb", "winoup_target", "igemm_xcd",
-    "bandconv", "bandconv_min_blocks", "bandconv_min_frames", "patch16", "patchup16", "patch16_min_blocks", "tail_prefetch", "tail_prefetch_at", "tail_prefetch_wgs", "tail_prefetch_mb", "rowup", "rowlast", "rowlast_fused", "rowconv", "fullk_split", "fullk_split_tiles", "fullk_s2",
+    "bandconv", "bandconv_min_blocks", "bandconv_min_frames", "patch16", "patchup16", "patch16_deep", "patch16_min_blocks", "tail_prefetch", "tail_prefetch_at", "tail_prefetch_wgs", "tail_prefetch_mb", "rowup", "rowlast", "rowlast_fused", "rowconv", "fullk_split", "fullk_split_tiles", "fullk_s2",
     "all_forms", "blob_pad_kb", "fused_splitk", "fused_splitk16", "fullk16", "fullk16_min_frames", "out_wt", "prefetch", "smallm_dma", "smallm_kb", "in_small_regs", "in_smallm_fused", "in_small_max_hw", "lastconv_direct", "lastconv", "firstconv"))
 _HOST_ENV = frozenset(("LSP_HIP_CAND_CACHE", "LSP_HIP_TUNE"))
 

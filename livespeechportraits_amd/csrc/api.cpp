@@ -165,6 +165,7 @@ int lspf2f_create_tuned(const lspf2f_config *cfg, const char *tune, lspf2f_handl
         else if (k == "bandconv_min_frames") P.bandconv_min_frames_small = v;
         else if (k == "patch16") P.use_patch16 = v != 0;
         else if (k == "patchup16") P.use_patchup16 = v != 0;
+        else if (k == "patch16_deep") P.patch16_deep = v != 0;
         else if (k == "patch16_min_blocks") P.patch16_min_blocks = v;
         else if (k == "rowup") P.use_rowup = v != 0;
         else if (k == "rowlast") P.use_rowlast = v != 0;
@@ -625,6 +626,7 @@ static int run_layer(lspf2f_handle *h, const LayerDesc &l, const float *feat, co
         p.src = tptr(l.src0); p.w = bptr(l.w_off); p.scale = bptr(l.scale_off); p.shift = bptr(l.shift_off);
         p.residual = tptr(l.res); p.out = tptr(l.out);
         p.B = batch; p.H = l.ho; p.W = l.ho; p.C = l.c0; p.Cout = l.cout; p.relu = l.relu; p.dtype = P.dtype;
+        p.deep = P.patch16_deep;
         e = launch_patch16(p, l.patch16, l.bn, s);
     } else if (l.bandconv) {
         BandConvParams p{};
@@ -1168,6 +1170,8 @@ int lspf2f_conv3x3(const void *src0, const void *src1, const void *w_packed, con
             PatchConvParams q{};
             q.src = src0; q.w = w_packed; q.scale = scale; q.shift = shift; q.residual = residual; q.out = out;
             q.B = batch; q.H = hs; q.W = ws; q.C = c0; q.Cout = cout; q.relu = relu; q.dtype = dtype;
+            q.deep = tile_n == 64;                  // tile_n 65 = 64 channels per workgroup in the FIRST form (copies in the load segment, 3-slot ring; A-B runs, the ablation and stamp builds)
+            if (tile_n == 65) tile_n = 64;
 #ifdef LSPF2F_ABLATE
             q.dbg = ablate_dbg();
 #endif

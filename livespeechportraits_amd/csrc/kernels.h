@@ -274,6 +274,7 @@ struct PatchConvParams {
     // weights = the implicit GEMM's up4 operand [4 parities][Cout][2][2][C + C1]
     const void *src1;
     int C1;
+    int deep;                     // 64 channels per workgroup: 1 = the deep-ring form (conv3x3_patch16d: copies between the MFMAs, weights four K-tiles ahead), 0 = the first form
     int dtype;                    // 1 = bf16, 2 = fp16
     int dbg;                      // -DLSPF2F_ABLATE builds: 1 no copies in the K loop, 2 no fragment reads, 4 no MFMAs, 16 no epilogue
     unsigned long long *stamps;   // -DLSPF2F_PATCH_STAMPS builds: [blocks][8 waves][8] cycle sums (tools/probes/patch16_stamps.py)

@@ -335,6 +335,254 @@ __global__ __launch_bounds__(512) void conv3x3_patch16(const PatchConvParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// 64 channels per workgroup (the 32x32 level at 8 frames: 128-channel tiles would leave the chip half empty): a wave owns 64 pixels x 32 channels, ONE 32-channel block,
+// so a K-tile is only 8 MFMAs (256 cycles) against 12 fragment reads and 2 copies -- in the form above the LOAD segment is then twice as long as the MFMA segment, and most
+// of it is the issue cost of the two LDS-DMA statements (100-185 cycles each next to the reads).  Here the copies are issued BETWEEN the MFMAs, where a wave has issue
+// slots to spare, and the weights run FOUR K-tiles ahead through a 6-slot ring (8 KB per slot at 64 channels: the LDS has room), so a copy has three and a half segments
+// to land: the load segment is fragment reads + one counted wait.  (The same move with the 3-slot ring of the 128-channel tiles measured slower: one and a half segments
+// are not enough, see conv3x3_patch16.)
+//   ring slot of K-tile t = t mod 6 = (3 cb + tap) mod 6: a scalar per block;  patch pieces of block cb + 1: two per tap over taps 0..3 (all older than the copies of
+//   taps 6 and 7, which are the ones still in flight when block cb + 1 is first read);
+//   counted wait at the end of load segment tau: everything but the pieces issued in the two MFMA segments before it -- K-tile tau + 1, issued four segments ago, has landed.
+template <bool F16, int TW, int TR>
+__global__ __launch_bounds__(512) void conv3x3_patch16d(const PatchConvParams p)
+{
+    typedef typename St16<F16>::type T;
+    constexpr int BN = 64, NSB = 6, DIST = 4;
+    constexpr int PW = TW + 2, PPX = PW * (TR + 2);
+    constexpr int NPIECE = (PPX + 7) / 8;
+    constexpr int NPA = (NPIECE + 7) / 8;
+    constexpr int PATCH_BYTES = (NPIECE + 1) * 1024;
+    constexpr int BRING = 2 * PATCH_BYTES;
+    constexpr int BTILE = BN * 128;
+    static_assert(TW * TR == 256 && TW % 32 == 0, "a wave's 32-pixel MFMA block is 32 consecutive pixels of one row");
+    static_assert(NPA <= 8, "two patch pieces per tap step over taps 0..3");
+    static_assert(8 * 32 * 36 * 4 <= PATCH_BYTES, "the epilogue's transpose patches live in the patch buffer of the last channel block");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_p16[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_char *)smem_p16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    asm volatile("" :: "s"(p.src), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.residual), "s"(p.out), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C), "s"(p.Cout),
+                       "s"(p.relu), "s"(p.ntm), "s"(p.ntn), "s"(p.div_tpi.m), "s"(p.div_tpi.s1), "s"(p.div_tpi.s2), "s"(p.div_tx.m), "s"(p.div_tx.s1), "s"(p.div_tx.s2),
+                       "s"(p.div_ntn.m), "s"(p.div_ntn.s1), "s"(p.div_ntn.s2));
+
+    unsigned lin = blockIdx.x;
+    {
+        const unsigned total = gridDim.x, q = total >> 3, r = total & 7, x = lin & 7;
+        lin = x * q + (x < r ? x : r) + (lin >> 3);
+    }
+    const int mt = (int)p.div_ntn.div(lin), nt = (int)lin - mt * p.ntn;
+    const int fb = (int)p.div_tpi.div((unsigned)mt);
+    const int rem = mt - fb * p.tiles_per_img;
+    const int ty = (int)p.div_tx.div((unsigned)rem), tx = rem - ty * p.tiles_x;
+    const int y0 = ty * TR, x0 = tx * TW, n0 = nt * BN;
+    const int NCB = p.C >> 6;
+    const int Krow = 9 * p.C;
+
+    unsigned voffA[NPA], dstA[NPA];
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int q = j * 8 + wave;
+        const int pp = q * 8 + (lane >> 3), s = lane & 7;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+        const bool ok = pp < PPX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        voffA[j] = ok ? (unsigned)((fb * p.H + y) * p.W + x) * (unsigned)(p.C * 2) + (unsigned)((s ^ ((pp >> 1) & 7)) << 4) : kOOBp;
+        dstA[j] = (unsigned)((q < NPIECE ? q : NPIECE) * 1024);
+    }
+    unsigned voffB;                                                        // one weight piece per wave and K-tile: rows 8 wave .. + 7 of the 64
+    {
+        const int row = wave * 8 + (lane >> 3), s = lane & 7;
+        voffB = (unsigned)((n0 + row) * Krow * 2) + (unsigned)((s ^ ((row >> 1) & 7)) << 4);
+    }
+    const i32x4 rsa = make_srd(p.src, (unsigned)(p.B * p.H * p.W) * (unsigned)(p.C * 2));
+    const i32x4 rsw = make_srd(p.w, (unsigned)(p.Cout * Krow * 2));
+    const unsigned ldsB = lds0 + BRING + (unsigned)(wave * 8 * 128);
+
+    const int l31 = lane & 31, hh = lane >> 5;
+    int p0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + l31;
+        p0[i] = (m / TW) * PW + (m % TW);
+    }
+    unsigned boff[4];
+    {
+        const int nl = wn * 32 + l31;
+        const unsigned base = (unsigned)BRING + (unsigned)(nl * 128) + (unsigned)(((hh ^ (nl >> 1)) & 7) << 4);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) boff[ks] = base ^ (unsigned)(ks << 5);
+    }
+
+    const int erow = lane >> 2, ecol = (lane & 3) * 8;
+    float4 scv[2], shv[2];
+    {
+        const int n = n0 + wn * 32 + ecol;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            scv[q] = make_float4(1.f, 1.f, 1.f, 1.f); shv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) {
+                scv[q] = *reinterpret_cast<const float4 *>(p.scale + n + 4 * q);
+                shv[q] = *reinterpret_cast<const float4 *>(p.shift + n + 4 * q);
+            }
+        }
+    }
+
+    // ---- prologue: patch of block 0, weights of K-tiles 0..3 (block 0, taps 0..3: NCB >= 2 and 9 taps per block)
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) dma16(lds0 + dstA[j], voffA[j], rsa, 0);
+#pragma unroll
+    for (int t = 0; t < DIST; ++t) dma16(ldsB + (unsigned)(t * BTILE), voffB, rsw, t * p.C * 2);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DIST - 1) : "memory");        // patch 0 and K-tile 0 have landed
+    PATCH_BAR();
+    if (grp == 1) PATCH_BAR();
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    bf16x8 fa[2][4], fb_[4];
+    int s0 = 0;                                                            // ring slot of this block's tap 0 = (9 cb) mod 6 = 0 | 3
+    for (int cb = 0; cb < NCB; ++cb) {
+        const unsigned abuf = (cb & 1) ? (unsigned)PATCH_BYTES : 0u, anext = (cb & 1) ? 0u : (unsigned)PATCH_BYTES;
+        const bool more = cb + 1 < NCB;
+        const bool last = !more;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            int sl = s0 + tap; if (sl >= NSB) sl -= NSB; if (sl >= NSB) sl -= NSB;
+            const unsigned slb = (unsigned)(sl * BTILE);
+            // ---- load segment: fragments only
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb_[ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + (boff[ks] + slb));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int P = p0[i] + ky * PW + kx;
+                const unsigned base = abuf + (unsigned)(P << 7) + (unsigned)(((hh ^ (P >> 1)) & 7) << 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    fa[i][ks] = *reinterpret_cast<const bf16x8 *>(smem_p16 + (base ^ (unsigned)(ks << 5)));
+            }
+            // K-tile tau + 1 has landed: what may still fly are the pieces of the two MFMA segments before this one -- taps tau - 2 and tau - 1 (mod 9: the weights of a tap and,
+            // for taps 0..3, two patch pieces)
+            {
+                const int t1 = (tap + 8) % 9, t2 = (tap + 7) % 9;
+                const int n = 2 + (t1 < 4 ? 2 : 0) + (t2 < 4 ? 2 : 0);
+                if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PATCH_BAR();
+            // ---- MFMA segment with this step's copies between the MFMAs: two pieces of the next block's patch (taps 0..3) and the weights of K-tile t + 4
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = mfma32_16b<F16>(fa[i][ks], fb_[ks], acc[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0 && tap < 4) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int j = tap * 2 + k;
+                        const unsigned va = (j < NPA && more) ? voffA[j < NPA ? j : 0] : kOOBp;
+                        const unsigned dk = j < NPA ? dstA[j < NPA ? j : 0] : (unsigned)(NPIECE * 1024);
+                        dma16(lds0 + anext + dk, va, rsa, (cb + 1) * 128);
+                    }
+                }
+                if (ks == 1) {
+                    const int tap2 = tap + DIST < 9 ? tap + DIST : tap + DIST - 9;
+                    const int cb2 = tap + DIST < 9 ? cb : cb + 1;
+                    const bool live = tap + DIST < 9 || more;
+                    int sl2 = sl + DIST; if (sl2 >= NSB) sl2 -= NSB;
+                    dma16(ldsB + (unsigned)(sl2 * BTILE), live ? voffB : kOOBp, rsw, (tap2 * p.C + cb2 * 64) * 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(tap == 8 && last && grp == 1)) PATCH_BAR();
+        }
+        s0 = s0 == 0 ? 3 : 0;
+    }
+
+    // ---- epilogue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int EP = 36;
+    float *patch = reinterpret_cast<float *>(smem_p16 + (((NCB - 1) & 1) ? PATCH_BYTES : 0)) + wave * (32 * EP);
+    const int ccol = lane & 31, crow = 4 * (lane >> 5);
+    T *outp = static_cast<T *>(p.out);
+    const T *resp = static_cast<const T *>(p.residual);
+    size_t opix[2][2];
+    u32x4 rres[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int m = wm * 64 + i * 32 + pass * 16 + erow;
+            opix[i][pass] = (size_t)(fb * p.H + y0 + m / TW) * p.W + x0 + (m % TW);
+        }
+    const int n = n0 + wn * 32 + ecol;
+    if (resp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+                rres[i][pass] = *reinterpret_cast<const u32x4 *>(resp + opix[i][pass] * p.Cout + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            patch[((r & 3) + 8 * (r >> 2) + crow) * EP + ccol] = acc[i][r];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 16 + erow;
+            float v[8];
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(patch + row * EP + ecol);
+            *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(patch + row * EP + ecol + 4);
+            const float sc[8] = {scv[0].x, scv[0].y, scv[0].z, scv[0].w, scv[1].x, scv[1].y, scv[1].z, scv[1].w};
+            const float sh[8] = {shv[0].x, shv[0].y, shv[0].z, shv[0].w, shv[1].x, shv[1].y, shv[1].z, shv[1].w};
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = v[2 * q] * sc[2 * q] + sh[2 * q], b = v[2 * q + 1] * sc[2 * q + 1] + sh[2 * q + 1];
+                if (resp) { a += lo16<F16>(rres[i][pass][q]); b += hi16<F16>(rres[i][pass][q]); }
+                if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                o[q] = pack16x2<F16>(a, b);
+            }
+            *reinterpret_cast<u32x4 *>(outp + opix[i][pass] * p.Cout + n) = o;
+        }
+    }
+}
+
+template <bool F16, int TW, int TR>
+static hipError_t launch_patch16d_t(const PatchConvParams &p_in, hipStream_t s)
+{
+    constexpr int PPX = (TW + 2) * (TR + 2), NPIECE = (PPX + 7) / 8;
+    constexpr size_t smem = (size_t)2 * (NPIECE + 1) * 1024 + (size_t)6 * 64 * 128;
+    static_assert(smem <= 160 * 1024, "LDS");
+    PatchConvParams p = p_in;
+    p.tiles_x = p.W / TW;
+    p.tiles_per_img = (p.H / TR) * p.tiles_x;
+    p.ntm = p.B * p.tiles_per_img; p.ntn = p.Cout / 64;
+    p.div_tpi = FastDiv::make((unsigned)p.tiles_per_img);
+    p.div_tx = FastDiv::make((unsigned)p.tiles_x);
+    p.div_ntn = FastDiv::make((unsigned)p.ntn);
+    static AttrMask attr_mask;
+    if (attr_needed_on_this_device(attr_mask)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_patch16d<F16, TW, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done_on_this_device(attr_mask);
+    }
+    hipLaunchKernelGGL((conv3x3_patch16d<F16, TW, TR>), dim3((unsigned)(p.ntm * p.ntn)), dim3(512), smem, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
 // The same structure for the sub-pixel up-convs (Upsample x2 + Conv3x3 over the concat of two equally wide sources, models/networks.py:610-611, in the implicit GEMM's
 // up4 form: 4 output parities x 2x2 taps on the LOW-res source with pre-summed weights [4][Cout][2][2][Cin]).  A workgroup = (parity, 256 low-res pixels, BN channels):
 // tap (a, b) of parity (py, px) reads patch records (r + py + a, c + px + b), so the same (TR + 2) x (TW + 2) patch serves every parity; the four workgroups of a
@@ -658,6 +906,11 @@ hipError_t launch_patchup16(const PatchConvParams &p, int tw, int bn, hipStream_
 hipError_t launch_patch16(const PatchConvParams &p, int tw, int bn, hipStream_t s)
 {
     if (!patch16_supported(p, tw, bn)) return hipErrorInvalidValue;
+    // 64 channels per workgroup: the deep-ring form (conv3x3_patch16d) unless the caller asks for the first one (deep == 0: A-B runs, tile_n 65 of lspf2f_conv3x3)
+    if (bn == 64 && p.deep) {
+        if (p.dtype == 2) return tw == 64 ? launch_patch16d_t<true, 64, 4>(p, s) : launch_patch16d_t<true, 32, 8>(p, s);
+        return tw == 64 ? launch_patch16d_t<false, 64, 4>(p, s) : launch_patch16d_t<false, 32, 8>(p, s);
+    }
     if (p.dtype == 2) {
         if (tw == 64) return bn == 128 ? launch_patch16_t<true, 64, 4, 128>(p, s) : launch_patch16_t<true, 64, 4, 64>(p, s);
         return bn == 128 ? launch_patch16_t<true, 32, 8, 128>(p, s) : launch_patch16_t<true, 32, 8, 64>(p, s);

@@ -95,6 +95,7 @@ struct Plan {
                                                // A-B-A-B); tune key `bandconv_min_frames` lowers it for measurements at larger batches   // ... and they only leave it when the launch has at least this many workgroups
     bool use_patch16 = true;   // 16-bit plans: tune key `patch16=0` keeps the stride-1 convs of the 64x64 / 32x32 levels on the implicit GEMM (A-B runs)
     bool use_patchup16 = true; // ... and `patchup16=0` the sub-pixel up-convs over 32x32 / 64x64 sources (conv3x3_patchup16)
+    int patch16_deep = 1;      // ... and `patch16_deep=0` its 64-channel tiles in the first form (3-slot ring, copies in the load segment) instead of conv3x3_patch16d (A-B runs)
     int patch16_min_blocks = 192;   // ... which they only leave when the launch has at least this many workgroups (tune key `patch16_min_blocks`)
     bool use_rowup = true;     // bf16 plans: tune key `rowup=0` keeps L1.up on the implicit GEMM (A-B runs)
     bool rowlast_fused = true; // bf16 plans: rowlast128 applies pixel shuffle + tanh in its epilogue when only fp32 frames are wanted (tune key `rowlast_fused=0`: the two-launch form, A-B runs)

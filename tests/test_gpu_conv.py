@@ -603,6 +603,9 @@ def test_conv3x3_patch_kernel_16bit(cfg, dtype, gpu_device):
     assert ((got - other).abs() <= 2 * tol).all(), (got - other).abs().max().item()
     again = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (7000 + tw, bn), 0, 0, dtype=dtype)
     assert torch.equal(got, again)
+    if bn == 64:      # tile_n 64 = the deep-ring form (conv3x3_patch16d), 65 = 64 channels per workgroup in the first form: same products in the same order -> the same bits
+        first = run_conv(gpu_device, x0, None, w, scale, shift, r, 1, 0, relu, (7000 + tw, 65), 0, 0, dtype=dtype)
+        assert torch.equal(got, first), (got - first).abs().max().item()
 
 
 PATCHUP16_CASES = [
