@@ -149,6 +149,34 @@ def test_winograd_kernel_instances_do_not_spill(tmp_path):
     assert seen >= 7
 
 
+def test_patch_staged_kernel_instances_do_not_spill_and_keep_two_waves_per_simd(tmp_path):
+    """conv3x3_patch16 / conv3x3_patch16d / conv3x3_patchup16 (round 6, csrc/patch16.hip) are planned for ONE workgroup of 8 waves per CU = two waves per SIMD, one of
+    each wave group: the schedule's overlap (one group's MFMAs under the other's fragment reads) exists only if both fit the register file -- <= 256 registers per lane, no scratch.
+    Read it off the compiler's resource report, as for the Winograd kernels."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "livespeechportraits_amd", "csrc", "patch16.hip")
+    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "p.o")],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    seen = {"patch16I": 0, "patch16d": 0, "patchup16": 0}
+    for b in re.split(r"remark: Function Name: ", p.stderr)[1:]:
+        name = b.split()[0]
+        if "conv3x3_patch" not in name:
+            continue
+        for k in seen:
+            if ("conv3x3_" + k) in name:
+                seen[k] += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vgpr = int(re.search(r" VGPRs: (\d+)", b).group(1))
+        agpr = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        assert scratch == 0 and vgpr + agpr <= 256 and occ >= 2, (name, scratch, vgpr, agpr, occ)
+    assert seen["patch16I"] == 8 and seen["patch16d"] == 4 and seen["patchup16"] == 10, seen      # {bf16, fp16} x {4x64, 8x32} x {128, 64}; deep: x 64 only; up: + 16x16 x 64
+
+
 def test_register_form_never_touches_a_u_register_in_flight():
     """The UR form of wino3x3 loads its U fragments by inline asm two K-steps ahead; hipcc does not know those registers are in flight.  A tied asm
     operand once made it copy them BEFORE the counted wait (stale values, caught on the CPU by reading the assembly): nothing but the MFMAs' B
