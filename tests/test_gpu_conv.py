@@ -609,29 +609,30 @@ def test_conv3x3_patch_kernel_16bit(cfg, dtype, gpu_device):
 
 
 PATCHUP16_CASES = [
-    # b, c0, c1, cout, low-res h, tile width, channels per workgroup, relu
-    (1, 128, 128, 128, 32, 32, 128, True),       # two sources, 8 x 32-pixel tiles
-    (2, 256, 0, 128, 32, 32, 64, False),         # one source, 64 channels per workgroup
-    (1, 64, 64, 64, 64, 64, 64, True),           # 4 x 64-pixel tiles, two channel blocks (one per source)
-    (1, 192, 192, 256, 64, 64, 128, True),       # six channel blocks: the ring slot of tap 0 walks 0, 1, 2, 0, 1, 2
-    (3, 128, 128, 128, 32, 32, 128, True),       # 48 workgroups: XCD chunks with a remainder
-    (2, 128, 128, 128, 16, 16, 64, True),        # 16 x 16-pixel tiles (a whole low-res frame): a wave's 32-pixel block is two half-rows
-    (1, 256, 256, 64, 16, 16, 64, False),
+    # b, c0, c1, cout, low-res h, tile width, channels per workgroup, relu, residual (at the output's resolution)
+    (1, 128, 128, 128, 32, 32, 128, True, False),       # two sources, 8 x 32-pixel tiles
+    (2, 256, 0, 128, 32, 32, 64, False, True),          # one source, 64 channels per workgroup, residual
+    (1, 64, 64, 64, 64, 64, 64, True, False),           # 4 x 64-pixel tiles, two channel blocks (one per source)
+    (1, 192, 192, 256, 64, 64, 128, True, True),        # six channel blocks: the ring slot of tap 0 walks 0, 1, 2, 0, 1, 2
+    (3, 128, 128, 128, 32, 32, 128, True, False),       # 48 workgroups: XCD chunks with a remainder
+    (2, 128, 128, 128, 16, 16, 64, True, False),        # 16 x 16-pixel tiles (a whole low-res frame): a wave's 32-pixel block is two half-rows
+    (1, 256, 256, 64, 16, 16, 64, False, True),
 ]
 
 
 @pytest.mark.parametrize("dtype", [1, 2], ids=["bf16", "f16"])
-@pytest.mark.parametrize("cfg", PATCHUP16_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_tw%d_bn%d_relu%d" % c)
+@pytest.mark.parametrize("cfg", PATCHUP16_CASES, ids=lambda c: "b%d_c%d+%d_o%d_h%d_tw%d_bn%d_relu%d_res%d" % c)
 def test_conv3x3_patch_kernel_upconv_16bit(cfg, dtype, gpu_device):
     """The sub-pixel up-conv form of the patch-staged kernel (conv3x3_patchup16): Upsample x2 + conv3x3 over the concat, against the fp64 evaluation of the four parity
     convolutions on the rounded operands (one 16-bit ulp) and against the implicit GEMM's up4 path (other summation order: two ulps); repeats bit-identical."""
-    b, c0, c1, cout, hs, tw, bn, relu = cfg
+    b, c0, c1, cout, hs, tw, bn, relu, res = cfg
     rt = (lambda t: t.half().float()) if dtype == 2 else bf16r
     x0 = rt(rnd(b, c0, hs, hs, seed=181))
     x1 = rt(rnd(b, c1, hs, hs, seed=182)) if c1 else None
     w = rnd(cout, c0 + c1, 3, 3, seed=183) * 0.05
     scale, shift = rnd(cout, seed=184) * 0.5 + 1.0, rnd(cout, seed=185) * 0.1
-    got = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, relu, (7100 + tw, bn), 0, 0, dtype=dtype)
+    r = rt(rnd(b, cout, 2 * hs, 2 * hs, seed=186)) if res else None
+    got = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, 2, relu, (7100 + tw, bn), 0, 0, dtype=dtype)
     wq = rt(pack_subpixel(w))
     x = x0 if x1 is None else torch.cat([x0, x1], 1)
     xp = F.pad(x.double(), (1, 1, 1, 1))
@@ -645,13 +646,15 @@ def test_conv3x3_patch_kernel_upconv_16bit(cfg, dtype, gpu_device):
                     acc = acc + torch.einsum("bchw,oc->bohw", patch, wq[py * 2 + px, :, a, bb, :].double())
             ref[:, :, py::2, px::2] = acc
     ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if r is not None:
+        ref = ref + r.double()
     ref = (F.relu(ref) if relu else ref).float()
     assert torch.isfinite(got).all()
     tol = (ref.abs() * 2.0 ** -8 + 1e-3) if dtype == 1 else (ref.abs() * 2.0 ** -11 + 2e-4)
     assert ((got - ref).abs() <= tol).all(), (got - ref).abs().max().item()
-    other = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, relu, (128, 128), 1, 1, dtype=dtype)
+    other = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, 2, relu, (128, 128), 1, 1, dtype=dtype)
     assert ((got - other).abs() <= 2 * tol).all(), (got - other).abs().max().item()
-    again = run_conv(gpu_device, x0, x1, w, scale, shift, None, 1, 2, relu, (7100 + tw, bn), 0, 0, dtype=dtype)
+    again = run_conv(gpu_device, x0, x1, w, scale, shift, r, 1, 2, relu, (7100 + tw, bn), 0, 0, dtype=dtype)
     assert torch.equal(got, again)
 
 
